@@ -1,0 +1,829 @@
+/*
+ * ckr_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference algorithm for the self-play hot path.
+ * Every function cites the reference file:line it follows.  Written in the
+ * reference's own (x = row, y = col) plane coordinates with scalar loops so
+ * that it can be read side by side with Checkers.py / MCTS.py; the HIP product
+ * code under checkers-mcts_amd/csrc is an independent bit-parallel design.
+ *
+ * See ckr_oracle.h for the parity status ("pinned" for rules / search /
+ * tuples / mask-renorm; the Keras network arithmetic itself is unpinned).
+ */
+#include "ckr_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* plane grid <-> board record                                               */
+/* ------------------------------------------------------------------------ */
+
+typedef struct { int pl[4][8][8]; } grid_t;   /* planes 0-3, Checkers.py:37-42 */
+
+static int sq_of(int x, int y) { return 4 * x + (y >> 1); }
+static int y_of(int s) { int x = s >> 2, k = s & 3; return 2 * k + ((x & 1) ? 0 : 1); }
+
+static void grid_from_board(const ckro_board* b, grid_t* g)
+{
+    memset(g, 0, sizeof(*g));
+    for (int s = 0; s < 32; ++s) {
+        int x = s >> 2, y = y_of(s);
+        uint32_t bit = 1u << s;
+        if (b->p1 & bit) g->pl[(b->kings & bit) ? 1 : 0][x][y] = 1;
+        if (b->p2 & bit) g->pl[(b->kings & bit) ? 3 : 2][x][y] = 1;
+    }
+}
+
+static void board_from_grid(const grid_t* g, uint32_t meta, ckro_board* b)
+{
+    b->p1 = b->p2 = b->kings = 0;
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y) {
+            if (x % 2 == y % 2) continue;
+            uint32_t bit = 1u << sq_of(x, y);
+            if (g->pl[0][x][y]) b->p1 |= bit;
+            if (g->pl[1][x][y]) { b->p1 |= bit; b->kings |= bit; }
+            if (g->pl[2][x][y]) b->p2 |= bit;
+            if (g->pl[3][x][y]) { b->p2 |= bit; b->kings |= bit; }
+        }
+    b->meta = meta;
+}
+
+void ckro_initial_board(ckro_board* out)
+{
+    /* Checkers.init_board, Checkers.py:415-423; history = [state] (:51) */
+    grid_t g; memset(&g, 0, sizeof(g));
+    for (int row = 0; row < 8; ++row)
+        for (int col = 0; col < 8; ++col)
+            if (row % 2 != col % 2) {
+                if (row < 3) g.pl[0][row][col] = 1;
+                else if (row > 4) g.pl[2][row][col] = 1;
+            }
+    /* side = player1; the "mover" into the initial state is player2
+     * (MCTS.determine_reward root fallback, MCTS.py:170-173). */
+    board_from_grid(&g, CKRO_META(0, 1, 0, 0, 0, 1), out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* rules: _check_moves / _check_jumps / _check_king_jumps                     */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    const ckro_board* parent;
+    int player, idx, opp_idx;
+    int occ[8][8];               /* `board` = sum of planes 0-3, pre-move (Checkers.py:117) */
+    uint32_t mask[8];            /* planes 6-13 written in place on the parent */
+    ckro_board legal[CKRO_MAX_CHILDREN]; int n_legal;
+    ckro_board jumps[CKRO_MAX_CHILDREN]; int n_jumps;
+} gen_t;
+
+static void set_mask(gen_t* G, int plane, int x, int y) { G->mask[plane - 6] |= 1u << sq_of(x, y); }
+
+static uint32_t child_meta(const gen_t* G, int toggled, int plane, int x, int y, int irreversible)
+{
+    uint32_t pm = G->parent->meta;
+    uint32_t side = toggled ? (uint32_t)(1 - G->player) : (uint32_t)G->player;  /* temp_state[4] */
+    uint32_t r = irreversible ? 0u : CKRO_R(pm) + 1u;
+    if (r > 127u) r = 127u;
+    uint32_t hist = CKRO_HIST(pm) + 1u;
+    if (hist > CKRO_HIST_MAX) hist = CKRO_HIST_MAX;
+    uint32_t action = (uint32_t)((plane - 6) * 64 + 8 * x + y);                  /* plane 14 */
+    return CKRO_META(side, G->player, action, 1, r, hist);
+}
+
+/* Level-1 continuation probe.  The reference recurses (_check_jumps /
+ * _check_king_jumps call themselves, Checkers.py:230-232,279-281) but only
+ * the emptiness of the returned list is used (:233-237,282-286); deeper
+ * levels write to discarded temporaries.  The probe sees the post-capture
+ * opponent planes (`temp`) and the PRE-move occupancy `board`. */
+static int man_probe(const gen_t* G, const grid_t* temp, int x, int y, int fwd)
+{
+    int found = 0;
+    for (int ydir = -1; ydir < 2; ydir += 2)
+        if (-1 < y + ydir && y + ydir < 8 && -1 < x + fwd && x + fwd < 8)
+            if (temp->pl[G->opp_idx][x + fwd][y + ydir] == 1 ||
+                temp->pl[G->opp_idx + 1][x + fwd][y + ydir] == 1)
+                if (-1 < y + 2 * ydir && y + 2 * ydir < 8 && -1 < x + 2 * fwd && x + 2 * fwd < 8)
+                    if (G->occ[x + fwd * 2][y + ydir * 2] == 0) found++;
+    return found;
+}
+
+static int king_probe(const gen_t* G, const grid_t* temp, int x, int y)
+{
+    int found = 0;
+    for (int ydir = -1; ydir < 2; ydir += 2)
+        for (int fwd = -1; fwd < 2; fwd += 2)
+            if (-1 < x + fwd && x + fwd < 8 && -1 < y + ydir && y + ydir < 8)
+                if (temp->pl[G->opp_idx][x + fwd][y + ydir] == 1 ||
+                    temp->pl[G->opp_idx + 1][x + fwd][y + ydir] == 1)
+                    if (-1 < x + 2 * fwd && x + 2 * fwd < 8 && -1 < y + 2 * ydir && y + 2 * ydir < 8)
+                        if (G->occ[x + fwd * 2][y + ydir * 2] == 0) found++;
+    return found;
+}
+
+static int jump_plane(int fwd, int ydir)
+{
+    /* Checkers.py:238-253 / :287-302 */
+    if (fwd == 1 && ydir == 1) return 13;
+    if (fwd == 1 && ydir == -1) return 12;
+    if (fwd == -1 && ydir == 1) return 11;
+    return 10;
+}
+
+/* Checkers._check_jumps, Checkers.py:202-255 (level 0) */
+static void check_jumps(gen_t* G, const grid_t* state, int x, int y, int fwd)
+{
+    for (int ydir = -1; ydir < 2; ydir += 2) {
+        if (!(-1 < y + ydir && y + ydir < 8 && -1 < x + fwd && x + fwd < 8)) continue;
+        if (!(state->pl[G->opp_idx][x + fwd][y + ydir] == 1 ||
+              state->pl[G->opp_idx + 1][x + fwd][y + ydir] == 1)) continue;
+        if (!(-1 < y + 2 * ydir && y + 2 * ydir < 8 && -1 < x + 2 * fwd && x + 2 * fwd < 8)) continue;
+        if (G->occ[x + fwd * 2][y + ydir * 2] != 0) continue;
+        grid_t temp = *state;
+        temp.pl[G->idx][x][y] = 0;
+        temp.pl[G->opp_idx][x + fwd][y + ydir] = 0;
+        temp.pl[G->opp_idx + 1][x + fwd][y + ydir] = 0;
+        int more = 0;
+        if ((fwd == 1 && x + 2 * fwd == 7) || (fwd == -1 && x + 2 * fwd == 0)) {
+            temp.pl[G->idx + 1][x + 2 * fwd][y + 2 * ydir] = 1;          /* kinged: turn over */
+        } else {
+            temp.pl[G->idx][x + 2 * fwd][y + 2 * ydir] = 1;
+            more = man_probe(G, &temp, x + 2 * fwd, y + 2 * ydir, fwd);
+        }
+        int toggled = more ? 0 : 1;
+        int plane = jump_plane(fwd, ydir);
+        set_mask(G, plane, x, y);
+        board_from_grid(&temp, child_meta(G, toggled, plane, x, y, 1), &G->jumps[G->n_jumps++]);
+    }
+}
+
+/* Checkers._check_king_jumps, Checkers.py:257-304 (level 0) */
+static void check_king_jumps(gen_t* G, const grid_t* state, int x, int y)
+{
+    for (int ydir = -1; ydir < 2; ydir += 2)
+        for (int fwd = -1; fwd < 2; fwd += 2) {
+            if (!(-1 < x + fwd && x + fwd < 8 && -1 < y + ydir && y + ydir < 8)) continue;
+            if (!(state->pl[G->opp_idx][x + fwd][y + ydir] == 1 ||
+                  state->pl[G->opp_idx + 1][x + fwd][y + ydir] == 1)) continue;
+            if (!(-1 < x + 2 * fwd && x + 2 * fwd < 8 && -1 < y + 2 * ydir && y + 2 * ydir < 8)) continue;
+            if (G->occ[x + fwd * 2][y + ydir * 2] != 0) continue;
+            grid_t temp = *state;
+            temp.pl[G->idx + 1][x][y] = 0;
+            temp.pl[G->opp_idx][x + fwd][y + ydir] = 0;
+            temp.pl[G->opp_idx + 1][x + fwd][y + ydir] = 0;
+            temp.pl[G->idx + 1][x + 2 * fwd][y + 2 * ydir] = 1;
+            int more = king_probe(G, &temp, x + 2 * fwd, y + 2 * ydir);
+            int toggled = more ? 0 : 1;
+            int plane = jump_plane(fwd, ydir);
+            set_mask(G, plane, x, y);
+            board_from_grid(&temp, child_meta(G, toggled, plane, x, y, 1), &G->jumps[G->n_jumps++]);
+        }
+}
+
+/* Checkers._check_moves, Checkers.py:94-200 */
+static void check_moves(const ckro_board* b, gen_t* G)
+{
+    grid_t state;
+    grid_from_board(b, &state);
+    memset(G, 0, sizeof(*G));
+    G->parent = b;
+    G->player = (int)CKRO_SIDE(b->meta);
+    G->idx = G->player * 2;
+    G->opp_idx = G->idx ? 0 : 2;
+    int fwd = G->player == 0 ? 1 : -1;
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y)
+            G->occ[x][y] = state.pl[0][x][y] + state.pl[1][x][y] + state.pl[2][x][y] + state.pl[3][x][y];
+    int idx = G->idx;
+    /* men, np.where order = row-major (Checkers.py:111-116,124) */
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y) {
+            if (state.pl[idx][x][y] != 1) continue;
+            if (y + 1 < 8 && -1 < x + fwd && x + fwd < 8 && G->occ[x + fwd][y + 1] == 0) {   /* :125-144 */
+                grid_t t = state;
+                t.pl[idx][x][y] = 0;
+                if ((fwd == 1 && x + fwd == 7) || (fwd == -1 && x + fwd == 0)) t.pl[idx + 1][x + fwd][y + 1] = 1;
+                else t.pl[idx][x + fwd][y + 1] = 1;
+                int plane = fwd == 1 ? 9 : 7;
+                set_mask(G, plane, x, y);
+                board_from_grid(&t, child_meta(G, 1, plane, x, y, 1), &G->legal[G->n_legal++]);
+            }
+            if (y - 1 > -1 && -1 < x + fwd && x + fwd < 8 && G->occ[x + fwd][y - 1] == 0) {  /* :145-164 */
+                grid_t t = state;
+                t.pl[idx][x][y] = 0;
+                if ((fwd == 1 && x + fwd == 7) || (fwd == -1 && x + fwd == 0)) t.pl[idx + 1][x + fwd][y - 1] = 1;
+                else t.pl[idx][x + fwd][y - 1] = 1;
+                int plane = fwd == 1 ? 8 : 6;
+                set_mask(G, plane, x, y);
+                board_from_grid(&t, child_meta(G, 1, plane, x, y, 1), &G->legal[G->n_legal++]);
+            }
+            check_jumps(G, &state, x, y, fwd);                                                   /* :166 */
+        }
+    /* kings (Checkers.py:168-196) */
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y) {
+            if (state.pl[idx + 1][x][y] != 1) continue;
+            for (int xmove = -1; xmove < 2; xmove += 2)
+                for (int ymove = -1; ymove < 2; ymove += 2) {
+                    if (!(-1 < x + xmove && x + xmove < 8 && -1 < y + ymove && y + ymove < 8)) continue;
+                    if (G->occ[x + xmove][y + ymove] != 0) continue;
+                    grid_t t = state;
+                    t.pl[idx + 1][x][y] = 0;
+                    t.pl[idx + 1][x + xmove][y + ymove] = 1;
+                    int plane = (xmove == 1) ? (ymove == 1 ? 9 : 8) : (ymove == 1 ? 7 : 6);
+                    set_mask(G, plane, x, y);
+                    board_from_grid(&t, child_meta(G, 1, plane, x, y, 0), &G->legal[G->n_legal++]);
+                }
+            check_king_jumps(G, &state, x, y);
+        }
+    if (G->n_jumps) G->mask[0] = G->mask[1] = G->mask[2] = G->mask[3] = 0;                      /* :197-199 */
+}
+
+static int popcnt(uint32_t v) { int c = 0; while (v) { v &= v - 1; ++c; } return c; }
+
+/* Checkers.determine_outcome, Checkers.py:306-364, with the 80-state scan
+ * expressed through r (plies since the last man move / capture): the first
+ * differing entry of reversed(history[-80:]) is at cnt = r + 1. */
+static uint32_t outcome_status(const ckro_board* b, int n_legal_actions, int jump_mode)
+{
+    uint32_t hist = CKRO_HIST(b->meta), r = CKRO_R(b->meta);
+    int side = (int)CKRO_SIDE(b->meta);
+    int man_moved = 1, piece_jumped = 1;
+    uint32_t k = 0;
+    if (hist >= 80) {
+        man_moved = 0; piece_jumped = 0;
+        if (r + 1 < 80) { man_moved = 1; k = r + 1; }      /* :335-343 (either flag; same effect) */
+    }
+    uint32_t outcome;
+    if (b->p2 == 0) outcome = 1;                             /* :344-346 */
+    else if (b->p1 == 0) outcome = 2;                        /* :347-349 */
+    else if (n_legal_actions == 0) outcome = (1 - side) == 0 ? 1 : 2;   /* :350-356 */
+    else if (!man_moved && !piece_jumped) { outcome = 3; k = 80; }      /* :357-360 */
+    else outcome = 0;
+    return outcome | ((uint32_t)(jump_mode ? 1 : 0) << 2) | ((uint32_t)n_legal_actions << 8) | (k << 16);
+}
+
+void ckro_movegen(const ckro_board* b, uint32_t mask[8], uint32_t* status)
+{
+    gen_t G;
+    check_moves(b, &G);
+    int n = G.n_jumps ? G.n_jumps : G.n_legal;
+    memcpy(mask, G.mask, sizeof(G.mask));
+    *status = outcome_status(b, n, G.n_jumps > 0);
+}
+
+int ckro_children(const ckro_board* b, ckro_board out[CKRO_MAX_CHILDREN])
+{
+    gen_t G;
+    check_moves(b, &G);
+    if (G.n_jumps) { memcpy(out, G.jumps, (size_t)G.n_jumps * sizeof(ckro_board)); return G.n_jumps; }
+    memcpy(out, G.legal, (size_t)G.n_legal * sizeof(ckro_board));
+    return G.n_legal;
+}
+
+/* ------------------------------------------------------------------------ */
+/* network adapter: Checkers.predict / set_prior_probs                       */
+/* ------------------------------------------------------------------------ */
+
+void ckro_features(const ckro_board* b, float* x896)
+{
+    /* np.moveaxis(state[:14],0,-1).reshape(1,8,8,14), Checkers.py:431-432 */
+    uint32_t mask[8], status;
+    ckro_movegen(b, mask, &status);
+    grid_t g; grid_from_board(b, &g);
+    float side = (float)CKRO_SIDE(b->meta);
+    float draw = (float)((double)CKRO_DRAWK(status) / 80.0);
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y) {
+            float* c = x896 + (x * 8 + y) * 14;
+            for (int p = 0; p < 4; ++p) c[p] = (float)g.pl[p][x][y];
+            c[4] = side; c[5] = draw;
+            for (int d = 0; d < 8; ++d)
+                c[6 + d] = (x % 2 != y % 2) ? (float)((mask[d] >> sq_of(x, y)) & 1u) : 0.0f;
+        }
+}
+
+static uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+
+void ckro_hashnet(const float* x896, uint32_t salt, float* p512, float* v)
+{
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 8; ++y) {
+            if (x % 2 == y % 2) continue;
+            for (int p = 0; p < 4; ++p)
+                if (x896[(x * 8 + y) * 14 + p] != 0.0f) w[p] |= 1u << sq_of(x, y);
+        }
+    uint32_t side = x896[4] != 0.0f ? 1u : 0u;
+    uint32_t k = (uint32_t)lrintf(x896[5] * 80.0f);
+    uint32_t h = 0x9E3779B9u ^ salt;
+    for (int i = 0; i < 4; ++i) h = fmix32(h ^ w[i]) + 0x7F4A7C15u;
+    h = fmix32(h ^ side) + 0x7F4A7C15u;
+    h = fmix32(h ^ k) + 0x7F4A7C15u;
+    for (uint32_t i = 0; i < 512; ++i)
+        p512[i] = (float)((fmix32(h + i * 0x9E3779B1u) >> 16) + 1u) * (1.0f / 33554432.0f);
+    *v = (float)((int)(fmix32(h ^ 0xDEADBEEFu) & 0xFFFFu) - 32768) * (1.0f / 65536.0f);
+}
+
+/* numpy's float32 pairwise summation (the reduction np.sum runs on the
+ * contiguous (8,8,8) float32 array in Checkers.py:437): blocks of 128 with 8
+ * strided accumulators, halves combined recursively. */
+static float pairwise_sum_f32(const float* a, int n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2; n2 -= n2 % 8;
+        return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+void ckro_mask_renorm(const uint32_t mask[8], const float* p512_in, float* p512_out)
+{
+    /* prob_planes *= action_mask; prob_planes /= np.sum(...)  Checkers.py:435-437 */
+    float m[512];
+    for (int layer = 0; layer < 8; ++layer)
+        for (int x = 0; x < 8; ++x)
+            for (int y = 0; y < 8; ++y) {
+                int a = layer * 64 + x * 8 + y;
+                int legal = (x % 2 != y % 2) && ((mask[layer] >> sq_of(x, y)) & 1u);
+                m[a] = legal ? p512_in[a] : p512_in[a] * 0.0f;
+            }
+    volatile float total = pairwise_sum_f32(m, 512);
+    for (int a = 0; a < 512; ++a) p512_out[a] = m[a] / total;
+}
+
+/* ------------------------------------------------------------------------ */
+/* search: MCTS.py                                                           */
+/* ------------------------------------------------------------------------ */
+
+typedef struct onode {
+    ckro_board b;
+    uint32_t mask[8];
+    uint32_t status;
+    struct onode* parent;
+    struct onode** children; int n_children;
+    ckro_board* unvisited;  int n_unvisited;  /* successor list, reference order */
+    int terminal;
+    int n;        /* _number_of_visits */
+    float w;      /* _total_reward (float32 under NEP 50) */
+    float p;      /* _prior_prob */
+} onode;
+
+typedef struct { uint64_t s[2]; } rng_t;
+
+static uint64_t rng_next(rng_t* r)
+{   /* xoroshiro128+ ; the stochastic paths are pinned only distributionally */
+    uint64_t s0 = r->s[0], s1 = r->s[1], res = s0 + s1;
+    s1 ^= s0;
+    r->s[0] = ((s0 << 24) | (s0 >> 40)) ^ s1 ^ (s1 << 16);
+    r->s[1] = (s1 << 37) | (s1 >> 27);
+    return res;
+}
+static double rng_uniform(rng_t* r) { return ((double)(rng_next(r) >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+static double rng_normal(rng_t* r)
+{
+    double u1 = rng_uniform(r), u2 = rng_uniform(r);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+static double rng_gamma(rng_t* r, double a)
+{   /* Marsaglia-Tsang */
+    if (a == 1.0) return -log(rng_uniform(r));
+    if (a < 1.0) return rng_gamma(r, a + 1.0) * pow(rng_uniform(r), 1.0 / a);
+    double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x = rng_normal(r), v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = rng_uniform(r);
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v;
+    }
+}
+
+enum { PH_NEW_GAME, PH_PLY_BEGIN, PH_SEARCH, PH_PLY_END, PH_GAME_END, PH_FINISHED };
+
+struct ckro_worker {
+    ckro_config cfg;
+    rng_t rng;
+    double tau;                      /* MCTS.tau: class attribute, never reset (MCTS.py:53) */
+    /* game_env */
+    ckro_board* history; int hist_len, hist_cap;
+    ckro_board state; uint32_t state_status;
+    int move_count, done, outcome;
+    /* per-game */
+    int game_idx, terminated_game, parent_player, p1_net;
+    onode* root[2]; onode* best[2];
+    onode* tree_top[2];              /* allocation root for freeing */
+    int mover;
+    int rollout_count;
+    onode* pending;
+    int phase;
+    ckro_tuple* tuples; int n_tuples, cap_tuples, game_first_tuple;
+    ckro_game_result* results; int n_results, cap_results;
+    uint64_t stats[8];
+    int last_tree;
+};
+
+static void node_free(onode* n)
+{
+    if (!n) return;
+    for (int i = 0; i < n->n_children; ++i) node_free(n->children[i]);
+    free(n->children); free(n->unvisited); free(n);
+}
+
+/* MCTS_Node.__init__, MCTS.py:350-376 (+ Checkers.get_legal_next_states :77-92) */
+static onode* node_new(ckro_worker* w, const ckro_board* b, onode* parent)
+{
+    onode* n = (onode*)calloc(1, sizeof(onode));
+    n->b = *b; n->parent = parent;
+    gen_t G; check_moves(b, &G);
+    int cnt = G.n_jumps ? G.n_jumps : G.n_legal;
+    memcpy(n->mask, G.mask, sizeof(G.mask));
+    n->status = outcome_status(b, cnt, G.n_jumps > 0);
+    if (CKRO_OUTCOME(n->status) == 0 && cnt > 0) {
+        n->unvisited = (ckro_board*)malloc((size_t)cnt * sizeof(ckro_board));
+        memcpy(n->unvisited, G.n_jumps ? G.jumps : G.legal, (size_t)cnt * sizeof(ckro_board));
+        n->n_unvisited = cnt;
+    }
+    n->terminal = n->n_unvisited ? 0 : 1;
+    w->stats[5]++;
+    return n;
+}
+
+static float node_q(const onode* n) { return n->n ? n->w / (float)n->n : 0.0f; }   /* MCTS.py:389-394 */
+
+/* MCTS.determine_reward, MCTS.py:149-186.  The credited player is the one
+ * who moved into the node (parent.player, or history[-2] for the root). */
+static void backprop_value(onode* node, float v, int sim_player)
+{   /* MCTS_Node.backpropagation, MCTS.py:419-430 */
+    for (onode* n = node; n; n = n->parent) {
+        int parent_player = (int)CKRO_MOVER(n->b.meta);
+        float reward = (sim_player != parent_player) ? -1.0f * v : v;
+        n->n += 1; n->w += reward;
+    }
+}
+static void backprop_outcome(onode* node, int outcome)
+{
+    for (onode* n = node; n; n = n->parent) {
+        int parent_player = (int)CKRO_MOVER(n->b.meta);
+        int reward = 0;
+        if (outcome == 1) reward = parent_player == 0 ? 1 : -1;
+        else if (outcome == 2) reward = parent_player == 1 ? 1 : -1;
+        n->n += 1; n->w += (float)reward;
+    }
+}
+
+/* np.argmax: first maximum, first NaN wins */
+static int argmax_f64(const double* v, int n)
+{
+    int best = 0; double mp = v[0];
+    if (isnan(mp)) return 0;
+    for (int i = 1; i < n; ++i)
+        if (!(v[i] <= mp)) { mp = v[i]; best = i; if (isnan(mp)) break; }
+    return best;
+}
+
+/* MCTS.select_child (NN branch), MCTS.py:102-116 */
+static onode* select_child(ckro_worker* w, onode* node)
+{
+    int nc = node->n_children;
+    double dir[CKRO_MAX_CHILDREN], uct[CKRO_MAX_CHILDREN];
+    double eps = w->cfg.epsilon;
+    if (eps != 0.0) {
+        double tot = 0.0;
+        for (int i = 0; i < nc; ++i) { dir[i] = rng_gamma(&w->rng, w->cfg.alpha); tot += dir[i]; }
+        for (int i = 0; i < nc; ++i) dir[i] /= tot;
+    } else {
+        for (int i = 0; i < nc; ++i) dir[i] = 0.0;
+    }
+    volatile double half = 0.5;
+    double sqrt_n = pow((double)node->n, half);            /* node.n ** 0.5 -> C pow() */
+    float one_minus = (float)(1.0 - eps);
+    for (int i = 0; i < nc; ++i) {
+        onode* c = node->children[i];
+        volatile float pf = one_minus * c->p;               /* float32 array product */
+        double psa = (double)pf + eps * dir[i];
+        volatile double t1 = w->cfg.uct_c * psa;
+        volatile double t2 = t1 * sqrt_n;
+        volatile double t3 = t2 / (double)(1 + c->n);
+        uct[i] = (double)node_q(c) + t3;
+    }
+    return node->children[argmax_f64(uct, nc)];
+}
+
+/* One pass of MCTS.tree_policy from the root (MCTS.py:60-99), iterative.
+ * Returns 1 if a network evaluation is pending, 0 if the simulation ended on
+ * a terminal child (already backed up). */
+static int sim_step(ckro_worker* w, onode* root)
+{
+    onode* node = root;
+    for (;;) {
+        if (node->n_unvisited) { w->pending = node; return 1; }
+        if (!node->terminal) {
+            onode* child = select_child(w, node);
+            if (child->terminal) {                           /* :93-94, default_policy :145-146 */
+                backprop_outcome(child, (int)CKRO_OUTCOME(child->status));
+                w->stats[1]++;
+                return 0;
+            }
+            node = child;
+        } else {                                             /* :97-99 (root terminal) */
+            backprop_outcome(node, (int)CKRO_OUTCOME(node->status));
+            w->stats[1]++;
+            return 0;
+        }
+    }
+}
+
+/* expansion branch of tree_policy, MCTS.py:70-77 + set_prior_probs Checkers.py:440-452 */
+static void expand_pending(ckro_worker* w, const float* p512, float v)
+{
+    onode* node = w->pending;
+    float planes[512];
+    ckro_mask_renorm(node->mask, p512, planes);
+    int cnt = node->n_unvisited;
+    node->children = (onode**)malloc((size_t)cnt * sizeof(onode*));
+    for (int i = 0; i < cnt; ++i) {                          /* pop() from the end => reversed order */
+        onode* c = node_new(w, &node->unvisited[cnt - 1 - i], node);
+        node->children[i] = c;
+    }
+    node->n_children = cnt; node->n_unvisited = 0;
+    free(node->unvisited); node->unvisited = NULL;
+    for (int i = 0; i < cnt; ++i)
+        node->children[i]->p = planes[CKRO_ACTION(node->children[i]->b.meta)];
+    backprop_value(node, v, (int)CKRO_SIDE(node->b.meta));
+    w->pending = NULL;
+    w->stats[0]++;
+}
+
+/* MCTS.best_child ('robust'), MCTS.py:227-248 */
+static onode* best_child(ckro_worker* w, onode* node)
+{
+    int nc = node->n_children;
+    if (!w->cfg.training || w->tau <= 0.0) {
+        int best = 0;
+        for (int i = 1; i < nc; ++i) if (node->children[i]->n > node->children[best]->n) best = i;
+        return node->children[best];
+    }
+    double ev[CKRO_MAX_CHILDREN], total = 0.0;
+    for (int i = 0; i < nc; ++i) { ev[i] = pow((double)node->children[i]->n, 1.0 / w->tau); total += ev[i]; }
+    if (w->move_count > w->cfg.tau_decay_delay) {
+        w->tau -= w->cfg.tau_decay;
+        if (fabs(w->tau) <= 1e-8) w->tau = 0.0;              /* np.isclose(tau, 0) */
+    }
+    double u = rng_uniform(&w->rng) * total, acc = 0.0;
+    for (int i = 0; i < nc; ++i) { acc += ev[i]; if (u < acc) return node->children[i]; }
+    return node->children[nc - 1];
+}
+
+static int board_eq(const ckro_board* a, const ckro_board* b)
+{
+    return a->p1 == b->p1 && a->p2 == b->p2 && a->kings == b->kings && a->meta == b->meta;
+}
+
+/* MCTS.new_root_node, MCTS.py:251-295.  On a missing reply the reference
+ * raises ValueError; the build (and therefore this oracle) takes the
+ * alternative the reference's own message suggests -- a fresh root -- and
+ * counts it. */
+static onode* new_root_node(ckro_worker* w, int tree, onode* old_root)
+{
+    int counter = 1, state_idx = -3;
+    for (;;) {
+        if (w->hist_len + state_idx < 0) break;             /* (IndexError never arises in play) */
+        if (CKRO_SIDE(w->history[w->hist_len - 2].meta) != CKRO_SIDE(w->history[w->hist_len + state_idx].meta)) break;
+        counter++; state_idx--;
+    }
+    onode* new_root = old_root;
+    for (int idx = -counter; idx < 0; ++idx)
+        for (int c = 0; c < new_root->n_children; ++c)
+            if (board_eq(&new_root->children[c]->b, &w->history[w->hist_len + idx])) { new_root = new_root->children[c]; break; }
+    if (board_eq(&new_root->b, &w->state)) {
+        /* detach: free everything except the retained subtree */
+        if (new_root != w->tree_top[tree]) {
+            onode* par = new_root->parent;
+            for (int c = 0; c < par->n_children; ++c) if (par->children[c] == new_root) par->children[c] = NULL;
+            node_free(w->tree_top[tree]);
+            w->tree_top[tree] = new_root;
+        }
+        new_root->parent = NULL;
+        return new_root;
+    }
+    w->stats[4]++;
+    node_free(w->tree_top[tree]);
+    onode* fresh = node_new(w, &w->state, NULL);
+    w->tree_top[tree] = fresh;
+    return fresh;
+}
+
+static void hist_push(ckro_worker* w, const ckro_board* b)
+{
+    if (w->hist_len == w->hist_cap) {
+        w->hist_cap = w->hist_cap ? 2 * w->hist_cap : 256;
+        w->history = (ckro_board*)realloc(w->history, (size_t)w->hist_cap * sizeof(ckro_board));
+    }
+    w->history[w->hist_len++] = *b;
+}
+
+static ckro_tuple* tuple_push(ckro_worker* w)
+{
+    if (w->n_tuples == w->cap_tuples) {
+        w->cap_tuples = w->cap_tuples ? 2 * w->cap_tuples : 256;
+        w->tuples = (ckro_tuple*)realloc(w->tuples, (size_t)w->cap_tuples * sizeof(ckro_tuple));
+    }
+    ckro_tuple* t = &w->tuples[w->n_tuples++];
+    memset(t, 0, sizeof(*t));
+    return t;
+}
+
+ckro_worker* ckro_worker_create(const ckro_config* cfg)
+{
+    ckro_worker* w = (ckro_worker*)calloc(1, sizeof(ckro_worker));
+    w->cfg = *cfg;
+    w->tau = cfg->tau;                                        /* MCTS(**kwargs): once per worker (training_pipeline.py:347) */
+    w->rng.s[0] = cfg->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    w->rng.s[1] = (cfg->seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull + 1ull;
+    for (int i = 0; i < 8; ++i) rng_next(&w->rng);
+    w->phase = PH_NEW_GAME;
+    return w;
+}
+
+void ckro_worker_destroy(ckro_worker* w)
+{
+    if (!w) return;
+    node_free(w->tree_top[0]); node_free(w->tree_top[1]);
+    free(w->history); free(w->tuples); free(w->results); free(w);
+}
+
+/* Checkers.step, Checkers.py:62-75 */
+static void env_step(ckro_worker* w, const onode* child)
+{
+    w->state = child->b;
+    hist_push(w, &w->state);
+    w->state_status = child->status;
+    w->outcome = (int)CKRO_OUTCOME(child->status);
+    w->done = w->outcome != 0;
+    w->move_count += 1;
+}
+
+int ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf)
+{
+    const ckro_config* cfg = &w->cfg;
+    for (;;) {
+        switch (w->phase) {
+        case PH_NEW_GAME: {
+            if (w->game_idx >= cfg->num_games) { w->phase = PH_FINISHED; return 0; }
+            /* game_env fresh / reset, Checkers.py:405-413 */
+            w->hist_len = 0;
+            ckro_initial_board(&w->state);
+            hist_push(w, &w->state);
+            w->move_count = 0; w->done = 0; w->outcome = 0;
+            node_free(w->tree_top[0]); node_free(w->tree_top[1]);
+            w->tree_top[0] = w->tree_top[1] = NULL;
+            w->root[0] = w->root[1] = w->best[0] = w->best[1] = NULL;
+            /* training_pipeline.py:351-355 / :523-531 */
+            w->p1_net = (cfg->tournament && w->game_idx >= cfg->num_games / 2) ? 1 : 0;
+            w->root[0] = w->tree_top[0] = node_new(w, &w->state, NULL);
+            w->terminated_game = 0;
+            w->parent_player = 1;
+            w->game_first_tuple = w->n_tuples;
+            w->phase = PH_PLY_BEGIN;
+            break;
+        }
+        case PH_PLY_BEGIN: {
+            if (w->done) { w->phase = PH_GAME_END; break; }
+            int mover = (int)CKRO_SIDE(w->state.meta);
+            w->mover = mover;
+            if (mover == 0) {                                 /* training_pipeline.py:357-361 */
+                if (w->move_count != 0) {
+                    w->parent_player = (int)CKRO_SIDE(w->history[w->hist_len - 2].meta);
+                    w->root[0] = new_root_node(w, 0, w->best[0]);
+                }
+            } else {                                          /* :370-378 */
+                if (w->move_count == 1) {
+                    w->root[1] = w->tree_top[1] = node_new(w, &w->state, NULL);
+                    w->parent_player = 0;
+                } else {
+                    w->parent_player = (int)CKRO_SIDE(w->history[w->hist_len - 2].meta);
+                    w->root[1] = new_root_node(w, 1, w->best[1]);
+                }
+            }
+            w->rollout_count = 0;                             /* MCTS.begin_tree_search, MCTS.py:216-217 */
+            w->last_tree = mover;
+            w->phase = PH_SEARCH;
+            break;
+        }
+        case PH_SEARCH: {
+            while (w->rollout_count < cfg->budget) {          /* MCTS.py:219-220, :189-201 */
+                if (sim_step(w, w->root[w->mover])) {
+                    ckro_features(&w->pending->b, x896);
+                    *net = (w->mover == 0) ? w->p1_net : 1 - w->p1_net;
+                    if (!cfg->tournament) *net = 0;
+                    if (leaf) *leaf = w->pending->b;
+                    return 1;
+                }
+                w->rollout_count++;
+            }
+            w->phase = PH_PLY_END;
+            break;
+        }
+        case PH_PLY_END: {
+            onode* root = w->root[w->mover];
+            onode* bc = best_child(w, root);                  /* :362 / :379 */
+            w->best[w->mover] = bc;
+            env_step(w, bc);                                  /* :363 / :380 */
+            /* _create_prob_planes + q sign, training_pipeline.py:364-369,421-437 */
+            ckro_tuple* t = tuple_push(w);
+            t->board = root->b; memcpy(t->mask, root->mask, sizeof(root->mask)); t->status = root->status;
+            t->game = w->game_idx; t->ply = w->move_count - 1;
+            t->n_children = root->n_children;
+            for (int i = 0; i < root->n_children; ++i) {
+                t->action[i] = (uint16_t)CKRO_ACTION(root->children[i]->b.meta);
+                t->visits[i] = (uint32_t)root->children[i]->n;
+                t->wsum[i] = root->children[i]->w; t->prior[i] = root->children[i]->p;
+            }
+            t->root_n = root->n; t->root_w = root->w; t->chosen = (int)CKRO_ACTION(bc->b.meta);
+            float q = node_q(root);
+            t->q = (w->parent_player != (int)CKRO_SIDE(root->b.meta)) ? -q : q;
+            w->stats[2]++;
+            if (!cfg->tournament && cfg->terminate_cnt > 0 && !w->done && w->move_count >= cfg->terminate_cnt) {
+                /* adjudication, training_pipeline.py:387-405 */
+                w->terminated_game = 1; w->done = 1;
+                int p1 = popcnt(w->state.p1), p2 = popcnt(w->state.p2);
+                int k1 = popcnt(w->state.p1 & w->state.kings), k2 = popcnt(w->state.p2 & w->state.kings);
+                if (p1 > p2) w->outcome = 1; else if (p1 < p2) w->outcome = 2;
+                else if (k1 > k2) w->outcome = 1; else if (k1 < k2) w->outcome = 2; else w->outcome = 3;
+            }
+            w->phase = PH_PLY_BEGIN;
+            break;
+        }
+        case PH_GAME_END: {
+            if (!cfg->tournament && !w->terminated_game) {    /* :406-409 */
+                ckro_tuple* t = tuple_push(w);
+                t->board = w->state; t->status = w->state_status;
+                uint32_t st; ckro_movegen(&w->state, t->mask, &st);
+                t->game = w->game_idx; t->ply = w->move_count; t->n_children = 0; t->chosen = -1;
+                t->q = (w->outcome == 3) ? 0.0f : -1.0f; t->q_is_int = 1;
+            }
+            for (int i = w->game_first_tuple; i < w->n_tuples; ++i) {   /* _add_rewards :439-455 */
+                int player = (int)CKRO_SIDE(w->tuples[i].board.meta), z = 0;
+                if (w->outcome == 1) z = player == 0 ? 1 : -1;
+                else if (w->outcome == 2) z = player == 1 ? 1 : -1;
+                w->tuples[i].z = z;
+            }
+            if (w->n_results == w->cap_results) {
+                w->cap_results = w->cap_results ? 2 * w->cap_results : 64;
+                w->results = (ckro_game_result*)realloc(w->results, (size_t)w->cap_results * sizeof(ckro_game_result));
+            }
+            ckro_game_result* r = &w->results[w->n_results++];
+            r->game = w->game_idx; r->outcome = w->outcome; r->move_count = w->move_count;
+            r->adjudicated = w->terminated_game; r->p1_net = w->p1_net;
+            w->stats[3]++;
+            w->game_idx++;
+            w->phase = PH_NEW_GAME;
+            break;
+        }
+        default:
+            return 0;
+        }
+    }
+}
+
+void ckro_worker_submit(ckro_worker* w, const float* p512, float v)
+{
+    expand_pending(w, p512, v);
+    w->rollout_count++;
+}
+
+int ckro_worker_num_tuples(const ckro_worker* w) { return w->n_tuples; }
+const ckro_tuple* ckro_worker_tuples(const ckro_worker* w) { return w->tuples; }
+int ckro_worker_num_results(const ckro_worker* w) { return w->n_results; }
+const ckro_game_result* ckro_worker_results(const ckro_worker* w) { return w->results; }
+void ckro_worker_stats(const ckro_worker* w, uint64_t out[8]) { memcpy(out, w->stats, sizeof(w->stats)); }
+
+int ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n, float* wsum,
+                          float* prior, int32_t* root_n, float* root_w)
+{
+    const onode* root = w->root[w->last_tree];
+    if (!root) return 0;
+    for (int i = 0; i < root->n_children; ++i) {
+        action[i] = (uint16_t)CKRO_ACTION(root->children[i]->b.meta);
+        n[i] = root->children[i]->n; wsum[i] = root->children[i]->w; prior[i] = root->children[i]->p;
+    }
+    *root_n = root->n; *root_w = root->w;
+    return root->n_children;
+}

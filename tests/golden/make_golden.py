@@ -1,0 +1,271 @@
+"""Generate the committed golden fixtures by RUNNING THE IMPORTED PYTHON
+REFERENCE (BUILD CONTAINER ONLY -- /root/reference is absent on the GPU box).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Fixture families:
+  rules_v1.npz       positions -> mask words, status, ordered successors
+  predict_v1.npz     Checkers.predict mask/renormalise on recorded raw outputs
+  hashnet_v1.npz     HashNet.predict vectors (pins the C / HIP re-statements)
+  search_v1.npz      deterministic searches via the MCTS API: per-ply root
+                     children (action, N, W, P) and the chosen action
+  selfplay_v1.npz    generate_Checkers_data._generate_data output (state, pi, q, z)
+  tournament_v1.npz  tournament_Checkers._start_tournament outcomes
+The fixtures are data (inputs + the reference's outputs); no reference source
+is stored.
+"""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+import ref_tools as rt
+import ref_shim
+import training_pipeline as tp
+from MCTS import MCTS, MCTS_Node
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+codec = rt.codec
+
+
+def mcts_kwargs(budget, eps=0.0, tau=0.0, training=True, env=None):
+    return dict(GAME_ENV=env, UCT_C=4, CONSTRAINT="rollout", BUDGET=budget, MULTIPROC=False,
+                NEURAL_NET=True, VERBOSE=False, TRAINING=training, DIRICHLET_ALPHA=1.0,
+                DIRICHLET_EPSILON=eps, TEMPERATURE_TAU=tau, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+
+
+# --------------------------------------------------------------------------- rules
+def gen_rules(seed=20260929, n_games=120, n_endgames=60, n_synth=6000):
+    rng = np.random.RandomState(seed)
+    boards, masks, status, off, kids, kind = [], [], [], [0], [], []
+
+    def add(env, history, k):
+        m, s, c = rt.ref_analyse(env, history)
+        boards.append(rt.record_of(history)); masks.append(m); status.append(s)
+        kids.append(c); off.append(off[-1] + len(c)); kind.append(k)
+
+    for g in range(n_games + n_endgames):
+        start = None
+        if g >= n_games:
+            import validate_oracle as vo
+            start = vo.endgame_start(rng)
+            if g % 2:                      # bare kings: reaches the 80-state draw
+                start = np.zeros((15, 8, 8))
+                sq = list(rng.permutation(32))
+                for side, cnt in ((0, 1 + g % 4 // 3), (1, 1)):
+                    for _ in range(cnt):
+                        q = sq.pop()
+                        start[side * 2 + 1, codec.SQ_X[q], codec.SQ_Y[q]] = 1
+                start[4] = rng.randint(0, 2)
+        env = rt.new_env(start)
+        while not env.done and env.move_count < 500:
+            add(env, env.history, 0 if start is None else 1)
+            nxt = env.legal_next_states
+            if not nxt:
+                break
+            env.step(nxt[rng.randint(len(nxt))])
+        add(env, env.history, 0 if start is None else 1)
+    env = rt.new_env()
+    for _ in range(n_synth):
+        add(env, [rt.synthetic_state(rng)], 2)
+    # maximum-branching and edge positions
+    for fn in (_all_kings_board, _empty_side_board):
+        for s in fn():
+            add(env, [s], 3)
+    np.savez_compressed(os.path.join(HERE, "rules_v1.npz"), boards=np.array(boards, np.uint32),
+                        masks=np.array(masks, np.uint32), status=np.array(status, np.uint32),
+                        child_off=np.array(off, np.int64), children=np.concatenate(kids).astype(np.uint32),
+                        kind=np.array(kind, np.uint8))
+    print("rules:", len(boards), "positions,", off[-1], "children, max b", int(np.diff(off).max()))
+
+
+def _all_kings_board():
+    out = []
+    for side in (0, 1):
+        s = np.zeros((15, 8, 8))
+        for sq in (9, 10, 13, 14, 17, 18, 21, 22, 5, 6, 25, 26):     # 12 kings mid-board
+            s[side * 2 + 1, codec.SQ_X[sq], codec.SQ_Y[sq]] = 1
+        s[(1 - side) * 2 + 1, codec.SQ_X[3 if side else 28], codec.SQ_Y[3 if side else 28]] = 1
+        s[4] = side
+        out.append(s)
+    return out
+
+
+def _empty_side_board():
+    out = []
+    for side in (0, 1):
+        for stm in (0, 1):
+            s = np.zeros((15, 8, 8))
+            s[side * 2, 3, 2] = 1
+            s[4] = stm
+            out.append(s)
+    s = np.zeros((15, 8, 8))          # blocked: side to move has no legal move
+    s[0, 0, 1] = 1; s[2, 1, 0] = 1; s[2, 1, 2] = 1; s[2, 2, 3] = 1
+    s[4] = 0
+    out.append(s)
+    return out
+
+
+# --------------------------------------------------------------------------- predict / hashnet
+def gen_predict(seed=7, n=200):
+    rng = np.random.RandomState(seed)
+    env = rt.new_env()
+    boards, masks, raw, outp, hx, hp, hv, hsalt = [], [], [], [], [], [], [], []
+
+    class Net:
+        def predict(self, x):
+            return [self.p.reshape(1, 512).copy(), np.array([[np.float32(0.25)]], np.float32)]
+
+    net = Net()
+    env.neural_net = net
+    for i in range(n):
+        s = rt.synthetic_state(rng, max_pieces=8)
+        kids = env._check_moves([s])
+        if not kids:
+            continue
+        env.determine_outcome([s], legal_moves=kids)
+        z = rng.randn(512).astype(np.float32) * np.float32(3.0)
+        e = np.exp(z - z.max()); net.p = (e / e.sum()).astype(np.float32)
+        planes, q = env.predict(s)
+        boards.append(rt.record_of([s])); masks.append(rt.pack_planes(s[6:14]))
+        raw.append(net.p.copy()); outp.append(np.asarray(planes, np.float32).reshape(512))
+        assert planes.dtype == np.float32
+        x = np.moveaxis(s[:14], 0, -1).reshape(1, 8, 8, 14)
+        salt = int(rng.randint(0, 5))
+        p, v = ref_shim.HashNet(salt).predict(x)
+        hx.append(x.astype(np.float32).reshape(896)); hp.append(p[0]); hv.append(v[0, 0]); hsalt.append(salt)
+    np.savez_compressed(os.path.join(HERE, "predict_v1.npz"), boards=np.array(boards, np.uint32),
+                        masks=np.array(masks, np.uint32), raw_p=np.array(raw, np.float32),
+                        planes=np.array(outp, np.float32))
+    np.savez_compressed(os.path.join(HERE, "hashnet_v1.npz"), x=np.array(hx, np.float32),
+                        p=np.array(hp, np.float32), v=np.array(hv, np.float32), salt=np.array(hsalt, np.uint32))
+    print("predict:", len(boards), "vectors")
+
+
+# --------------------------------------------------------------------------- search (MCTS API)
+def gen_search(cases=((30, 0, 24), (100, 1, 10), (12, 2, 400))):
+    """Drive MCTS / MCTS_Node exactly as training_pipeline.py:353-386 does and
+    record the root statistics after every search."""
+    out = {}
+    for ci, (budget, salt, max_plies) in enumerate(cases):
+        env = rt.new_env()
+        env.neural_net = ref_shim.HashNet(salt)
+        MCTS(**mcts_kwargs(budget, training=False, env=env))
+        rows, acts, ns, ws, ps, off = [], [], [], [], [], [0]
+        initial = env.state
+        root1 = MCTS_Node(initial, parent=None)
+        best1 = best2 = root2 = None
+        while not env.done and env.move_count < max_plies:
+            if env.current_player(env.state) == "player1":
+                if env.move_count != 0:
+                    root1 = MCTS.new_root_node(best1)
+                root = root1
+            else:
+                if env.move_count == 1:
+                    root2 = MCTS_Node(env.state, parent=None, initial_state=initial)
+                else:
+                    root2 = MCTS.new_root_node(best2)
+                root = root2
+            MCTS.begin_tree_search(root)
+            best = MCTS.best_child(root)
+            if root is root1:
+                best1 = best
+            else:
+                best2 = best
+            for c in root.children:
+                a = (int(c.state[14, 0, 0]) - 6) * 64 + 8 * int(c.state[14, 0, 1]) + int(c.state[14, 0, 2])
+                acts.append(a); ns.append(c.n); ws.append(np.float32(c.w)); ps.append(np.float32(c.p))
+            off.append(len(acts))
+            ba = (int(best.state[14, 0, 0]) - 6) * 64 + 8 * int(best.state[14, 0, 1]) + int(best.state[14, 0, 2])
+            rows.append((root.n, np.float32(root.w), ba, int(root.state[4, 0, 0])))
+            env.step(best.state)
+        out["c%d_cfg" % ci] = np.array([budget, salt, max_plies, env.move_count,
+                                         rt.OUTCOME_CODE[env.outcome]], np.int64)
+        out["c%d_root_n" % ci] = np.array([r[0] for r in rows], np.int64)
+        out["c%d_root_w" % ci] = np.array([r[1] for r in rows], np.float32)
+        out["c%d_chosen" % ci] = np.array([r[2] for r in rows], np.int64)
+        out["c%d_side" % ci] = np.array([r[3] for r in rows], np.int64)
+        out["c%d_off" % ci] = np.array(off, np.int64)
+        out["c%d_action" % ci] = np.array(acts, np.int64)
+        out["c%d_n" % ci] = np.array(ns, np.int64)
+        out["c%d_w" % ci] = np.array(ws, np.float32)
+        out["c%d_p" % ci] = np.array(ps, np.float32)
+        print("search case", ci, "budget", budget, "plies", len(rows), "outcome", env.outcome)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "search_v1.npz"), **out)
+
+
+# --------------------------------------------------------------------------- self-play tuples
+def gen_selfplay(cases=((30, 40, 2, 0), (20, 1000, 1, 1), (8, 1000, 1, 4), (25, 1000, 1, 6), (50, 12, 3, 9))):
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "training_data"))
+    os.chdir(tmp)
+    try:
+        for ci, (budget, terminate, games, salt) in enumerate(cases):
+            mk = mcts_kwargs(budget)
+            sk = dict(NUM_SELFPLAY_GAMES=games, TRAINING_ITERATION=0, TERMINATE_CNT=terminate, NUM_CPUS=1,
+                      NN_FN="hash_salt%d.h5" % salt)
+            fn = tp.generate_Checkers_data(sk, mk).generate_data()
+            mem = pickle.load(open(fn, "rb"))
+            out["c%d_cfg" % ci] = np.array([budget, terminate, games, salt], np.int64)
+            out["c%d_state" % ci] = np.array([m[0] for m in mem], np.float64)
+            out["c%d_pi" % ci] = np.array([m[1] for m in mem], np.float64)
+            out["c%d_q" % ci] = np.array([np.float32(m[2]) for m in mem], np.float32)
+            out["c%d_q_is_int" % ci] = np.array([type(m[2]) is int for m in mem], np.bool_)
+            out["c%d_z" % ci] = np.array([m[3] for m in mem], np.int64)
+            print("selfplay case", ci, (budget, terminate, games, salt), len(mem), "tuples")
+    finally:
+        os.chdir(cwd)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "selfplay_v1.npz"), **out)
+
+
+# --------------------------------------------------------------------------- tournament
+def gen_tournament(cases=((30, 4, 1, 2), (24, 2, 3, 5), (40, 2, 7, 8))):
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "tournament_results"))
+    os.chdir(tmp)
+    try:
+        for ci, (budget, games, salt_new, salt_old) in enumerate(cases):
+            mk = mcts_kwargs(budget, training=False)
+            mk["TEMPERATURE_DECAY"] = 0; mk["TEMP_DECAY_DELAY"] = 0
+            tk = dict(NEW_NN_FN="data/model/new_salt%d.h5" % salt_new, OLD_NN_FN="data/model/old_salt%d.h5" % salt_old,
+                      TOURNEY_GAMES=games, NUM_CPUS=1)
+            t = tp.tournament_Checkers(tk, mk)
+            try:
+                res = t._start_tournament()
+            except ValueError as e:      # reply node missing (MCTS.py:292): reference aborts; not a fixture
+                print("case", ci, "reference raised", e, file=sys.stderr)
+                out["c%d_cfg" % ci] = np.array([budget, games, salt_new, salt_old], np.int64)
+                out["c%d_raised" % ci] = np.array(True)
+                continue
+            out["c%d_raised" % ci] = np.array(False)
+            out["c%d_cfg" % ci] = np.array([budget, games, salt_new, salt_old], np.int64)
+            out["c%d_p1_is_new" % ci] = np.array([r[1].startswith("new") for r in res], np.bool_)
+            out["c%d_outcome" % ci] = np.array([rt.OUTCOME_CODE[r[3]] for r in res], np.int64)
+            out["c%d_moves" % ci] = np.array([r[4] for r in res], np.int64)
+            print("tournament case", ci, res)
+    finally:
+        os.chdir(cwd)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "tournament_v1.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament"]
+    devnull = open(os.devnull, "w")
+    real_stdout = sys.stdout
+    for w in which:
+        fn = globals()["gen_" + w]
+        sys.stdout = devnull if w in ("selfplay", "tournament") else real_stdout   # the reference prints per game
+        try:
+            fn()
+        finally:
+            sys.stdout = real_stdout
+        print("done", w)

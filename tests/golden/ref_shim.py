@@ -1,0 +1,112 @@
+"""Import harness for the Python reference (BUILD CONTAINER ONLY).
+
+/root/reference does not exist on the GPU box; nothing under tests/ that runs
+with `-m gpu`, smoke() or bench.py imports this module.  It exists so that
+make_golden.py / validate_oracle.py can (a) import Checkers.py, MCTS.py and
+training_pipeline.py unmodified (TensorFlow/Keras are absent, so a
+`sys.modules` stand-in provides the few names imported at module scope) and
+(b) drive them with a deterministic integer "hash net".
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE = os.environ.get("CKR_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isfile(os.path.join(REFERENCE, "Checkers.py"))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_installed = False
+
+
+def install():
+    """Make `import Checkers, MCTS, training_pipeline` work."""
+    global _installed
+    if _installed:
+        return
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+
+    class Sequence:  # noqa: D401 - stand-in
+        pass
+
+    class Callback:
+        pass
+
+    _mod("tensorflow")
+    _mod("tensorflow.keras")
+    _mod("tensorflow.keras.utils", Sequence=Sequence)
+    _mod("tensorflow.keras.callbacks", Callback=Callback, __all__=["Callback"])
+    _mod("tensorflow.keras.backend")
+    _mod("tensorflow.keras.models", load_model=lambda fn: HashNet(salt_of(fn)))
+    _mod("keras")
+    _mod("keras.callbacks", Callback=Callback)
+    _mod("keras.backend")
+    import matplotlib
+    matplotlib.use("Agg")
+    _installed = True
+
+
+def salt_of(fn):
+    """File name -> hash-net salt ('...salt7...' -> 7; default 0)."""
+    import re
+    m = re.search(r"salt(\d+)", str(fn))
+    return int(m.group(1)) if m else 0
+
+
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _fmix32(h):
+    h = np.uint64(h) & _M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+_SQ_X = np.repeat(np.arange(8), 4)
+_SQ_Y = 2 * np.tile(np.arange(4), 8) + (1 - (_SQ_X & 1))
+
+
+class HashNet:
+    """Deterministic integer network with the Keras `.predict` contract
+    (Checkers.py:433): x[1,8,8,14] -> [p[1,512] float32, v[1,1] float32].
+    Same arithmetic as ckro_hashnet (oracle/ckr_oracle.c) and the engine's
+    built-in test evaluator; every output is an exact float32."""
+
+    def __init__(self, salt=0):
+        self.salt = int(salt)
+        self.calls = 0
+
+    def predict(self, x):
+        self.calls += 1
+        x = np.asarray(x).reshape(8, 8, 14)
+        words = []
+        for p in range(4):
+            bits = (x[_SQ_X, _SQ_Y, p] != 0).astype(np.uint64)
+            words.append(int((bits << np.arange(32, dtype=np.uint64)).sum()))
+        side = 1 if x[0, 0, 4] != 0 else 0
+        k = int(np.rint(np.float32(x[0, 0, 5]) * np.float32(80.0)))
+        h = np.uint64(0x9E3779B9 ^ (self.salt & 0xFFFFFFFF))
+        for wd in words + [side, k]:
+            h = (_fmix32(h ^ np.uint64(wd)) + np.uint64(0x7F4A7C15)) & _M32
+        i = np.arange(512, dtype=np.uint64)
+        hv = _fmix32((h + i * np.uint64(0x9E3779B1)) & _M32)
+        p = ((hv >> np.uint64(16)) + np.uint64(1)).astype(np.float32) * np.float32(1.0 / 33554432.0)
+        vv = int(_fmix32(h ^ np.uint64(0xDEADBEEF)) & np.uint64(0xFFFF)) - 32768
+        v = np.float32(vv) * np.float32(1.0 / 65536.0)
+        return [p.reshape(1, 512), np.array([[v]], np.float32)]

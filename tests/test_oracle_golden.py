@@ -1,0 +1,130 @@
+"""CPU: the C oracle against the golden vectors produced by the imported
+Python reference (tests/golden/make_golden.py).  Bit-exact everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+import checkers_mcts_amd.codec as codec
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_rules_masks_status_children(oracle, golden_dir):
+    g = _load(golden_dir, "rules_v1.npz")
+    boards, off = g["boards"], g["child_off"]
+    mask, status = oracle.movegen(boards)
+    assert (mask == g["masks"]).all()
+    assert (status == g["status"]).all()
+    # popcount(mask) == number of successors
+    pop = np.array([bin(int(w)).count("1") for w in mask.reshape(-1)]).reshape(-1, 8).sum(1)
+    assert (pop == np.diff(off)).all()
+    step = max(1, len(boards) // 4000)
+    for i in range(0, len(boards), step):
+        kids = oracle.children(boards[i])
+        assert kids.shape[0] == off[i + 1] - off[i]
+        assert (kids == g["children"][off[i]:off[i + 1]]).all()
+    assert int(np.diff(off).max()) >= 30          # max-branching position is covered
+    assert (codec.status_drawk(status) > 0).any() # 80-state draw plane exercised
+    assert (codec.status_outcome(status) == 3).any()
+
+
+def test_initial_position(oracle):
+    b = oracle.initial_board()
+    assert b[0] == 0x00000FFF and b[1] == 0xFFF00000 and b[2] == 0
+    mask, status = oracle.movegen(b[None])
+    assert codec.status_nlegal(status)[0] == 7
+    assert bin(int(mask[0, 2])).count("1") == 4 and bin(int(mask[0, 3])).count("1") == 3
+
+
+def test_codec_roundtrip(oracle, golden_dir):
+    g = _load(golden_dir, "rules_v1.npz")
+    boards = g["boards"][::37]
+    planes = codec.records_to_planes(boards, g["masks"][::37], g["status"][::37])
+    back = codec.planes_to_boards(planes, r=codec.meta_r(boards[:, 3]), hist=codec.meta_hist(boards[:, 3]),
+                                  mover=codec.meta_mover(boards[:, 3]))
+    assert (back == boards).all()
+
+
+def test_hashnet_matches_python(oracle, golden_dir):
+    g = _load(golden_dir, "hashnet_v1.npz")
+    for x, p, v, salt in zip(g["x"], g["p"], g["v"], g["salt"]):
+        op, ov = oracle.hashnet(x, int(salt))
+        assert (op == p).all() and ov == v
+
+
+def test_predict_mask_renorm(oracle, golden_dir):
+    g = _load(golden_dir, "predict_v1.npz")
+    for m, raw, planes in zip(g["masks"], g["raw_p"], g["planes"]):
+        out = oracle.mask_renorm(m, raw)
+        assert (out.view(np.uint32) == planes.view(np.uint32)).all()
+
+
+def test_features_match_planes(oracle, golden_dir):
+    g = _load(golden_dir, "rules_v1.npz")
+    for i in range(0, len(g["boards"]), 211):
+        x = oracle.features(g["boards"][i])
+        planes = codec.records_to_planes(g["boards"][i][None], g["masks"][i][None], g["status"][i:i + 1])[0]
+        ref = np.moveaxis(planes[:14], 0, -1).astype(np.float32)      # Checkers.py:431-432
+        assert (x == ref).all()
+
+
+def _mk(budget, training=True):
+    return dict(UCT_C=4, BUDGET=budget, TRAINING=training, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.0,
+                TEMPERATURE_TAU=0.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+
+
+def test_selfplay_tuples_bit_exact(oracle, golden_dir):
+    g = _load(golden_dir, "selfplay_v1.npz")
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games, salt = (int(v) for v in g["c%d_cfg" % ci])
+        w = oracle.Worker(oracle.make_config(_mk(budget), terminate_cnt=terminate, num_games=games))
+        w.run(lambda x, net: oracle.hashnet(x, salt))
+        tu = w.tuples()
+        assert len(tu) == len(g["c%d_z" % ci])
+        st = codec.records_to_planes(np.array([t["board"] for t in tu]), np.array([t["mask"] for t in tu]),
+                                     np.array([t["status"] for t in tu], np.uint32))
+        assert (st == g["c%d_state" % ci]).all()
+        for i, t in enumerate(tu):
+            assert (codec.pi_planes(t["action"], t["visits"]) == g["c%d_pi" % ci][i]).all()
+            assert t["q"] == g["c%d_q" % ci][i] and t["q_is_int"] == bool(g["c%d_q_is_int" % ci][i])
+            assert t["z"] == g["c%d_z" % ci][i]
+
+
+def test_search_root_statistics_bit_exact(oracle, golden_dir):
+    g = _load(golden_dir, "search_v1.npz")
+    for ci in range(int(g["n_cases"])):
+        budget, salt, max_plies, moves, outcome = (int(v) for v in g["c%d_cfg" % ci])
+        # the fixture stops after max_plies plies: emulate with TERMINATE_CNT
+        w = oracle.Worker(oracle.make_config(_mk(budget, training=False), terminate_cnt=max_plies, num_games=1))
+        w.run(lambda x, net: oracle.hashnet(x, salt))
+        tu = [t for t in w.tuples() if t["chosen"] >= 0]
+        off = g["c%d_off" % ci]
+        assert len(tu) == len(off) - 1 == moves
+        for i, t in enumerate(tu):
+            sl = slice(off[i], off[i + 1])
+            assert (t["action"] == g["c%d_action" % ci][sl]).all()
+            assert (t["visits"] == g["c%d_n" % ci][sl]).all()
+            assert (t["wsum"].view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert (t["prior"].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
+            assert t["root_n"] == g["c%d_root_n" % ci][i] and t["root_w"] == g["c%d_root_w" % ci][i]
+            assert t["chosen"] == g["c%d_chosen" % ci][i]
+
+
+def test_tournament_outcomes(oracle, golden_dir):
+    g = _load(golden_dir, "tournament_v1.npz")
+    checked = 0
+    for ci in range(int(g["n_cases"])):
+        if bool(g["c%d_raised" % ci]):
+            continue
+        budget, games, salt_new, salt_old = (int(v) for v in g["c%d_cfg" % ci])
+        w = oracle.Worker(oracle.make_config(_mk(budget, training=False), num_games=games, tournament=True))
+        w.run(lambda x, net: oracle.hashnet(x, salt_new if net == 0 else salt_old))
+        res = w.results()
+        assert [r["outcome"] for r in res] == list(g["c%d_outcome" % ci])
+        assert [r["move_count"] for r in res] == list(g["c%d_moves" % ci])
+        assert [r["p1_net"] == 0 for r in res] == list(g["c%d_p1_is_new" % ci])
+        checked += 1
+    assert checked >= 1
