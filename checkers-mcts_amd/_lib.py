@@ -1,0 +1,89 @@
+"""ctypes loader for libckr.so (the hand-written HIP library; C-ABI in
+include/ckr.h).  There is no fallback: if the library is missing or a call
+fails, an exception is raised."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libckr.so")
+MAX_CHILDREN = 48
+
+
+class CkrError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("n_slots", C.c_int32), ("games_per_slot", C.c_int32), ("first_worker_id", C.c_int32),
+                ("budget", C.c_int32), ("terminate_cnt", C.c_int32), ("training", C.c_int32),
+                ("tournament", C.c_int32), ("tau_decay_delay", C.c_int32),
+                ("uct_c", C.c_double), ("alpha", C.c_double), ("epsilon", C.c_double),
+                ("tau", C.c_double), ("tau_decay", C.c_double),
+                ("reset_tau_each_game", C.c_int32), ("nodes_per_tree", C.c_int32),
+                ("feature_dtype", C.c_int32), ("max_sims_per_step", C.c_int32),
+                ("record_root_stats", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64)]
+
+
+class Tuple(C.Structure):
+    _fields_ = [("board", C.c_uint32 * 4), ("mask", C.c_uint32 * 8), ("status", C.c_uint32),
+                ("worker", C.c_int32), ("game", C.c_int32), ("ply", C.c_int32), ("n_children", C.c_int32),
+                ("q", C.c_float), ("q_is_int", C.c_int32), ("z", C.c_int32), ("root_n", C.c_int32),
+                ("root_w", C.c_float), ("chosen", C.c_int32), ("reserved", C.c_int32),
+                ("pi", C.c_uint32 * MAX_CHILDREN)]
+
+
+class GameResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("worker", "game", "outcome", "move_count", "adjudicated",
+                                         "p1_net", "n_tuples", "failed")]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("expansions", "terminal_visits", "plies", "games", "reroot_misses",
+                                          "nodes_created", "compactions", "pool_overflows", "steps",
+                                          "active_slots")]
+
+
+EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",
+           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_engine_create",
+           "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_stats", "ckr_engine_results",
+           "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves"]
+
+_lib = None
+
+
+def load():
+    """Load libckr.so; raises CkrError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CkrError("libckr.so is missing (%s): build it with `python -m checkers_mcts_amd.build` "
+                       "-- there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64 = C.c_void_p, C.c_int64
+    L.ckr_last_error.restype = C.c_char_p
+    L.ckr_movegen_batch.argtypes = [vp, i64, vp, vp, vp]
+    L.ckr_children_batch.argtypes = [vp, i64, vp, vp, vp]
+    L.ckr_features_batch.argtypes = [vp, i64, vp, vp]
+    L.ckr_mask_renorm_batch.argtypes = [vp, i64, vp, vp, vp]
+    L.ckr_hashnet_batch.argtypes = [vp, i64, C.c_uint32, vp, vp, vp]
+    if hasattr(L, "ckr_engine_create"):
+        L.ckr_engine_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.ckr_engine_destroy.argtypes = [vp]
+        L.ckr_engine_step.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.ckr_engine_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.ckr_engine_results.argtypes = [vp, vp, i64, C.POINTER(i64)]
+        L.ckr_engine_tuples.argtypes = [vp, vp, i64, C.POINTER(i64)]
+        L.ckr_engine_pack_tuples.argtypes = [vp, vp, i64, C.POINTER(i64), vp]
+        L.ckr_engine_root_stats.argtypes = [vp, vp, vp, i64]
+        L.ckr_engine_leaves.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ckr_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise CkrError("libckr error %d: %s" % (rc, msg))

@@ -1,0 +1,786 @@
+// ckr_engine.hip -- batched self-play / arena engine for gfx950.
+//
+// Thousands of independent games ("slots"; one slot = one worker process of
+// the reference, training_pipeline.py:325-329) advance in lock-step: per step
+// every slot runs exactly one simulation of MCTS.tree_policy that needs a
+// network evaluation (plus any number of network-free simulations that end on
+// terminal children), so the network always sees one leaf per slot.
+//
+// Layout in HBM: structure-of-arrays node pool, two trees per slot (one per
+// player, training_pipeline.py:353-386), each tree a pair of semispaces of
+// `nodes_per_tree` nodes; the children of a node are contiguous so that the
+// PUCT scan of a node is one coalesced read of N/W/P by the lanes of a wave.
+// One wavefront owns one slot: lanes = children for select / expand, lanes =
+// board cells for the feature build.  No inter-workgroup communication exists
+// (a slot's memory is touched by its own wave only).
+#include "ckr_host.h"
+#include "ckr_wave_ops.hip.h"
+#include <hip/hip_fp16.h>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace ckr {
+
+enum { PH_PLAYING = 0, PH_FINISHED = 1 };
+enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_N };
+
+struct Dev {
+    // configuration
+    int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
+    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n;
+    double uct_c, alpha, epsilon, tau0, tau_decay;
+    uint32_t seed_lo, seed_hi;
+    // node pool, index = ((slot*2 + tree)*2 + half)*C + local
+    uint4* n_board; int32_t* n_parent; uint32_t* n_kids; int32_t* n_N; float* n_W; float* n_P; uint32_t* n_status;
+    // per slot
+    uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
+    int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
+    // per tree (slot*2 + tree)
+    int32_t* t_cursor; int32_t* t_used; int32_t* t_half; int32_t* t_searched;
+    // outputs
+    ckr_tuple* tuples; float* rs_w; float* rs_p; ckr_game_result* results;
+    unsigned long long* counters; const double* sqrt_tab; uint4* leaves;
+};
+
+struct WaveLds {
+    union { float p[512]; float feat[896]; double ev[64]; } u;   // raw probabilities | features | sampling
+    ckr_board kids[CKR_MAX_CHILDREN];
+    uint32_t mask[8];
+};
+
+struct Wave {
+    const Dev& D; WaveLds& L; int slot, lane;
+    unsigned long long cnt[CNT_N];
+    __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
+    __device__ size_t tb(int t) const { return tbase(t, D.t_half[slot * 2 + t]); }
+};
+
+__device__ __forceinline__ ckr_board ld_board(const uint4* p) { const uint4 v = *p; return ckr_board{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st_board(uint4* p, const ckr_board b) { *p = make_uint4(b.p1, b.p2, b.kings, b.meta); }
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
+
+// ---- gamma / Dirichlet noise (MCTS.py:107-108); distribution-level parity only
+__device__ double gamma_sample(const Dev& D, double a, uint32_t c0, uint32_t c1, uint32_t c2) {
+    uint32_t it = 0;
+    double boost = 1.0;
+    if (a < 1.0) {
+        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0x80000000u);
+        boost = pow(u01(r.x, r.y), 1.0 / a); a += 1.0;
+    }
+    if (a == 1.0) {
+        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0u);
+        return -log(u01(r.x, r.y)) * boost;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (;; ++it) {
+        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, it);
+        const u32x4 q = philox(D.seed_lo, D.seed_hi, c0, c1, c2, it | 0x40000000u);
+        const double nrm = sqrt(-2.0 * log(u01(r.x, r.y))) * cos(6.283185307179586 * u01(r.z, r.w));
+        double vv = 1.0 + c * nrm;
+        if (vv <= 0.0) continue;
+        vv = vv * vv * vv;
+        if (log(u01(q.x, q.y)) < 0.5 * nrm * nrm + d - d * vv + d * log(vv) || it > 64u) return d * vv * boost;
+    }
+}
+
+// ---- backups: MCTS_Node.backpropagation + MCTS.determine_reward (MCTS.py:149-186,419-430)
+__device__ void backup_value(Wave& w, int t, int node, float v, uint32_t sim_player) {
+    const size_t tb = w.tb(t);
+    const int root = w.D.t_cursor[w.slot * 2 + t];
+    for (int n = node;;) {
+        const uint32_t st = w.D.n_status[tb + n];
+        const uint32_t mover = (st >> 4) & 1u;
+        const float reward = (sim_player != mover) ? -1.0f * v : v;
+        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.D.n_W[tb + n] += reward; }
+        if (n == root) break;
+        n = w.D.n_parent[tb + n];
+    }
+}
+__device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
+    const size_t tb = w.tb(t);
+    const int root = w.D.t_cursor[w.slot * 2 + t];
+    for (int n = node;;) {
+        const uint32_t st = w.D.n_status[tb + n];
+        const uint32_t mover = (st >> 4) & 1u;
+        float reward = 0.0f;
+        if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
+        else if (outcome == 2u) reward = mover == 1u ? 1.0f : -1.0f;
+        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.D.n_W[tb + n] += reward; }
+        if (n == root) break;
+        n = w.D.n_parent[tb + n];
+    }
+}
+
+// ---- tree bookkeeping
+__device__ void write_node(const Dev& D, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
+    st_board(&D.n_board[idx], b);
+    D.n_parent[idx] = parent; D.n_kids[idx] = 0u; D.n_N[idx] = 0; D.n_W[idx] = 0.0f; D.n_P[idx] = prior;
+    D.n_status[idx] = status;
+}
+
+// MCTS_Node(state) for a tree that has no node for the live game state
+// (start of the game, MCTS.py:350-376, or the reply-missing case :289-295).
+__device__ void fresh_root(Wave& w, int t) {
+    const Dev& D = w.D;
+    const int ti = w.slot * 2 + t;
+    const ckr_board b = ld_board(&D.g_board[w.slot]);
+    uint32_t m[8], st;
+    movegen(b, m, st);
+    if (w.lane == 0) {
+        D.t_half[ti] = 0;
+        write_node(D, w.tbase(t, 0), b, -1, 0.0f, st | (meta_mover(b.meta) << 4));
+        D.t_cursor[ti] = 0; D.t_used[ti] = 1;
+    }
+    w.cnt[CNT_NODES] += 1;
+    wave_mem_fence();
+}
+
+// Semispace copy of the subtree under the cursor (breadth first, children stay
+// contiguous).  64 nodes per pass: lane = node, wave scan assigns child blocks.
+__device__ void compact(Wave& w, int t) {
+    const Dev& D = w.D;
+    const int ti = w.slot * 2 + t;
+    const int half = D.t_half[ti];
+    const size_t src = w.tbase(t, half), dst = w.tbase(t, half ^ 1);
+    const int root = D.t_cursor[ti];
+    if (w.lane == 0) {
+        D.n_board[dst] = D.n_board[src + root]; D.n_parent[dst] = -1; D.n_kids[dst] = D.n_kids[src + root];
+        D.n_N[dst] = D.n_N[src + root]; D.n_W[dst] = D.n_W[src + root]; D.n_P[dst] = D.n_P[src + root];
+        D.n_status[dst] = D.n_status[src + root];
+    }
+    wave_mem_fence();
+    int q = 0, free_ = 1;
+    while (q < free_) {
+        const int cnt = min(64, free_ - q), idx = q + w.lane;
+        const bool valid = w.lane < cnt;
+        const uint32_t kids = valid ? D.n_kids[dst + idx] : 0u;
+        const uint32_t st = valid ? D.n_status[dst + idx] : 0u;
+        const bool exp = valid && (st & ST_EXPANDED);
+        const int nk = exp ? (int)(kids >> 24) : 0, ob = (int)(kids & 0xFFFFFFu);
+        const int incl = wave_incl_scan(nk);
+        const int total = bcast_i32(incl, 63);
+        const int nb = free_ + incl - nk;
+        if (exp) D.n_kids[dst + idx] = (uint32_t)nb | ((uint32_t)nk << 24);
+        for (int c = 0; c < nk; ++c) {
+            const size_t s = src + ob + c, d = dst + nb + c;
+            D.n_board[d] = D.n_board[s]; D.n_parent[d] = idx; D.n_kids[d] = D.n_kids[s];
+            D.n_N[d] = D.n_N[s]; D.n_W[d] = D.n_W[s]; D.n_P[d] = D.n_P[s]; D.n_status[d] = D.n_status[s];
+        }
+        free_ += total; q += cnt;
+        wave_mem_fence();
+    }
+    if (w.lane == 0) { D.t_half[ti] = half ^ 1; D.t_used[ti] = free_; D.t_cursor[ti] = 0; }
+    w.cnt[CNT_COMPACT] += 1;
+    wave_mem_fence();
+}
+
+// Start of a ply's search for the side to move: (re)root its tree
+// (MCTS.new_root_node, MCTS.py:251-295 -- the cursor already followed every
+// ply played, see advance_cursor) and reset the rollout counter (:216-217).
+__device__ void start_search(Wave& w) {
+    const Dev& D = w.D;
+    const ckr_board gb = ld_board(&D.g_board[w.slot]);
+    const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
+    if (D.t_cursor[ti] < 0) {
+        if (D.t_searched[ti]) w.cnt[CNT_MISS] += 1;
+        fresh_root(w, t);
+    } else if (D.C - D.t_used[ti] < D.margin) {
+        compact(w, t);
+    }
+    if (w.lane == 0) { D.t_searched[ti] = 1; D.g_sims[w.slot] = 0; }
+    wave_mem_fence();
+}
+
+__device__ void new_game(Wave& w) {
+    const Dev& D = w.D;
+    if (w.lane == 0) {
+        // Checkers.reset / init_board (Checkers.py:405-423); the mover into the
+        // initial state is player 2 (MCTS.py:170-173)
+        D.g_board[w.slot] = make_uint4(0x00000FFFu, 0xFFF00000u, 0u, make_meta(0, 1, 0, 0, 0, 1));
+        D.g_status[w.slot] = 7u << 8;
+        D.g_moves[w.slot] = 0;
+        for (int t = 0; t < 2; ++t) {
+            D.t_cursor[w.slot * 2 + t] = -1; D.t_used[w.slot * 2 + t] = 0;
+            D.t_half[w.slot * 2 + t] = 0; D.t_searched[w.slot * 2 + t] = 0;
+        }
+        if (D.reset_tau || D.g_game[w.slot] == 0) D.g_tau[w.slot] = D.tau0;
+    }
+    wave_mem_fence();
+    start_search(w);
+}
+
+// ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
+// Checkers.predict's mask/renormalise (Checkers.py:435-437) and
+// set_prior_probs (:440-452).  Returns false on pool overflow.
+__device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v) {
+    const Dev& D = w.D;
+    const int ti = w.slot * 2 + t;
+    const size_t tb = w.tb(t);
+    const ckr_board b = ld_board(&D.n_board[tb + leaf]);
+    uint32_t m[8], st;
+    movegen(b, m, st);
+    if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
+    {
+        const float4* src = reinterpret_cast<const float4*>(prow);
+        float4* dl = reinterpret_cast<float4*>(w.L.u.p);
+        dl[w.lane] = src[w.lane]; dl[w.lane + 64] = src[w.lane + 64];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float total = wave_masked_sum(w.L.u.p, w.L.mask);
+    const int n = wave_children(b, m, w.L.kids, true);
+    __builtin_amdgcn_wave_barrier();
+    const int used = D.t_used[ti];
+    if (used + n > D.C) return false;
+    if (w.lane < n) {
+        const ckr_board c = w.L.kids[w.lane];
+        uint32_t cm[8], cst;
+        movegen(c, cm, cst);
+        const float prior = w.L.u.p[meta_action(c.meta)] / total;
+        write_node(D, tb + used + w.lane, c, leaf, prior, cst | ((b.meta & 1u) << 4));
+    }
+    if (w.lane == 0) {
+        D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
+        D.n_status[tb + leaf] |= ST_EXPANDED;
+        D.t_used[ti] = used + n;
+    }
+    w.cnt[CNT_EXP] += 1; w.cnt[CNT_NODES] += (unsigned long long)n;
+    wave_mem_fence();
+    backup_value(w, t, leaf, v, b.meta & 1u);
+    wave_mem_fence();
+    return true;
+}
+
+// ---- selection: MCTS.select_child (MCTS.py:102-116) repeated down the tree
+// (:90-96).  Returns the unexpanded leaf, or -1 after backing up a terminal
+// child (:93-94).  Scores are float64 exactly as NumPy evaluates them:
+//   q32 + ((c * P') * N_parent**0.5) / (1 + N_child),
+//   P' = float32((1-eps) * P) + eps * dirichlet.
+__device__ int descend(Wave& w, int t) {
+    const Dev& D = w.D;
+    const size_t tb = w.tb(t);
+    int node = D.t_cursor[w.slot * 2 + t];
+    const float one_minus = (float)(1.0 - D.epsilon);
+    for (;;) {
+        const uint32_t st = D.n_status[tb + node];
+        if (!(st & ST_EXPANDED)) return node;
+        const uint32_t kids = D.n_kids[tb + node];
+        const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
+        const int np = D.n_N[tb + node];
+        const bool act = w.lane < n;
+        const size_t ci = tb + base + (act ? w.lane : 0);
+        const int cn = D.n_N[ci];
+        const float cw = D.n_W[ci], cp = D.n_P[ci];
+        const uint32_t cst = D.n_status[ci];
+        double dir = 0.0;
+        if (D.epsilon != 0.0) {
+            const uint32_t ctr = D.g_rng[w.slot];
+            const double g = act ? gamma_sample(D, D.alpha, (uint32_t)(D.first_worker + w.slot), ctr, (uint32_t)w.lane) : 0.0;
+            dir = g / wave_sum_f64(g);
+            if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
+        }
+        const double sqrt_n = np < D.sqrt_n ? D.sqrt_tab[np] : sqrt((double)np);
+        const float q = cn ? cw / (float)cn : 0.0f;
+        const float pf = one_minus * cp;
+        const double psa = (double)pf + D.epsilon * dir;
+        const double u = ((D.uct_c * psa) * sqrt_n) / (double)(1 + cn);
+        const double score = (double)q + u;
+        const int best = wave_argmax_first(score, n);
+        const uint32_t bst = (uint32_t)bcast_i32((int)cst, best);
+        const int child = base + best;
+        if (st_outcome(bst) != 0u) {
+            backup_outcome(w, t, child, st_outcome(bst));
+            w.cnt[CNT_TERM] += 1;
+            wave_mem_fence();
+            return -1;
+        }
+        node = child;
+    }
+}
+
+// ---- tuple helpers (training_pipeline.py:364-369,406-410,421-455)
+__device__ size_t tuple_index(const Wave& w, int ply) {
+    return ((size_t)w.slot * w.D.games_per_slot + (size_t)w.D.g_game[w.slot]) * (size_t)w.D.tuples_per_game + (size_t)ply;
+}
+
+__device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
+    const Dev& D = w.D;
+    const int game = D.g_game[w.slot], moves = D.g_moves[w.slot];
+    int n_tuples = 0;
+    if (!D.tournament && !failed) {
+        n_tuples = moves + (adjudicated ? 0 : 1);
+        if (!adjudicated) {                                // terminal tuple, :406-409
+            const ckr_board gb = ld_board(&D.g_board[w.slot]);
+            uint32_t m[8], st;
+            movegen(gb, m, st);
+            ckr_tuple* T = &D.tuples[tuple_index(w, moves)];
+            if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
+            if (w.lane == 0) {
+                T->board = gb; T->status = st; T->worker = D.first_worker + w.slot; T->game = game; T->ply = moves;
+                T->n_children = 0; T->q = outcome == 3u ? 0.0f : -1.0f; T->q_is_int = 1; T->root_n = 0;
+                T->root_w = 0.0f; T->chosen = -1;
+            }
+        }
+        wave_mem_fence();
+        for (int i = w.lane; i < n_tuples; i += 64) {      // _add_rewards, :439-455
+            ckr_tuple* T = &D.tuples[tuple_index(w, i)];
+            const uint32_t player = T->board.meta & 1u;
+            int z = 0;
+            if (outcome == 1u) z = player == 0u ? 1 : -1;
+            else if (outcome == 2u) z = player == 1u ? 1 : -1;
+            T->z = z;
+        }
+    }
+    if (w.lane == 0) {
+        ckr_game_result* R = &D.results[(size_t)w.slot * D.games_per_slot + game];
+        R->worker = D.first_worker + w.slot; R->game = game; R->outcome = (int)outcome; R->move_count = moves;
+        R->adjudicated = adjudicated; R->p1_net = (D.tournament && game >= D.games_per_slot / 2) ? 1 : 0;
+        R->n_tuples = n_tuples; R->failed = failed;
+        D.g_game[w.slot] = game + 1;
+        D.g_pending[w.slot] = -1;
+    }
+    w.cnt[CNT_GAMES] += 1;
+    wave_mem_fence();
+    if (game + 1 < D.games_per_slot) new_game(w);
+    else { if (w.lane == 0) D.g_phase[w.slot] = PH_FINISHED; wave_mem_fence(); }
+}
+
+// ---- end of a ply: MCTS.best_child (MCTS.py:227-248), Checkers.step
+// (Checkers.py:62-75), tuple emission, TERMINATE_CNT adjudication
+// (training_pipeline.py:387-405), cursor updates for both trees.
+__device__ void finish_ply(Wave& w) {
+    const Dev& D = w.D;
+    const ckr_board gb = ld_board(&D.g_board[w.slot]);
+    const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
+    const size_t tb = w.tb(t);
+    const int root = D.t_cursor[ti];
+    const uint32_t kids = D.n_kids[tb + root];
+    const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
+    const bool act = w.lane < n;
+    const int cn = act ? D.n_N[tb + base + w.lane] : -1;
+    const int moves = D.g_moves[w.slot];
+    int pick;
+    double tau = D.g_tau[w.slot];
+    if (!D.training || tau <= 0.0) {
+        const int mx = wave_max_i32(cn);
+        pick = first_lane(__ballot(act && cn == mx));
+    } else {
+        const double ev = act ? pow((double)cn, 1.0 / tau) : 0.0;
+        w.L.u.ev[w.lane] = ev;
+        __builtin_amdgcn_wave_barrier();
+        double cum = 0.0;
+        for (int j = 0; j <= w.lane && j < n; ++j) cum += w.L.u.ev[j];
+        const double total = __hiloint2double(bcast_i32(__double2hiint(cum), 63), bcast_i32(__double2loint(cum), 63));
+        if (moves > D.tau_decay_delay) {                   // :243-245
+            tau -= D.tau_decay;
+            if (fabs(tau) <= 1e-8) tau = 0.0;
+            if (w.lane == 0) D.g_tau[w.slot] = tau;
+        }
+        const uint32_t ctr = D.g_rng[w.slot];
+        const u32x4 r = philox(D.seed_lo, D.seed_hi, (uint32_t)(D.first_worker + w.slot), ctr, 0xFFFFFFFFu, 0x7A0u);
+        if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
+        const double uu = u01(r.x, r.y) * total;
+        const unsigned long long hit = __ballot(act && uu < cum);
+        pick = hit ? first_lane(hit) : n - 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int chosen = base + pick;
+    const ckr_board cb = ld_board(&D.n_board[tb + chosen]);
+    const uint32_t cst = D.n_status[tb + chosen];
+    if (!D.tournament) {
+        const ckr_board rb = ld_board(&D.n_board[tb + root]);
+        uint32_t m[8], st;
+        movegen(rb, m, st);
+        const size_t tix = tuple_index(w, moves);
+        ckr_tuple* T = &D.tuples[tix];
+        if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
+        if (act) T->pi[w.lane] = (meta_action(ld_board(&D.n_board[tb + base + w.lane]).meta) << 23) | (uint32_t)cn;
+        if (D.record_root && act) {
+            D.rs_w[tix * CKR_MAX_CHILDREN + w.lane] = D.n_W[tb + base + w.lane];
+            D.rs_p[tix * CKR_MAX_CHILDREN + w.lane] = D.n_P[tb + base + w.lane];
+        }
+        if (w.lane == 0) {
+            const int rn = D.n_N[tb + root];
+            const float rw = D.n_W[tb + root];
+            const float q = rn ? rw / (float)rn : 0.0f;
+            T->board = rb; T->status = st; T->worker = D.first_worker + w.slot; T->game = D.g_game[w.slot];
+            T->ply = moves; T->n_children = n;
+            T->q = (meta_mover(rb.meta) != (rb.meta & 1u)) ? -q : q;     // :365-368
+            T->q_is_int = 0; T->z = 0; T->root_n = rn; T->root_w = rw; T->chosen = (int)meta_action(cb.meta);
+        }
+    }
+    // Checkers.step: the chosen child becomes the live state
+    if (w.lane == 0) {
+        st_board(&D.g_board[w.slot], cb);
+        D.g_status[w.slot] = cst & ~(ST_EXPANDED | ST_MOVER);
+        D.g_moves[w.slot] = moves + 1;
+        D.t_cursor[ti] = chosen;
+    }
+    // the opponent's tree follows the ply just played (MCTS.py:274-288)
+    {
+        const int o = t ^ 1, oi = w.slot * 2 + o;
+        const int oc = D.t_cursor[oi];
+        if (oc >= 0) {
+            const size_t ob = w.tb(o);
+            const uint32_t ost = D.n_status[ob + oc];
+            int nc = -1;
+            if (ost & ST_EXPANDED) {
+                const uint32_t ok = D.n_kids[ob + oc];
+                const int on = (int)(ok >> 24), obase = (int)(ok & 0xFFFFFFu);
+                const bool oa = w.lane < on;
+                const uint32_t ameta = oa ? D.n_board[ob + obase + w.lane].w : 0u;
+                const unsigned long long hit = __ballot(oa && meta_action(ameta) == meta_action(cb.meta));
+                if (hit) nc = obase + first_lane(hit);
+            }
+            if (w.lane == 0) D.t_cursor[oi] = nc;
+        }
+    }
+    w.cnt[CNT_PLIES] += 1;
+    wave_mem_fence();
+    uint32_t outcome = st_outcome(cst);
+    int adjudicated = 0;
+    if (!outcome && !D.tournament && D.terminate_cnt > 0 && moves + 1 >= D.terminate_cnt) {
+        adjudicated = 1;                                   // :387-405
+        const int p1 = __popc(cb.p1), p2 = __popc(cb.p2);
+        const int k1 = __popc(cb.p1 & cb.kings), k2 = __popc(cb.p2 & cb.kings);
+        outcome = p1 > p2 ? 1u : p1 < p2 ? 2u : k1 > k2 ? 1u : k1 < k2 ? 2u : 3u;
+    }
+    if (outcome) end_game(w, outcome, adjudicated, 0);
+    else start_search(w);
+}
+
+__device__ void write_features(Wave& w, const ckr_board b, void* x) {
+    const Dev& D = w.D;
+    uint32_t m[8], st;
+    movegen(b, m, st);
+    __builtin_amdgcn_wave_barrier();
+    wave_features(b, m, st, w.L.u.feat);
+    __builtin_amdgcn_wave_barrier();
+    if (D.feature_dtype == 0) {
+        float4* dst = reinterpret_cast<float4*>((float*)x + (size_t)w.slot * 896);
+        const float4* src = reinterpret_cast<const float4*>(w.L.u.feat);
+        for (int k = w.lane; k < 224; k += 64) dst[k] = src[k];
+    } else {
+        uint4* dst = reinterpret_cast<uint4*>((uint16_t*)x + (size_t)w.slot * 896);
+        for (int k = w.lane; k < 112; k += 64) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = w.L.u.feat[k * 8 + 2 * j], c = w.L.u.feat[k * 8 + 2 * j + 1];
+                uint32_t lo, hi;
+                if (D.feature_dtype == 1) { lo = __half_as_ushort(__float2half(a)); hi = __half_as_ushort(__float2half(c)); }
+                else {
+                    const uint32_t ua = __float_as_uint(a), uc = __float_as_uint(c);
+                    lo = (ua + 0x7FFFu + ((ua >> 16) & 1u)) >> 16; hi = (uc + 0x7FFFu + ((uc >> 16) & 1u)) >> 16;
+                }
+                pk[j] = lo | (hi << 16);
+            }
+            dst[k] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void flush_counters(Wave& w) {
+    if (w.lane != 0) return;
+#pragma unroll
+    for (int i = 0; i < CNT_N; ++i)
+        if (w.cnt[i]) atomicAdd(&w.D.counters[i], w.cnt[i]);
+}
+
+__global__ __launch_bounds__(256) void k_init(Dev D) {
+    __shared__ WaveLds lds[4];
+    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    if (slot >= D.n_slots) return;
+    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0}};
+    if (w.lane == 0) { D.g_game[slot] = 0; D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; }
+    wave_mem_fence();
+    new_game(w);
+    flush_counters(w);
+}
+
+// One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
+__global__ __launch_bounds__(256) void k_step(Dev D, const float* __restrict__ p, const float* __restrict__ v,
+                                              void* x, int32_t* net_out) {
+    __shared__ WaveLds lds[4];
+    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    if (slot >= D.n_slots) return;
+    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0}};
+    // A. consume the network output for the leaf handed out by the previous step
+    const int pending = D.g_pending[slot];
+    if (pending >= 0 && D.g_phase[slot] == PH_PLAYING) {
+        const int t = (int)(D.g_board[slot].w & 1u);
+        if (expand(w, t, pending, p + (size_t)slot * 512, v[slot])) {
+            if (w.lane == 0) D.g_sims[slot] += 1;
+        } else {
+            w.cnt[CNT_OVERFLOW] += 1;
+            end_game(w, 0u, 0, 1);
+        }
+        if (w.lane == 0 && D.g_pending[slot] == pending) D.g_pending[slot] = -1;
+        wave_mem_fence();
+    }
+    // B. advance until a leaf needs the network
+    int leaf = -1, net = -1, free_sims = 0;
+    ckr_board lb{0u, 0u, 0u, 0u};
+    while (D.g_phase[slot] == PH_PLAYING) {
+        if (D.g_sims[slot] >= D.budget) { finish_ply(w); continue; }     // MCTS.computational_budget, :189-201
+        if (free_sims >= D.max_sims) break;
+        const int t = (int)(D.g_board[slot].w & 1u);
+        leaf = descend(w, t);
+        if (leaf < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
+        lb = ld_board(&D.n_board[w.tb(t) + leaf]);
+        if (D.tournament) {
+            const int p1_net = D.g_game[slot] >= D.games_per_slot / 2 ? 1 : 0;
+            net = t == 0 ? p1_net : 1 - p1_net;                          // training_pipeline.py:523-529,536,546
+        } else net = 0;
+        break;
+    }
+    if (w.lane == 0) {
+        D.g_pending[slot] = leaf;
+        D.leaves[slot] = make_uint4(lb.p1, lb.p2, lb.kings, lb.meta);
+        if (net_out) net_out[slot] = leaf >= 0 ? net : -1;
+    }
+    if (leaf >= 0) write_features(w, lb, x);
+    flush_counters(w);
+}
+
+// tuples of finished games -> contiguous buffer (offsets computed on the host)
+__global__ void k_pack(const ckr_tuple* __restrict__ tuples, const int64_t* __restrict__ src_first,
+                       const int64_t* __restrict__ dst_first, int n_games, ckr_tuple* __restrict__ out) {
+    const int g = blockIdx.x;
+    if (g >= n_games) return;
+    const int64_t s = src_first[g], d = dst_first[g], cnt = dst_first[g + 1] - d;
+    const uint4* src = reinterpret_cast<const uint4*>(tuples + s);
+    uint4* dst = reinterpret_cast<uint4*>(out + d);
+    const int64_t words = cnt * (int64_t)(sizeof(ckr_tuple) / 16);
+    for (int64_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace ckr
+
+using namespace ckr;
+
+struct ckr_engine {
+    ckr_config cfg;
+    Dev dev;
+    std::vector<void*> allocs;
+    hipStream_t last_stream = nullptr;
+    int64_t n_games_total = 0;
+    uint64_t steps = 0;
+    ckr_tuple* d_pack = nullptr; int64_t pack_cap = 0;
+    int64_t* d_off = nullptr; int64_t off_cap = 0;
+};
+
+template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool zero = true) {
+    void* q = nullptr;
+    const size_t bytes = count * sizeof(T) + 16;
+    CKR_HIP(hipMalloc(&q, bytes));
+    if (zero) CKR_HIP(hipMemset(q, 0, bytes));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return CKR_OK;
+}
+
+static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
+
+extern "C" {
+
+int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
+    if (!c || !out) return fail(CKR_ERR_INVALID, "ckr_engine_create: null argument");
+    if (int rc = require_device()) return rc;
+    if (c->n_slots <= 0 || c->games_per_slot <= 0) return fail(CKR_ERR_INVALID, "n_slots and games_per_slot must be positive");
+    if (c->budget <= 0) return fail(CKR_ERR_INVALID, "BUDGET must be a positive rollout count (CONSTRAINT == 'rollout')");
+    if (!c->tournament && c->terminate_cnt <= 0) return fail(CKR_ERR_INVALID, "self-play needs TERMINATE_CNT > 0");
+    if (c->nodes_per_tree < 256 || c->nodes_per_tree >= (1 << 24)) return fail(CKR_ERR_INVALID, "nodes_per_tree must be in [256, 2^24)");
+    if (c->feature_dtype < 0 || c->feature_dtype > 2) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1 or 2");
+    if (c->alpha <= 0.0 && c->epsilon != 0.0) return fail(CKR_ERR_INVALID, "DIRICHLET_ALPHA must be > 0");
+    CKR_HIP(hipSetDevice(c->device));
+    ckr_engine* e = new ckr_engine();
+    e->cfg = *c;
+    Dev& D = e->dev;
+    memset(&D, 0, sizeof(D));
+    D.n_slots = c->n_slots; D.games_per_slot = c->games_per_slot; D.first_worker = c->first_worker_id;
+    D.budget = c->budget; D.terminate_cnt = c->terminate_cnt; D.training = c->training; D.tournament = c->tournament;
+    D.tau_decay_delay = c->tau_decay_delay; D.reset_tau = c->reset_tau_each_game; D.C = c->nodes_per_tree;
+    D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 64;
+    D.record_root = c->record_root_stats;
+    D.tuples_per_game = c->tournament ? 0 : c->terminate_cnt + 1;
+    D.margin = c->budget * 16 + 64; if (D.margin > D.C / 2) D.margin = D.C / 2;
+    D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
+    D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32);
+    e->n_games_total = (int64_t)c->n_slots * c->games_per_slot;
+    const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C;
+    int rc = CKR_OK;
+#define A(ptr, count, zero) if (rc == CKR_OK) rc = dalloc(e, &ptr, (count), (zero))
+    A(D.n_board, NN, false); A(D.n_parent, NN, false); A(D.n_kids, NN, false); A(D.n_N, NN, false);
+    A(D.n_W, NN, false); A(D.n_P, NN, false); A(D.n_status, NN, false);
+    A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
+    A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
+    A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
+    const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
+    A(D.tuples, NT ? NT : 1, true);
+    if (D.record_root) { A(D.rs_w, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); A(D.rs_p, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); }
+    A(D.results, (size_t)e->n_games_total, true);
+    A(D.counters, (size_t)CNT_N, true);
+    A(D.leaves, S, true);
+    // node.n ** 0.5 is C pow() in the reference (python int ** float), which is
+    // NOT always sqrt(): keep a host-computed table for the counts that occur.
+    D.sqrt_n = 1 << 16;
+    double* d_sqrt = nullptr;
+    A(d_sqrt, (size_t)D.sqrt_n, false);
+#undef A
+    if (rc != CKR_OK) { ckr_engine_destroy(e); return rc; }
+    {
+        std::vector<double> tab((size_t)D.sqrt_n);
+        volatile double half = 0.5;
+        for (int i = 0; i < D.sqrt_n; ++i) tab[(size_t)i] = pow((double)i, half);
+        if (hipMemcpy(d_sqrt, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "sqrt table upload failed");
+        }
+        D.sqrt_tab = d_sqrt;
+    }
+    // results: mark all games unfinished
+    if (hipMemset(D.results, 0xFF, (size_t)e->n_games_total * sizeof(ckr_game_result)) != hipSuccess) {
+        ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "memset failed");
+    }
+    hipLaunchKernelGGL(k_init, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, D);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+        ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "engine init kernel failed");
+    }
+    *out = e;
+    return CKR_OK;
+}
+
+int ckr_engine_destroy(ckr_engine* e) {
+    if (!e) return CKR_OK;
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->d_pack) (void)hipFree(e->d_pack);
+    if (e->d_off) (void)hipFree(e->d_off);
+    delete e;
+    return CKR_OK;
+}
+
+int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
+    if (!e || !d_x) return fail(CKR_ERR_INVALID, "ckr_engine_step: null engine or feature buffer");
+    if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
+    e->last_stream = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->dev, d_p, d_v, d_x, d_net);
+    CKR_HIP(hipGetLastError());
+    e->steps++;
+    return CKR_OK;
+}
+
+int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
+    if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_stats: null argument");
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    unsigned long long c[CNT_N];
+    CKR_HIP(hipMemcpy(c, e->dev.counters, sizeof(c), hipMemcpyDeviceToHost));
+    std::vector<int32_t> ph((size_t)e->cfg.n_slots);
+    CKR_HIP(hipMemcpy(ph.data(), e->dev.g_phase, ph.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    uint64_t active = 0;
+    for (int32_t v : ph) active += (v == PH_PLAYING);
+    out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
+    out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
+    out->pool_overflows = c[CNT_OVERFLOW]; out->steps = e->steps; out->active_slots = active;
+    return CKR_OK;
+}
+
+static int fetch_results(ckr_engine* e, std::vector<ckr_game_result>& all) {
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    all.resize((size_t)e->n_games_total);
+    CKR_HIP(hipMemcpy(all.data(), e->dev.results, all.size() * sizeof(ckr_game_result), hipMemcpyDeviceToHost));
+    return CKR_OK;
+}
+
+int ckr_engine_results(ckr_engine* e, ckr_game_result* out, int64_t cap, int64_t* n) {
+    if (!e || !n) return fail(CKR_ERR_INVALID, "ckr_engine_results: null argument");
+    std::vector<ckr_game_result> all;
+    if (int rc = fetch_results(e, all)) return rc;
+    int64_t k = 0;
+    for (const auto& r : all)
+        if (r.game >= 0) { if (out && k < cap) out[k] = r; ++k; }
+    *n = k;
+    if (out && k > cap) return fail(CKR_ERR_INVALID, "ckr_engine_results: buffer too small (%lld > %lld)", (long long)k, (long long)cap);
+    return CKR_OK;
+}
+
+int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t* n, void* stream) {
+    if (!e || !n) return fail(CKR_ERR_INVALID, "ckr_engine_pack_tuples: null argument");
+    std::vector<ckr_game_result> all;
+    if (int rc = fetch_results(e, all)) return rc;
+    std::vector<int64_t> off;      // [src_first (G)] [dst_first (G+1)]
+    std::vector<int64_t> src, dst(1, 0);
+    for (size_t g = 0; g < all.size(); ++g)
+        if (all[g].game >= 0 && all[g].n_tuples > 0) {
+            src.push_back((int64_t)g * e->dev.tuples_per_game);
+            dst.push_back(dst.back() + all[g].n_tuples);
+        }
+    *n = dst.back();
+    if (!d_out) return CKR_OK;
+    if (*n > cap) return fail(CKR_ERR_INVALID, "ckr_engine_pack_tuples: buffer too small (%lld > %lld)", (long long)*n, (long long)cap);
+    const int G = (int)src.size();
+    if (G == 0) return CKR_OK;
+    const int64_t need = (int64_t)(2 * G + 1);
+    if (need > e->off_cap) {
+        if (e->d_off) (void)hipFree(e->d_off);
+        CKR_HIP(hipMalloc((void**)&e->d_off, (size_t)need * sizeof(int64_t)));
+        e->off_cap = need;
+    }
+    CKR_HIP(hipMemcpy(e->d_off, src.data(), (size_t)G * sizeof(int64_t), hipMemcpyHostToDevice));
+    CKR_HIP(hipMemcpy(e->d_off + G, dst.data(), (size_t)(G + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pack, dim3(G), dim3(256), 0, (hipStream_t)stream, e->dev.tuples, e->d_off, e->d_off + G, G, d_out);
+    CKR_HIP(hipGetLastError());
+    CKR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return CKR_OK;
+}
+
+int ckr_engine_tuples(ckr_engine* e, ckr_tuple* out, int64_t cap, int64_t* n) {
+    if (!e || !n) return fail(CKR_ERR_INVALID, "ckr_engine_tuples: null argument");
+    int64_t k = 0;
+    if (int rc = ckr_engine_pack_tuples(e, nullptr, 0, &k, nullptr)) return rc;
+    *n = k;
+    if (!out || k == 0) return CKR_OK;
+    if (k > cap) return fail(CKR_ERR_INVALID, "ckr_engine_tuples: buffer too small (%lld > %lld)", (long long)k, (long long)cap);
+    if (k > e->pack_cap) {
+        if (e->d_pack) (void)hipFree(e->d_pack);
+        CKR_HIP(hipMalloc((void**)&e->d_pack, (size_t)k * sizeof(ckr_tuple)));
+        e->pack_cap = k;
+    }
+    if (int rc = ckr_engine_pack_tuples(e, e->d_pack, e->pack_cap, &k, nullptr)) return rc;
+    CKR_HIP(hipMemcpy(out, e->d_pack, (size_t)k * sizeof(ckr_tuple), hipMemcpyDeviceToHost));
+    return CKR_OK;
+}
+
+int ckr_engine_root_stats(ckr_engine* e, float* w_out, float* p_out, int64_t cap) {
+    if (!e || !w_out || !p_out) return fail(CKR_ERR_INVALID, "ckr_engine_root_stats: null argument");
+    if (!e->dev.record_root) return fail(CKR_ERR_STATE, "engine was created without record_root_stats");
+    std::vector<ckr_game_result> all;
+    if (int rc = fetch_results(e, all)) return rc;
+    int64_t k = 0;
+    const size_t row = CKR_MAX_CHILDREN * sizeof(float);
+    for (size_t g = 0; g < all.size(); ++g)
+        if (all[g].game >= 0 && all[g].n_tuples > 0) {
+            const int64_t cnt = all[g].n_tuples;
+            if (k + cnt > cap) return fail(CKR_ERR_INVALID, "ckr_engine_root_stats: buffer too small");
+            const size_t s = g * (size_t)e->dev.tuples_per_game * CKR_MAX_CHILDREN;
+            CKR_HIP(hipMemcpy(w_out + k * CKR_MAX_CHILDREN, e->dev.rs_w + s, (size_t)cnt * row, hipMemcpyDeviceToHost));
+            CKR_HIP(hipMemcpy(p_out + k * CKR_MAX_CHILDREN, e->dev.rs_p + s, (size_t)cnt * row, hipMemcpyDeviceToHost));
+            k += cnt;
+        }
+    return CKR_OK;
+}
+
+int ckr_engine_leaves(ckr_engine* e, ckr_board* out) {
+    if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_leaves: null argument");
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipMemcpy(out, e->dev.leaves, (size_t)e->cfg.n_slots * sizeof(ckr_board), hipMemcpyDeviceToHost));
+    return CKR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+// ckr_rules.hip -- stand-alone rules kernels (K1 movegen_terminal, K2
+// make_children, K8 planes_from_bitboards, predict post-processing, test
+// network) and their C-ABI entry points (include/ckr.h).  gfx950 only.
+#include "ckr_host.h"
+#include "ckr_wave_ops.hip.h"
+
+namespace ckr {
+
+static thread_local char g_err[512] = "";
+char* last_error_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+
+// K1: one board per lane.  16 B in (one dwordx4 load), 36 B out.  HBM-bound:
+// 52 algorithmic bytes per board.
+__global__ __launch_bounds__(256) void k_movegen(const uint4* __restrict__ boards, int64_t n,
+                                                 uint4* __restrict__ mask8, uint32_t* __restrict__ status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 v = boards[i];
+        const ckr_board b{v.x, v.y, v.z, v.w};
+        uint32_t m[8], st;
+        movegen(b, m, st);
+        mask8[2 * i]     = make_uint4(m[0], m[1], m[2], m[3]);
+        mask8[2 * i + 1] = make_uint4(m[4], m[5], m[6], m[7]);
+        status[i] = st;
+    }
+}
+
+// K2: one wavefront per board; successors compacted through LDS and written
+// as contiguous 16-B records (coalesced), reference list order.
+__global__ __launch_bounds__(256) void k_children(const uint4* __restrict__ boards, int64_t n,
+                                                  uint4* __restrict__ children, int32_t* __restrict__ count) {
+    __shared__ ckr_board lds[4][CKR_MAX_CHILDREN];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += nwaves) {
+        const uint4 v = boards[i];
+        const ckr_board b{v.x, v.y, v.z, v.w};
+        uint32_t m[8], st;
+        movegen(b, m, st);
+        const int k = wave_children(b, m, lds[wave], false);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < k) {
+            const ckr_board c = lds[wave][lane];
+            children[i * CKR_MAX_CHILDREN + lane] = make_uint4(c.p1, c.p2, c.kings, c.meta);
+        }
+        if (lane == 0) count[i] = k;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_features(const uint4* __restrict__ boards, int64_t n, float* __restrict__ x) {
+    __shared__ __attribute__((aligned(16))) float feat[4][896];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += nwaves) {
+        const uint4 v = boards[i];
+        const ckr_board b{v.x, v.y, v.z, v.w};
+        uint32_t m[8], st;
+        movegen(b, m, st);
+        wave_features(b, m, st, feat[wave]);
+        __builtin_amdgcn_wave_barrier();
+        float4* dst = reinterpret_cast<float4*>(x + i * 896);
+        const float4* src = reinterpret_cast<const float4*>(feat[wave]);
+        for (int k = lane; k < 224; k += 64) dst[k] = src[k];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mask_renorm(const uint4* __restrict__ boards, int64_t n,
+                                                     const float* __restrict__ p, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float pl[4][512];
+    __shared__ uint32_t ml[4][8];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += nwaves) {
+        const uint4 v = boards[i];
+        const ckr_board b{v.x, v.y, v.z, v.w};
+        uint32_t m[8], st;
+        movegen(b, m, st);
+        if (lane < 8) ml[wave][lane] = sel8(m, lane);
+        const float4* src = reinterpret_cast<const float4*>(p + i * 512);
+        float4* dl = reinterpret_cast<float4*>(pl[wave]);
+        dl[lane] = src[lane]; dl[lane + 64] = src[lane + 64];
+        __builtin_amdgcn_wave_barrier();
+        const float total = wave_masked_sum(pl[wave], ml[wave]);
+        for (int a = lane; a < 512; a += 64) {
+            const float pv = pl[wave][a];
+            out[i * 512 + a] = (action_legal(ml[wave], a) ? pv : pv * 0.0f) / total;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// compress the even bits of a 64-bit word (cell index c -> square c>>1)
+__device__ __forceinline__ uint32_t squares_of_cells(unsigned long long b) {
+    unsigned long long t = (b | (b >> 1)) & 0x5555555555555555ull;
+    t = (t | (t >> 1)) & 0x3333333333333333ull;
+    t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
+    t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+    t = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)t;
+}
+
+__global__ __launch_bounds__(256) void k_hashnet(const float* __restrict__ x, int64_t n, uint32_t salt,
+                                                 float* __restrict__ p, float* __restrict__ vout) {
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += nwaves) {
+        const float* c = x + i * 896 + lane * 14;
+        const bool dark = ((lane >> 3) ^ lane) & 1;
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = squares_of_cells(__ballot(dark && c[q] != 0.0f));
+        const uint32_t side = (x[i * 896 + 4] != 0.0f) ? 1u : 0u;
+        const uint32_t k = (uint32_t)lrintf(x[i * 896 + 5] * 80.0f);
+        uint32_t h = 0x9E3779B9u ^ salt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h = fmix32(h ^ w[q]) + 0x7F4A7C15u;
+        h = fmix32(h ^ side) + 0x7F4A7C15u;
+        h = fmix32(h ^ k) + 0x7F4A7C15u;
+        for (uint32_t a = lane; a < 512; a += 64)
+            p[i * 512 + a] = (float)((fmix32(h + a * 0x9E3779B1u) >> 16) + 1u) * (1.0f / 33554432.0f);
+        if (lane == 0)
+            vout[i] = (float)((int)(fmix32(h ^ 0xDEADBEEFu) & 0xFFFFu) - 32768) * (1.0f / 65536.0f);
+    }
+}
+
+static inline int grid_for(int64_t units, int per_block) {
+    int64_t g = (units + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;        // 8 blocks per CU, grid-stride the rest
+    return (int)g;
+}
+
+}  // namespace ckr
+
+using namespace ckr;
+
+extern "C" {
+
+const char* ckr_last_error(void) { return last_error_buf(); }
+int ckr_version(void) { return CKR_VERSION; }
+int ckr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+#define CKR_CHECK_ARGS(cond, what)                                         \
+    do { if (!(cond)) return fail(CKR_ERR_INVALID, "%s: %s", __func__, what); } while (0)
+
+int ckr_movegen_batch(const ckr_board* d_boards, int64_t n, uint32_t* d_mask8, uint32_t* d_status, void* stream) {
+    CKR_CHECK_ARGS(n >= 0, "n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_boards && d_mask8 && d_status, "null device pointer");
+    hipLaunchKernelGGL(k_movegen, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)d_boards, n, (uint4*)d_mask8, d_status);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_children_batch(const ckr_board* d_boards, int64_t n, ckr_board* d_children, int32_t* d_count, void* stream) {
+    CKR_CHECK_ARGS(n >= 0, "n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_boards && d_children && d_count, "null device pointer");
+    hipLaunchKernelGGL(k_children, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)d_boards, n, (uint4*)d_children, d_count);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_features_batch(const ckr_board* d_boards, int64_t n, float* d_x, void* stream) {
+    CKR_CHECK_ARGS(n >= 0, "n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_boards && d_x, "null device pointer");
+    hipLaunchKernelGGL(k_features, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)d_boards, n, d_x);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_mask_renorm_batch(const ckr_board* d_boards, int64_t n, const float* d_p, float* d_out, void* stream) {
+    CKR_CHECK_ARGS(n >= 0, "n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_boards && d_p && d_out, "null device pointer");
+    hipLaunchKernelGGL(k_mask_renorm, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)d_boards, n, d_p, d_out);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, float* d_p, float* d_v, void* stream) {
+    CKR_CHECK_ARGS(n >= 0, "n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_x && d_p && d_v, "null device pointer");
+    hipLaunchKernelGGL(k_hashnet, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, d_x, n, salt, d_p, d_v);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+}  // extern "C"

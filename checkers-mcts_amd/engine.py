@@ -1,0 +1,182 @@
+"""Python handle on the batched self-play / arena engine of libckr.so.
+
+torch supplies device memory and the HIP stream; every tree operation runs in
+the hand-written HIP kernels behind the C-ABI (include/ckr.h).  The evaluator
+is any callable `x -> (p[S,512], v[S])` on device tensors: the PyTorch-ROCm
+policy/value network (net.py) in production, the built-in integer hash net in
+the parity tests.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FEATURE_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+# MCTS(**kwargs) keys (MCTS.py:43-55)
+MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOSE", "TRAINING",
+             "DIRICHLET_ALPHA", "DIRICHLET_EPSILON", "TEMPERATURE_TAU", "TEMPERATURE_DECAY", "TEMP_DECAY_DELAY")
+
+
+def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
+                       first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
+                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=64, device=0):
+    """Build a ckr_config from the reference's kwargs dicts, with the
+    reference's own error behaviour for unsupported settings."""
+    k = mcts_kwargs
+    for key in MCTS_KEYS:
+        if key not in k:
+            raise KeyError(key)                       # MCTS.__init__ indexes kwargs directly
+    if k["CONSTRAINT"] != "rollout":
+        if k["CONSTRAINT"] == "time":
+            raise ValueError("CONSTRAINT='time' is not supported by the batched engine (lock-step rollouts)")
+        raise ValueError("Invalid MCTS computational constraint!")        # MCTS.py:200
+    if not k["NEURAL_NET"]:
+        raise ValueError("the batched engine implements the NEURAL_NET=True search path")
+    budget = int(k["BUDGET"])
+    if nodes_per_tree is None:
+        nodes_per_tree = max(4096, 48 * budget)
+    return _lib.Config(n_slots=int(n_slots), games_per_slot=int(games_per_slot), first_worker_id=int(first_worker_id),
+                       budget=budget, terminate_cnt=int(terminate_cnt or 0), training=int(bool(k["TRAINING"])),
+                       tournament=int(bool(tournament)), tau_decay_delay=int(k["TEMP_DECAY_DELAY"]),
+                       uct_c=float(k["UCT_C"]), alpha=float(k["DIRICHLET_ALPHA"]), epsilon=float(k["DIRICHLET_EPSILON"]),
+                       tau=float(k["TEMPERATURE_TAU"]), tau_decay=float(k["TEMPERATURE_DECAY"]),
+                       reset_tau_each_game=int(bool(reset_tau_each_game)), nodes_per_tree=int(nodes_per_tree),
+                       feature_dtype=FEATURE_DTYPES[feature_dtype], max_sims_per_step=int(max_sims_per_step),
+                       record_root_stats=int(bool(record_root_stats)), device=int(device), seed=int(seed))
+
+
+class Engine:
+    """One engine per GPU / process.  Calls are serialised by the caller."""
+
+    def __init__(self, cfg, feature_dtype=torch.float32):
+        self._L = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CkrError("no HIP device: the self-play engine has no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device("cuda", cfg.device)
+        h = C.c_void_p()
+        _lib.check(self._L.ckr_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        S = cfg.n_slots
+        self.feature_dtype = feature_dtype
+        # NHWC network input written by the engine; channels-last view for torch
+        self.x = torch.zeros((S, 8, 8, 14), dtype=feature_dtype, device=self.device)
+        self.net_id = torch.full((S,), -1, dtype=torch.int32, device=self.device)
+        self._first = True
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ckr_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def x_nchw(self):
+        """Zero-copy [S,14,8,8] view with channels-last strides."""
+        return self.x.permute(0, 3, 1, 2)
+
+    def step(self, p=None, v=None):
+        """One lock-step simulation.  p [S,512] float32 softmax output and
+        v [S] float32 for the leaves of the previous step (None on the first)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if p is not None:
+            if not (p.dtype == torch.float32 and p.is_contiguous() and v.dtype == torch.float32 and v.is_contiguous()):
+                raise ValueError("p and v must be contiguous float32 device tensors")
+            pp, vp = p.data_ptr(), v.data_ptr()
+        else:
+            pp = vp = None
+        _lib.check(self._L.ckr_engine_step(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
+        self._first = False
+
+    def stats(self):
+        s = _lib.Stats()
+        _lib.check(self._L.ckr_engine_stats(self._h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in _lib.Stats._fields_}
+
+    def results(self):
+        n = C.c_int64(0)
+        _lib.check(self._L.ckr_engine_results(self._h, None, 0, C.byref(n)))
+        buf = (_lib.GameResult * max(1, n.value))()
+        _lib.check(self._L.ckr_engine_results(self._h, buf, n.value, C.byref(n)))
+        return [{f: getattr(buf[i], f) for f, _ in _lib.GameResult._fields_} for i in range(n.value)]
+
+    def tuples_raw(self):
+        """Finished games' tuples as a numpy structured array (compact form)."""
+        n = C.c_int64(0)
+        _lib.check(self._L.ckr_engine_tuples(self._h, None, 0, C.byref(n)))
+        arr = np.zeros(max(1, n.value), dtype=TUPLE_DTYPE)
+        if n.value:
+            _lib.check(self._L.ckr_engine_tuples(self._h, arr.ctypes.data, n.value, C.byref(n)))
+        return arr[:n.value]
+
+    def pack_tuples_device(self):
+        """Finished tuples as a contiguous DEVICE uint8 tensor [n, 288] (gather payload)."""
+        n = C.c_int64(0)
+        _lib.check(self._L.ckr_engine_pack_tuples(self._h, None, 0, C.byref(n), None))
+        out = torch.zeros((max(1, n.value), TUPLE_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        if n.value:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._L.ckr_engine_pack_tuples(self._h, out.data_ptr(), n.value, C.byref(n), stream))
+        return out[:n.value]
+
+    def root_stats(self, n_tuples):
+        w = np.zeros((max(1, n_tuples), _lib.MAX_CHILDREN), np.float32)
+        p = np.zeros_like(w)
+        _lib.check(self._L.ckr_engine_root_stats(self._h, w.ctypes.data, p.ctypes.data, n_tuples))
+        return w[:n_tuples], p[:n_tuples]
+
+    def leaves(self):
+        out = np.zeros((self.cfg.n_slots, 4), np.uint32)
+        _lib.check(self._L.ckr_engine_leaves(self._h, out.ctypes.data))
+        return out
+
+    def run(self, evaluator, max_steps=None):
+        """Drive to completion: evaluator(engine) -> (p, v) for engine.x."""
+        p = v = None
+        steps = 0
+        while True:
+            self.step(p, v)
+            steps += 1
+            if steps % 64 == 0 or (max_steps and steps >= max_steps):
+                if self.stats()["active_slots"] == 0 or (max_steps and steps >= max_steps):
+                    break
+            p, v = evaluator(self)
+        return steps
+
+
+TUPLE_DTYPE = np.dtype([("board", np.uint32, 4), ("mask", np.uint32, 8), ("status", np.uint32),
+                        ("worker", np.int32), ("game", np.int32), ("ply", np.int32), ("n_children", np.int32),
+                        ("q", np.float32), ("q_is_int", np.int32), ("z", np.int32), ("root_n", np.int32),
+                        ("root_w", np.float32), ("chosen", np.int32), ("reserved", np.int32),
+                        ("pi", np.uint32, _lib.MAX_CHILDREN)])
+assert TUPLE_DTYPE.itemsize == C.sizeof(_lib.Tuple) == 288
+
+
+def tuple_actions_visits(t):
+    """(action codes, visit counts) of one compact tuple, tree order."""
+    k = int(t["n_children"])
+    return (t["pi"][:k] >> 23).astype(np.int64), (t["pi"][:k] & 0x7FFFFF).astype(np.int64)
+
+
+def hashnet_evaluator(salt_new=0, salt_old=None):
+    """Evaluator using the built-in integer test network (parity tests)."""
+    from . import rules
+
+    def ev(engine):
+        x = engine.x if engine.x.dtype == torch.float32 else engine.x.float()
+        p, v = rules.hashnet(x, salt_new)
+        if salt_old is not None:
+            p2, v2 = rules.hashnet(x, salt_old)
+            sel = (engine.net_id == 1)
+            p = torch.where(sel[:, None], p2, p)
+            v = torch.where(sel, v2, v)
+        return p.contiguous(), v.contiguous()
+    return ev

@@ -1,0 +1,190 @@
+/*
+ * ckr.h -- C-ABI of libckr.so, the MI355X (gfx950) self-play engine for the
+ * MCTS + Checkers hot path of AlexMGitHub/Checkers-MCTS.
+ *
+ * The reference has no FFI: its boundary is a duck-typed Python protocol
+ * (SURVEY.md 8(b)).  Each entry point below names the reference interface it
+ * replaces (file:line in the reference tree); INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `d_` parameters are DEVICE pointers
+ *     (HBM, e.g. torch tensor .data_ptr()); `stream` is a hipStream_t passed
+ *     as void* (0 = the null stream).  Kernels are launched asynchronously on
+ *     that stream; nothing here synchronises unless documented.
+ *   - every function returns 0 on success or a negative ckr_status; the text
+ *     of the last failure on the calling thread is ckr_last_error().
+ *   - there is no CPU fallback: without a HIP device every compute entry
+ *     point fails with CKR_ERR_NO_DEVICE.
+ */
+#ifndef CKR_H
+#define CKR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CKR_VERSION 100          /* 0.1.0 */
+
+typedef enum {
+    CKR_OK = 0,
+    CKR_ERR_INVALID = -1,        /* bad argument (ValueError in the facade) */
+    CKR_ERR_NO_DEVICE = -2,
+    CKR_ERR_HIP = -3,            /* a HIP runtime call failed */
+    CKR_ERR_OOM = -4,
+    CKR_ERR_STATE = -5           /* call order violated */
+} ckr_status;
+
+/* 16-byte board record: one per position / tree node.
+ * Square index s = 4*x + (y>>1) over the playable squares (x%2 != y%2) of
+ * the reference's 8x8 planes (Checkers.py:37-49,415-423); bit s of each word.
+ *   p1, p2 : all pieces of player 1 / 2 (planes 0|1, 2|3); kings: planes 1|3
+ *   meta   : bit 0 side to move (plane 4) | bit 1 mover (player who moved into
+ *            this state) | bits 2-10 action a = (plane-6)*64 + 8x + y (plane 14)
+ *            | bit 11 has_action | bits 12-18 r = plies since the last man move
+ *            or capture | bits 19-31 len(history) (saturating)              */
+typedef struct { uint32_t p1, p2, kings, meta; } ckr_board;
+
+/* status word produced by move generation:
+ *   bits 0-1 outcome (0 none, 1 player1_wins, 2 player2_wins, 3 draw;
+ *            Checkers.determine_outcome, Checkers.py:306-364)
+ *   bit 2    capture available (only jumps are legal, Checkers.py:197-199)
+ *   bits 8-15  number of legal actions; bits 16-23 draw-plane numerator k
+ *            (plane 5 = k/80)                                                */
+#define CKR_MAX_CHILDREN 48
+
+const char* ckr_last_error(void);
+int  ckr_version(void);
+int  ckr_device_count(void);
+
+/* ---- rules kernels ------------------------------------------------------ */
+
+/* K1 movegen_terminal.  Replaces Checkers._check_moves + determine_outcome
+ * (Checkers.py:94-200, 306-364) for n positions: d_mask8[n][8] legal-action
+ * words (word d = plane 6+d: moves UL,UR,BL,BR then jumps UL,UR,BL,BR) and
+ * d_status[n].  One board per lane, 16-byte coalesced loads. */
+int ckr_movegen_batch(const ckr_board* d_boards, int64_t n, uint32_t* d_mask8,
+                      uint32_t* d_status, void* stream);
+
+/* K2 make_children.  Replaces the successor construction inside
+ * _check_moves/_check_jumps/_check_king_jumps (Checkers.py:121-304): for each
+ * position writes its successors, in the reference's list order, to
+ * d_children[n][CKR_MAX_CHILDREN] and the count to d_count[n].  One wavefront
+ * per position, LDS compaction of the variable-length lists. */
+int ckr_children_batch(const ckr_board* d_boards, int64_t n, ckr_board* d_children,
+                       int32_t* d_count, void* stream);
+
+/* K8 planes_from_bitboards.  Replaces the network-input build of
+ * Checkers.predict (Checkers.py:431-432): NHWC float32 x[n][8][8][14]. */
+int ckr_features_batch(const ckr_board* d_boards, int64_t n, float* d_x, void* stream);
+
+/* Checkers.predict post-processing (Checkers.py:435-437) on raw network
+ * output d_p[n][512]: mask with the legal planes and renormalise with NumPy's
+ * float32 pairwise summation order.  d_out[n][512]. */
+int ckr_mask_renorm_batch(const ckr_board* d_boards, int64_t n, const float* d_p,
+                          float* d_out, void* stream);
+
+/* Deterministic integer test network (same arithmetic as the oracle's
+ * ckro_hashnet and tests/golden/ref_shim.HashNet): x[n][896] -> p[n][512], v[n]. */
+int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, float* d_p, float* d_v,
+                      void* stream);
+
+/* ---- batched self-play / arena engine ----------------------------------- */
+
+/* Fields mirror the reference's kwargs dicts: MCTS(**kwargs) (MCTS.py:43-55),
+ * selfplay_kwargs (training_pipeline.py:314-318), tourney_kwargs (:480-484). */
+typedef struct {
+    int32_t  n_slots;            /* concurrent games on this GPU; one slot = one reference worker */
+    int32_t  games_per_slot;     /* NUM_SELFPLAY_GAMES / TOURNEY_GAMES per worker */
+    int32_t  first_worker_id;    /* global id of slot 0 (RNG stream + reporting; sharding) */
+    int32_t  budget;             /* BUDGET with CONSTRAINT == 'rollout' */
+    int32_t  terminate_cnt;      /* TERMINATE_CNT; <= 0: play to a natural end */
+    int32_t  training;           /* TRAINING */
+    int32_t  tournament;         /* 1: tournament_Checkers loop (two nets, no tuples) */
+    int32_t  tau_decay_delay;    /* TEMP_DECAY_DELAY */
+    double   uct_c;              /* UCT_C */
+    double   alpha, epsilon;     /* DIRICHLET_ALPHA, DIRICHLET_EPSILON */
+    double   tau, tau_decay;     /* TEMPERATURE_TAU, TEMPERATURE_DECAY */
+    int32_t  reset_tau_each_game;/* 0 = reference behaviour: tau is per worker, never reset (Q18) */
+    int32_t  nodes_per_tree;     /* semispace capacity of one search tree */
+    int32_t  feature_dtype;      /* 0 float32, 1 float16, 2 bfloat16 */
+    int32_t  max_sims_per_step;  /* cap on NN-free simulations run back-to-back in one step */
+    int32_t  record_root_stats;  /* 1: keep per-ply child W / P next to the tuples (tests) */
+    int32_t  device;             /* HIP device ordinal */
+    uint64_t seed;               /* Philox key for Dirichlet noise / temperature sampling */
+} ckr_config;
+
+/* One training tuple, compact form (training_pipeline.py:364-369,406-410,
+ * 421-455): root board + legal mask + status reproduce planes 0-14; pi is
+ * (action, visit count) pairs in tree order; q, z as in the reference. */
+typedef struct {
+    ckr_board board;
+    uint32_t  mask[8];
+    uint32_t  status;
+    int32_t   worker;            /* global worker (slot) id */
+    int32_t   game;              /* game index within the worker */
+    int32_t   ply;
+    int32_t   n_children;        /* 0: terminal tuple */
+    float     q;
+    int32_t   q_is_int;          /* terminal tuple carries a python int */
+    int32_t   z;
+    int32_t   root_n;
+    float     root_w;
+    int32_t   chosen;            /* action code played; -1: terminal tuple */
+    int32_t   reserved;          /* pads the record to 288 bytes (18 x 16) */
+    uint32_t  pi[CKR_MAX_CHILDREN];   /* action << 23 | visits */
+} ckr_tuple;
+
+typedef struct {
+    int32_t worker, game, outcome, move_count, adjudicated, p1_net, n_tuples, failed;
+} ckr_game_result;
+
+typedef struct {
+    uint64_t expansions;         /* executions of the expand branch, MCTS.py:70-77 */
+    uint64_t terminal_visits;    /* simulations ended on a terminal child, MCTS.py:93-94 */
+    uint64_t plies, games;
+    uint64_t reroot_misses;      /* reply node missing (MCTS.py:289-294): fresh root */
+    uint64_t nodes_created, compactions, pool_overflows;
+    uint64_t steps;
+    uint64_t active_slots;       /* slots still playing after the last step */
+} ckr_stats;
+
+typedef struct ckr_engine ckr_engine;
+
+int ckr_engine_create(const ckr_config* cfg, ckr_engine** out);
+int ckr_engine_destroy(ckr_engine* e);
+
+/* One lock-step simulation for every slot.  Consumes the network output for
+ * the leaves handed out by the previous step (d_p[n_slots][512] softmax
+ * probabilities, d_v[n_slots]; ignored on the first step) -- expand + backup
+ * (MCTS.py:70-77, Checkers.py:435-452) -- then advances every slot (select
+ * MCTS.py:90-116, terminal backups :93-94,149-186,419-430, end-of-ply move
+ * choice :227-248, tuple emission, re-rooting :251-295, next game) until it
+ * needs a network evaluation, and writes that leaf's NHWC features to
+ * d_x[n_slots][8][8][14] (dtype = feature_dtype) and the network to use
+ * (tournament: 0 = NEW_NN, 1 = OLD_NN; -1 = slot idle) to d_net[n_slots]
+ * (may be NULL). */
+int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x,
+                    int32_t* d_net, void* stream);
+
+/* Counters (synchronises the stream the last step ran on). */
+int ckr_engine_stats(ckr_engine* e, ckr_stats* out);
+
+/* Finished games and their tuples, copied to HOST buffers (synchronises).
+ * Pass NULL buffers to query counts. */
+int ckr_engine_results(ckr_engine* e, ckr_game_result* out, int64_t cap, int64_t* n);
+int ckr_engine_tuples(ckr_engine* e, ckr_tuple* out, int64_t cap, int64_t* n);
+/* Device-side compaction of the finished tuples into a caller-provided
+ * contiguous DEVICE buffer (what the multi-GPU gather ships). */
+int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t* n, void* stream);
+/* Per-ply root child statistics (record_root_stats = 1): W and P for tuple i
+ * at out[i][CKR_MAX_CHILDREN]. */
+int ckr_engine_root_stats(ckr_engine* e, float* w_out, float* p_out, int64_t cap);
+/* Leaf boards handed out by the last step (parity tests): HOST out[n_slots]. */
+int ckr_engine_leaves(ckr_engine* e, ckr_board* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,275 @@
+"""GPU: the batched self-play engine (HIP kernels behind the C-ABI) against the
+golden vectors of the Python reference and against the CPU oracle in lock-step.
+Deterministic configurations (epsilon = 0, tau = 0) are bit-exact; stochastic
+ones are checked through invariants and distributions."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import checkers_mcts_amd.codec as codec
+
+
+def mk(budget, training=True, eps=0.0, tau=0.0):
+    return dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=budget, MULTIPROC=False, NEURAL_NET=True,
+                VERBOSE=False, TRAINING=training, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=eps,
+                TEMPERATURE_TAU=tau, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torch
+    assert torch.cuda.is_available()
+    from checkers_mcts_amd import engine
+    return engine
+
+
+def run_engine(E, kwargs, salts, **cfg_kw):
+    """Engine with one slot per salt (slot i evaluated by hash net salts[i])."""
+    import torch
+    from checkers_mcts_amd import rules
+    cfg = E.config_from_kwargs(kwargs, n_slots=len(salts), **cfg_kw)
+    eng = E.Engine(cfg)
+    uniq = sorted(set(salts))
+    salt_t = torch.tensor(salts, device="cuda")
+
+    def ev(e):
+        p = v = None
+        for s in uniq:
+            ps, vs = rules.hashnet(e.x, s)
+            if p is None:
+                p, v = ps, vs
+            else:
+                sel = salt_t == s
+                p = torch.where(sel[:, None], ps, p)
+                v = torch.where(sel, vs, v)
+        return p.contiguous(), v.contiguous()
+    return eng, ev
+
+
+def sorted_tuples(eng):
+    t = eng.tuples_raw()
+    order = np.lexsort((t["ply"], t["game"], t["worker"]))
+    return t[order]
+
+
+def test_selfplay_tuples_match_reference_golden(E, golden_dir):
+    """(state, pi, q, z) of generate_Checkers_data._generate_data, bit for bit."""
+    g = np.load(os.path.join(golden_dir, "selfplay_v1.npz"))
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games, salt = (int(v) for v in g["c%d_cfg" % ci])
+        eng, ev = run_engine(E, mk(budget), [salt, salt], games_per_slot=games, terminate_cnt=terminate)
+        eng.run(ev)
+        t = sorted_tuples(eng)
+        n = len(g["c%d_z" % ci])
+        assert len(t) == 2 * n
+        for w in range(2):                                   # both slots replay the same deterministic game
+            tw = t[t["worker"] == w]
+            st = codec.records_to_planes(tw["board"], tw["mask"], tw["status"])
+            assert (st == g["c%d_state" % ci]).all()
+            for i in range(n):
+                a, nv = E.tuple_actions_visits(tw[i])
+                assert (codec.pi_planes(a, nv) == g["c%d_pi" % ci][i]).all()
+            assert (tw["q"] == g["c%d_q" % ci]).all()
+            assert (tw["q_is_int"].astype(bool) == g["c%d_q_is_int" % ci]).all()
+            assert (tw["z"] == g["c%d_z" % ci]).all()
+        s = eng.stats()
+        assert s["pool_overflows"] == 0 and s["reroot_misses"] == 0
+        eng.close()
+
+
+def test_search_root_statistics_match_reference_golden(E, golden_dir):
+    g = np.load(os.path.join(golden_dir, "search_v1.npz"))
+    for ci in range(int(g["n_cases"])):
+        budget, salt, max_plies, moves, outcome = (int(v) for v in g["c%d_cfg" % ci])
+        eng, ev = run_engine(E, mk(budget, training=False), [salt], games_per_slot=1, terminate_cnt=max_plies,
+                             record_root_stats=True)
+        eng.run(ev)
+        t = sorted_tuples(eng)
+        t = t[t["chosen"] >= 0]
+        w, p = eng.root_stats(len(eng.tuples_raw()))
+        off = g["c%d_off" % ci]
+        assert len(t) == moves
+        for i in range(moves):
+            sl = slice(off[i], off[i + 1])
+            a, nv = E.tuple_actions_visits(t[i])
+            k = len(a)
+            assert (a == g["c%d_action" % ci][sl]).all() and (nv == g["c%d_n" % ci][sl]).all()
+            assert (w[i, :k].view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert (p[i, :k].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
+            assert t["root_n"][i] == g["c%d_root_n" % ci][i] and t["root_w"][i] == g["c%d_root_w" % ci][i]
+            assert t["chosen"][i] == g["c%d_chosen" % ci][i]
+        eng.close()
+
+
+def test_tournament_matches_reference_golden(E, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tournament_v1.npz"))
+    checked = 0
+    for ci in range(int(g["n_cases"])):
+        if bool(g["c%d_raised" % ci]):
+            continue
+        budget, games, salt_new, salt_old = (int(v) for v in g["c%d_cfg" % ci])
+        cfg = E.config_from_kwargs(mk(budget, training=False), n_slots=2, games_per_slot=games, tournament=True)
+        eng = E.Engine(cfg)
+        eng.run(E.hashnet_evaluator(salt_new, salt_old))
+        res = sorted(eng.results(), key=lambda r: (r["worker"], r["game"]))
+        for w in range(2):
+            rw = [r for r in res if r["worker"] == w]
+            assert [r["outcome"] for r in rw] == list(g["c%d_outcome" % ci])
+            assert [r["move_count"] for r in rw] == list(g["c%d_moves" % ci])
+            assert [r["p1_net"] == 0 for r in rw] == list(g["c%d_p1_is_new" % ci])
+        eng.close()
+        checked += 1
+    assert checked >= 1
+
+
+def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts_old=None, **kw):
+    """Engine slots and oracle workers advanced one evaluation at a time; the
+    leaf every slot asks for must be the oracle's, at every step."""
+    import torch
+    from checkers_mcts_amd import rules
+    cfg = E.config_from_kwargs(kwargs, n_slots=len(salts), games_per_slot=games, terminate_cnt=terminate,
+                               tournament=tournament, record_root_stats=not tournament,
+                               max_sims_per_step=1 << 30, **kw)
+    eng = E.Engine(cfg)
+    workers = [oracle.Worker(oracle.make_config(kwargs, terminate_cnt=terminate, num_games=games, tournament=tournament))
+               for _ in salts]
+    p = v = None
+    steps = 0
+    while True:
+        eng.step(p, v)
+        steps += 1
+        leaves = eng.leaves()
+        nets = eng.net_id.cpu().numpy()
+        x = eng.x.cpu().numpy()
+        pn = np.zeros((len(salts), 512), np.float32)
+        vn = np.zeros(len(salts), np.float32)
+        any_active = False
+        for i, w in enumerate(workers):
+            if w.advance():
+                any_active = True
+                assert nets[i] == (w.net if tournament else 0), (steps, i)
+                assert (leaves[i] == w.leaf).all(), (steps, i, leaves[i], w.leaf)
+                assert (x[i].reshape(-1) == w.x).all(), (steps, i)
+                salt = salts[i] if (not tournament or w.net == 0) else salts_old[i]
+                pn[i], vn[i] = oracle.hashnet(w.x, salt)
+                w.submit(pn[i], vn[i])
+            else:
+                assert nets[i] == -1, (steps, i)
+        if not any_active:
+            break
+        p, v = torch.from_numpy(pn).cuda(), torch.from_numpy(vn).cuda()
+    return eng, workers, steps
+
+
+def compare_final(E, eng, workers, tournament=False):
+    res = sorted(eng.results(), key=lambda r: (r["worker"], r["game"]))
+    s = eng.stats()
+    tot = dict(expansions=0, terminal_visits=0, plies=0, games=0, reroot_misses=0)
+    t_all = sorted_tuples(eng) if not tournament else None
+    if not tournament:
+        rw_all, rp_all = eng.root_stats(len(eng.tuples_raw()))
+        raw = eng.tuples_raw()
+        order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
+        rw_all, rp_all = rw_all[order], rp_all[order]
+    for i, w in enumerate(workers):
+        ores = w.results()
+        eres = [r for r in res if r["worker"] == i]
+        assert [(r["outcome"], r["move_count"], int(r["adjudicated"]), r["p1_net"]) for r in ores] == \
+               [(r["outcome"], r["move_count"], r["adjudicated"], r["p1_net"]) for r in eres]
+        for k, val in w.stats().items():
+            if k in tot:
+                tot[k] += val
+        if tournament:
+            continue
+        sel = t_all["worker"] == i
+        et, ew, ep = t_all[sel], rw_all[sel], rp_all[sel]
+        ot = w.tuples()
+        assert len(et) == len(ot)
+        for j, o in enumerate(ot):
+            e = et[j]
+            assert (e["board"] == o["board"]).all() and (e["mask"] == o["mask"]).all() and e["status"] == o["status"]
+            assert e["game"] == o["game"] and e["ply"] == o["ply"] and e["z"] == o["z"]
+            assert e["q"] == o["q"] and bool(e["q_is_int"]) == o["q_is_int"] and e["chosen"] == o["chosen"]
+            a, nv = E.tuple_actions_visits(e)
+            assert (a == o["action"]).all() and (nv == o["visits"]).all()
+            k = len(a)
+            if k:
+                assert e["root_n"] == o["root_n"] and e["root_w"] == o["root_w"]
+                assert (ew[j, :k].view(np.uint32) == o["wsum"].view(np.uint32)).all()
+                assert (ep[j, :k].view(np.uint32) == o["prior"].view(np.uint32)).all()
+    for k, val in tot.items():
+        assert s[k] == val, (k, s[k], val)
+    assert s["pool_overflows"] == 0
+
+
+def test_lockstep_selfplay_vs_oracle(E, oracle):
+    salts = [11, 12, 13, 14, 15, 16, 17, 18]
+    eng, workers, steps = lockstep(E, oracle, mk(16), salts, games=2, terminate=60)
+    compare_final(E, eng, workers)
+    eng.close()
+
+
+def test_lockstep_natural_end_and_reroot_miss(E, oracle):
+    """Low budgets reach natural game ends, terminal backups and the
+    reply-missing re-root (reference raises; build and oracle take a fresh root)."""
+    salts = [3, 4, 5, 21, 22, 23, 24, 25]
+    eng, workers, steps = lockstep(E, oracle, mk(8), salts, games=1, terminate=400)
+    compare_final(E, eng, workers)
+    assert eng.stats()["terminal_visits"] > 0
+    eng.close()
+
+
+def test_lockstep_with_forced_compaction(E, oracle):
+    """A tiny node pool forces a semispace compaction on most plies; results
+    must not change."""
+    salts = [31, 32, 33, 34]
+    eng, workers, steps = lockstep(E, oracle, mk(24), salts, games=1, terminate=50, nodes_per_tree=1024)
+    compare_final(E, eng, workers)
+    assert eng.stats()["compactions"] > 10
+    eng.close()
+
+
+def test_lockstep_tournament_vs_oracle(E, oracle):
+    salts, salts_old = [41, 42, 43, 44], [51, 52, 53, 54]
+    eng, workers, steps = lockstep(E, oracle, mk(30, training=False), salts, games=2, terminate=0,
+                                   tournament=True, salts_old=salts_old)
+    compare_final(E, eng, workers, tournament=True)
+    eng.close()
+
+
+def test_stochastic_selfplay_invariants(E):
+    """Dirichlet noise + temperature sampling (reference defaults): tuples are
+    well formed; visit counts are consistent; different slots diverge."""
+    eng, ev = run_engine(E, mk(32, eps=0.25, tau=1.0), [1] * 64, games_per_slot=1, terminate_cnt=40, seed=123)
+    eng.run(ev)
+    t = sorted_tuples(eng)
+    res = eng.results()
+    assert len(res) == 64 and all(r["failed"] == 0 for r in res)
+    assert len({tuple(x) for x in t[t["ply"] == 6]["board"][:, :3]}) > 8         # games diverged
+    for e in t:
+        a, nv = E.tuple_actions_visits(e)
+        if e["n_children"] == 0:
+            assert e["chosen"] == -1 and e["q"] in (0.0, -1.0)
+            continue
+        assert nv.sum() == e["root_n"] - 1                   # every simulation after the expansion picks a child
+        assert e["root_n"] >= 32 + 0 and e["chosen"] in a
+        assert abs(codec.pi_planes(a, nv).sum() - 1.0) < 1e-12
+        assert -1.0 <= e["q"] <= 1.0 and e["z"] in (-1, 0, 1)
+    # same seed -> same games; different seed -> different games
+    eng2, ev2 = run_engine(E, mk(32, eps=0.25, tau=1.0), [1] * 64, games_per_slot=1, terminate_cnt=40, seed=123)
+    eng2.run(ev2)
+    t2 = sorted_tuples(eng2)
+    assert (t2["board"] == t["board"]).all() and (t2["pi"] == t["pi"]).all()
+    eng.close(); eng2.close()
+
+
+def test_config_errors(E):
+    with pytest.raises(ValueError):
+        E.config_from_kwargs(dict(mk(10), CONSTRAINT="bogus"), n_slots=1, games_per_slot=1, terminate_cnt=10)
+    with pytest.raises(KeyError):
+        E.config_from_kwargs({"UCT_C": 4}, n_slots=1, games_per_slot=1, terminate_cnt=10)
+    with pytest.raises(ValueError):
+        E.Engine(E.config_from_kwargs(mk(10), n_slots=1, games_per_slot=1, terminate_cnt=0))   # self-play needs TERMINATE_CNT

@@ -1,0 +1,124 @@
+"""GPU: the HIP rules kernels (through the C-ABI) against the oracle and the
+committed golden vectors.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    import torch
+    assert torch.cuda.is_available()
+    from checkers_mcts_amd import rules
+    return rules
+
+
+def _np(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def random_boards(n, seed):
+    """Synthetic positions (SURVEY cfg2 generator) as records, numpy-vectorised."""
+    rng = np.random.RandomState(seed)
+    out = np.zeros((n, 4), np.uint32)
+    for i in range(n):
+        sq = rng.permutation(32)
+        n1, n2 = rng.randint(0, 13), rng.randint(0, 13)
+        kf = rng.rand()
+        p1 = p2 = k = 0
+        for j, s in enumerate(sq[:n1 + n2]):
+            side = 0 if j < n1 else 1
+            king = rng.rand() < kf or (side == 0 and s >= 28) or (side == 1 and s < 4)
+            if side == 0:
+                p1 |= 1 << int(s)
+            else:
+                p2 |= 1 << int(s)
+            if king:
+                k |= 1 << int(s)
+        side = rng.randint(0, 2)
+        hist = int(rng.choice([1, 5, 79, 80, 81, 200]))
+        r = int(rng.randint(0, min(hist, 80)))
+        out[i] = (p1, p2, k, side | ((1 - side) << 1) | (r << 12) | (hist << 19))
+    return out
+
+
+def test_golden_rules(R, oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "rules_v1.npz"))
+    b = R.boards_to_device(g["boards"])
+    mask, status = R.movegen(b)
+    assert (_np(mask) == g["masks"]).all()
+    assert (_np(status) == g["status"]).all()
+    kids, cnt = R.children(b)
+    kids, cnt = _np(kids), cnt.cpu().numpy()
+    off = g["child_off"]
+    assert (cnt == np.diff(off)).all()
+    for i in range(len(off) - 1):
+        assert (kids[i, :cnt[i]] == g["children"][off[i]:off[i + 1]]).all()
+
+
+def test_random_boards_vs_oracle(R, oracle):
+    boards = random_boards(20000, 11)
+    b = R.boards_to_device(boards)
+    mask, status = R.movegen(b)
+    omask, ostatus = oracle.movegen(boards)
+    assert (_np(mask) == omask).all() and (_np(status) == ostatus).all()
+    kids, cnt = R.children(b)
+    kids, cnt = _np(kids), cnt.cpu().numpy()
+    for i in range(0, len(boards), 7):
+        ok = oracle.children(boards[i])
+        assert cnt[i] == len(ok) and (kids[i, :cnt[i]] == ok).all()
+
+
+def test_cfg2_65536_boards(R, oracle):
+    """BASELINE config 2: 65 536 boards, bit-exact masks + status."""
+    boards = random_boards(65536, 20260929)
+    mask, status = R.movegen(R.boards_to_device(boards))
+    omask, ostatus = oracle.movegen(boards)
+    assert (_np(mask) == omask).all() and (_np(status) == ostatus).all()
+    # size-independent property: popcount(mask) == legal count in the status word
+    pop = np.unpackbits(_np(mask).view(np.uint8), axis=1).sum(1)
+    assert (pop == ((_np(status) >> 8) & 0xFF)).all()
+
+
+def test_empty_and_ragged(R):
+    import torch
+    e = torch.empty((0, 4), dtype=torch.int32, device="cuda")
+    m, s = R.movegen(e)
+    assert m.shape == (0, 8) and s.shape == (0,)
+    for n in (1, 63, 65, 257):
+        boards = random_boards(n, n)
+        m, s = R.movegen(R.boards_to_device(boards))
+        assert m.shape == (n, 8)
+    with pytest.raises(ValueError):
+        R.movegen(torch.zeros((3, 5), dtype=torch.int32, device="cuda"))
+
+
+def test_features_hashnet_renorm(R, oracle, golden_dir):
+    import torch
+    g = np.load(os.path.join(golden_dir, "predict_v1.npz"))
+    b = R.boards_to_device(g["boards"])
+    out = R.mask_renorm(b, torch.from_numpy(g["raw_p"]).cuda())
+    assert (out.cpu().numpy().view(np.uint32) == g["planes"].view(np.uint32)).all()
+    x = R.features(b).cpu().numpy()
+    for i in range(0, len(g["boards"]), 5):
+        assert (x[i] == oracle.features(g["boards"][i])).all()
+    h = np.load(os.path.join(golden_dir, "hashnet_v1.npz"))
+    for salt in np.unique(h["salt"]):
+        sel = h["salt"] == salt
+        p, v = R.hashnet(torch.from_numpy(h["x"][sel]).cuda().reshape(-1, 8, 8, 14), int(salt))
+        assert (p.cpu().numpy() == h["p"][sel]).all() and (v.cpu().numpy() == h["v"][sel]).all()
+
+
+def test_large_batch_properties(R):
+    """2^22 boards (tiled): determinism and agreement between K1 and K2 counts."""
+    import torch
+    base = R.boards_to_device(random_boards(4096, 5))
+    big = base.repeat(1024, 1).contiguous()
+    m, s = R.movegen(big)
+    m0, s0 = R.movegen(base)
+    assert torch.equal(m.view(1024, 4096, 8)[777], m0) and torch.equal(s.view(1024, 4096)[1023], s0)
+    kids, cnt = R.children(base)
+    assert torch.equal(cnt, (s0 >> 8) & 0xFF)
