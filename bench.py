@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Benchmark of the self-play hot path (BASELINE.json config 3): batched MCTS,
+100 simulations per move, 4 096 concurrent self-play games per GPU, random-init
+policy/value network (Keras-default initialisation), synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one lock-step simulation for every game slot: the tree kernel
+(expand + backup of the previous leaves, PUCT descent, end-of-ply work, feature
+build) followed by one network forward over the S leaves.  Metric: MCTS
+node-expansions/s (executions of the expand branch, MCTS.py:70-77), whole job.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; game
+slots are sharded by worker id, there is no per-step collective (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two
+extra objects: `roofline` (dominant kernel group, HIP-event timed on the launch
+stream in this run) and `cpu_baseline` (the CPU oracle + PyTorch-CPU network,
+timed on this host's cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# MCTS parameters exactly as train_Checkers.py:88-102 except BUDGET = 100 (BASELINE cfg 3)
+MCTS_KWARGS = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=100, MULTIPROC=False, NEURAL_NET=True,
+                   VERBOSE=False, TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25,
+                   TEMPERATURE_TAU=1.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+TERMINATE_CNT = 200
+DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--slots", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--budget", type=int, default=100)
+    ap.add_argument("--nn-dtype", choices=list(DTYPES), default="bf16")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
+    return ap.parse_args()
+
+
+def cpu_baseline(budget, seconds):
+    """CPU oracle (C restatement of the reference search, proven bit-exact to
+    it) + the same network on PyTorch-CPU fp32, W games in lock-step so the
+    network sees a batch of W leaves per step.  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    from checkers_mcts_amd.net import make_net
+    orc.build()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))        # PyTorch-CPU convs of this size stop scaling (and regress) beyond ~32 threads
+    torch.set_num_threads(cores)
+    W = 8 * cores
+    kw = dict(MCTS_KWARGS, BUDGET=budget)
+    batch = orc.WorkerBatch([orc.make_config(kw, terminate_cnt=TERMINATE_CNT, num_games=1000, seed=1000 + i)
+                             for i in range(W)])
+    net = make_net(128, seed=0, device="cpu", dtype=torch.float32)
+
+    def one_step():
+        batch.advance()
+        x = torch.from_numpy(batch.x).permute(0, 3, 1, 2)
+        p, v = net(x)
+        batch.submit(p.numpy(), v.numpy())
+
+    steps = 0
+    with torch.no_grad():
+        one_step()                         # untimed: oneDNN primitive creation
+        e0 = batch.stats()["expansions"]
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            one_step()
+            steps += 1
+    dt = time.perf_counter() - t0
+    done = batch.stats()["expansions"] - e0
+    return {"value": done / dt, "unit": "node-expansions/s", "cores": cores, "kind": "port",
+            "sample": "%d lock-step games x %d steps (%.1f s) of the same workload: C oracle search (1 thread) + "
+                      "PyTorch-CPU fp32 network on %d threads, batch %d" % (W, steps, dt, cores, W)}
+
+
+def movegen_probe(device):
+    """K1 movegen_terminal on 2^24 boards: achieved HBM bandwidth (52 B/board)."""
+    from checkers_mcts_amd import _lib
+    L = _lib.load()
+    n = 1 << 24
+    g = torch.Generator(device="cpu").manual_seed(1)
+    occ = torch.randint(0, 2 ** 31 - 1, (65536, 2), generator=g, dtype=torch.int64)
+    p1 = (occ[:, 0] & occ[:, 1]).to(torch.int32)
+    p2 = ((occ[:, 0] >> 3) & ~occ[:, 1] & ~p1.to(torch.int64)).to(torch.int32)
+    kings = (occ[:, 1] >> 7).to(torch.int32) & (p1 | p2)
+    side = torch.arange(65536, dtype=torch.int32) & 1
+    boards = torch.stack([p1, p2, kings, side | (1 << 19)], dim=1).contiguous().to(device).repeat(n // 65536, 1).contiguous()
+    mask = torch.empty((n, 8), dtype=torch.int32, device=device)
+    status = torch.empty((n,), dtype=torch.int32, device=device)
+    s = torch.cuda.current_stream(device).cuda_stream
+    for _ in range(3):
+        L.ckr_movegen_batch(boards.data_ptr(), n, mask.data_ptr(), status.data_ptr(), s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 20
+    for _ in range(reps):
+        L.ckr_movegen_batch(boards.data_ptr(), n, mask.data_ptr(), status.data_ptr(), s)
+    e1.record()
+    torch.cuda.synchronize(device)
+    sec = e0.elapsed_time(e1) / 1e3 / reps
+    return {"kernel": "k_movegen", "boards": n, "boards_per_s": n / sec, "us_per_launch": sec * 1e6,
+            "bound": "hbm", "achieved": 52.0 * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": 52.0 * n / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": 52}
+
+
+def main():
+    a = parse()
+    from checkers_mcts_amd import build as ckbuild, dist as ckdist, engine as ckengine
+    from checkers_mcts_amd.net import FLOPS_PER_EVAL, NetEvaluator, make_net
+    from checkers_mcts_amd.pipeline import StepRunner
+
+    rank, local_rank, world = ckdist.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if rank == 0:
+        ckbuild.build()
+    ckdist.barrier()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dtype = DTYPES[a.nn_dtype]
+    kw = dict(MCTS_KWARGS, BUDGET=a.budget)
+    first, _ = ckdist.shard_range(a.slots * world, rank, world)
+    games_per_slot = max(2, (a.steps + a.warmup) // (a.budget * 30) + 2)
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
+                                      first_worker_id=first, feature_dtype=dtype, seed=20260929, device=local_rank)
+    eng = ckengine.Engine(cfg, feature_dtype=dtype)
+    net = make_net(128, seed=0, device=dev, dtype=dtype)
+    runner = StepRunner(eng, NetEvaluator(net), use_graph=not a.no_graph)
+
+    runner.warmup(3)
+    done = runner.steps
+    if a.warmup > done:
+        runner.step(a.warmup - done)
+    torch.cuda.synchronize(dev)
+    s0 = eng.stats()
+    ckdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    runner.step(a.steps)
+    torch.cuda.synchronize(dev)
+    ckdist.barrier()
+    dt_local = time.perf_counter() - t0
+    s1 = eng.stats()
+    dt = ckdist.max_over_ranks(dt_local, dev)
+    exp_local = s1["expansions"] - s0["expansions"]
+    exp_total = ckdist.sum_over_ranks(exp_local, dev)
+    term_total = ckdist.sum_over_ranks(s1["terminal_visits"] - s0["terminal_visits"], dev)
+    plies_total = ckdist.sum_over_ranks(s1["plies"] - s0["plies"], dev)
+
+    # instrumented eager pass (not part of the timed region): HIP events on the launch stream
+    t_tree = t_nn = 0.0
+    if a.profile_steps > 0:
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.profile_steps)]
+        evaluator = runner.evaluator
+        with torch.no_grad():
+            for e0, e1, e2 in ev:
+                e0.record()
+                eng.step(runner.p, runner.v)
+                e1.record()
+                p, v = evaluator(eng)
+                runner.p.copy_(p); runner.v.copy_(v)
+                e2.record()
+        torch.cuda.synchronize(dev)
+        t_tree = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in ev])) / 1e3
+        t_nn = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in ev])) / 1e3
+    stats_end = eng.stats()
+
+    out = None
+    if rank == 0:
+        nn_tflops = FLOPS_PER_EVAL * a.slots / t_nn / 1e12 if t_nn else None
+        roofline = {"bound": "mfma", "kernel": "network forward (conv3x3 x8 + heads), one launch group per step",
+                    "achieved": nn_tflops, "peak": MFMA_PEAK_TFLOPS[a.nn_dtype], "unit": "TFLOP/s",
+                    "frac": (nn_tflops / MFMA_PEAK_TFLOPS[a.nn_dtype]) if nn_tflops else None, "traffic": None,
+                    "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots,
+                    "tree_kernel": {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "bound": "latency",
+                                    "algorithmic_bytes_per_sim": 536,
+                                    "achieved_GBps": 536.0 * a.slots / t_tree / 1e9 if t_tree else None}}
+        extra = {"movegen_k1": movegen_probe(dev)}
+        cpu = None
+        if world == 1 and a.cpu_seconds > 0:
+            cpu = cpu_baseline(a.budget, a.cpu_seconds)
+        value = exp_total / dt
+        out = {"metric": "MCTS node-expansions/sec (whole node) at 100 sims/move", "value": value,
+               "unit": "node-expansions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.nn_dtype, "data": "synthetic",
+               "config": {"workload": "cfg3: batched MCTS %d sims/move, %d concurrent self-play games per GPU, "
+                                      "random-init policy/value net (Keras-default init), TERMINATE_CNT 200"
+                                      % (a.budget, a.slots),
+                          "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": a.nn_dtype,
+                          "hip_graph": not a.no_graph, "parallelism": "games sharded x%d, no per-step collective" % world},
+               "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total,
+               "sims_per_s": (exp_total + term_total) / dt,
+               "games_per_hour_est": (plies_total / dt) * 3600.0 / 100.0 if plies_total else None,
+               "engine_stats": stats_end, "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+    eng.close()
+    ckdist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime under the same soname (libamdhip64.so.7):
+    # import it FIRST so that libckr binds to the runtime that owns the
+    # process's streams and device pointers (two runtimes cannot share a GPU).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CkrError("libckr.so is missing (%s): build it with `python -m checkers_mcts_amd.build` "
                        "-- there is no CPU fallback" % LIB_PATH)

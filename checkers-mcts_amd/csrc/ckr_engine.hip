@@ -23,7 +23,7 @@
 namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1 };
-enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_N };
+enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS, CNT_N };
 
 struct Dev {
     // configuration
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_init(Dev D) {
     __shared__ WaveLds lds[4];
     const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0}};
+    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0, 0}};
     if (w.lane == 0) { D.g_game[slot] = 0; D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; }
     wave_mem_fence();
     new_game(w);
@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256) void k_step(Dev D, const float* __restrict__ p
     __shared__ WaveLds lds[4];
     const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0}};
+    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    if (slot == 0) w.cnt[CNT_STEPS] = 1;
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
     if (pending >= 0 && D.g_phase[slot] == PH_PLAYING) {
@@ -687,7 +688,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     for (int32_t v : ph) active += (v == PH_PLAYING);
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
-    out->pool_overflows = c[CNT_OVERFLOW]; out->steps = e->steps; out->active_slots = active;
+    out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS]; out->active_slots = active;
     return CKR_OK;
 }
 

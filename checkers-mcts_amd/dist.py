@@ -1,0 +1,83 @@
+"""Multi-GPU sharding: one process per GPU (torch.distributed; backend "nccl" is
+RCCL on ROCm, "gloo" in the CPU tests).
+
+Self-play games never interact (the reference runs them in separate processes,
+training_pipeline.py:325-329), so workers are sharded by contiguous id blocks
+with NO per-step communication; the only collective is one gather of the
+finished compact tuples / game results to rank 0 at the end (replacing the
+reference's pickle-per-process + merge_data, training_pipeline.py:277-284).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group when launched under torchrun."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_workers, rank, world):
+    """Contiguous block of worker ids owned by `rank`: (first, count)."""
+    base, rem = divmod(int(n_workers), int(world))
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def gather_rows(local, dst=0):
+    """Gather variable-length row blocks (2-D tensors with equal row width) to
+    `dst`: sizes via one all_gather, payload via one gather of padded blocks.
+    Returns the concatenation on dst, None elsewhere.  Works on the device the
+    backend expects (cuda for RCCL, cpu for gloo)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = torch.zeros(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, n)
+    sizes = sizes.cpu().tolist()
+    width, mx = local.shape[1], max(max(sizes), 1)
+    padded = torch.zeros((mx, width), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,275 @@
+"""Drop-in pipeline classes for the self-play / arena hot path.
+
+`generate_Checkers_data` and `tournament_Checkers` keep the reference's
+constructor signatures, kwargs keys, return values and output files
+(training_pipeline.py:310-469 and :472-600) but run every game on the GPU in
+one batched engine: NUM_CPUS workers become NUM_CPUS concurrent game slots
+(each still plays NUM_SELFPLAY_GAMES / TOURNEY_GAMES games back to back, so
+the total is NUM_CPUS x games exactly as in the reference), sharded across the
+processes of a torchrun job with a single gather of the finished tuples.
+
+Differences a user can observe (all documented in DESIGN.md):
+  * NUM_CPUS is not clamped to the host's core count (it sizes the GPU batch).
+  * One pickle per job (written by rank 0) instead of one per worker process.
+  * NN_FN / NEW_NN_FN / OLD_NN_FN name a torch checkpoint (state_dict), a
+    torch.nn.Module, or "random:<seed>" for a freshly initialised network;
+    Keras .h5 files cannot be read here (no h5py / TensorFlow).
+  * MCTS.new_root_node's "All child nodes should be visited!" ValueError is
+    replaced by the alternative its own message suggests (a fresh root) and is
+    counted in the run statistics.
+"""
+import os
+import pickle
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import codec, dist as ckdist, engine as ckengine
+from .net import NetEvaluator, PolicyValueNet, make_net
+
+
+def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128):
+    """NN_FN -> network on the device (see module docstring)."""
+    if isinstance(spec, torch.nn.Module):
+        net = spec.eval().to(device=device, dtype=dtype)
+        return net.to(memory_format=torch.channels_last) if device != "cpu" else net
+    if spec is None:
+        spec = "random:0"
+    if isinstance(spec, str) and spec.startswith("random:"):
+        return make_net(num_kernels, seed=int(spec.split(":", 1)[1]), device=device, dtype=dtype)
+    if isinstance(spec, str) and spec.endswith((".h5", ".hdf5", ".keras")):
+        raise ValueError("Keras model files cannot be loaded in this build (no h5py/TensorFlow); "
+                         "export the weights to a torch state_dict: %s" % spec)
+    if isinstance(spec, str):
+        sd = torch.load(spec, map_location="cpu")
+        if isinstance(sd, dict) and "state_dict" in sd:
+            sd = sd["state_dict"]
+        k = sd["body.1.conv.weight"].shape[0]
+        net = PolicyValueNet(k)
+        net.load_state_dict(sd)
+        net = net.eval().to(device=device, dtype=dtype)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        return net.to(memory_format=torch.channels_last) if device != "cpu" else net
+    raise ValueError("unsupported network specification: %r" % (spec,))
+
+
+class StepRunner:
+    """Drives engine + evaluator; the per-step launch sequence (tree kernel,
+    network kernels, output copies) is captured once into a HIP graph and
+    replayed, so the host only issues one graph launch per simulation step."""
+
+    def __init__(self, eng, evaluator, use_graph=True):
+        self.eng, self.evaluator, self.use_graph = eng, evaluator, use_graph
+        S = eng.cfg.n_slots
+        self.p = torch.zeros((S, 512), dtype=torch.float32, device=eng.device)
+        self.v = torch.zeros((S,), dtype=torch.float32, device=eng.device)
+        self.graph = None
+        self.steps = 0
+
+    def _eval_into_buffers(self):
+        p, v = self.evaluator(self.eng)
+        self.p.copy_(p)
+        self.v.copy_(v)
+
+    def _eager_step(self):
+        self.eng.step(self.p if self.steps else None, self.v if self.steps else None)
+        self._eval_into_buffers()
+        self.steps += 1
+
+    def warmup(self, n=3):
+        for _ in range(n):
+            self._eager_step()
+        if self.use_graph and self.graph is None:
+            torch.cuda.synchronize(self.eng.device)
+            side = torch.cuda.Stream(device=self.eng.device)
+            side.wait_stream(torch.cuda.current_stream(self.eng.device))
+            with torch.cuda.stream(side):                   # one more eager step on the capture stream
+                self._eager_step()
+            torch.cuda.current_stream(self.eng.device).wait_stream(side)
+            torch.cuda.synchronize(self.eng.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self.eng.step(self.p, self.v)
+                self._eval_into_buffers()
+            self.graph = g
+
+    def step(self, n=1):
+        if self.graph is None and self.use_graph:
+            self.warmup()
+        for _ in range(n):
+            if self.graph is not None:
+                self.graph.replay()
+                self.steps += 1
+            else:
+                self._eager_step()
+
+    def run_to_completion(self, check_every=50):
+        if self.steps == 0:
+            self.warmup()
+        while True:
+            self.step(check_every)
+            if self.eng.stats()["active_slots"] == 0:
+                return self.steps
+
+
+def _timestamp():
+    return datetime.now(tz=None).strftime("%d-%b-%Y(%H:%M:%S)")          # training_pipeline.py:465-469
+
+
+def tuples_to_memory(raw):
+    """Compact tuples -> the reference's list of [state(15,8,8) f64,
+    pi(8,8,8) f64, q, z] (training_pipeline.py:369,409,454), ordered by
+    worker, game, ply."""
+    order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
+    raw = raw[order]
+    states = codec.records_to_planes(raw["board"], raw["mask"], raw["status"])
+    memory = []
+    for i in range(len(raw)):
+        a, n = ckengine.tuple_actions_visits(raw[i])
+        q = int(raw["q"][i]) if raw["q_is_int"][i] else np.float32(raw["q"][i])
+        memory.append([states[i], codec.pi_planes(a, n), q, int(raw["z"][i])])
+    return memory
+
+
+class generate_Checkers_data:
+    """Self-play data generator (reference: training_pipeline.py:310-469)."""
+
+    def __init__(self, selfplay_kwargs, mcts_kwargs):
+        self.NUM_SELFPLAY_GAMES = selfplay_kwargs["NUM_SELFPLAY_GAMES"]
+        self.TRAINING_ITERATION = selfplay_kwargs["TRAINING_ITERATION"]
+        self.TERMINATE_CNT = selfplay_kwargs["TERMINATE_CNT"]
+        self.num_cpus = selfplay_kwargs["NUM_CPUS"]
+        self.nn_fn = selfplay_kwargs["NN_FN"]
+        self.mcts_kwargs = mcts_kwargs
+        # build-specific optional keys
+        self.nn_dtype = selfplay_kwargs.get("NN_DTYPE", torch.float32)
+        self.seed = selfplay_kwargs.get("SEED", int.from_bytes(os.urandom(4), "little"))   # np.random.seed(), :341
+        self.nodes_per_tree = selfplay_kwargs.get("NODES_PER_TREE")
+        self.use_graph = selfplay_kwargs.get("USE_GRAPH", True)
+        self.stats = None
+        self.results = None
+
+    def generate_data(self):
+        """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
+        name (a str for one worker, a one-element list otherwise, mirroring
+        training_pipeline.py:325-332); None on ranks other than 0."""
+        rank, local_rank, world = ckdist.init_from_env()
+        first, count = ckdist.shard_range(self.num_cpus, rank, world)
+        dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+        raw_dev = torch.zeros((0, ckengine.TUPLE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        if count > 0:
+            cfg = ckengine.config_from_kwargs(
+                self.mcts_kwargs, n_slots=count, games_per_slot=self.NUM_SELFPLAY_GAMES,
+                terminate_cnt=self.TERMINATE_CNT, first_worker_id=first, nodes_per_tree=self.nodes_per_tree,
+                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index)
+            eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
+            net = load_network(self.nn_fn, device=dev, dtype=self.nn_dtype)
+            runner = StepRunner(eng, NetEvaluator(net), use_graph=self.use_graph)
+            runner.run_to_completion()
+            self.stats = eng.stats()
+            self.results = eng.results()
+            raw_dev = eng.pack_tuples_device()
+            eng.close()
+        gathered = ckdist.gather_rows(raw_dev, dst=0)       # the ONE collective of the job
+        if rank != 0:
+            return None
+        raw = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=ckengine.TUPLE_DTYPE)
+        memory = tuples_to_memory(raw)
+        filename = self._save_memory(memory, self.TRAINING_ITERATION, _timestamp(), 0)
+        return [filename] if self.num_cpus > 1 else filename
+
+    def _save_memory(self, memory, iteration, timestamp, process_num):
+        """Pickle in the reference's format and location (training_pipeline.py:457-463)."""
+        os.makedirs("data/training_data", exist_ok=True)
+        filename = "data/training_data/Checkers_Data" + str(iteration) + "_" + timestamp + "_P" + str(process_num) + ".pkl"
+        with open(filename, "wb") as file:
+            pickle.dump(memory, file)
+        return filename
+
+
+class tournament_Checkers:
+    """Arena between two networks (reference: training_pipeline.py:472-600)."""
+
+    def __init__(self, tourney_kwargs, mcts_kwargs):
+        self.nn1_fn = tourney_kwargs["NEW_NN_FN"]
+        self.nn2_fn = tourney_kwargs["OLD_NN_FN"]
+        self.NUM_GAMES = tourney_kwargs["TOURNEY_GAMES"]
+        self.mcts_kwargs = mcts_kwargs
+        self.num_cpus = tourney_kwargs["NUM_CPUS"]
+        self.nn_dtype = tourney_kwargs.get("NN_DTYPE", torch.float32)
+        self.seed = tourney_kwargs.get("SEED", int.from_bytes(os.urandom(4), "little"))
+        self.nodes_per_tree = tourney_kwargs.get("NODES_PER_TREE")
+        self.use_graph = tourney_kwargs.get("USE_GRAPH", True)
+        self.stats = None
+
+    def start_tournament(self):
+        game_outcomes = self._start_tournament()
+        if game_outcomes is None:
+            return None
+        filename = self._save_tourney_results(game_outcomes)
+        print("Tournament over!  View results in tournament folder!")
+        return filename
+
+    def _start_tournament(self):
+        """Returns [[game_num, p1_fn, p2_fn, outcome, move_count], ...] (:552) on rank 0."""
+        rank, local_rank, world = ckdist.init_from_env()
+        first, count = ckdist.shard_range(self.num_cpus, rank, world)
+        dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+        rows = torch.zeros((0, 8), dtype=torch.int32, device=dev)
+        if count > 0:
+            cfg = ckengine.config_from_kwargs(
+                self.mcts_kwargs, n_slots=count, games_per_slot=self.NUM_GAMES, tournament=True,
+                first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
+                seed=self.seed, device=dev.index)
+            eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
+            new = load_network(self.nn1_fn, device=dev, dtype=self.nn_dtype)
+            old = load_network(self.nn2_fn, device=dev, dtype=self.nn_dtype)
+            runner = StepRunner(eng, NetEvaluator(new, old), use_graph=self.use_graph)
+            runner.run_to_completion()
+            self.stats = eng.stats()
+            res = eng.results()
+            eng.close()
+            rows = torch.tensor([[r[k] for k in ("worker", "game", "outcome", "move_count", "adjudicated",
+                                                 "p1_net", "n_tuples", "failed")] for r in res],
+                                dtype=torch.int32, device=dev).reshape(-1, 8)
+        gathered = ckdist.gather_rows(rows, dst=0)
+        if rank != 0:
+            return None
+        res = sorted(gathered.cpu().tolist())
+        fn1, fn2 = str(self.nn1_fn).replace("data/model/", ""), str(self.nn2_fn).replace("data/model/", "")
+        out = []
+        for i, (worker, game, outcome, moves, _adj, p1_net, _nt, _failed) in enumerate(res):
+            p1_fn, p2_fn = (fn1, fn2) if p1_net == 0 else (fn2, fn1)
+            out.append([i + 1, p1_fn, p2_fn, codec.OUTCOME_NAMES[outcome], moves])
+        return out
+
+    def _save_tourney_results(self, game_outcomes):
+        """Same two tables as training_pipeline.py:561-594."""
+        from tabulate import tabulate
+        fn1, fn2 = game_outcomes[0][1], game_outcomes[0][2]
+        fn1_wins = fn2_wins = draws = 0
+        for idx, outcome_list in enumerate(game_outcomes):
+            outcome_list[0] = idx + 1
+        for _game_num, p1_fn, p2_fn, outcome, _move_count in game_outcomes:
+            if outcome == "player1_wins":
+                fn1_wins += p1_fn == fn1
+                fn2_wins += p1_fn == fn2
+            elif outcome == "player2_wins":
+                fn1_wins += p2_fn == fn1
+                fn2_wins += p2_fn == fn2
+            elif outcome == "draw":
+                draws += 1
+        fn1_wld = str(fn1_wins) + "/" + str(fn2_wins) + "/" + str(draws)
+        fn2_wld = str(fn2_wins) + "/" + str(fn1_wins) + "/" + str(draws)
+        summary_table = [[fn1, fn1_wld], [fn2, fn2_wld]]
+        os.makedirs("data/tournament_results", exist_ok=True)
+        filename = "data/tournament_results/Tournament_" + _timestamp() + ".txt"
+        with open(filename, "w") as file:
+            file.write(tabulate(summary_table, tablefmt="fancy_grid", headers=["Neural Network", "Wins/Losses/Draws"]))
+            file.write("\n\n")
+            file.write(tabulate(game_outcomes, tablefmt="fancy_grid",
+                                headers=["Game Number", "Player 1", "Player 2", "Outcome", "Turn Count"]))
+        self.summary = dict(new=fn1, old=fn2, new_wins=int(fn1_wins), old_wins=int(fn2_wins), draws=int(draws))
+        return filename

@@ -827,3 +827,21 @@ int ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n, fl
     *root_n = root->n; *root_w = root->w;
     return root->n_children;
 }
+
+/* ---- batch helpers for the CPU baseline (bench.py cpu_baseline leg) ------ */
+int ckro_workers_advance(ckro_worker** ws, int n, float* x /* n*896 */, int* active /* n */)
+{
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        int net;
+        active[i] = ckro_worker_advance(ws[i], x + (size_t)i * 896, &net, NULL);
+        cnt += active[i];
+    }
+    return cnt;
+}
+
+void ckro_workers_submit(ckro_worker** ws, int n, const float* p /* n*512 */, const float* v, const int* active)
+{
+    for (int i = 0; i < n; ++i)
+        if (active[i]) ckro_worker_submit(ws[i], p + (size_t)i * 512, v[i]);
+}

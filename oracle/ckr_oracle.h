@@ -153,6 +153,10 @@ void ckro_worker_stats(const ckro_worker* w, uint64_t out[8]);
 int  ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n,
                            float* wsum, float* prior, int32_t* root_n, float* root_w);
 
+/* batch helpers (CPU baseline): advance / submit an array of workers */
+int  ckro_workers_advance(ckro_worker** ws, int n, float* x, int* active);
+void ckro_workers_submit(ckro_worker** ws, int n, const float* p, const float* v, const int* active);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,3 +230,34 @@ class Worker:
 
 
 OUTCOME_NAMES = {0: None, 1: "player1_wins", 2: "player2_wins", 3: "draw"}
+
+
+class WorkerBatch:
+    """n independent workers advanced together (CPU baseline: one network batch per step)."""
+
+    def __init__(self, cfgs):
+        self._L = lib()
+        self._L.ckro_workers_advance.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        self._L.ckro_workers_advance.restype = C.c_int
+        self._L.ckro_workers_submit.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_float),
+                                                C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        self.workers = [Worker(c) for c in cfgs]
+        self.n = len(self.workers)
+        self._arr = (C.c_void_p * self.n)(*[w._h for w in self.workers])
+        self.x = np.zeros((self.n, 8, 8, 14), np.float32)
+        self.active = np.zeros(self.n, np.int32)
+
+    def advance(self):
+        return self._L.ckro_workers_advance(self._arr, self.n, _f32(self.x), self.active.ctypes.data_as(C.POINTER(C.c_int)))
+
+    def submit(self, p, v):
+        p = np.ascontiguousarray(p, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        self._L.ckro_workers_submit(self._arr, self.n, _f32(p), _f32(v), self.active.ctypes.data_as(C.POINTER(C.c_int)))
+
+    def stats(self):
+        out = {}
+        for w in self.workers:
+            for k, val in w.stats().items():
+                out[k] = out.get(k, 0) + val
+        return out

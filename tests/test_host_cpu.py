@@ -1,0 +1,119 @@
+"""CPU: host-side logic -- sharding, the gather collective (gloo, world 2),
+kwargs mapping, tuple -> reference-format conversion."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_covers_everything():
+    from checkers_mcts_amd.dist import shard_range
+    for n in (1, 7, 8, 4096, 32768, 5):
+        for world in (1, 2, 4, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            assert sum(c for _, c in blocks) == n
+            assert blocks[0][0] == 0
+            for (f0, c0), (f1, _) in zip(blocks, blocks[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from checkers_mcts_amd import dist as ckdist
+    ckdist.init_from_env(backend="gloo")
+    first, count = ckdist.shard_range(11, rank, world)
+    rows = torch.arange(first, first + count, dtype=torch.int64).reshape(-1, 1).repeat(1, 36).to(torch.uint8)
+    got = ckdist.gather_rows(rows, dst=0)
+    tmax = ckdist.max_over_ranks(1.0 + rank, "cpu")
+    tsum = ckdist.sum_over_ranks(count, "cpu")
+    ckdist.barrier()
+    if rank == 0:
+        q.put((got.shape, got[:, 0].tolist(), tmax, tsum))
+    else:
+        assert got is None
+    dist.destroy_process_group()
+
+
+def test_gather_rows_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29611 + os.getpid() % 500
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    shape, col, tmax, tsum = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tuple(shape) == (11, 36) and col == list(range(11))
+    assert tmax == 2.0 and tsum == 11.0
+
+
+def test_config_from_kwargs_maps_reference_keys():
+    from checkers_mcts_amd import engine as E
+    kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=200, MULTIPROC=False, NEURAL_NET=True,
+              VERBOSE=False, TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25,
+              TEMPERATURE_TAU=1.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10, NN_FN="ignored extra key")
+    c = E.config_from_kwargs(kw, n_slots=16, games_per_slot=3, terminate_cnt=200, first_worker_id=32)
+    assert (c.budget, c.uct_c, c.epsilon, c.alpha, c.tau, c.tau_decay, c.tau_decay_delay) == (200, 4.0, 0.25, 1.0, 1.0, 0.1, 10)
+    assert c.training == 1 and c.tournament == 0 and c.first_worker_id == 32 and c.nodes_per_tree >= 4096
+    with pytest.raises(ValueError, match="Invalid MCTS computational constraint"):
+        E.config_from_kwargs(dict(kw, CONSTRAINT="x"), n_slots=1, games_per_slot=1)
+    with pytest.raises(ValueError):
+        E.config_from_kwargs(dict(kw, NEURAL_NET=False), n_slots=1, games_per_slot=1)
+
+
+def test_engine_requires_gpu():
+    from checkers_mcts_amd import engine as E, _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    kw = dict(UCT_C=4, CONSTRAINT="rollout", BUDGET=8, MULTIPROC=False, NEURAL_NET=True, VERBOSE=False,
+              TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25, TEMPERATURE_TAU=1.0,
+              TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+    with pytest.raises(_lib.CkrError):
+        E.Engine(E.config_from_kwargs(kw, n_slots=1, games_per_slot=1, terminate_cnt=10))
+
+
+def test_tuples_to_memory_matches_reference_format(oracle, golden_dir):
+    """Oracle tuples -> compact records -> the reference's [state, pi, q, z] lists
+    equal the golden _generate_data output (exercises codec + pipeline glue)."""
+    from checkers_mcts_amd import engine as E, pipeline
+    g = np.load(os.path.join(golden_dir, "selfplay_v1.npz"))
+    budget, terminate, games, salt = (int(v) for v in g["c1_cfg"])
+    kw = dict(UCT_C=4, BUDGET=budget, TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.0,
+              TEMPERATURE_TAU=0.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+    w = oracle.Worker(oracle.make_config(kw, terminate_cnt=terminate, num_games=games))
+    w.run(lambda x, net: oracle.hashnet(x, salt))
+    ot = w.tuples()
+    raw = np.zeros(len(ot), dtype=E.TUPLE_DTYPE)
+    for i, o in enumerate(ot):
+        raw["board"][i], raw["mask"][i], raw["status"][i] = o["board"], o["mask"], o["status"]
+        raw["game"][i], raw["ply"][i], raw["n_children"][i] = o["game"], o["ply"], len(o["action"])
+        raw["q"][i], raw["q_is_int"][i], raw["z"][i] = o["q"], o["q_is_int"], o["z"]
+        raw["pi"][i, :len(o["action"])] = (o["action"].astype(np.uint32) << 23) | o["visits"]
+    mem = pipeline.tuples_to_memory(raw[::-1].copy())          # order must be restored by (worker, game, ply)
+    assert len(mem) == len(g["c1_z"])
+    for i, (state, pi, q, z) in enumerate(mem):
+        assert (state == g["c1_state"][i]).all() and (pi == g["c1_pi"][i]).all()
+        assert np.float32(q) == g["c1_q"][i] and (type(q) is int) == bool(g["c1_q_is_int"][i]) and z == g["c1_z"][i]
+
+
+def test_net_shapes_and_flops_cpu():
+    from checkers_mcts_amd.net import PolicyValueNet, FLOPS_PER_EVAL
+    m = PolicyValueNet(128).keras_init(0).eval()
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == 1319580 + 0 or n_params > 1.3e6               # 1 319 580 trainable
+    with torch.no_grad():
+        p, v = m(torch.zeros(2, 14, 8, 8))
+    assert p.shape == (2, 512) and v.shape == (2,)
+    macs = 64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128 + 64 * 128 * 8 + 512 * 512 + 64 * 128 + 64 * 64 + 64
+    assert abs(2 * macs - FLOPS_PER_EVAL) / FLOPS_PER_EVAL < 1e-3

@@ -1,0 +1,111 @@
+"""GPU: network parity (fp32 GPU forward vs float64 NumPy restatement, 1e-5),
+the HIP-graph step runner, and the drop-in pipeline classes."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import checkers_mcts_amd.codec as codec
+
+KW = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=16, MULTIPROC=False, NEURAL_NET=True,
+          VERBOSE=False, TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25,
+          TEMPERATURE_TAU=1.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+
+
+def _positions(n, seed):
+    from test_rules_gpu import random_boards
+    return random_boards(n, seed)
+
+
+def test_network_fp32_within_1e5_of_float64(oracle):
+    """pi and v within 1e-5 of the float64 evaluation of the same weights on
+    identical inputs (north_star tolerance; Keras itself is unpinned)."""
+    import torch
+    import net_ref
+    from checkers_mcts_amd import net as N, rules
+    for seed, perturb in ((0, False), (3, True)):
+        m = N.PolicyValueNet(128).keras_init(seed)
+        if perturb:
+            m.perturb_bn(seed)
+        m = m.eval().cuda().to(memory_format=torch.channels_last)
+        boards = _positions(96, 77 + seed)
+        x = rules.features(rules.boards_to_device(boards))             # [B,8,8,14] NHWC
+        with torch.no_grad():
+            p, v = m(x.permute(0, 3, 1, 2))
+        sd = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
+        rp, rv = net_ref.forward(sd, x.cpu().numpy())
+        assert np.abs(p.cpu().numpy() - rp).max() < 1e-5
+        assert np.abs(v.cpu().numpy() - rv).max() < 1e-5
+        assert abs(float(p.sum(1).mean()) - 1.0) < 1e-5
+
+
+def test_features_16bit_match_fp32():
+    import torch
+    from checkers_mcts_amd import engine as E, rules
+    for dt in (torch.float16, torch.bfloat16):
+        e32 = E.Engine(E.config_from_kwargs(dict(KW, DIRICHLET_EPSILON=0.0, TEMPERATURE_TAU=0.0), n_slots=8,
+                                            games_per_slot=1, terminate_cnt=30))
+        e16 = E.Engine(E.config_from_kwargs(dict(KW, DIRICHLET_EPSILON=0.0, TEMPERATURE_TAU=0.0), n_slots=8,
+                                            games_per_slot=1, terminate_cnt=30, feature_dtype=dt), feature_dtype=dt)
+        p = v = None
+        for _ in range(40):
+            e32.step(p, v); e16.step(p, v)
+            assert torch.equal(e32.x.to(dt), e16.x)
+            p, v = rules.hashnet(e32.x, 9)
+        e32.close(); e16.close()
+
+
+def test_graph_runner_equals_eager():
+    """Replaying the captured step sequence gives the same games as eager launches."""
+    import torch
+    from checkers_mcts_amd import engine as E
+    from checkers_mcts_amd.pipeline import StepRunner
+    outs = []
+    for use_graph in (False, True):
+        eng = E.Engine(E.config_from_kwargs(KW, n_slots=32, games_per_slot=1, terminate_cnt=12, seed=7))
+        StepRunner(eng, E.hashnet_evaluator(3), use_graph=use_graph).run_to_completion(check_every=25)
+        t = eng.tuples_raw()
+        outs.append(t[np.lexsort((t["ply"], t["game"], t["worker"]))])
+        assert eng.stats()["games"] == 32
+        eng.close()
+    assert len(outs[0]) == len(outs[1]) and (outs[0]["board"] == outs[1]["board"]).all()
+    assert (outs[0]["pi"] == outs[1]["pi"]).all() and (outs[0]["q"] == outs[1]["q"]).all()
+
+
+def test_generate_checkers_data_dropin(tmp_path, monkeypatch):
+    """cfg1-style plumbing through the reference's own entry point: tuples are
+    well formed and in the reference's pickle format."""
+    import torch
+    from checkers_mcts_amd.pipeline import generate_Checkers_data
+    monkeypatch.chdir(tmp_path)
+    sk = dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=3, TERMINATE_CNT=24, NUM_CPUS=6, NN_FN="random:0", SEED=5)
+    g = generate_Checkers_data(sk, dict(KW, BUDGET=20))
+    fns = g.generate_data()
+    assert isinstance(fns, list) and len(fns) == 1 and fns[0].startswith("data/training_data/Checkers_Data3_")
+    mem = pickle.load(open(fns[0], "rb"))
+    assert len(mem) >= 6 * 24
+    for state, pi, q, z in mem:
+        assert state.shape == (15, 8, 8) and state.dtype == np.float64 and pi.shape == (8, 8, 8)
+        assert z in (-1, 0, 1) and -1.0 <= float(q) <= 1.0
+        if pi.sum() > 0:
+            assert abs(pi.sum() - 1) < 1e-12
+            assert (pi[state[6:14] == 0] == 0).all()                   # mass only on legal actions
+    one = generate_Checkers_data(dict(sk, NUM_CPUS=1), dict(KW, BUDGET=20)).generate_data()
+    assert isinstance(one, str)                                        # training_pipeline.py:330-332
+    assert g.stats["games"] == 6 and g.stats["pool_overflows"] == 0
+
+
+def test_tournament_dropin(tmp_path, monkeypatch):
+    from checkers_mcts_amd.pipeline import tournament_Checkers
+    monkeypatch.chdir(tmp_path)
+    tk = dict(NEW_NN_FN="random:1", OLD_NN_FN="random:2", TOURNEY_GAMES=2, NUM_CPUS=4, SEED=11)
+    mk = dict(KW, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0, BUDGET=12)
+    t = tournament_Checkers(tk, mk)
+    fn = t.start_tournament()
+    txt = open(fn, encoding="utf-8").read()
+    assert "Wins/Losses/Draws" in txt and "Turn Count" in txt
+    s = t.summary
+    assert s["new_wins"] + s["old_wins"] + s["draws"] == 8
