@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--budget", type=int, default=100)
     ap.add_argument("--nn-dtype", choices=list(DTYPES), default="bf16")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--evaluator", choices=["fused", "torch"], default=None,
+                    help="fused: conv stack in the hand-written MFMA kernel (bf16 only); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
     return ap.parse_args()
@@ -147,8 +149,15 @@ def main():
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
                                       first_worker_id=first, feature_dtype=dtype, seed=20260929, device=local_rank)
     eng = ckengine.Engine(cfg, feature_dtype=dtype)
-    net = make_net(128, seed=0, device=dev, dtype=dtype)
-    runner = StepRunner(eng, NetEvaluator(net), use_graph=not a.no_graph)
+    which = a.evaluator or ("fused" if a.nn_dtype == "bf16" else "torch")
+    if which == "fused":
+        if a.nn_dtype != "bf16":
+            raise SystemExit("--evaluator fused needs --nn-dtype bf16")
+        from checkers_mcts_amd.fused import FusedEvaluator
+        evaluator = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots)
+    else:
+        evaluator = NetEvaluator(make_net(128, seed=0, device=dev, dtype=dtype))
+    runner = StepRunner(eng, evaluator, use_graph=not a.no_graph)
 
     runner.warmup(3)
     done = runner.steps
@@ -191,7 +200,8 @@ def main():
     out = None
     if rank == 0:
         nn_tflops = FLOPS_PER_EVAL * a.slots / t_nn / 1e12 if t_nn else None
-        roofline = {"bound": "mfma", "kernel": "network forward (conv3x3 x8 + heads), one launch group per step",
+        roofline = {"bound": "mfma", "kernel": ("k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers, one launch) + torch heads"
+                                                if which == "fused" else "network forward via PyTorch/MIOpen (conv3x3 x8 + heads)"),
                     "achieved": nn_tflops, "peak": MFMA_PEAK_TFLOPS[a.nn_dtype], "unit": "TFLOP/s",
                     "frac": (nn_tflops / MFMA_PEAK_TFLOPS[a.nn_dtype]) if nn_tflops else None, "traffic": None,
                     "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots,
@@ -211,7 +221,7 @@ def main():
                                       "random-init policy/value net (Keras-default init), TERMINATE_CNT 200"
                                       % (a.budget, a.slots),
                           "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": a.nn_dtype,
-                          "hip_graph": not a.no_graph, "parallelism": "games sharded x%d, no per-step collective" % world},
+                          "hip_graph": not a.no_graph, "evaluator": which, "parallelism": "games sharded x%d, no per-step collective" % world},
                "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total,
                "sims_per_s": (exp_total + term_total) / dt,
                "games_per_hour_est": (plies_total / dt) * 3600.0 / 100.0 if plies_total else None,

@@ -1,0 +1,230 @@
+// ckr_conv.hip -- the network body as ONE fused MFMA kernel for gfx950.
+//
+// Reference semantics: the 3x3 'same' convolutions of training_pipeline.create_nn
+// (training_pipeline.py:60-92): y = BatchNorm(ReLU(conv3x3(x) + bias)), 7 body layers
+// + the first policy-head conv, all 128 kernels wide.  This is the only MFMA user of
+// the path (BASELINE north_star).
+//
+// Design (MI355X-first): an 8x8 board's activations are only 16 KB in bf16, so a
+// workgroup keeps FOUR boards (256 positions x 128 channels = 64 KB) resident in LDS
+// through ALL layers -- activations never round-trip through HBM between layers; only
+// the weights stream (L2-resident, 288 KB per layer, pre-swizzled on the host so the
+// global image IS the LDS image).  Per layer the workgroup computes the implicit GEMM
+//   C'[channel][position] = sum_{tap,k} W[tap][channel][k] * X[position + tap][k]
+// with v_mfma_f32_32x32x16_bf16: A = weights (rows = out channels), B = activations
+// (columns = positions), so each lane ends up with 4 consecutive channels of ONE
+// position -- an 8-byte store back into the NHWC LDS image (in place: accumulators
+// hold the whole 128 x 256 output tile, 128 VGPRs per lane).  Zero padding = a zero
+// row in LDS.  Rows are 256 B; 16-B slots are XOR-swizzled with (row & 15) so every
+// ds_read_b128 lane group touches 16 distinct slots (conflict-free).
+// 4 waves (one per SIMD): wave (wc, wp) owns channels [64wc,+64) x positions [128wp,+128)
+// = 2 x 4 MFMA tiles; per 16-deep k-step 6 fragment reads feed 8 MFMAs.
+#include "ckr_host.h"
+#include <hip/hip_runtime.h>
+
+namespace ckr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int CONV_MAX_LAYERS = 9;
+constexpr int ACT_ROWS = 256, ACT_PITCH = 256;                   // bytes
+constexpr int ACT_BYTES = (ACT_ROWS + 1) * ACT_PITCH;            // + zero row
+constexpr int W_BYTES = 128 * 256;                               // one tap, cin = 128
+constexpr int PRM_BYTES = 3 * 128 * 4;
+constexpr int LDS_BYTES = ACT_BYTES + W_BYTES + PRM_BYTES;
+
+struct ConvLayerDev {
+    const uint4* w;            // [9][128 rows][cin_pad*2 bytes], slots pre-swizzled
+    const float* bias; const float* scale; const float* shift;
+    uint16_t* out;             // optional [B,8,8,128] bf16 NHWC
+    int cin_pad;               // 32 or 128
+};
+struct ConvArgs {
+    const uint16_t* x;         // [B,8,8,14] bf16 NHWC
+    long long n_boards;
+    int n_layers;
+    ConvLayerDev L[CONV_MAX_LAYERS];
+};
+
+__device__ __forceinline__ uint32_t f2bf(float f) {              // round to nearest even
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+// Register staging of one tap's weights (N uint4 per thread).  Written with named
+// members instead of an array: hipcc otherwise promotes the array to LDS (40 KB).
+template <int N> struct Stage;
+template <> struct Stage<2> {
+    uint4 a, b;
+    __device__ __forceinline__ void load(const uint4* p, int t) { a = p[t]; b = p[t + 256]; }
+    __device__ __forceinline__ void store(uint4* p, int t) const { p[t] = a; p[t + 256] = b; }
+};
+template <> struct Stage<8> {
+    uint4 a, b, c, d, e, f, g, h;
+    __device__ __forceinline__ void load(const uint4* p, int t) {
+        a = p[t]; b = p[t + 256]; c = p[t + 512]; d = p[t + 768]; e = p[t + 1024]; f = p[t + 1280]; g = p[t + 1536]; h = p[t + 1792];
+    }
+    __device__ __forceinline__ void store(uint4* p, int t) const {
+        p[t] = a; p[t + 256] = b; p[t + 512] = c; p[t + 768] = d; p[t + 1024] = e; p[t + 1280] = f; p[t + 1536] = g; p[t + 1792] = h;
+    }
+};
+
+template <int CIN>
+__device__ __forceinline__ void tap_compute(const char* __restrict__ act, const char* __restrict__ wbuf,
+                                            int prow0, int dy, int dx, int wrow0, int lane,
+                                            f32x16 (&acc)[2][4]) {
+    constexpr int KSTEPS = CIN / 16;
+    constexpr int WPITCH = CIN * 2;
+    const int hi = lane >> 5;
+    int4v brow, bsw;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {                              // zero padding: out-of-board taps read the zero row
+        const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7;
+        const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
+        const int r = ok ? p + 8 * dy + dx : ACT_ROWS;
+        brow[pt] = r * ACT_PITCH; bsw[pt] = r & 15;
+    }
+#pragma unroll 2
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int slot = 2 * kk + hi;
+        bf16x8 a[2], b[4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int r = wrow0 + 32 * ct;
+            const int sw = (CIN == 128) ? (r & 15) : ((r >> 2) & 3);
+            a[ct] = *reinterpret_cast<const bf16x8*>(wbuf + r * WPITCH + ((slot ^ sw) << 4));
+        }
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+            b[pt] = *reinterpret_cast<const bf16x8*>(act + brow[pt] + ((slot ^ bsw[pt]) << 4));
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
+    }
+}
+
+// One layer for the workgroup's 256 positions: 9 taps of weights streamed through
+// `wbuf` (register-staged prefetch of the next tap while the current one computes),
+// then the fused epilogue written back into the LDS activation image in place.
+template <int CIN>
+__device__ __forceinline__ void run_layer(const ConvLayerDev& L, char* act, char* wbuf, float* prm, int tid, int lane,
+                                          int wc, int prow0, int wrow0) {
+    constexpr int TAP_U4 = 128 * CIN * 2 / 16;                    // uint4 per tap (512 or 2048)
+    constexpr int PER_THREAD = TAP_U4 / 256;                      // 2 or 8
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][pt][i] = 0.0f;
+    Stage<PER_THREAD> pre;
+    pre.load(L.w, tid);
+    if (tid < 128) { prm[tid] = L.bias[tid]; prm[128 + tid] = L.scale[tid]; prm[256 + tid] = L.shift[tid]; }
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();                                          // previous tap's reads of wbuf are done
+        pre.store(reinterpret_cast<uint4*>(wbuf), tid);
+        __syncthreads();
+        if (tap < 8) pre.load(L.w + (size_t)(tap + 1) * TAP_U4, tid);
+        tap_compute<CIN>(act, wbuf, prow0, tap / 3 - 1, tap % 3 - 1, wrow0, lane, acc);
+    }
+    __syncthreads();                                              // every read of the old activations is done
+    // epilogue: bias + ReLU + BatchNorm affine, bf16, back into the LDS image (in place)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 64 * wc + 32 * ct + 8 * g + 4 * (lane >> 5);
+            const float4 bi = *reinterpret_cast<const float4*>(prm + c0);
+            const float4 sc = *reinterpret_cast<const float4*>(prm + 128 + c0);
+            const float4 sh = *reinterpret_cast<const float4*>(prm + 256 + c0);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const float y0 = sc.x * fmaxf(acc[ct][pt][4 * g + 0] + bi.x, 0.0f) + sh.x;
+                const float y1 = sc.y * fmaxf(acc[ct][pt][4 * g + 1] + bi.y, 0.0f) + sh.y;
+                const float y2 = sc.z * fmaxf(acc[ct][pt][4 * g + 2] + bi.z, 0.0f) + sh.z;
+                const float y3 = sc.w * fmaxf(acc[ct][pt][4 * g + 3] + bi.w, 0.0f) + sh.w;
+                const int r = prow0 + 32 * pt;
+                uint2 pk;
+                pk.x = f2bf(y0) | (f2bf(y1) << 16);
+                pk.y = f2bf(y2) | (f2bf(y3) << 16);
+                *reinterpret_cast<uint2*>(act + r * ACT_PITCH + (((c0 >> 3) ^ (r & 15)) << 4) + ((c0 & 7) << 1)) = pk;
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    char* act = smem;
+    char* wbuf = smem + ACT_BYTES;
+    float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + W_BYTES);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wc = wave >> 1, wp = wave & 1;
+    const long long board0 = (long long)blockIdx.x * 4;
+    const int rows_valid = (int)min((long long)ACT_ROWS, (A.n_boards - board0) * 64);
+
+    // zero the activation image (channel padding of layer 0, tail boards, zero row)
+    for (int i = tid; i < ACT_BYTES / 16; i += 256) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < rows_valid) {                                       // 14 bf16 = 28 B per position
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(A.x + (board0 * 64 + tid) * 14);
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) v[i] = src[i];
+        v[7] = 0u;
+        const int sw = tid & 15;
+        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH + ((0 ^ sw) << 4)) = make_uint4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH + ((1 ^ sw) << 4)) = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+    const int prow0 = 128 * wp + (lane & 31);                     // this lane's position in B tile 0 (+32 per tile)
+    const int wrow0 = 64 * wc + (lane & 31);
+
+    for (int l = 0; l < A.n_layers; ++l) {
+        const ConvLayerDev& L = A.L[l];
+        if (l == 0) run_layer<32>(L, act, wbuf, prm, tid, lane, wc, prow0, wrow0);
+        else run_layer<128>(L, act, wbuf, prm, tid, lane, wc, prow0, wrow0);
+        if (L.out) {                                              // coalesced un-swizzled copy-out
+            uint4* dst = reinterpret_cast<uint4*>(L.out + board0 * 64 * 128);
+            for (int q = tid; q < rows_valid * 16; q += 256) {
+                const int r = q >> 4, s = q & 15;
+                dst[q] = *reinterpret_cast<const uint4*>(act + r * ACT_PITCH + ((s ^ (r & 15)) << 4));
+            }
+        }
+    }
+}
+
+}  // namespace ckr
+
+using namespace ckr;
+
+extern "C" {
+
+/* Layer descriptor of the C-ABI (include/ckr.h): device pointers. */
+int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers, int n_layers, void* stream) {
+    if (n_boards < 0 || n_layers < 1 || n_layers > CONV_MAX_LAYERS || !layers)
+        return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: bad n_boards / n_layers");
+    if (int rc = require_device()) return rc;
+    if (n_boards == 0) return CKR_OK;
+    if (!d_x) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null input");
+    ConvArgs A;
+    A.x = (const uint16_t*)d_x; A.n_boards = n_boards; A.n_layers = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        const ckr_conv_layer& s = layers[i];
+        if (!s.weights || !s.bias || !s.scale || !s.shift) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null layer pointer");
+        if ((i == 0 && s.cin_pad != 32) || (i > 0 && s.cin_pad != 128))
+            return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: layer 0 must have cin_pad 32, later layers 128");
+        A.L[i] = ConvLayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (uint16_t*)s.out, s.cin_pad};
+    }
+    const int grid = (int)((n_boards + 3) / 4);
+    hipLaunchKernelGGL(k_conv_stack, dim3(grid), dim3(256), 0, (hipStream_t)stream, A);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+}  // extern "C"

@@ -90,6 +90,32 @@ int ckr_mask_renorm_batch(const ckr_board* d_boards, int64_t n, const float* d_p
 int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, float* d_p, float* d_v,
                       void* stream);
 
+/* ---- network body (the only MFMA user) ---------------------------------- */
+
+/* One 3x3 'same' convolution + bias + ReLU + BatchNorm(inference) layer of
+ * training_pipeline.create_nn (training_pipeline.py:60-92), 128 kernels wide.
+ * All pointers are DEVICE pointers.
+ *   weights : bf16 [9 taps = ky*3+kx][128 out][cin_pad in], every 16-byte slot
+ *             of a row XOR-swizzled (slot ^ (out & 15) for cin_pad 128,
+ *             slot ^ ((out >> 2) & 3) for cin_pad 32) -- net.py prepares it
+ *   bias    : conv bias [128]; scale/shift: the BatchNorm affine
+ *             gamma/sqrt(var+eps), beta - mean*scale [128] (float32)
+ *   out     : optional bf16 NHWC [n_boards][8][8][128] copy of this layer's output */
+typedef struct {
+    const void*  weights;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    void*        out;
+    int32_t      cin_pad;        /* 32 for the first layer (14 planes padded), else 128 */
+} ckr_conv_layer;
+
+/* Runs n_layers (<= 9) such layers back to back for n_boards positions with the
+ * activations resident in LDS (never written to HBM between layers).
+ * d_x: bf16 NHWC [n_boards][8][8][14], the engine's feature buffer. */
+int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers,
+                        int32_t n_layers, void* stream);
+
 /* ---- batched self-play / arena engine ----------------------------------- */
 
 /* Fields mirror the reference's kwargs dicts: MCTS(**kwargs) (MCTS.py:43-55),

@@ -109,3 +109,32 @@ def test_tournament_dropin(tmp_path, monkeypatch):
     assert "Wins/Losses/Draws" in txt and "Turn Count" in txt
     s = t.summary
     assert s["new_wins"] + s["old_wins"] + s["draws"] == 8
+
+
+def test_fused_conv_stack_matches_fp32_network():
+    """Hand-written MFMA conv stack (bf16, fused bias+ReLU+BN, LDS-resident
+    activations) vs the fp32 PyTorch network on identical weights and inputs."""
+    import torch
+    from checkers_mcts_amd import net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    for n_boards in (256, 1023, 6):                                   # incl. ragged tails (not a multiple of 4)
+        m = N.PolicyValueNet(128).keras_init(2).perturb_bn(5).eval().cuda()
+        boards = _positions(n_boards, 900 + n_boards)
+        x = rules.features(rules.boards_to_device(boards))
+        fe = FusedEvaluator(m, n_boards)
+        p, v = fe.forward_features(x.to(torch.bfloat16).contiguous())
+        with torch.no_grad():
+            mm = m.to(memory_format=torch.channels_last)
+            xr = x.permute(0, 3, 1, 2)
+            h = xr
+            for blk in mm.body:
+                h = mm._block(blk, h)
+            body_ref = h.permute(0, 2, 3, 1).contiguous()
+            pol_ref = mm._block(mm.pol1, h).permute(0, 2, 3, 1).contiguous()
+            pr, vr = mm(xr)
+        nets = fe.nets[0]
+        for got, ref in ((nets["y_body"], body_ref), (nets["y_pol"], pol_ref)):
+            err = (got.float() - ref).norm() / ref.norm()
+            assert float(err) < 2e-2, float(err)
+        assert float((p - pr).abs().max()) < 5e-3 and float((v - vr).abs().max()) < 5e-2
+        assert float((p.sum(1) - 1).abs().max()) < 1e-4

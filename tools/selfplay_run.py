@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Play complete self-play games (BASELINE cfg 3/4 shape) and report whole-run
+throughput: games/hour, expansions/s, plies, game-length and outcome histograms.
+    python tools/selfplay_run.py --slots 4096 --budget 100 --nn-dtype bf16
+Under torchrun the slots are per GPU and the tuples are gathered to rank 0."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--slots", type=int, default=4096)
+    ap.add_argument("--games-per-slot", type=int, default=1)
+    ap.add_argument("--budget", type=int, default=100)
+    ap.add_argument("--terminate", type=int, default=200)
+    ap.add_argument("--nn-dtype", default="bf16")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--tournament", action="store_true")
+    a = ap.parse_args()
+    from checkers_mcts_amd import dist as ckdist, engine as E
+    from checkers_mcts_amd.net import NetEvaluator, make_net
+    from checkers_mcts_amd.pipeline import StepRunner
+    rank, local_rank, world = ckdist.init_from_env()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.nn_dtype]
+    kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=a.budget, MULTIPROC=False, NEURAL_NET=True,
+              VERBOSE=False, TRAINING=not a.tournament, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25,
+              TEMPERATURE_TAU=0.0 if a.tournament else 1.0, TEMPERATURE_DECAY=0.0 if a.tournament else 0.1,
+              TEMP_DECAY_DELAY=0 if a.tournament else 10)
+    first, _ = ckdist.shard_range(a.slots * world, rank, world)
+    cfg = E.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=a.games_per_slot,
+                               terminate_cnt=0 if a.tournament else a.terminate, tournament=a.tournament,
+                               first_worker_id=first, feature_dtype=dt, seed=a.seed, device=local_rank)
+    eng = E.Engine(cfg, feature_dtype=dt)
+    new = make_net(128, seed=0, device=dev, dtype=dt)
+    old = make_net(128, seed=1, device=dev, dtype=dt) if a.tournament else None
+    runner = StepRunner(eng, NetEvaluator(new, old))
+    ckdist.barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    steps = runner.run_to_completion(check_every=200)
+    torch.cuda.synchronize(dev)
+    t_play = time.perf_counter() - t0
+    st = eng.stats()
+    res = eng.results()
+    payload = eng.pack_tuples_device() if not a.tournament else torch.zeros((0, 288), dtype=torch.uint8, device=dev)
+    g0 = time.perf_counter()
+    gathered = ckdist.gather_rows(payload, dst=0)
+    torch.cuda.synchronize(dev)
+    t_gather = time.perf_counter() - g0
+    t_all = ckdist.max_over_ranks(time.perf_counter() - t0, dev)
+    exp = ckdist.sum_over_ranks(st["expansions"], dev)
+    games = ckdist.sum_over_ranks(st["games"], dev)
+    if rank == 0:
+        moves = np.array([r["move_count"] for r in res])
+        out = dict(n_gpus=world, slots_per_gpu=a.slots, budget=a.budget, nn_dtype=a.nn_dtype, steps=steps,
+                   seconds=t_all, play_seconds=t_play, gather_seconds=t_gather, games=games,
+                   games_per_hour=games / t_all * 3600, expansions=exp, expansions_per_s=exp / t_all,
+                   tuples_gathered=int(gathered.shape[0]), rank0_stats=st,
+                   rank0_game_length=dict(mean=float(moves.mean()), min=int(moves.min()), max=int(moves.max())),
+                   rank0_outcomes={str(k): int((np.array([r["outcome"] for r in res]) == k).sum()) for k in (1, 2, 3)},
+                   rank0_adjudicated=int(sum(r["adjudicated"] for r in res)), rank0_failed=int(sum(r["failed"] for r in res)))
+        print(json.dumps(out))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
