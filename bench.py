@@ -195,19 +195,41 @@ def main():
         torch.cuda.synchronize(dev)
         t_tree = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in ev])) / 1e3
         t_nn = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in ev])) / 1e3
+    # the dominant kernel on its own: k_conv_stack, one launch per step, timed with HIP
+    # events on the launch stream against the engine's current leaf features
+    t_conv = 0.0
+    if which == "fused" and a.profile_steps > 0:
+        cev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(a.profile_steps)]
+        for e0, e1 in cev:
+            e0.record()
+            evaluator.conv_only(eng.x)
+            e1.record()
+        torch.cuda.synchronize(dev)
+        t_conv = float(np.median([e0.elapsed_time(e1) for e0, e1 in cev])) / 1e3
     stats_end = eng.stats()
 
     out = None
     if rank == 0:
+        peak = MFMA_PEAK_TFLOPS[a.nn_dtype]
         nn_tflops = FLOPS_PER_EVAL * a.slots / t_nn / 1e12 if t_nn else None
-        roofline = {"bound": "mfma", "kernel": ("k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers, one launch) + torch heads"
-                                                if which == "fused" else "network forward via PyTorch/MIOpen (conv3x3 x8 + heads)"),
-                    "achieved": nn_tflops, "peak": MFMA_PEAK_TFLOPS[a.nn_dtype], "unit": "TFLOP/s",
-                    "frac": (nn_tflops / MFMA_PEAK_TFLOPS[a.nn_dtype]) if nn_tflops else None, "traffic": None,
-                    "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots,
-                    "tree_kernel": {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "bound": "latency",
-                                    "algorithmic_bytes_per_sim": 536,
-                                    "achieved_GBps": 536.0 * a.slots / t_tree / 1e9 if t_tree else None}}
+        tree = {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "bound": "latency", "algorithmic_bytes_per_sim": 536,
+                "achieved_GBps": 536.0 * a.slots / t_tree / 1e9 if t_tree else None}
+        if which == "fused":
+            conv_flops = evaluator.CONV_FLOPS_PER_BOARD
+            conv_tflops = conv_flops * a.slots / t_conv / 1e12 if t_conv else None
+            roofline = {"bound": "mfma", "kernel": "k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, "
+                                                   "LDS-resident activations; one launch per step)",
+                        "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
+                        "frac": conv_tflops / peak if conv_tflops else None, "traffic": None,
+                        "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": a.slots,
+                        "network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
+                        "tree_kernel": tree}
+        else:
+            roofline = {"bound": "mfma", "kernel": "network forward via PyTorch/MIOpen (conv3x3 x8 + heads), launch group per step",
+                        "achieved": nn_tflops, "peak": peak, "unit": "TFLOP/s",
+                        "frac": (nn_tflops / peak) if nn_tflops else None, "traffic": None,
+                        "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots,
+                        "tree_kernel": tree}
         extra = {"movegen_k1": movegen_probe(dev)}
         cpu = None
         if world == 1 and a.cpu_seconds > 0:

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libckr.so")
+LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
 
 
@@ -44,7 +44,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",
-           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_conv_stack_bf16", "ckr_engine_create",
+           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_conv_stack_bf16", "ckr_value_mlp", "ckr_engine_create",
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_stats", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves"]
 

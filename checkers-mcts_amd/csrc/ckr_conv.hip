@@ -17,8 +17,9 @@
 // (columns = positions), so each lane ends up with 4 consecutive channels of ONE
 // position -- an 8-byte store back into the NHWC LDS image (in place: accumulators
 // hold the whole 128 x 256 output tile, 128 VGPRs per lane).  Zero padding = a zero
-// row in LDS.  Rows are 256 B; 16-B slots are XOR-swizzled with (row & 15) so every
-// ds_read_b128 lane group touches 16 distinct slots (conflict-free).
+// row in LDS.  Rows are padded by one 16-B slot (pitch 272 B; 80 B for the 32-channel
+// first layer) so every ds_read_b128 lane group touches 16 distinct slots (conflict-free)
+// while the k-offset stays an instruction immediate (no per-read address arithmetic).
 // 4 waves (one per SIMD): wave (wc, wp) owns channels [64wc,+64) x positions [128wp,+128)
 // = 2 x 4 MFMA tiles; per 16-deep k-step 6 fragment reads feed 8 MFMAs, fragments
 // double-buffered in registers one k-step ahead.
@@ -34,14 +35,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int CONV_MAX_LAYERS = 9;
-constexpr int ACT_ROWS = 256, ACT_PITCH = 256;                   // bytes
+constexpr int ACT_ROWS = 256, ACT_PITCH = 272;                   // bytes (256 + one pad slot)
 constexpr int ACT_BYTES = (ACT_ROWS + 1) * ACT_PITCH;            // + zero row
-constexpr int W_BYTES = 128 * 256;                               // one tap, cin = 128
+constexpr int W_BYTES = 128 * 272;                               // one tap, cin = 128 (padded rows)
 constexpr int PRM_BYTES = 3 * 128 * 4;
-constexpr int LDS_BYTES = ACT_BYTES + 2 * W_BYTES + PRM_BYTES;   // 132 864 B: one workgroup per CU
+constexpr int LDS_BYTES = ACT_BYTES + 2 * W_BYTES + PRM_BYTES;   // 141 072 B: one workgroup per CU
 
 struct ConvLayerDev {
-    const uint4* w;            // [9][128 rows][cin_pad*2 bytes], slots pre-swizzled
+    const uint4* w;            // [9][128 rows][cin_pad*2 + 16 bytes] (row-padded LDS image)
     const float* bias; const float* scale; const float* shift;
     uint16_t* out;             // optional [B,8,8,128] bf16 NHWC
     int cin_pad;               // 32 or 128
@@ -50,6 +51,8 @@ struct ConvArgs {
     const uint16_t* x;         // [B,8,8,14] bf16 NHWC
     long long n_boards;
     int n_layers;
+    int has_heads;
+    ckr_conv_heads H;
     ConvLayerDev L[CONV_MAX_LAYERS];
 };
 
@@ -58,32 +61,30 @@ __device__ __forceinline__ uint32_t f2bf(float f) {              // round to nea
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-// DMA one tap of weights (CIN*256 bytes) from global memory into an LDS buffer:
+// DMA one tap of weights (128 padded rows) from global memory into an LDS buffer:
 // every wave-instruction moves 64 lanes x 16 B = 1 KB to a wave-uniform LDS base.
 template <int CIN>
 __device__ __forceinline__ void issue_tap(const uint4* __restrict__ src, char* dst, int wave, int lane) {
-    constexpr int CHUNKS_PER_WAVE = CIN * 256 / 1024 / 4;         // 2 or 8
+    constexpr int CHUNKS = 128 * (CIN * 2 + 16) / 1024;           // 10 or 34
 #pragma unroll
-    for (int i = 0; i < CHUNKS_PER_WAVE; ++i) {
+    for (int i = 0; i < (CHUNKS + 3) / 4; ++i) {
         const int c = wave + 4 * i;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
+        if (c < CHUNKS)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
     }
 }
 
 template <int CIN>
 __device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int kk, int hi,
-                                           int wrow0, int4v brow, int4v bsw, bf16x8 (&a)[2], bf16x8 (&b)[4]) {
-    constexpr int WPITCH = CIN * 2;
-    const int slot = 2 * kk + hi;
+                                           int wrow0, int4v brow, bf16x8 (&a)[2], bf16x8 (&b)[4]) {
+    constexpr int WPITCH = CIN * 2 + 16;
+    const int koff = 32 * kk + 16 * hi;                           // byte offset of this lane's 8 k-values
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int r = wrow0 + 32 * ct;
-        const int sw = (CIN == 128) ? (r & 15) : ((r >> 2) & 3);
-        a[ct] = *reinterpret_cast<const bf16x8*>(wbuf + r * WPITCH + ((slot ^ sw) << 4));
-    }
+    for (int ct = 0; ct < 2; ++ct)
+        a[ct] = *reinterpret_cast<const bf16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + koff);
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
-        b[pt] = *reinterpret_cast<const bf16x8*>(act + brow[pt] + ((slot ^ bsw[pt]) << 4));
+        b[pt] = *reinterpret_cast<const bf16x8*>(act + brow[pt] + koff);
 }
 
 __device__ __forceinline__ void mfma_block(const bf16x8 (&a)[2], const bf16x8 (&b)[4], f32x16 (&acc)[2][4]) {
@@ -94,27 +95,46 @@ __device__ __forceinline__ void mfma_block(const bf16x8 (&a)[2], const bf16x8 (&
             acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
 }
 
+// Scheduling directive for one pipelined k-step: issue the 6 ds_read_b128 of the NEXT
+// k-step between the first MFMAs of the CURRENT one (one wave per SIMD: the matrix pipe
+// only stays busy if LDS latency is covered inside the wave).  Without it hipcc re-uses
+// the fragment registers and waits lgkmcnt(0) in front of every MFMA block.
+__device__ __forceinline__ void interleave_reads_with_mfma() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // 2 DS reads
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);            // remaining 5 MFMAs cover the LDS latency
+}
+
 template <int CIN>
 __device__ __forceinline__ void tap_compute(const char* __restrict__ act, const char* __restrict__ wbuf,
                                             int prow0, int dy, int dx, int wrow0, int lane, f32x16 (&acc)[2][4]) {
     constexpr int KSTEPS = CIN / 16;
     const int hi = lane >> 5;
-    int4v brow, bsw;
+    int4v brow;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {                              // zero padding: out-of-board taps read the zero row
         const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7;
         const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
-        const int r = ok ? p + 8 * dy + dx : ACT_ROWS;
-        brow[pt] = r * ACT_PITCH; bsw[pt] = r & 15;
+        brow[pt] = (ok ? p + 8 * dy + dx : ACT_ROWS) * ACT_PITCH;
     }
     bf16x8 a0[2], b0[4], a1[2], b1[4];
-    load_frags<CIN>(act, wbuf, 0, hi, wrow0, brow, bsw, a0, b0);
+    load_frags<CIN>(act, wbuf, 0, hi, wrow0, brow, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);                            // prologue reads stay ahead of the pipelined region
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; kk += 2) {                      // fragments one k-step ahead of the MFMAs
-        load_frags<CIN>(act, wbuf, kk + 1, hi, wrow0, brow, bsw, a1, b1);
+        load_frags<CIN>(act, wbuf, kk + 1, hi, wrow0, brow, a1, b1);
         mfma_block(a0, b0, acc);
-        if (kk + 2 < KSTEPS) load_frags<CIN>(act, wbuf, kk + 2, hi, wrow0, brow, bsw, a0, b0);
-        mfma_block(a1, b1, acc);
+        interleave_reads_with_mfma();
+        if (kk + 2 < KSTEPS) {
+            load_frags<CIN>(act, wbuf, kk + 2, hi, wrow0, brow, a0, b0);
+            mfma_block(a1, b1, acc);
+            interleave_reads_with_mfma();
+        } else {
+            mfma_block(a1, b1, acc);
+        }
     }
 }
 
@@ -138,9 +158,48 @@ __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, in
                 uint2 pk;
                 pk.x = f2bf(y0) | (f2bf(y1) << 16);
                 pk.y = f2bf(y2) | (f2bf(y3) << 16);
-                *reinterpret_cast<uint2*>(act + r * ACT_PITCH + (((c0 >> 3) ^ (r & 15)) << 4) + ((c0 & 7) << 1)) = pk;
+                *reinterpret_cast<uint2*>(act + r * ACT_PITCH + (c0 << 1)) = pk;
             }
         }
+}
+
+// 1x1 convolution head on the LDS-resident activations: thread = position, NOUT kernels,
+// + bias + ReLU + BatchNorm affine, float32 out in Keras Flatten order (pos*NOUT + c).
+// Weights are staged in `stage` (an idle half of the weight ring) and read as broadcasts.
+template <int NOUT>
+__device__ __forceinline__ void head_1x1(const char* act, float* stage, const float* __restrict__ w,
+                                         const float* __restrict__ b, const float* __restrict__ sc,
+                                         const float* __restrict__ sh, float* __restrict__ out,
+                                         long long board0, int rows_valid, int tid) {
+#pragma clang fp contract(fast)
+    for (int i = tid; i < NOUT * 128; i += 256) stage[i] = w[i];
+    if (tid < NOUT) { stage[NOUT * 128 + tid] = b[tid]; stage[NOUT * 129 + tid] = sc[tid]; stage[NOUT * 130 + tid] = sh[tid]; }
+    __syncthreads();
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = 0.0f;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+        const uint4 q = *reinterpret_cast<const uint4*>(act + tid * ACT_PITCH + (s << 4));
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[2 * j] = __uint_as_float(u[j] << 16); xv[2 * j + 1] = __uint_as_float(u[j] & 0xFFFF0000u); }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float4 w0 = *reinterpret_cast<const float4*>(stage + o * 128 + 8 * s);
+            const float4 w1 = *reinterpret_cast<const float4*>(stage + o * 128 + 8 * s + 4);
+            acc[o] += xv[0] * w0.x + xv[1] * w0.y + xv[2] * w0.z + xv[3] * w0.w +
+                      xv[4] * w1.x + xv[5] * w1.y + xv[6] * w1.z + xv[7] * w1.w;
+        }
+    }
+    if (tid < rows_valid) {
+        float* dst = out + (board0 * 64 + tid) * NOUT;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+            dst[o] = stage[NOUT * 129 + o] * fmaxf(acc[o] + stage[NOUT * 128 + o], 0.0f) + stage[NOUT * 130 + o];
+    }
+    __syncthreads();
 }
 
 // One layer for the workgroup's 256 positions.  `g` counts taps globally (LDS ring parity);
@@ -148,7 +207,7 @@ __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, in
 template <int CIN>
 __device__ __forceinline__ void run_layer(const ConvArgs& A, int l, char* act, char* wring, float* prm, int tid, int wave,
                                           int lane, int wc, int prow0, int wrow0, int& g) {
-    constexpr int TAP_U4 = 128 * CIN * 2 / 16;                    // uint4 per tap (512 or 2048)
+    constexpr int TAP_U4 = 128 * (CIN * 2 + 16) / 16;             // uint4 per tap (640 or 2176)
     const ConvLayerDev& L = A.L[l];
     f32x16 acc[2][4];
 #pragma unroll
@@ -160,8 +219,10 @@ __device__ __forceinline__ void run_layer(const ConvArgs& A, int l, char* act, c
     if (tid < 128) { prm[tid] = L.bias[tid]; prm[128 + tid] = L.scale[tid]; prm[256 + tid] = L.shift[tid]; }
     for (int tap = 0; tap < 9; ++tap) {
         char* nxt = wring + ((g + 1) & 1) * W_BYTES;
+#ifndef CKR_CONV_NO_STREAM
         if (tap < 8) issue_tap<CIN>(L.w + (size_t)(tap + 1) * TAP_U4, nxt, wave, lane);
         else if (l + 1 < A.n_layers) issue_tap<128>(A.L[l + 1].w, nxt, wave, lane);
+#endif
         tap_compute<CIN>(act, wring + (g & 1) * W_BYTES, prow0, tap / 3 - 1, tap % 3 - 1, wrow0, lane, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tap has landed (it had a whole tap of MFMAs)
         __syncthreads();                                          // ... for every wave, and this tap's LDS reads are done
@@ -176,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
     char* act = smem;
     char* wring = smem + ACT_BYTES;
     float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + 2 * W_BYTES);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wc = wave >> 1, wp = wave & 1;
     const long long board0 = (long long)blockIdx.x * 4;
     const int rows_valid = (int)min((long long)ACT_ROWS, (A.n_boards - board0) * 64);
@@ -188,9 +249,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
     if (tid < rows_valid) {                                       // 14 bf16 = 28 B per position
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.x + (board0 * 64 + tid) * 14);
         const uint32_t v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
-        const int sw = tid & 15;
-        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH + ((0 ^ sw) << 4)) = make_uint4(v0, v1, v2, v3);
-        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH + ((1 ^ sw) << 4)) = make_uint4(v4, v5, v6, 0u);
+        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH) = make_uint4(v0, v1, v2, v3);
+        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH + 16) = make_uint4(v4, v5, v6, 0u);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -205,9 +265,41 @@ __global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
             uint4* dst = reinterpret_cast<uint4*>(out + board0 * 64 * 128);
             for (int q = tid; q < rows_valid * 16; q += 256) {
                 const int r = q >> 4, s = q & 15;
-                dst[q] = *reinterpret_cast<const uint4*>(act + r * ACT_PITCH + ((s ^ (r & 15)) << 4));
+                dst[q] = *reinterpret_cast<const uint4*>(act + r * ACT_PITCH + (s << 4));
             }
         }
+        if (A.has_heads) {                                        // heads' 1x1 convs while the activations are in LDS
+            float* stage = reinterpret_cast<float*>(wring + ((g + 1) & 1) * W_BYTES);   // the idle half of the ring
+            if (l == A.n_layers - 2 && A.H.val_out)
+                head_1x1<1>(act, stage, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid);
+            if (l == A.n_layers - 1 && A.H.pol_out)
+                head_1x1<8>(act, stage, A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift, A.H.pol_out, board0, rows_valid, tid);
+        }
+    }
+}
+
+// Value head tail (training_pipeline.py:106-112): one wavefront per position batch
+// element; lane = hidden unit.  Dense(64)+ReLU -> BatchNorm -> Dense(1) -> tanh.
+__global__ __launch_bounds__(256) void k_value_mlp(const float* __restrict__ in, long long n, const float* __restrict__ w1t,
+                                                   const float* __restrict__ b1, const float* __restrict__ sc,
+                                                   const float* __restrict__ sh, const float* __restrict__ w2, float b2,
+                                                   float* __restrict__ v) {
+#pragma clang fp contract(fast)
+    const int lane = threadIdx.x & 63;
+    const long long nw = (long long)gridDim.x * 4;
+    float wcol[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wcol[i] = w1t[i * 64 + lane];    // this hidden unit's 64 weights, reused for every row
+    const float bb = b1[lane], s1 = sc[lane], s2 = sh[lane], ww = w2[lane];
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nw) {
+        const float xi = in[r * 64 + lane];
+        float h = bb;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) h += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xi), i)) * wcol[i];
+        float y = (s1 * fmaxf(h, 0.0f) + s2) * ww;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) y += __shfl_xor(y, d);
+        if (lane == 0) v[r] = tanhf(y + b2);
     }
 }
 
@@ -218,7 +310,20 @@ using namespace ckr;
 extern "C" {
 
 /* Layer descriptor of the C-ABI (include/ckr.h): device pointers. */
-int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers, int n_layers, void* stream) {
+int ckr_value_mlp(const float* d_in, int64_t n, const float* w1t, const float* b1, const float* scale, const float* shift,
+                  const float* w2, float b2, float* d_v, void* stream) {
+    if (n < 0) return fail(CKR_ERR_INVALID, "ckr_value_mlp: n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    if (!d_in || !w1t || !b1 || !scale || !shift || !w2 || !d_v) return fail(CKR_ERR_INVALID, "ckr_value_mlp: null pointer");
+    int grid = (int)((n + 3) / 4); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_value_mlp, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in, (long long)n, w1t, b1, scale, shift, w2, b2, d_v);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers, int n_layers,
+                        const ckr_conv_heads* heads, void* stream) {
     if (n_boards < 0 || n_layers < 1 || n_layers > CONV_MAX_LAYERS || !layers)
         return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: bad n_boards / n_layers");
     if (int rc = require_device()) return rc;
@@ -226,6 +331,17 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
     if (!d_x) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null input");
     ConvArgs A;
     A.x = (const uint16_t*)d_x; A.n_boards = n_boards; A.n_layers = n_layers;
+    A.has_heads = heads ? 1 : 0;
+    if (heads) {
+        A.H = *heads;
+        if (n_layers < 2) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: heads need at least two layers");
+        if (A.H.pol_out && !(A.H.pol_w && A.H.pol_b && A.H.pol_scale && A.H.pol_shift))
+            return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null policy-head pointer");
+        if (A.H.val_out && !(A.H.val_w && A.H.val_b && A.H.val_scale && A.H.val_shift))
+            return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null value-head pointer");
+    } else {
+        A.H = ckr_conv_heads{};
+    }
     for (int i = 0; i < n_layers; ++i) {
         const ckr_conv_layer& s = layers[i];
         if (!s.weights || !s.bias || !s.scale || !s.shift) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null layer pointer");

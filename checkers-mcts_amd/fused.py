@@ -1,17 +1,19 @@
-"""bf16 inference path with the network body in ONE hand-written MFMA kernel.
+"""bf16 inference path with the network in hand-written HIP kernels.
 
 The eight 128-wide 3x3 convolutions (7 body layers + the first policy conv,
-training_pipeline.py:60-92) carry 99.5 % of the network's FLOPs; here they run
-inside `ckr_conv_stack_bf16` (csrc/ckr_conv.hip) with the activations resident
-in LDS from the input planes to the policy-head features.  The small heads
-(1x1 convs, dense layers, softmax / tanh; training_pipeline.py:93-112) stay in
-PyTorch.  Weights come from a `net.PolicyValueNet`; conv bias, ReLU and the
-inference BatchNorm affine are fused into the kernel's epilogue.
+training_pipeline.py:60-92) carry 99.5 % of the network's FLOPs; they run inside
+`ckr_conv_stack_bf16` (csrc/ckr_conv.hip) with the activations resident in LDS
+from the input planes to the head features, conv bias + ReLU + inference
+BatchNorm fused into the epilogue, and the heads' two 1x1 convolutions
+(training_pipeline.py:93-96,102-105) applied before anything leaves the chip.
+What reaches HBM per position is 512 + 64 floats.  The tail is three launches:
+the policy Dense(512) GEMM (fp32, hipBLASLt through torch.addmm) + softmax, and
+`ckr_value_mlp` (Dense(64)+ReLU -> BN -> Dense(1) -> tanh).
+Weights come from a float32 `net.PolicyValueNet`.
 """
 import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
@@ -21,20 +23,20 @@ class ConvLayer(C.Structure):
                 ("out", C.c_void_p), ("cin_pad", C.c_int32)]
 
 
+class ConvHeads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pol_w", "pol_b", "pol_scale", "pol_shift", "pol_out",
+                                          "val_w", "val_b", "val_scale", "val_shift", "val_out")]
+
+
 def pack_conv_weights(w, cin_pad):
-    """torch conv weight [128, cin, 3, 3] -> bf16 [9][128][cin_pad] with the
-    16-byte slots of every row XOR-swizzled exactly as the kernel reads them."""
+    """torch conv weight [128, cin, 3, 3] -> bf16 [9 taps][128 out][cin_pad + 8]:
+    the kernel's LDS image (k contiguous per output channel, every row padded by
+    one 16-byte slot so that ds_read_b128 is bank-conflict free)."""
     cout, cin = w.shape[0], w.shape[1]
     assert cout == 128 and w.shape[2:] == (3, 3) and cin <= cin_pad
-    t = torch.zeros((9, cout, cin_pad), dtype=torch.float32, device=w.device)
+    t = torch.zeros((9, cout, cin_pad + 8), dtype=torch.float32, device=w.device)
     t[:, :, :cin] = w.permute(2, 3, 0, 1).reshape(9, cout, cin)           # tap = ky*3 + kx
-    t = t.to(torch.bfloat16).reshape(9, cout, cin_pad // 8, 8)
-    rows = torch.arange(cout, device=w.device)
-    sw = (rows & 15) if cin_pad == 128 else ((rows >> 2) & 3)
-    slots = torch.arange(cin_pad // 8, device=w.device)
-    src = slots[None, :] ^ sw[:, None]                                    # physical slot p holds logical slot p ^ sw
-    out = torch.gather(t, 2, src[None, :, :, None].expand(9, cout, cin_pad // 8, 8))
-    return out.reshape(9, cout, cin_pad).contiguous()
+    return t.to(torch.bfloat16).contiguous()
 
 
 def bn_affine(bn):
@@ -43,62 +45,72 @@ def bn_affine(bn):
     return scale.contiguous(), shift.contiguous()
 
 
-class FusedEvaluator:
-    """engine -> (p, v) with the conv stack in the HIP kernel.  `net` is a
-    PolicyValueNet holding float32 weights on the device."""
+def _f32(t):
+    return t.detach().float().contiguous()
 
-    def __init__(self, net, n_slots, net_old=None):
+
+class FusedEvaluator:
+    """engine -> (p, v).  `net` is a PolicyValueNet holding float32 weights on
+    the device; `debug_outputs` additionally keeps the bf16 body / policy-conv
+    activations in HBM (tests)."""
+
+    def __init__(self, net, n_slots, net_old=None, debug_outputs=False):
         self._L = _lib.load()
-        self._L.ckr_conv_stack_bf16.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.c_void_p]
+        vp = C.c_void_p
+        self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp]
+        self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self.S = n_slots
+        self.debug = debug_outputs
         self.nets = [self._prepare(net)]
         if net_old is not None:
             self.nets.append(self._prepare(net_old))
 
     def _prepare(self, net):
         dev = next(net.parameters()).device
+        S = self.S
         blocks = list(net.body) + [net.pol1]
         keep = []                                                          # keep device tensors alive
         layers = (ConvLayer * len(blocks))()
-        y_body = torch.empty((self.S, 8, 8, 128), dtype=torch.bfloat16, device=dev)
-        y_pol = torch.empty((self.S, 8, 8, 128), dtype=torch.bfloat16, device=dev)
+        y_body = torch.empty((S, 8, 8, 128), dtype=torch.bfloat16, device=dev) if self.debug else None
+        y_pol = torch.empty((S, 8, 8, 128), dtype=torch.bfloat16, device=dev) if self.debug else None
         for i, blk in enumerate(blocks):
             cin_pad = 32 if i == 0 else 128
-            w = pack_conv_weights(blk["conv"].weight.detach().float(), cin_pad)
-            b = blk["conv"].bias.detach().float().contiguous()
+            w = pack_conv_weights(_f32(blk["conv"].weight), cin_pad)
+            b = _f32(blk["conv"].bias)
             sc, sh = bn_affine(blk["bn"])
             keep += [w, b, sc, sh]
             out = y_body if i == len(blocks) - 2 else (y_pol if i == len(blocks) - 1 else None)
             layers[i] = ConvLayer(w.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                   out.data_ptr() if out is not None else None, cin_pad)
-        heads = dict(
-            pol2_w=net.pol2["conv"].weight.detach().float().reshape(8, 128).t().contiguous().to(torch.bfloat16),
-            pol2_b=net.pol2["conv"].bias.detach().float(), pol2_bn=bn_affine(net.pol2["bn"]),
-            pol_fc_w=net.pol_fc.weight.detach().float().t().contiguous().to(torch.bfloat16),
-            pol_fc_b=net.pol_fc.bias.detach().float(),
-            val1_w=net.val1["conv"].weight.detach().float().reshape(1, 128).t().contiguous().to(torch.bfloat16),
-            val1_b=net.val1["conv"].bias.detach().float(), val1_bn=bn_affine(net.val1["bn"]),
-            fc1_w=net.val_fc1.weight.detach().float().t().contiguous(), fc1_b=net.val_fc1.bias.detach().float(),
-            val_bn=bn_affine(net.val_bn),
-            fc2_w=net.val_fc2.weight.detach().float().t().contiguous(), fc2_b=net.val_fc2.bias.detach().float())
-        return dict(layers=layers, n=len(blocks), keep=keep, y_body=y_body, y_pol=y_pol, heads=heads)
+        pol_feat = torch.empty((S, 512), dtype=torch.float32, device=dev)
+        val_feat = torch.empty((S, 64), dtype=torch.float32, device=dev)
+        t = dict(pol_w=_f32(net.pol2["conv"].weight).reshape(8, 128).contiguous(), pol_b=_f32(net.pol2["conv"].bias),
+                 val_w=_f32(net.val1["conv"].weight).reshape(128).contiguous(), val_b=_f32(net.val1["conv"].bias))
+        t["pol_scale"], t["pol_shift"] = bn_affine(net.pol2["bn"])
+        t["val_scale"], t["val_shift"] = bn_affine(net.val1["bn"])
+        heads = ConvHeads(t["pol_w"].data_ptr(), t["pol_b"].data_ptr(), t["pol_scale"].data_ptr(), t["pol_shift"].data_ptr(),
+                          pol_feat.data_ptr(), t["val_w"].data_ptr(), t["val_b"].data_ptr(), t["val_scale"].data_ptr(),
+                          t["val_shift"].data_ptr(), val_feat.data_ptr())
+        vsc, vsh = bn_affine(net.val_bn)
+        tail = dict(fc_w=_f32(net.pol_fc.weight).t().contiguous(), fc_b=_f32(net.pol_fc.bias),
+                    w1t=_f32(net.val_fc1.weight).t().contiguous(), b1=_f32(net.val_fc1.bias), sc=vsc, sh=vsh,
+                    w2=_f32(net.val_fc2.weight).reshape(64).contiguous(), b2=float(net.val_fc2.bias.detach().float().item()))
+        return dict(layers=layers, n=len(blocks), heads=heads, keep=keep + list(t.values()), y_body=y_body, y_pol=y_pol,
+                    pol_feat=pol_feat, val_feat=val_feat, tail=tail,
+                    logits=torch.empty((S, 512), dtype=torch.float32, device=dev),
+                    p=torch.empty((S, 512), dtype=torch.float32, device=dev),
+                    v=torch.empty((S,), dtype=torch.float32, device=dev))
 
     def _forward(self, n, x):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], stream))
-        h = n["heads"]
-        S = self.S
-        # policy head: conv1x1(8)+ReLU -> BN -> flatten (H,W,C) -> dense(512) -> softmax
-        t = (n["y_pol"].reshape(S * 64, 128) @ h["pol2_w"]).float() + h["pol2_b"]
-        t = F.relu(t) * h["pol2_bn"][0] + h["pol2_bn"][1]
-        logits = (t.to(torch.bfloat16).reshape(S, 512) @ h["pol_fc_w"]).float() + h["pol_fc_b"]
-        p = F.softmax(logits, dim=1)
-        # value head: conv1x1(1)+ReLU -> BN -> flatten -> dense(64)+ReLU -> BN -> dense(1) -> tanh
-        u = (n["y_body"].reshape(S * 64, 128) @ h["val1_w"]).float() + h["val1_b"]
-        u = (F.relu(u) * h["val1_bn"][0] + h["val1_bn"][1]).reshape(S, 64)
-        u = F.relu(u @ h["fc1_w"] + h["fc1_b"]) * h["val_bn"][0] + h["val_bn"][1]
-        v = torch.tanh(u @ h["fc2_w"] + h["fc2_b"]).reshape(-1)
-        return p, v
+        _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), stream))
+        t = n["tail"]
+        torch.addmm(t["fc_b"], n["pol_feat"], t["fc_w"], out=n["logits"])              # Dense(512)
+        torch.softmax(n["logits"], dim=1, out=n["p"])
+        _lib.check(self._L.ckr_value_mlp(n["val_feat"].data_ptr(), self.S, t["w1t"].data_ptr(), t["b1"].data_ptr(),
+                                         t["sc"].data_ptr(), t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"],
+                                         n["v"].data_ptr(), stream))
+        return n["p"], n["v"]
 
     @torch.no_grad()
     def __call__(self, engine):
@@ -111,7 +123,15 @@ class FusedEvaluator:
             sel = engine.net_id == 1
             p = torch.where(sel[:, None], p2, p)
             v = torch.where(sel, v2, v)
-        return p.contiguous(), v.contiguous()
+        return p, v
+
+    CONV_FLOPS_PER_BOARD = 2 * (64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128)      # the 8 convs of the stack
+
+    def conv_only(self, x_bf16):
+        """Launch just the conv-stack kernel (bench.py times it with HIP events)."""
+        n = self.nets[0]
+        stream = torch.cuda.current_stream(x_bf16.device).cuda_stream
+        _lib.check(self._L.ckr_conv_stack_bf16(x_bf16.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), stream))
 
     @torch.no_grad()
     def forward_features(self, x_bf16):

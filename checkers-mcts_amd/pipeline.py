@@ -55,6 +55,20 @@ def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128):
     raise ValueError("unsupported network specification: %r" % (spec,))
 
 
+def make_evaluator(spec, device, dtype, n_slots, spec_old=None):
+    """Evaluator for the engine: bfloat16 runs the hand-written MFMA conv stack
+    (fused.FusedEvaluator, weights taken from the float32 network); float32 /
+    float16 run the PyTorch module."""
+    if dtype == torch.bfloat16:
+        from .fused import FusedEvaluator
+        new = load_network(spec, device=device, dtype=torch.float32)
+        old = load_network(spec_old, device=device, dtype=torch.float32) if spec_old is not None else None
+        return FusedEvaluator(new, n_slots, net_old=old)
+    new = load_network(spec, device=device, dtype=dtype)
+    old = load_network(spec_old, device=device, dtype=dtype) if spec_old is not None else None
+    return NetEvaluator(new, old)
+
+
 class StepRunner:
     """Drives engine + evaluator; the per-step launch sequence (tree kernel,
     network kernels, output copies) is captured once into a HIP graph and
@@ -165,8 +179,7 @@ class generate_Checkers_data:
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first, nodes_per_tree=self.nodes_per_tree,
                 feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
-            net = load_network(self.nn_fn, device=dev, dtype=self.nn_dtype)
-            runner = StepRunner(eng, NetEvaluator(net), use_graph=self.use_graph)
+            runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count), use_graph=self.use_graph)
             runner.run_to_completion()
             self.stats = eng.stats()
             self.results = eng.results()
@@ -224,9 +237,8 @@ class tournament_Checkers:
                 first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
                 seed=self.seed, device=dev.index)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
-            new = load_network(self.nn1_fn, device=dev, dtype=self.nn_dtype)
-            old = load_network(self.nn2_fn, device=dev, dtype=self.nn_dtype)
-            runner = StepRunner(eng, NetEvaluator(new, old), use_graph=self.use_graph)
+            runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn),
+                                use_graph=self.use_graph)
             runner.run_to_completion()
             self.stats = eng.stats()
             res = eng.results()

@@ -95,9 +95,9 @@ int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, float* d_p, fl
 /* One 3x3 'same' convolution + bias + ReLU + BatchNorm(inference) layer of
  * training_pipeline.create_nn (training_pipeline.py:60-92), 128 kernels wide.
  * All pointers are DEVICE pointers.
- *   weights : bf16 [9 taps = ky*3+kx][128 out][cin_pad in], every 16-byte slot
- *             of a row XOR-swizzled (slot ^ (out & 15) for cin_pad 128,
- *             slot ^ ((out >> 2) & 3) for cin_pad 32) -- net.py prepares it
+ *   weights : bf16 [9 taps = ky*3+kx][128 out][cin_pad + 8]: k contiguous per
+ *             output channel, each row padded by one 16-byte slot (the
+ *             kernel's bank-conflict-free LDS image; fused.py prepares it)
  *   bias    : conv bias [128]; scale/shift: the BatchNorm affine
  *             gamma/sqrt(var+eps), beta - mean*scale [128] (float32)
  *   out     : optional bf16 NHWC [n_boards][8][8][128] copy of this layer's output */
@@ -110,11 +110,38 @@ typedef struct {
     int32_t      cin_pad;        /* 32 for the first layer (14 planes padded), else 128 */
 } ckr_conv_layer;
 
+/* The two 1x1 convolutions that open the heads (training_pipeline.py:93-96,
+ * 102-105), fused behind the stack while the activations are still in LDS:
+ * the value conv (1 kernel) reads the output of layer n_layers-2 (the body),
+ * the policy conv (8 kernels) the output of layer n_layers-1 (policy conv 1).
+ * Each is conv1x1 + bias + ReLU + BatchNorm affine, written in Keras Flatten
+ * (H, W, C) order: pol_out[n][pos*8 + c], val_out[n][pos] (float32). */
+typedef struct {
+    const float* pol_w;          /* [8][128] */
+    const float* pol_b;          /* [8] */
+    const float* pol_scale;      /* [8] */
+    const float* pol_shift;      /* [8] */
+    float*       pol_out;        /* [n_boards][512] */
+    const float* val_w;          /* [128] */
+    const float* val_b;          /* [1] */
+    const float* val_scale;      /* [1] */
+    const float* val_shift;      /* [1] */
+    float*       val_out;        /* [n_boards][64] */
+} ckr_conv_heads;
+
 /* Runs n_layers (<= 9) such layers back to back for n_boards positions with the
  * activations resident in LDS (never written to HBM between layers).
- * d_x: bf16 NHWC [n_boards][8][8][14], the engine's feature buffer. */
+ * d_x: bf16 NHWC [n_boards][8][8][14], the engine's feature buffer.
+ * heads may be NULL. */
 int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers,
-                        int32_t n_layers, void* stream);
+                        int32_t n_layers, const ckr_conv_heads* heads, void* stream);
+
+/* Value head tail (training_pipeline.py:106-112): Dense(64)+ReLU -> BatchNorm ->
+ * Dense(1) -> tanh on d_in[n][64] (the fused value conv's output).
+ * w1t: [64 in][64 out] (transposed Dense kernel), b1/scale/shift/w2: [64]. */
+int ckr_value_mlp(const float* d_in, int64_t n, const float* w1t, const float* b1,
+                  const float* scale, const float* shift, const float* w2, float b2,
+                  float* d_v, void* stream);
 
 /* ---- batched self-play / arena engine ----------------------------------- */
 

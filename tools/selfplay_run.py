@@ -35,9 +35,8 @@ def main():
                                terminate_cnt=0 if a.tournament else a.terminate, tournament=a.tournament,
                                first_worker_id=first, feature_dtype=dt, seed=a.seed, device=local_rank)
     eng = E.Engine(cfg, feature_dtype=dt)
-    new = make_net(128, seed=0, device=dev, dtype=dt)
-    old = make_net(128, seed=1, device=dev, dtype=dt) if a.tournament else None
-    runner = StepRunner(eng, NetEvaluator(new, old))
+    from checkers_mcts_amd.pipeline import make_evaluator
+    runner = StepRunner(eng, make_evaluator("random:0", dev, dt, a.slots, spec_old="random:1" if a.tournament else None))
     ckdist.barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     steps = runner.run_to_completion(check_every=200)
