@@ -22,13 +22,13 @@
 
 namespace ckr {
 
-enum { PH_PLAYING = 0, PH_FINISHED = 1 };
+enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS, CNT_N };
 
 struct Dev {
     // configuration
     int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
-    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n;
+    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual;
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256) void k_init(Dev D) {
     if (w.lane == 0) { D.g_game[slot] = 0; D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; }
     wave_mem_fence();
     new_game(w);
+    if (D.manual && w.lane == 0) D.g_phase[slot] = PH_IDLE;
     flush_counters(w);
 }
 
@@ -530,7 +531,10 @@ __global__ __launch_bounds__(256) void k_step(Dev D, const float* __restrict__ p
     int leaf = -1, net = -1, free_sims = 0;
     ckr_board lb{0u, 0u, 0u, 0u};
     while (D.g_phase[slot] == PH_PLAYING) {
-        if (D.g_sims[slot] >= D.budget) { finish_ply(w); continue; }     // MCTS.computational_budget, :189-201
+        if (D.g_sims[slot] >= D.budget) {                                // MCTS.computational_budget, :189-201
+            if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
+            finish_ply(w); continue;
+        }
         if (free_sims >= D.max_sims) break;
         const int t = (int)(D.g_board[slot].w & 1u);
         leaf = descend(w, t);
@@ -548,6 +552,73 @@ __global__ __launch_bounds__(256) void k_step(Dev D, const float* __restrict__ p
         if (net_out) net_out[slot] = leaf >= 0 ? net : -1;
     }
     if (leaf >= 0) write_features(w, lb, x);
+    flush_counters(w);
+}
+
+// ---- interactive commands (manual_play): Checkers.step / reset and begin_tree_search
+// for the per-tree search interface of the reference (MCTS.py:211-295, Checkers.py:62-75).
+__device__ int apply_action(Wave& w, int action) {
+    const Dev& D = w.D;
+    const ckr_board gb = ld_board(&D.g_board[w.slot]);
+    uint32_t m[8], st;
+    movegen(gb, m, st);
+    const int d = action >> 6, x = (action >> 3) & 7, y = action & 7, s = 4 * x + (y >> 1);
+    if (st_outcome(st) != 0u || action < 0 || action >= 512 || !((x ^ y) & 1) || !((sel8(m, d) >> s) & 1u))
+        return 1;                                          // 'Illegal next state (invalid move)!' Checkers.py:75
+    const ckr_board cb = make_child(gb, d, s);
+    uint32_t cm[8], cst;
+    movegen(cb, cm, cst);
+    for (int t = 0; t < 2; ++t) {                          // both trees follow the ply (MCTS.py:274-288)
+        const int ti = w.slot * 2 + t, c = D.t_cursor[ti];
+        int nc = -1;
+        if (c >= 0) {
+            const size_t tb = w.tb(t);
+            if (D.n_status[tb + c] & ST_EXPANDED) {
+                const uint32_t k = D.n_kids[tb + c];
+                const int n = (int)(k >> 24), base = (int)(k & 0xFFFFFFu);
+                const bool a = w.lane < n;
+                const uint32_t ameta = a ? D.n_board[tb + base + w.lane].w : 0u;
+                const unsigned long long hit = __ballot(a && meta_action(ameta) == (uint32_t)action);
+                if (hit) nc = base + first_lane(hit);
+            }
+        }
+        if (w.lane == 0) D.t_cursor[ti] = nc;
+    }
+    if (w.lane == 0) {
+        st_board(&D.g_board[w.slot], cb);
+        D.g_status[w.slot] = cst;
+        D.g_moves[w.slot] += 1;
+        D.g_pending[w.slot] = -1;
+        D.g_phase[w.slot] = PH_IDLE;
+    }
+    w.cnt[CNT_PLIES] += 1;
+    wave_mem_fence();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_command(Dev D, const int32_t* __restrict__ cmd, const int32_t* __restrict__ arg,
+                                                 int32_t* __restrict__ err) {
+    __shared__ WaveLds lds[4];
+    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    if (slot >= D.n_slots) return;
+    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    const int c = cmd[slot];
+    int e = 0;
+    if (c == CKR_CMD_SEARCH) {
+        if (st_outcome(D.g_status[slot]) != 0u) e = 2;      // game over: nothing to search
+        else {
+            start_search(w);
+            if (w.lane == 0) { D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; }
+        }
+    } else if (c == CKR_CMD_PLAY) {
+        e = apply_action(w, arg[slot]);
+    } else if (c == CKR_CMD_RESET) {
+        if (w.lane == 0) { D.g_game[slot] = 0; D.g_pending[slot] = -1; }
+        wave_mem_fence();
+        new_game(w);
+        if (w.lane == 0) D.g_phase[slot] = PH_IDLE;
+    }
+    if (w.lane == 0) err[slot] = e;
     flush_counters(w);
 }
 
@@ -576,6 +647,7 @@ struct ckr_engine {
     uint64_t steps = 0;
     ckr_tuple* d_pack = nullptr; int64_t pack_cap = 0;
     int64_t* d_off = nullptr; int64_t off_cap = 0;
+    int32_t* d_cmd = nullptr;
 };
 
 template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool zero = true) {
@@ -597,7 +669,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (int rc = require_device()) return rc;
     if (c->n_slots <= 0 || c->games_per_slot <= 0) return fail(CKR_ERR_INVALID, "n_slots and games_per_slot must be positive");
     if (c->budget <= 0) return fail(CKR_ERR_INVALID, "BUDGET must be a positive rollout count (CONSTRAINT == 'rollout')");
-    if (!c->tournament && c->terminate_cnt <= 0) return fail(CKR_ERR_INVALID, "self-play needs TERMINATE_CNT > 0");
+    if (!c->tournament && !c->manual_play && c->terminate_cnt <= 0) return fail(CKR_ERR_INVALID, "self-play needs TERMINATE_CNT > 0");
     if (c->nodes_per_tree < 256 || c->nodes_per_tree >= (1 << 24)) return fail(CKR_ERR_INVALID, "nodes_per_tree must be in [256, 2^24)");
     if (c->feature_dtype < 0 || c->feature_dtype > 2) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1 or 2");
     if (c->alpha <= 0.0 && c->epsilon != 0.0) return fail(CKR_ERR_INVALID, "DIRICHLET_ALPHA must be > 0");
@@ -610,8 +682,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.budget = c->budget; D.terminate_cnt = c->terminate_cnt; D.training = c->training; D.tournament = c->tournament;
     D.tau_decay_delay = c->tau_decay_delay; D.reset_tau = c->reset_tau_each_game; D.C = c->nodes_per_tree;
     D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 64;
-    D.record_root = c->record_root_stats;
-    D.tuples_per_game = c->tournament ? 0 : c->terminate_cnt + 1;
+    D.record_root = c->record_root_stats; D.manual = c->manual_play;
+    D.tuples_per_game = (c->tournament || c->manual_play) ? 0 : c->terminate_cnt + 1;
     D.margin = c->budget * 16 + 64; if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
     D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32);
@@ -663,6 +735,7 @@ int ckr_engine_destroy(ckr_engine* e) {
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->d_pack) (void)hipFree(e->d_pack);
     if (e->d_off) (void)hipFree(e->d_off);
+    if (e->d_cmd) (void)hipFree(e->d_cmd);
     delete e;
     return CKR_OK;
 }
@@ -774,6 +847,67 @@ int ckr_engine_root_stats(ckr_engine* e, float* w_out, float* p_out, int64_t cap
             CKR_HIP(hipMemcpy(p_out + k * CKR_MAX_CHILDREN, e->dev.rs_p + s, (size_t)cnt * row, hipMemcpyDeviceToHost));
             k += cnt;
         }
+    return CKR_OK;
+}
+
+int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, int32_t* err) {
+    if (!e || !cmd || !arg || !err) return fail(CKR_ERR_INVALID, "ckr_engine_command: null argument");
+    if (!e->dev.manual) return fail(CKR_ERR_STATE, "ckr_engine_command needs an engine created with manual_play = 1");
+    const size_t S = (size_t)e->cfg.n_slots;
+    if (!e->d_cmd) CKR_HIP(hipMalloc((void**)&e->d_cmd, 3 * S * sizeof(int32_t)));
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipMemcpy(e->d_cmd, cmd, S * sizeof(int32_t), hipMemcpyHostToDevice));
+    CKR_HIP(hipMemcpy(e->d_cmd + S, arg, S * sizeof(int32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_command, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, e->dev,
+                       (const int32_t*)e->d_cmd, (const int32_t*)(e->d_cmd + S), e->d_cmd + 2 * S);
+    CKR_HIP(hipGetLastError());
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipMemcpy(err, e->d_cmd + 2 * S, S * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return CKR_OK;
+}
+
+int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* status, int32_t* move_count, int32_t* searching) {
+    if (!e || slot < 0 || slot >= e->cfg.n_slots || !board || !status || !move_count || !searching)
+        return fail(CKR_ERR_INVALID, "ckr_engine_game: bad argument");
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    int32_t ph = 0;
+    CKR_HIP(hipMemcpy(board, e->dev.g_board + slot, sizeof(ckr_board), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(status, e->dev.g_status + slot, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(move_count, e->dev.g_moves + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&ph, e->dev.g_phase + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *searching = ph == PH_PLAYING;
+    return CKR_OK;
+}
+
+static int read_node(ckr_engine* e, size_t idx, ckr_node_info* out) {
+    CKR_HIP(hipMemcpy(&out->board, e->dev.n_board + idx, sizeof(ckr_board), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&out->status, e->dev.n_status + idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&out->n, e->dev.n_N + idx, sizeof(int32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&out->w, e->dev.n_W + idx, sizeof(float), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&out->p, e->dev.n_P + idx, sizeof(float), hipMemcpyDeviceToHost));
+    out->status &= ~(ST_EXPANDED | ST_MOVER);
+    return CKR_OK;
+}
+
+int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* root, ckr_node_info* children, int32_t* n_children) {
+    if (!e || slot < 0 || slot >= e->cfg.n_slots || tree < 0 || tree > 1 || !root || !children || !n_children)
+        return fail(CKR_ERR_INVALID, "ckr_engine_root: bad argument");
+    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    const int ti = slot * 2 + tree;
+    int32_t cursor = -1, half = 0;
+    CKR_HIP(hipMemcpy(&cursor, e->dev.t_cursor + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&half, e->dev.t_half + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (cursor < 0) { *n_children = -1; return CKR_OK; }
+    const size_t tb = ((size_t)(ti * 2 + half)) * (size_t)e->dev.C;
+    uint32_t kids = 0, st = 0;
+    CKR_HIP(hipMemcpy(&st, e->dev.n_status + tb + cursor, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&kids, e->dev.n_kids + tb + cursor, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (int rc = read_node(e, tb + (size_t)cursor, root)) return rc;
+    int n = (st & ST_EXPANDED) ? (int)(kids >> 24) : 0;
+    const size_t base = tb + (kids & 0xFFFFFFu);
+    for (int i = 0; i < n; ++i)
+        if (int rc = read_node(e, base + (size_t)i, &children[i])) return rc;
+    *n_children = n;
     return CKR_OK;
 }
 

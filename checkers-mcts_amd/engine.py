@@ -22,7 +22,8 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
-                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=64, device=0):
+                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=64, device=0,
+                       manual_play=False):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings."""
     k = mcts_kwargs
@@ -45,7 +46,8 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        tau=float(k["TEMPERATURE_TAU"]), tau_decay=float(k["TEMPERATURE_DECAY"]),
                        reset_tau_each_game=int(bool(reset_tau_each_game)), nodes_per_tree=int(nodes_per_tree),
                        feature_dtype=FEATURE_DTYPES[feature_dtype], max_sims_per_step=int(max_sims_per_step),
-                       record_root_stats=int(bool(record_root_stats)), device=int(device), seed=int(seed))
+                       record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
+                       device=int(device), seed=int(seed))
 
 
 class Engine:
@@ -132,6 +134,35 @@ class Engine:
         p = np.zeros_like(w)
         _lib.check(self._L.ckr_engine_root_stats(self._h, w.ctypes.data, p.ctypes.data, n_tuples))
         return w[:n_tuples], p[:n_tuples]
+
+    # ---- interactive API (manual_play engines; backs mcts.MCTS / mcts.Checkers) ----
+    def command(self, cmd, arg=None):
+        """cmd / arg: per-slot int arrays (CKR_CMD_*).  Returns the per-slot error codes."""
+        S = self.cfg.n_slots
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(cmd, np.int32), (S,)))
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(0 if arg is None else arg, np.int32), (S,)))
+        err = np.zeros(S, np.int32)
+        _lib.check(self._L.ckr_engine_command(self._h, c.ctypes.data, a.ctypes.data, err.ctypes.data))
+        return err
+
+    def game(self, slot=0):
+        board = np.zeros(4, np.uint32)
+        status, moves, searching = C.c_uint32(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(self._L.ckr_engine_game(self._h, slot, board.ctypes.data, C.addressof(status), C.addressof(moves),
+                                           C.addressof(searching)))
+        return board, status.value, moves.value, bool(searching.value)
+
+    def root(self, slot, tree):
+        """(root info, [child infos]) of one tree, or (None, None) if the tree has no node for the live state."""
+        root = _lib.NodeInfo()
+        kids = (_lib.NodeInfo * _lib.MAX_CHILDREN)()
+        n = C.c_int32(0)
+        _lib.check(self._L.ckr_engine_root(self._h, slot, tree, C.byref(root), kids, C.byref(n)))
+        if n.value < 0:
+            return None, None
+        conv = lambda k: dict(board=np.array(k.board[:], np.uint32), status=int(k.status), n=int(k.n),
+                              w=np.float32(k.w), p=np.float32(k.p))
+        return conv(root), [conv(kids[i]) for i in range(n.value)]
 
     def leaves(self):
         out = np.zeros((self.cfg.n_slots, 4), np.uint32)

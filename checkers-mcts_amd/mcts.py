@@ -1,0 +1,332 @@
+"""Search interface (T2) and game-environment protocol (T3) of the reference,
+backed by the GPU engine.
+
+`MCTS`, `MCTS_Node` and `Checkers` keep the names, call sequence, attributes and
+error messages of MCTS.py:35-430 and Checkers.py:28-452 so that loops written
+against the reference (training_pipeline.py:353-386, play_Checkers.py:125-160)
+run unchanged:
+
+    game_env = Checkers(neural_net)          # neural_net: device evaluator or .predict object
+    MCTS(**mcts_kwargs)                      # GAME_ENV = game_env
+    root = MCTS_Node(game_env.state)
+    MCTS.begin_tree_search(root); best = MCTS.best_child(root); game_env.step(best.state)
+    root = MCTS.new_root_node(best) ...
+
+One interactive engine slot (ckr manual_play) holds both players' trees; every
+simulation, expansion and backup runs in the HIP kernels.  The host side keeps
+only what the reference keeps in Python objects: the move choice rule
+(best_child, MCTS.py:227-248), the state planes handed to callers, and the
+history list.
+"""
+import numpy as np
+import torch
+
+from . import _lib, codec, engine as ckengine, rules
+
+CMD_SEARCH, CMD_PLAY, CMD_RESET = 1, 2, 3
+
+
+def _action_of(state):
+    return (int(state[14, 0, 0]) - 6) * 64 + 8 * int(state[14, 0, 1]) + int(state[14, 0, 2])
+
+
+class Checkers:
+    """Game environment (reference: Checkers.py:28-452).  Rules run in the K1/K2
+    kernels; this class only converts between 16-byte records and state planes."""
+
+    def __init__(self, neural_net=None):
+        self.neural_net = neural_net
+        self.player1_man, self.player1_king, self.player2_man, self.player2_king = "x", u"Ж", "o", u"Ǒ"
+        self.reset()
+
+    # -- helpers ---------------------------------------------------------
+    @staticmethod
+    def _analyse(board):
+        """record -> (state planes with masks / draw plane populated, status, successor records)."""
+        b = rules.boards_to_device(board[None])
+        mask, status = rules.movegen(b)
+        kids, cnt = rules.children(b)
+        m, s = mask.cpu().numpy().view(np.uint32), status.cpu().numpy().view(np.uint32)
+        k = kids.cpu().numpy().view(np.uint32)[0, :int(cnt[0])]
+        return codec.records_to_planes(board[None], m, s)[0], int(s[0]), k
+
+    @staticmethod
+    def _successor_planes(records):
+        """Successor states as the reference lists them: planes 0-4 and 14 set,
+        5-13 cleared (Checkers.py:128-143)."""
+        if len(records) == 0:
+            return []
+        z = np.zeros((len(records), 8), np.uint32)
+        st = codec.records_to_planes(records, z, np.zeros(len(records), np.uint32))
+        return [st[i] for i in range(len(records))]
+
+    def _set(self, board):
+        self._board = np.array(board, np.uint32)
+        self.state, self._status, self._succ = self._analyse(self._board)
+        self.legal_next_states = self._successor_planes(self._succ)
+
+    # -- reference API ---------------------------------------------------
+    def reset(self):
+        self._set(np.array([0x00000FFF, 0xFFF00000, 0, codec.make_meta(0, 1, 0, 0, 0, 1)], np.uint32))
+        self.history = [self.state]
+        self._records = [self._board]
+        self.move_count = 0
+        self.done = False
+        self.outcome = None
+        if codec.status_outcome(self._status):
+            self.legal_next_states = []
+
+    def step(self, next_state):
+        """Execute a legal move given as a successor state (Checkers.py:62-75)."""
+        for rec, st in zip(self._succ, self.legal_next_states):
+            if (np.asarray(next_state)[:5] == st[:5]).all():
+                self._set(rec)
+                self.history.append(self.state)
+                self._records.append(self._board)
+                out = int(codec.status_outcome(self._status))
+                self.done, self.outcome = out != 0, codec.OUTCOME_NAMES[out]
+                self.move_count += 1
+                return self.state, self.outcome, self.done
+        raise ValueError("Illegal next state (invalid move)!")
+
+    def get_legal_next_states(self, history):
+        if history is self.history or (len(history) == len(self.history) and history[-1] is self.state):
+            return [] if codec.status_outcome(self._status) else list(self.legal_next_states)
+        board = codec.planes_to_boards(history[-1], hist=len(history))[0]
+        _, status, succ = self._analyse(board)
+        return [] if codec.status_outcome(status) else self._successor_planes(succ)
+
+    def determine_outcome(self, history, legal_moves=[]):
+        if history is self.history:
+            status = self._status
+        else:
+            _, status, _ = self._analyse(codec.planes_to_boards(history[-1], hist=len(history))[0])
+        out = int(codec.status_outcome(status))
+        return out != 0, codec.OUTCOME_NAMES[out]
+
+    def current_player(self, state):
+        return "player1" if int(state[4, 0, 0]) == 0 else "player2"            # Checkers.py:397-403
+
+    def predict(self, state):
+        """Masked, renormalised priors (8,8,8) and value of one state (Checkers.py:425-438)."""
+        board = codec.planes_to_boards(state)[0]
+        b = rules.boards_to_device(board[None])
+        x = rules.features(b)
+        p, v = _evaluate_features(self.neural_net, x)
+        planes = rules.mask_renorm(b, p.contiguous())
+        return planes.cpu().numpy().reshape(8, 8, 8), np.float32(v.cpu().numpy()[0])
+
+    def set_prior_probs(self, child_nodes, prob_planes):
+        for child in child_nodes:                                               # Checkers.py:440-452
+            layer, x, y = int(child.state[14, 0, 0]) - 6, int(child.state[14, 0, 1]), int(child.state[14, 0, 2])
+            if x % 2 == y % 2:
+                raise ValueError("Invalid (x,y) locations for probabilities!")
+            if not (0 <= layer <= 7):
+                raise ValueError("Invalid layer for probabilities!")
+            child._prior_prob = prob_planes[layer, x, y]
+
+
+def _evaluate_features(net, x):
+    """x [S,8,8,14] float32 on device -> (p [S,512], v [S]) through whatever `net` is."""
+    if net is None:
+        raise ValueError("the game environment has no neural_net")
+    if isinstance(net, torch.nn.Module):
+        with torch.no_grad():
+            p, v = net(x.permute(0, 3, 1, 2).to(next(net.parameters()).dtype))
+        return p.float().contiguous(), v.float().contiguous()
+    if hasattr(net, "predict"):                                                # Keras-style host object (Checkers.py:433)
+        xs = x.float().cpu().numpy()
+        ps, vs = [], []
+        for i in range(xs.shape[0]):
+            p, v = net.predict(xs[i:i + 1])
+            ps.append(np.asarray(p, np.float32).reshape(512)); vs.append(np.float32(np.asarray(v).reshape(-1)[0]))
+        return (torch.from_numpy(np.stack(ps)).to(x.device).contiguous(),
+                torch.from_numpy(np.array(vs, np.float32)).to(x.device).contiguous())
+    raise ValueError("unsupported neural_net object: %r" % (net,))
+
+
+class MCTS:
+    """Class-level search controller (reference: MCTS.py:35-342)."""
+    game_env = None
+    _engine = None
+
+    @classmethod
+    def __init__(cls, **kwargs):
+        cls.game_env = kwargs["GAME_ENV"]
+        cls.uct_c = kwargs["UCT_C"]
+        cls.constraint = kwargs["CONSTRAINT"]
+        cls.budget = kwargs["BUDGET"]
+        cls.multiproc = kwargs["MULTIPROC"]
+        cls.neural_net = kwargs["NEURAL_NET"]
+        cls.verbose = kwargs["VERBOSE"]
+        cls.training = kwargs["TRAINING"]
+        cls.alpha = kwargs["DIRICHLET_ALPHA"]
+        cls.epsilon = kwargs["DIRICHLET_EPSILON"]
+        cls.tau = kwargs["TEMPERATURE_TAU"]
+        cls.tau_decay = kwargs["TEMPERATURE_DECAY"]
+        cls.tau_decay_delay = kwargs["TEMP_DECAY_DELAY"]
+        if cls._engine is not None:
+            cls._engine.close()
+        cfg = ckengine.config_from_kwargs(kwargs, n_slots=1, games_per_slot=1, manual_play=True,
+                                          seed=int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))),
+                                          max_sims_per_step=1 << 30, nodes_per_tree=kwargs.get("NODES_PER_TREE"))
+        cls._engine = ckengine.Engine(cfg)
+        cls._applied = []                  # board records of the plies the engine has been told about
+        cls.rollout_count = 0
+        cls.reroot_misses = 0
+
+    # -- engine <-> environment synchronisation -------------------------
+    @classmethod
+    def _sync(cls):
+        recs = cls.game_env._records
+        common = 0
+        while common < min(len(recs) - 1, len(cls._applied)) and (recs[common + 1] == cls._applied[common]).all():
+            common += 1
+        if common < len(cls._applied):                      # environment was reset / diverged: replay from the start
+            cls._engine.command(CMD_RESET)
+            cls._applied, common = [], 0
+        for rec in recs[common + 1:]:
+            err = cls._engine.command(CMD_PLAY, int(codec.meta_action(rec[3])))
+            if err[0]:
+                raise ValueError("Illegal next state (invalid move)!")
+            cls._applied.append(np.array(rec, np.uint32))
+
+    @classmethod
+    def _evaluator(cls):
+        net = cls.game_env.neural_net
+        if callable(net) and not isinstance(net, torch.nn.Module) and not hasattr(net, "predict"):
+            return net                                      # device evaluator: engine -> (p, v)
+        return lambda eng: _evaluate_features(net, eng.x)
+
+    # -- reference API ---------------------------------------------------
+    @classmethod
+    def begin_tree_search(cls, root_node):
+        """BUDGET simulations from the live position (MCTS.py:211-224)."""
+        if cls.constraint != "rollout":
+            raise ValueError("Invalid MCTS computational constraint!")
+        cls._sync()
+        if cls._engine.command(CMD_SEARCH)[0]:
+            raise ValueError("begin_tree_search on a finished game")
+        ev = cls._evaluator()
+        dev = cls._engine.device                             # nothing is pending when a search starts: p, v unused
+        p, v = torch.zeros((1, 512), device=dev), torch.zeros((1,), device=dev)
+        while True:
+            cls._engine.step(p, v)
+            if not cls._engine.game(0)[3]:
+                break
+            p, v = ev(cls._engine)
+        cls.rollout_count = cls.budget
+        root_node._load()
+        if cls.verbose:
+            print("Stopped  search after {} rollouts!".format(cls.rollout_count))
+
+    @classmethod
+    def best_child(cls, node, criterion="robust"):
+        """Most-visited child, or a temperature sample while training (MCTS.py:227-248)."""
+        if not cls.neural_net and criterion not in ("robust",):
+            raise ValueError("Invalid winner selection criterion!")
+        visits = [child.n for child in node.children]
+        if not cls.training or cls.tau <= 0:
+            return node.children[int(np.argmax(visits))]
+        expon_visits = [n ** (1 / cls.tau) for n in visits]
+        total = np.sum(expon_visits)
+        probs = [n / total for n in expon_visits]
+        if cls.game_env.move_count > cls.tau_decay_delay:
+            cls.tau -= cls.tau_decay
+            if np.isclose(cls.tau, 0):
+                cls.tau = 0
+        return node.children[int(np.random.choice(len(node.children), p=probs))]
+
+    @classmethod
+    def new_root_node(cls, old_root):
+        """Root for the live state in the side-to-move's tree, statistics retained
+        (MCTS.py:251-295).  Where the reference raises 'All child nodes should be
+        visited!' a fresh root is returned and counted (cls.reroot_misses)."""
+        cls._sync()
+        node = MCTS_Node(cls.game_env.state, parent=None)
+        if node._missing:
+            cls.reroot_misses += 1
+        return node
+
+    @classmethod
+    def current_player(cls, state):
+        return cls.game_env.current_player(state)
+
+    @classmethod
+    def get_legal_next_states(cls, history):
+        return cls.game_env.get_legal_next_states(history)
+
+    @classmethod
+    def determine_outcome(cls, node):
+        return cls.game_env.determine_outcome(node.history)
+
+    @classmethod
+    def print_tree(cls, root_node, max_tree_depth=10):
+        print("|- ({}/{}) ({:.1f}%)".format(root_node.w, root_node.n, root_node.pwin))
+        for c in root_node.children:
+            print("\t|- ({}/{}) ({:.1f}%)".format(c.w, c.n, c.pwin))
+
+
+class MCTS_Node:
+    """Handle on a node of the engine's tree (reference: MCTS.py:345-430)."""
+
+    def __init__(self, state, parent=None, initial_state=None):
+        self.state = state
+        self.player = MCTS.current_player(state)
+        self.parent = parent
+        self.history = list(MCTS.game_env.history) if parent is None else parent.history + [state]
+        self.depth = len(self.history)
+        self.children = []
+        self._number_of_visits = 0
+        self._total_reward = 0
+        self._prior_prob = 0
+        self._missing = False
+        self.printed = False
+        if parent is None:
+            MCTS._sync()
+            self._load()
+        self.terminal = bool(codec.status_outcome(getattr(self, "_status", 0))) if parent is not None else MCTS.game_env.done
+
+    def _load(self):
+        """Pull this root's statistics and children from the engine."""
+        env, eng = MCTS.game_env, MCTS._engine
+        tree = int(env.state[4, 0, 0])
+        root, kids = eng.root(0, tree)
+        if root is None:
+            self._missing = True
+            return
+        self._missing = False
+        self._number_of_visits, self._total_reward, self._prior_prob = root["n"], root["w"], root["p"]
+        self.children = []
+        if kids:
+            recs = np.array([k["board"] for k in kids], np.uint32)
+            mask, status = rules.movegen(rules.boards_to_device(recs))
+            planes = codec.records_to_planes(recs, mask.cpu().numpy().view(np.uint32), status.cpu().numpy().view(np.uint32))
+            for i, k in enumerate(kids):
+                c = MCTS_Node.__new__(MCTS_Node)
+                c.state, c.parent, c.children, c.printed, c._missing = planes[i], self, [], False, False
+                c.player = MCTS.current_player(c.state)
+                c.history = self.history + [c.state]
+                c.depth = len(c.history)
+                c._number_of_visits, c._total_reward, c._prior_prob = k["n"], k["w"], k["p"]
+                c._status = k["status"]
+                c.terminal = bool(codec.status_outcome(k["status"]))
+                self.children.append(c)
+
+    w = property(lambda self: self._total_reward)
+    n = property(lambda self: self._number_of_visits)
+    p = property(lambda self: self._prior_prob)
+
+    @property
+    def q(self):
+        try:
+            return self.w / self.n
+        except ZeroDivisionError:
+            return 0
+
+    @property
+    def pwin(self):
+        return np.round((self.q + 1) / 2 * 100, 1)
+
+    def selection(self):
+        raise NotImplementedError("single simulations run inside the GPU engine; use MCTS.begin_tree_search")

@@ -164,6 +164,8 @@ typedef struct {
     int32_t  feature_dtype;      /* 0 float32, 1 float16, 2 bfloat16 */
     int32_t  max_sims_per_step;  /* cap on NN-free simulations run back-to-back in one step */
     int32_t  record_root_stats;  /* 1: keep per-ply child W / P next to the tuples (tests) */
+    int32_t  manual_play;        /* 1: interactive search API (MCTS / MCTS_Node facade): slots park after
+                                    BUDGET simulations and moves are applied by ckr_engine_command */
     int32_t  device;             /* HIP device ordinal */
     uint64_t seed;               /* Philox key for Dirichlet noise / temperature sampling */
 } ckr_config;
@@ -236,6 +238,32 @@ int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t
 int ckr_engine_root_stats(ckr_engine* e, float* w_out, float* p_out, int64_t cap);
 /* Leaf boards handed out by the last step (parity tests): HOST out[n_slots]. */
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out);
+
+/* ---- interactive search API (manual_play = 1) --------------------------- *
+ * Backs the reference's per-tree search interface: MCTS.begin_tree_search /
+ * best_child / new_root_node and Checkers.step (MCTS.py:211-295,
+ * Checkers.py:62-75).  Synchronous, HOST arrays of n_slots entries. */
+#define CKR_CMD_NONE   0
+#define CKR_CMD_SEARCH 1         /* begin_tree_search for the side to move: run BUDGET simulations */
+#define CKR_CMD_PLAY   2         /* Checkers.step: apply action code arg; err = 1 if it is not legal */
+#define CKR_CMD_RESET  3         /* Checkers.reset: new game */
+int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, int32_t* err);
+
+typedef struct {
+    ckr_board board;
+    uint32_t  status;
+    int32_t   n;                 /* visits */
+    float     w;                 /* total reward */
+    float     p;                 /* prior */
+} ckr_node_info;
+
+/* Live game of one slot: board, status word, move count, 1 if a search is still running. */
+int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* status,
+                    int32_t* move_count, int32_t* searching);
+/* Root of tree `tree` (0 = player 1's, 1 = player 2's) of a slot and its children in
+ * tree order; *n_children = -1 when the tree has no node for the live state. */
+int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* root,
+                    ckr_node_info* children, int32_t* n_children);
 
 #ifdef __cplusplus
 }

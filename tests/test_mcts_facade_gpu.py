@@ -1,0 +1,134 @@
+"""GPU: the reference's per-tree search interface (MCTS / MCTS_Node / Checkers)
+on top of the engine, driven exactly like training_pipeline.py:353-386, against
+the golden root statistics recorded from the reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def kwargs(budget, env, training=False, eps=0.0, tau=0.0):
+    return dict(GAME_ENV=env, UCT_C=4, CONSTRAINT="rollout", BUDGET=budget, MULTIPROC=False, NEURAL_NET=True,
+                VERBOSE=False, TRAINING=training, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=eps,
+                TEMPERATURE_TAU=tau, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
+
+
+def action_of(state):
+    return (int(state[14, 0, 0]) - 6) * 64 + 8 * int(state[14, 0, 1]) + int(state[14, 0, 2])
+
+
+def play(budget, net, max_plies):
+    """The reference's own loop (training_pipeline.py:353-386) on the facade."""
+    from checkers_mcts_amd.mcts import MCTS, MCTS_Node, Checkers
+    env = Checkers(net)
+    MCTS(**kwargs(budget, env))
+    initial = env.state
+    root1 = MCTS_Node(initial, parent=None)
+    best1 = best2 = None
+    log = []
+    while not env.done and env.move_count < max_plies:
+        if env.current_player(env.state) == "player1":
+            if env.move_count != 0:
+                root1 = MCTS.new_root_node(best1)
+            root = root1
+        else:
+            if env.move_count == 1:
+                root2 = MCTS_Node(env.state, parent=None, initial_state=initial)
+            else:
+                root2 = MCTS.new_root_node(best2)
+            root = root2
+        MCTS.begin_tree_search(root)
+        best = MCTS.best_child(root)
+        if root is root1:
+            best1 = best
+        else:
+            best2 = best
+        log.append(dict(root_n=root.n, root_w=root.w, chosen=action_of(best.state),
+                        action=[action_of(c.state) for c in root.children], n=[c.n for c in root.children],
+                        w=[c.w for c in root.children], p=[c.p for c in root.children], side=int(root.state[4, 0, 0])))
+        env.step(best.state)
+    return env, log
+
+
+def check_against_golden(g, ci, env, log):
+    off = g["c%d_off" % ci]
+    assert len(log) == len(off) - 1
+    for i, e in enumerate(log):
+        sl = slice(off[i], off[i + 1])
+        assert e["action"] == list(g["c%d_action" % ci][sl]) and e["n"] == list(g["c%d_n" % ci][sl])
+        assert (np.array(e["w"], np.float32).view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+        assert (np.array(e["p"], np.float32).view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
+        assert e["root_n"] == g["c%d_root_n" % ci][i] and np.float32(e["root_w"]) == g["c%d_root_w" % ci][i]
+        assert e["chosen"] == g["c%d_chosen" % ci][i] and e["side"] == g["c%d_side" % ci][i]
+
+
+def test_search_api_matches_reference_golden(golden_dir):
+    from checkers_mcts_amd import rules
+    g = np.load(os.path.join(golden_dir, "search_v1.npz"))
+    for ci in (0, 2):
+        budget, salt, max_plies, moves, outcome = (int(v) for v in g["c%d_cfg" % ci])
+        env, log = play(budget, lambda eng, s=salt: rules.hashnet(eng.x, s), max_plies)
+        check_against_golden(g, ci, env, log)
+        assert env.move_count == moves
+        assert {None: 0, "player1_wins": 1, "player2_wins": 2, "draw": 3}[env.outcome] == outcome
+
+
+def test_keras_style_predict_object(oracle, golden_dir):
+    """A host object with the Keras `.predict(x[1,8,8,14]) -> (p[1,512], v[1,1])`
+    contract (Checkers.py:433) drives the same search."""
+    g = np.load(os.path.join(golden_dir, "search_v1.npz"))
+    budget, salt, max_plies, moves, outcome = (int(v) for v in g["c0_cfg"])
+
+    class HostNet:
+        def predict(self, x):
+            p, v = oracle.hashnet(np.asarray(x, np.float32).reshape(-1), salt)
+            return [p.reshape(1, 512), np.array([[v]], np.float32)]
+
+    env, log = play(budget, HostNet(), 6)
+    off = g["c0_off"]
+    for i, e in enumerate(log):
+        assert e["n"] == list(g["c0_n"][off[i]:off[i + 1]]) and e["chosen"] == g["c0_chosen"][i]
+
+
+def test_environment_protocol(oracle):
+    from checkers_mcts_amd.mcts import Checkers
+    import checkers_mcts_amd.codec as codec
+    env = Checkers()
+    assert len(env.legal_next_states) == 7 and env.move_count == 0 and not env.done
+    assert env.current_player(env.state) == "player1" and env.state.shape == (15, 8, 8)
+    rng = np.random.RandomState(4)
+    while not env.done and env.move_count < 300:
+        rec = env._board
+        ok = oracle.children(rec)
+        assert len(ok) == len(env.legal_next_states)
+        omask, ostatus = oracle.movegen(rec[None])
+        assert (codec.records_to_planes(rec[None], omask, ostatus)[0] == env.state).all()
+        env.step(env.legal_next_states[rng.randint(len(env.legal_next_states))])
+    assert env.done and env.outcome in ("player1_wins", "player2_wins", "draw")
+    with pytest.raises(ValueError, match="Illegal next state"):
+        env.step(np.zeros((15, 8, 8)))
+    env.reset()
+    assert env.move_count == 0 and len(env.history) == 1 and not env.done
+    with pytest.raises(ValueError, match="Illegal next state"):
+        env.step(np.ones((15, 8, 8)))
+
+
+def test_human_move_then_search(golden_dir):
+    """play_Checkers.py pattern: a move the engine did not choose is stepped on
+    the environment; the next search re-roots (or rebuilds) from the live state."""
+    from checkers_mcts_amd import rules
+    from checkers_mcts_amd.mcts import MCTS, MCTS_Node, Checkers
+    env = Checkers(lambda eng: rules.hashnet(eng.x, 1))
+    MCTS(**kwargs(20, env))
+    env.step(env.legal_next_states[3])                       # "human" plays first
+    root = MCTS_Node(env.state, parent=None)
+    MCTS.begin_tree_search(root)
+    assert root.n == 20 and sum(c.n for c in root.children) == 19
+    best = MCTS.best_child(root)
+    env.step(best.state)
+    env.step(env.legal_next_states[0])                       # human reply
+    root = MCTS.new_root_node(best)
+    MCTS.begin_tree_search(root)
+    assert root.n >= 20 and abs(root.q) <= 1
