@@ -47,11 +47,12 @@ struct WaveLds {
     union { float p[512]; float feat[896]; double ev[64]; } u;   // raw probabilities | features | sampling
     ckr_board kids[CKR_MAX_CHILDREN];
     uint32_t mask[8];
+    uint32_t cnt[CNT_N];                                         // per-wave event counters (lane 0), flushed once
 };
 
 struct Wave {
     const Dev& D; WaveLds& L; int slot, lane;
-    unsigned long long cnt[CNT_N];
+    __device__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
     __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
     __device__ size_t tb(int t) const { return tbase(t, D.t_half[slot * 2 + t]); }
 };
@@ -138,7 +139,7 @@ __device__ void fresh_root(Wave& w, int t) {
         write_node(D, w.tbase(t, 0), b, -1, 0.0f, st | (meta_mover(b.meta) << 4));
         D.t_cursor[ti] = 0; D.t_used[ti] = 1;
     }
-    w.cnt[CNT_NODES] += 1;
+    w.count(CNT_NODES);
     wave_mem_fence();
 }
 
@@ -177,7 +178,7 @@ __device__ void compact(Wave& w, int t) {
         wave_mem_fence();
     }
     if (w.lane == 0) { D.t_half[ti] = half ^ 1; D.t_used[ti] = free_; D.t_cursor[ti] = 0; }
-    w.cnt[CNT_COMPACT] += 1;
+    w.count(CNT_COMPACT);
     wave_mem_fence();
 }
 
@@ -189,7 +190,7 @@ __device__ void start_search(Wave& w) {
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
     if (D.t_cursor[ti] < 0) {
-        if (D.t_searched[ti]) w.cnt[CNT_MISS] += 1;
+        if (D.t_searched[ti]) w.count(CNT_MISS);
         fresh_root(w, t);
     } else if (D.C - D.t_used[ti] < D.margin) {
         compact(w, t);
@@ -250,7 +251,7 @@ __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow,
         D.n_status[tb + leaf] |= ST_EXPANDED;
         D.t_used[ti] = used + n;
     }
-    w.cnt[CNT_EXP] += 1; w.cnt[CNT_NODES] += (unsigned long long)n;
+    w.count(CNT_EXP); w.count(CNT_NODES, (uint32_t)n);
     wave_mem_fence();
     backup_value(w, t, leaf, v, b.meta & 1u);
     wave_mem_fence();
@@ -296,7 +297,7 @@ __device__ int descend(Wave& w, int t) {
         const int child = base + best;
         if (st_outcome(bst) != 0u) {
             backup_outcome(w, t, child, st_outcome(bst));
-            w.cnt[CNT_TERM] += 1;
+            w.count(CNT_TERM);
             wave_mem_fence();
             return -1;
         }
@@ -345,7 +346,7 @@ __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed)
         D.g_game[w.slot] = game + 1;
         D.g_pending[w.slot] = -1;
     }
-    w.cnt[CNT_GAMES] += 1;
+    w.count(CNT_GAMES);
     wave_mem_fence();
     if (game + 1 < D.games_per_slot) new_game(w);
     else { if (w.lane == 0) D.g_phase[w.slot] = PH_FINISHED; wave_mem_fence(); }
@@ -441,7 +442,7 @@ __device__ void finish_ply(Wave& w) {
             if (w.lane == 0) D.t_cursor[oi] = nc;
         }
     }
-    w.cnt[CNT_PLIES] += 1;
+    w.count(CNT_PLIES);
     wave_mem_fence();
     uint32_t outcome = st_outcome(cst);
     int adjudicated = 0;
@@ -491,14 +492,19 @@ __device__ __forceinline__ void flush_counters(Wave& w) {
     if (w.lane != 0) return;
 #pragma unroll
     for (int i = 0; i < CNT_N; ++i)
-        if (w.cnt[i]) atomicAdd(&w.D.counters[i], w.cnt[i]);
+        if (w.L.cnt[i]) atomicAdd(&w.D.counters[i], (unsigned long long)w.L.cnt[i]);
 }
 
-__global__ __launch_bounds__(256) void k_init(Dev D) {
+// Kernels take the engine descriptor by POINTER to device memory: every field read is a
+// uniform scalar load (a by-value struct whose address is taken is copied to scratch and
+// turned ~0.5 KB/lane of private-memory traffic per launch).
+__global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
+    const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    Wave w{D, lds[wave], slot, lane_id()};
+    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (w.lane == 0) { D.g_game[slot] = 0; D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; }
     wave_mem_fence();
     new_game(w);
@@ -507,13 +513,15 @@ __global__ __launch_bounds__(256) void k_init(Dev D) {
 }
 
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
-__global__ __launch_bounds__(256) void k_step(Dev D, const float* __restrict__ p, const float* __restrict__ v,
-                                              void* x, int32_t* net_out) {
+__global__ __launch_bounds__(256) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
+                                              const float* __restrict__ v, void* x, int32_t* net_out) {
+    const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0, 0}};
-    if (slot == 0) w.cnt[CNT_STEPS] = 1;
+    Wave w{D, lds[wave], slot, lane_id()};
+    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
+    if (slot == 0) w.count(CNT_STEPS);
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
     if (pending >= 0 && D.g_phase[slot] == PH_PLAYING) {
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(256) void k_step(Dev D, const float* __restrict__ p
         if (expand(w, t, pending, p + (size_t)slot * 512, v[slot])) {
             if (w.lane == 0) D.g_sims[slot] += 1;
         } else {
-            w.cnt[CNT_OVERFLOW] += 1;
+            w.count(CNT_OVERFLOW);
             end_game(w, 0u, 0, 1);
         }
         if (w.lane == 0 && D.g_pending[slot] == pending) D.g_pending[slot] = -1;
@@ -591,17 +599,19 @@ __device__ int apply_action(Wave& w, int action) {
         D.g_pending[w.slot] = -1;
         D.g_phase[w.slot] = PH_IDLE;
     }
-    w.cnt[CNT_PLIES] += 1;
+    w.count(CNT_PLIES);
     wave_mem_fence();
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_command(Dev D, const int32_t* __restrict__ cmd, const int32_t* __restrict__ arg,
-                                                 int32_t* __restrict__ err) {
+__global__ __launch_bounds__(256) void k_command(const Dev* __restrict__ Dp, const int32_t* __restrict__ cmd,
+                                                 const int32_t* __restrict__ arg, int32_t* __restrict__ err) {
+    const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id(), {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    Wave w{D, lds[wave], slot, lane_id()};
+    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     const int c = cmd[slot];
     int e = 0;
     if (c == CKR_CMD_SEARCH) {
@@ -648,6 +658,7 @@ struct ckr_engine {
     ckr_tuple* d_pack = nullptr; int64_t pack_cap = 0;
     int64_t* d_off = nullptr; int64_t off_cap = 0;
     int32_t* d_cmd = nullptr;
+    Dev* d_dev = nullptr;              // device copy of `dev` (owned by allocs)
 };
 
 template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool zero = true) {
@@ -722,7 +733,15 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (hipMemset(D.results, 0xFF, (size_t)e->n_games_total * sizeof(ckr_game_result)) != hipSuccess) {
         ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "memset failed");
     }
-    hipLaunchKernelGGL(k_init, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, D);
+    {
+        Dev* d_dev = nullptr;
+        if (dalloc(e, &d_dev, 1, false) != CKR_OK ||
+            hipMemcpy(d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice) != hipSuccess) {
+            ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "engine descriptor upload failed");
+        }
+        e->d_dev = d_dev;
+    }
+    hipLaunchKernelGGL(k_init, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
         ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "engine init kernel failed");
     }
@@ -744,7 +763,7 @@ int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x
     if (!e || !d_x) return fail(CKR_ERR_INVALID, "ckr_engine_step: null engine or feature buffer");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
     e->last_stream = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->dev, d_p, d_v, d_x, d_net);
+    hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net);
     CKR_HIP(hipGetLastError());
     e->steps++;
     return CKR_OK;
@@ -858,7 +877,7 @@ int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, in
     CKR_HIP(hipStreamSynchronize(e->last_stream));
     CKR_HIP(hipMemcpy(e->d_cmd, cmd, S * sizeof(int32_t), hipMemcpyHostToDevice));
     CKR_HIP(hipMemcpy(e->d_cmd + S, arg, S * sizeof(int32_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_command, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, e->dev,
+    hipLaunchKernelGGL(k_command, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, (const Dev*)e->d_dev,
                        (const int32_t*)e->d_cmd, (const int32_t*)(e->d_cmd + S), e->d_cmd + 2 * S);
     CKR_HIP(hipGetLastError());
     CKR_HIP(hipStreamSynchronize(e->last_stream));
