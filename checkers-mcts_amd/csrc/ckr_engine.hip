@@ -24,6 +24,7 @@ namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS, CNT_N };
+constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
 
 struct Dev {
     // configuration
@@ -492,7 +493,8 @@ __device__ __forceinline__ void flush_counters(Wave& w) {
     if (w.lane != 0) return;
 #pragma unroll
     for (int i = 0; i < CNT_N; ++i)
-        if (w.L.cnt[i]) atomicAdd(&w.D.counters[i], (unsigned long long)w.L.cnt[i]);
+        if (w.L.cnt[i])                                     // 64 shards, one 128-B line each: no hot word
+            atomicAdd(&w.D.counters[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + i], (unsigned long long)w.L.cnt[i]);
 }
 
 // Kernels take the engine descriptor by POINTER to device memory: every field read is a
@@ -711,7 +713,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.tuples, NT ? NT : 1, true);
     if (D.record_root) { A(D.rs_w, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); A(D.rs_p, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); }
     A(D.results, (size_t)e->n_games_total, true);
-    A(D.counters, (size_t)CNT_N, true);
+    A(D.counters, (size_t)CNT_SHARDS * CNT_STRIDE, true);
     A(D.leaves, S, true);
     // node.n ** 0.5 is C pow() in the reference (python int ** float), which is
     // NOT always sqrt(): keep a host-computed table for the counts that occur.
@@ -772,8 +774,10 @@ int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_stats: null argument");
     CKR_HIP(hipStreamSynchronize(e->last_stream));
-    unsigned long long c[CNT_N];
-    CKR_HIP(hipMemcpy(c, e->dev.counters, sizeof(c), hipMemcpyDeviceToHost));
+    unsigned long long shards[CNT_SHARDS * CNT_STRIDE], c[CNT_N] = {0};
+    CKR_HIP(hipMemcpy(shards, e->dev.counters, sizeof(shards), hipMemcpyDeviceToHost));
+    for (int s = 0; s < CNT_SHARDS; ++s)
+        for (int i = 0; i < CNT_N; ++i) c[i] += shards[s * CNT_STRIDE + i];
     std::vector<int32_t> ph((size_t)e->cfg.n_slots);
     CKR_HIP(hipMemcpy(ph.data(), e->dev.g_phase, ph.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     uint64_t active = 0;
