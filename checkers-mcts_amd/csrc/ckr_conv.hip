@@ -108,57 +108,47 @@ __device__ __forceinline__ void interleave_reads_with_mfma() {
     __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);            // remaining 5 MFMAs cover the LDS latency
 }
 
-template <int CIN>
-__device__ __forceinline__ void tap_compute(const char* __restrict__ act, const char* __restrict__ wbuf,
-                                            int prow0, int dy, int dx, int wrow0, int lane, f32x16 (&acc)[2][4]) {
-    constexpr int KSTEPS = CIN / 16;
-    const int hi = lane >> 5;
+// byte offsets of the four B-tile rows this lane reads for tap (dy, dx); out-of-board taps
+// (zero padding of the 'same' convolution) read the zero row
+__device__ __forceinline__ int4v tap_rows(int prow0, int tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     int4v brow;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {                              // zero padding: out-of-board taps read the zero row
+    for (int pt = 0; pt < 4; ++pt) {
         const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7;
         const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
         brow[pt] = (ok ? p + 8 * dy + dx : ACT_ROWS) * ACT_PITCH;
     }
-    bf16x8 a0[2], b0[4], a1[2], b1[4];
-    load_frags<CIN>(act, wbuf, 0, hi, wrow0, brow, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);                            // prologue reads stay ahead of the pipelined region
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; kk += 2) {                      // fragments one k-step ahead of the MFMAs
-        load_frags<CIN>(act, wbuf, kk + 1, hi, wrow0, brow, a1, b1);
-        mfma_block(a0, b0, acc);
-        interleave_reads_with_mfma();
-        if (kk + 2 < KSTEPS) {
-            load_frags<CIN>(act, wbuf, kk + 2, hi, wrow0, brow, a0, b0);
-            mfma_block(a1, b1, acc);
-            interleave_reads_with_mfma();
-        } else {
-            mfma_block(a1, b1, acc);
-        }
-    }
+    return brow;
 }
 
-// fused epilogue: bias + ReLU + BatchNorm affine, bf16, back into the LDS image in place
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2 v = {a, b};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&r);
+}
+
+// fused epilogue: ReLU + BatchNorm affine (the conv bias is already in the accumulators),
+// bf16, back into the LDS image in place
 __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][4]) {
+#pragma clang fp contract(fast)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = 64 * wc + 32 * ct + 8 * g + 4 * (lane >> 5);
-            const float4 bi = *reinterpret_cast<const float4*>(prm + c0);
-            const float4 sc = *reinterpret_cast<const float4*>(prm + 128 + c0);
-            const float4 sh = *reinterpret_cast<const float4*>(prm + 256 + c0);
+            const float4 sc = *reinterpret_cast<const float4*>(prm + c0);
+            const float4 sh = *reinterpret_cast<const float4*>(prm + 128 + c0);
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
-                const float y0 = sc.x * fmaxf(acc[ct][pt][4 * g + 0] + bi.x, 0.0f) + sh.x;
-                const float y1 = sc.y * fmaxf(acc[ct][pt][4 * g + 1] + bi.y, 0.0f) + sh.y;
-                const float y2 = sc.z * fmaxf(acc[ct][pt][4 * g + 2] + bi.z, 0.0f) + sh.z;
-                const float y3 = sc.w * fmaxf(acc[ct][pt][4 * g + 3] + bi.w, 0.0f) + sh.w;
+                const float y0 = sc.x * fmaxf(acc[ct][pt][4 * g + 0], 0.0f) + sh.x;
+                const float y1 = sc.y * fmaxf(acc[ct][pt][4 * g + 1], 0.0f) + sh.y;
+                const float y2 = sc.z * fmaxf(acc[ct][pt][4 * g + 2], 0.0f) + sh.z;
+                const float y3 = sc.w * fmaxf(acc[ct][pt][4 * g + 3], 0.0f) + sh.w;
                 const int r = prow0 + 32 * pt;
-                uint2 pk;
-                pk.x = f2bf(y0) | (f2bf(y1) << 16);
-                pk.y = f2bf(y2) | (f2bf(y3) << 16);
-                *reinterpret_cast<uint2*>(act + r * ACT_PITCH + (c0 << 1)) = pk;
+                *reinterpret_cast<uint2*>(act + r * ACT_PITCH + (c0 << 1)) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
             }
         }
 }
@@ -208,27 +198,71 @@ template <int CIN>
 __device__ __forceinline__ void run_layer(const ConvArgs& A, int l, char* act, char* wring, float* prm, int tid, int wave,
                                           int lane, int wc, int prow0, int wrow0, int& g) {
     constexpr int TAP_U4 = 128 * (CIN * 2 + 16) / 16;             // uint4 per tap (640 or 2176)
+    constexpr int TAP_U4_NEXT = 128 * (128 * 2 + 16) / 16;        // taps of every later layer
+    constexpr int KSTEPS = CIN / 16;
     const ConvLayerDev& L = A.L[l];
-    f32x16 acc[2][4];
+    const int hi = lane >> 5;
+    f32x16 acc[2][4];                                             // accumulators start at the conv bias
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int q = 0; q < 4; ++q) {
+            const float4 bi = *reinterpret_cast<const float4*>(L.bias + 64 * wc + 32 * ct + 8 * q + 4 * hi);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[ct][pt][i] = 0.0f;
-    if (tid < 128) { prm[tid] = L.bias[tid]; prm[128 + tid] = L.scale[tid]; prm[256 + tid] = L.shift[tid]; }
+            for (int pt = 0; pt < 4; ++pt) {
+                acc[ct][pt][4 * q + 0] = bi.x; acc[ct][pt][4 * q + 1] = bi.y;
+                acc[ct][pt][4 * q + 2] = bi.z; acc[ct][pt][4 * q + 3] = bi.w;
+            }
+        }
+    if (tid < 128) { prm[tid] = L.scale[tid]; prm[128 + tid] = L.shift[tid]; }
+    // Flattened k-step pipeline over the 9 taps: fragments are always one k-step ahead of the
+    // MFMAs, also across tap boundaries.  The boundary (DMA landed + barrier) sits in front of a
+    // tap's LAST k-step: by then every wave has read all it needs from this tap's ring buffer,
+    // so the buffer is re-filled (tap g+2) immediately and the first fragments of tap g+1 load
+    // under the last MFMAs of tap g.
+    bf16x8 a0[2], b0[4], a1[2], b1[4];
+    int4v brow = tap_rows(prow0, 0);
+    load_frags<CIN>(act, wring + (g & 1) * W_BYTES, 0, hi, wrow0, brow, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
     for (int tap = 0; tap < 9; ++tap) {
-        char* nxt = wring + ((g + 1) & 1) * W_BYTES;
-#ifndef CKR_CONV_NO_STREAM
-        if (tap < 8) issue_tap<CIN>(L.w + (size_t)(tap + 1) * TAP_U4, nxt, wave, lane);
-        else if (l + 1 < A.n_layers) issue_tap<128>(A.L[l + 1].w, nxt, wave, lane);
+        char* cur = wring + (g & 1) * W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS - 2; kk += 2) {
+            load_frags<CIN>(act, cur, kk + 1, hi, wrow0, brow, a1, b1);
+            mfma_block(a0, b0, acc);
+            interleave_reads_with_mfma();
+            load_frags<CIN>(act, cur, kk + 2, hi, wrow0, brow, a0, b0);
+            mfma_block(a1, b1, acc);
+            interleave_reads_with_mfma();
+        }
+        load_frags<CIN>(act, cur, KSTEPS - 1, hi, wrow0, brow, a1, b1);
+        mfma_block(a0, b0, acc);
+        interleave_reads_with_mfma();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tap g+1 has landed (it had a whole tap of MFMAs)
+#ifndef CKR_CONV_NO_BARRIER                                       // (timing experiments only)
+        __syncthreads();                                          // ... for every wave; all reads of `cur` are done
 #endif
-        tap_compute<CIN>(act, wring + (g & 1) * W_BYTES, prow0, tap / 3 - 1, tap % 3 - 1, wrow0, lane, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next tap has landed (it had a whole tap of MFMAs)
-        __syncthreads();                                          // ... for every wave, and this tap's LDS reads are done
+#ifndef CKR_CONV_NO_STREAM
+        if (tap + 2 < 9) issue_tap<CIN>(L.w + (size_t)(tap + 2) * TAP_U4, cur, wave, lane);
+        else if (l + 1 < A.n_layers) issue_tap<128>(A.L[l + 1].w + (size_t)(tap + 2 - 9) * TAP_U4_NEXT, cur, wave, lane);
+#endif
+        if (tap < 8) {
+            brow = tap_rows(prow0, tap + 1);
+            load_frags<CIN>(act, wring + ((g + 1) & 1) * W_BYTES, 0, hi, wrow0, brow, a0, b0);
+            mfma_block(a1, b1, acc);
+            interleave_reads_with_mfma();
+        } else {
+            mfma_block(a1, b1, acc);
+        }
         ++g;
     }
+#ifndef CKR_CONV_NO_EPILOGUE
     epilogue(act, prm, wc, lane, prow0, acc);
+#else
+    { float s = 0.0f;
+      for (int ct = 0; ct < 2; ++ct) for (int pt = 0; pt < 4; ++pt) for (int i = 0; i < 16; ++i) s += acc[ct][pt][i];
+      if (s == 12345.0f) act[0] = 1; }
+#endif
     __syncthreads();
 }
 
@@ -242,7 +276,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
     const long long board0 = (long long)blockIdx.x * 4;
     const int rows_valid = (int)min((long long)ACT_ROWS, (A.n_boards - board0) * 64);
 
-    issue_tap<32>(A.L[0].w, wring, wave, lane);                   // first tap of the first layer
+    issue_tap<32>(A.L[0].w, wring, wave, lane);                   // first two taps of the first layer
+    issue_tap<32>(A.L[0].w + 128 * (32 * 2 + 16) / 16, wring + W_BYTES, wave, lane);
     // zero the activation image (channel padding of layer 0, tail boards, zero row)
     for (int i = tid; i < ACT_BYTES / 16; i += 256) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -269,11 +304,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
             }
         }
         if (A.has_heads) {                                        // heads' 1x1 convs while the activations are in LDS
-            float* stage = reinterpret_cast<float*>(wring + ((g + 1) & 1) * W_BYTES);   // the idle half of the ring
+            // staging: the value head (131 floats) fits the per-layer parameter block, which is idle
+            // between layers; the policy head runs after the last layer, when the weight ring is idle
             if (l == A.n_layers - 2 && A.H.val_out)
-                head_1x1<1>(act, stage, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid);
+                head_1x1<1>(act, prm, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid);
             if (l == A.n_layers - 1 && A.H.pol_out)
-                head_1x1<8>(act, stage, A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift, A.H.pol_out, board0, rows_valid, tid);
+                head_1x1<8>(act, reinterpret_cast<float*>(wring), A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift,
+                            A.H.pol_out, board0, rows_valid, tid);
         }
     }
 }
