@@ -18,14 +18,31 @@ int fail(int code, const char* fmt, ...) {
 __global__ __launch_bounds__(256) void k_movegen(const uint4* __restrict__ boards, int64_t n,
                                                  uint4* __restrict__ mask8, uint32_t* __restrict__ status) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint4 v = boards[i];
-        const ckr_board b{v.x, v.y, v.z, v.w};
-        uint32_t m[8], st;
-        movegen(b, m, st);
-        mask8[2 * i]     = make_uint4(m[0], m[1], m[2], m[3]);
-        mask8[2 * i + 1] = make_uint4(m[4], m[5], m[6], m[7]);
-        status[i] = st;
+    const int lane = lane_id();
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
+        const int64_t i = i0 + lane;
+        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st = 0;
+        if (i < n) {
+            const uint4 v = boards[i];
+            movegen(ckr_board{v.x, v.y, v.z, v.w}, m, st);
+            status[i] = st;
+        }
+        // The wave's 64 mask records are 2 KB contiguous: transpose through ds_bpermute so that every
+        // store instruction writes 64 consecutive 16-B chunks (chunk c = half (c&1) of board c>>1)
+        // instead of 16 B at a 32-B stride.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int src = (32 * h + (lane >> 1)) << 2;
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m[j]);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)m[4 + j]);
+                o[j] = (lane & 1) ? hi : lo;
+            }
+            const int64_t board = i0 + 32 * h + (lane >> 1);
+            if (board < n) mask8[2 * i0 + 64 * h + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
