@@ -64,6 +64,7 @@ class FusedEvaluator:
         self.nets = [self._prepare(net)]
         if net_old is not None:
             self.nets.append(self._prepare(net_old))
+        self.static_outputs = net_old is None   # one net: p / v are always the same device buffers
 
     def _prepare(self, net):
         dev = next(net.parameters()).device
