@@ -220,7 +220,12 @@ def main():
             roofline = {"bound": "mfma", "kernel": "k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, "
                                                    "LDS-resident activations; one launch per step)",
                         "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
-                        "frac": conv_tflops / peak if conv_tflops else None, "traffic": None,
+                        "frac": conv_tflops / peak if conv_tflops else None,
+                        # HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/
+                        # (r01_pmc_summary.csv: FETCH_SIZE 12 831 KB + WRITE_SIZE 9 216 KB at 4 096 boards),
+                        # scaled to this launch size; not re-measured by this script
+                        "traffic": (12831.067 + 9216.0) * 1024.0 * a.slots / 4096.0,
+                        "traffic_source": "profiles/r01_pmc_summary.csv (separate --pmc passes)",
                         "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": a.slots,
                         "network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
                         "tree_kernel": tree}

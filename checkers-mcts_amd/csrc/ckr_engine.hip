@@ -29,7 +29,7 @@ constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x
 struct Dev {
     // configuration
     int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
-    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual;
+    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual, dynamic, total_games;
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local
@@ -37,6 +37,8 @@ struct Dev {
     // per slot
     uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
+    int32_t* g_gid;              // storage index of the slot's current game (results / tuple region)
+    int32_t* next_game;          // dynamic queue: next unclaimed game index
     // per tree (slot*2 + tree)
     int32_t* t_cursor; int32_t* t_used; int32_t* t_half; int32_t* t_searched;
     // outputs
@@ -306,9 +308,15 @@ __device__ int descend(Wave& w, int t) {
     }
 }
 
+// tournament: which network plays player 1 (0 = NEW_NN): the first half of a worker's games
+// (training_pipeline.py:523-528); with the dynamic queue, every other game
+__device__ __forceinline__ int p1_net_of(const Dev& D, int slot) {
+    return D.dynamic ? (D.g_gid[slot] & 1) : (D.g_game[slot] >= D.games_per_slot / 2 ? 1 : 0);
+}
+
 // ---- tuple helpers (training_pipeline.py:364-369,406-410,421-455)
 __device__ size_t tuple_index(const Wave& w, int ply) {
-    return ((size_t)w.slot * w.D.games_per_slot + (size_t)w.D.g_game[w.slot]) * (size_t)w.D.tuples_per_game + (size_t)ply;
+    return (size_t)w.D.g_gid[w.slot] * (size_t)w.D.tuples_per_game + (size_t)ply;
 }
 
 __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
@@ -340,17 +348,34 @@ __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed)
         }
     }
     if (w.lane == 0) {
-        ckr_game_result* R = &D.results[(size_t)w.slot * D.games_per_slot + game];
+        ckr_game_result* R = &D.results[D.g_gid[w.slot]];
         R->worker = D.first_worker + w.slot; R->game = game; R->outcome = (int)outcome; R->move_count = moves;
-        R->adjudicated = adjudicated; R->p1_net = (D.tournament && game >= D.games_per_slot / 2) ? 1 : 0;
+        R->adjudicated = adjudicated; R->p1_net = D.tournament ? p1_net_of(D, w.slot) : 0;
         R->n_tuples = n_tuples; R->failed = failed;
         D.g_game[w.slot] = game + 1;
         D.g_pending[w.slot] = -1;
     }
     w.count(CNT_GAMES);
     wave_mem_fence();
-    if (game + 1 < D.games_per_slot) new_game(w);
-    else { if (w.lane == 0) D.g_phase[w.slot] = PH_FINISHED; wave_mem_fence(); }
+    // next game of this worker: the fixed per-worker count of the reference (training_pipeline.py:349),
+    // or -- dynamic queue -- the next unclaimed game of the whole engine (no idle tail)
+    int gid = -1;
+    if (D.dynamic) {
+        int claimed = 0;
+        if (w.lane == 0) claimed = atomicAdd(D.next_game, 1);
+        claimed = bcast_i32(claimed, 0);
+        if (claimed < D.total_games) gid = claimed;
+    } else if (game + 1 < D.games_per_slot) {
+        gid = w.slot * D.games_per_slot + game + 1;
+    }
+    if (gid >= 0) {
+        if (w.lane == 0) D.g_gid[w.slot] = gid;
+        wave_mem_fence();
+        new_game(w);
+    } else {
+        if (w.lane == 0) D.g_phase[w.slot] = PH_FINISHED;
+        wave_mem_fence();
+    }
 }
 
 // ---- end of a ply: MCTS.best_child (MCTS.py:227-248), Checkers.step
@@ -507,9 +532,13 @@ __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
     if (slot >= D.n_slots) return;
     Wave w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
-    if (w.lane == 0) { D.g_game[slot] = 0; D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; }
+    const int gid0 = D.dynamic ? slot : slot * D.games_per_slot;
+    if (w.lane == 0) {
+        D.g_game[slot] = 0; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; D.g_gid[slot] = gid0;
+        D.g_phase[slot] = gid0 < D.total_games ? PH_PLAYING : PH_FINISHED;
+    }
     wave_mem_fence();
-    new_game(w);
+    if (gid0 < D.total_games) new_game(w);
     if (D.manual && w.lane == 0) D.g_phase[slot] = PH_IDLE;
     flush_counters(w);
 }
@@ -551,7 +580,7 @@ __global__ __launch_bounds__(256) void k_step(const Dev* __restrict__ Dp, const 
         if (leaf < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
         lb = ld_board(&D.n_board[w.tb(t) + leaf]);
         if (D.tournament) {
-            const int p1_net = D.g_game[slot] >= D.games_per_slot / 2 ? 1 : 0;
+            const int p1_net = p1_net_of(D, slot);
             net = t == 0 ? p1_net : 1 - p1_net;                          // training_pipeline.py:523-529,536,546
         } else net = 0;
         break;
@@ -695,7 +724,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.budget = c->budget; D.terminate_cnt = c->terminate_cnt; D.training = c->training; D.tournament = c->tournament;
     D.tau_decay_delay = c->tau_decay_delay; D.reset_tau = c->reset_tau_each_game; D.C = c->nodes_per_tree;
     D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 64;
-    D.record_root = c->record_root_stats; D.manual = c->manual_play;
+    D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
+    D.total_games = c->n_slots * c->games_per_slot;
     D.tuples_per_game = (c->tournament || c->manual_play) ? 0 : c->terminate_cnt + 1;
     D.margin = c->budget * 16 + 64; if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
@@ -708,6 +738,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.n_W, NN, false); A(D.n_P, NN, false); A(D.n_status, NN, false);
     A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
+    A(D.g_gid, S, true); A(D.next_game, (size_t)1, true);
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
     A(D.tuples, NT ? NT : 1, true);
@@ -730,6 +761,12 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
             ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "sqrt table upload failed");
         }
         D.sqrt_tab = d_sqrt;
+    }
+    if (D.dynamic) {
+        const int32_t first_unclaimed = c->n_slots < D.total_games ? c->n_slots : D.total_games;
+        if (hipMemcpy(D.next_game, &first_unclaimed, sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "queue init failed");
+        }
     }
     // results: mark all games unfinished
     if (hipMemset(D.results, 0xFF, (size_t)e->n_games_total * sizeof(ckr_game_result)) != hipSuccess) {

@@ -23,7 +23,7 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=64, device=0,
-                       manual_play=False):
+                       manual_play=False, dynamic_queue=False):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings."""
     k = mcts_kwargs
@@ -47,7 +47,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        reset_tau_each_game=int(bool(reset_tau_each_game)), nodes_per_tree=int(nodes_per_tree),
                        feature_dtype=FEATURE_DTYPES[feature_dtype], max_sims_per_step=int(max_sims_per_step),
                        record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
-                       device=int(device), seed=int(seed))
+                       device=int(device), dynamic_queue=int(bool(dynamic_queue)), seed=int(seed))
 
 
 class Engine:

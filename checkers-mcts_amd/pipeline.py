@@ -165,6 +165,9 @@ class generate_Checkers_data:
         self.seed = selfplay_kwargs.get("SEED", int.from_bytes(os.urandom(4), "little"))   # np.random.seed(), :341
         self.nodes_per_tree = selfplay_kwargs.get("NODES_PER_TREE")
         self.use_graph = selfplay_kwargs.get("USE_GRAPH", True)
+        # False (default) = the reference's fixed NUM_SELFPLAY_GAMES per worker; True = a finished slot pulls the
+        # next unplayed game of the job (same total, no idle tail; ~1.4x games/hour on a 16 384-game run)
+        self.dynamic_queue = selfplay_kwargs.get("DYNAMIC_QUEUE", False)
         self.stats = None
         self.results = None
 
@@ -180,7 +183,7 @@ class generate_Checkers_data:
             cfg = ckengine.config_from_kwargs(
                 self.mcts_kwargs, n_slots=count, games_per_slot=self.NUM_SELFPLAY_GAMES,
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first, nodes_per_tree=self.nodes_per_tree,
-                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index)
+                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
             runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count), use_graph=self.use_graph)
             runner.run_to_completion()

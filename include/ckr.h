@@ -167,6 +167,8 @@ typedef struct {
     int32_t  manual_play;        /* 1: interactive search API (MCTS / MCTS_Node facade): slots park after
                                     BUDGET simulations and moves are applied by ckr_engine_command */
     int32_t  device;             /* HIP device ordinal */
+    int32_t  dynamic_queue;      /* 1: a slot that finishes a game takes the next unplayed one of the engine
+                                    (n_slots x games_per_slot in total) instead of a fixed per-worker count */
     uint64_t seed;               /* Philox key for Dirichlet noise / temperature sampling */
 } ckr_config;
 

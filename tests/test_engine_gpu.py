@@ -273,3 +273,30 @@ def test_config_errors(E):
         E.config_from_kwargs({"UCT_C": 4}, n_slots=1, games_per_slot=1, terminate_cnt=10)
     with pytest.raises(ValueError):
         E.Engine(E.config_from_kwargs(mk(10), n_slots=1, games_per_slot=1, terminate_cnt=0))   # self-play needs TERMINATE_CNT
+
+
+def test_dynamic_queue_bookkeeping(E, oracle):
+    """Dynamic game queue: slots pull the next unplayed game; every game (all
+    identical in a deterministic configuration) must still equal the oracle's."""
+    salt = 61
+    eng, ev = run_engine(E, mk(10), [salt] * 6, games_per_slot=4, terminate_cnt=30, dynamic_queue=True)
+    eng.run(ev)
+    res = eng.results()
+    assert len(res) == 24 and all(r["failed"] == 0 for r in res)
+    w = oracle.Worker(oracle.make_config(mk(10), terminate_cnt=30, num_games=1))
+    w.run(lambda x, net: oracle.hashnet(x, salt))
+    ot = w.tuples()
+    t = eng.tuples_raw()
+    assert len(t) == 24 * len(ot)
+    keys = sorted({(int(a), int(b)) for a, b in zip(t["worker"], t["game"])})
+    assert len(keys) == 24
+    for wk, gm in keys:
+        tg = t[(t["worker"] == wk) & (t["game"] == gm)]
+        tg = tg[np.argsort(tg["ply"])]
+        assert len(tg) == len(ot)
+        for e, o in zip(tg, ot):
+            assert (e["board"] == o["board"]).all() and e["z"] == o["z"] and e["q"] == o["q"]
+            a, nv = E.tuple_actions_visits(e)
+            assert (a == o["action"]).all() and (nv == o["visits"]).all()
+    assert eng.stats()["games"] == 24
+    eng.close()

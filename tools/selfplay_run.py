@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--nn-dtype", default="bf16")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tournament", action="store_true")
+    ap.add_argument("--dynamic", action="store_true", help="dynamic game queue instead of a fixed count per slot")
     a = ap.parse_args()
     from checkers_mcts_amd import dist as ckdist, engine as E
     from checkers_mcts_amd.net import NetEvaluator, make_net
@@ -33,7 +34,8 @@ def main():
     first, _ = ckdist.shard_range(a.slots * world, rank, world)
     cfg = E.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=a.games_per_slot,
                                terminate_cnt=0 if a.tournament else a.terminate, tournament=a.tournament,
-                               first_worker_id=first, feature_dtype=dt, seed=a.seed, device=local_rank)
+                               first_worker_id=first, feature_dtype=dt, seed=a.seed, device=local_rank,
+                               dynamic_queue=a.dynamic)
     eng = E.Engine(cfg, feature_dtype=dt)
     from checkers_mcts_amd.pipeline import make_evaluator
     runner = StepRunner(eng, make_evaluator("random:0", dev, dt, a.slots, spec_old="random:1" if a.tournament else None))
@@ -54,7 +56,7 @@ def main():
     games = ckdist.sum_over_ranks(st["games"], dev)
     if rank == 0:
         moves = np.array([r["move_count"] for r in res])
-        out = dict(n_gpus=world, slots_per_gpu=a.slots, budget=a.budget, nn_dtype=a.nn_dtype, steps=steps,
+        out = dict(n_gpus=world, slots_per_gpu=a.slots, games_per_slot=a.games_per_slot, dynamic_queue=a.dynamic, budget=a.budget, nn_dtype=a.nn_dtype, steps=steps,
                    seconds=t_all, play_seconds=t_play, gather_seconds=t_gather, games=games,
                    games_per_hour=games / t_all * 3600, expansions=exp, expansions_per_s=exp / t_all,
                    tuples_gathered=int(gathered.shape[0]), rank0_stats=st,
