@@ -22,7 +22,7 @@ class Config(C.Structure):
                 ("reset_tau_each_game", C.c_int32), ("nodes_per_tree", C.c_int32),
                 ("feature_dtype", C.c_int32), ("max_sims_per_step", C.c_int32),
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
-                ("dynamic_queue", C.c_int32), ("seed", C.c_uint64)]
+                ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("seed", C.c_uint64)]
 
 
 class NodeInfo(C.Structure):
@@ -52,7 +52,7 @@ EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_bat
            "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_conv_stack_bf16", "ckr_value_mlp", "ckr_engine_create",
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_stats", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
-           "ckr_engine_command", "ckr_engine_game", "ckr_engine_root"]
+           "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_set_ln_table"]
 
 _lib = None
 
@@ -88,6 +88,8 @@ def load():
         L.ckr_engine_root_stats.argtypes = [vp, vp, vp, i64]
         L.ckr_engine_leaves.argtypes = [vp, vp]
         L.ckr_engine_command.argtypes = [vp, vp, vp, vp]
+        L.ckr_engine_rollout.argtypes = [vp, C.c_int32, vp]
+        L.ckr_engine_set_ln_table.argtypes = [vp, vp, C.c_int32]
         L.ckr_engine_game.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
         L.ckr_engine_root.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(NodeInfo), C.POINTER(NodeInfo), C.POINTER(C.c_int32)]
     _lib = L

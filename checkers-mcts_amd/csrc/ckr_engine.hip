@@ -29,7 +29,7 @@ constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x
 struct Dev {
     // configuration
     int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
-    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual, dynamic, total_games;
+    int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual, dynamic, total_games, neural, rollout_first, ln_n, uct_n;
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local
@@ -44,6 +44,8 @@ struct Dev {
     // outputs
     ckr_tuple* tuples; float* rs_w; float* rs_p; ckr_game_result* results;
     unsigned long long* counters; const double* sqrt_tab; uint4* leaves;
+    const double* ln_tab;        // rollout mode: ln(n) as the host's np.log computes it
+    const double* uct_tab;       // rollout mode: pow(2 ln(N) / n, 0.5) for n <= N < uct_n, row N at N(N+1)/2
 };
 
 struct WaveLds {
@@ -168,15 +170,18 @@ __device__ void compact(Wave& w, int t) {
         const uint32_t st = valid ? D.n_status[dst + idx] : 0u;
         const bool exp = valid && (st & ST_EXPANDED);
         const int nk = exp ? (int)(kids >> 24) : 0, ob = (int)(kids & 0xFFFFFFu);
-        const int incl = wave_incl_scan(nk);
+        // rollout mode adds children one at a time into a block reserved for all legal successors
+        const int reserve = D.neural ? nk : (exp ? (int)st_nlegal(st) : 0);
+        const int incl = wave_incl_scan(reserve);
         const int total = bcast_i32(incl, 63);
-        const int nb = free_ + incl - nk;
+        const int nb = free_ + incl - reserve;
         if (exp) D.n_kids[dst + idx] = (uint32_t)nb | ((uint32_t)nk << 24);
         for (int c = 0; c < nk; ++c) {
             const size_t s = src + ob + c, d = dst + nb + c;
             D.n_board[d] = D.n_board[s]; D.n_parent[d] = idx; D.n_kids[d] = D.n_kids[s];
             D.n_N[d] = D.n_N[s]; D.n_W[d] = D.n_W[s]; D.n_P[d] = D.n_P[s]; D.n_status[d] = D.n_status[s];
         }
+        for (int c = nk; c < reserve; ++c) { D.n_kids[dst + nb + c] = 0u; D.n_status[dst + nb + c] = 0u; }
         free_ += total; q += cnt;
         wave_mem_fence();
     }
@@ -303,6 +308,138 @@ __device__ int descend(Wave& w, int t) {
             w.count(CNT_TERM);
             wave_mem_fence();
             return -1;
+        }
+        node = child;
+    }
+}
+
+// ---- random-rollout mode (NEURAL_NET = False): MCTS.tree_policy non-NN branch (MCTS.py:78-89),
+// UCT selection (:112-116), default_policy playouts (:132-143).  All inside the tree kernel: no network.
+
+// the (plane, square) of the successor with index g of the reference's legal_next_states list
+// (same enumeration as wave_children); all lanes pass the same board / masks
+__device__ __forceinline__ void kth_action(const ckr_board b, const uint32_t m[8], int g, int& d_out, int& s_out) {
+    const int lane = lane_id(), s = lane & 31;
+    const bool kinglane = lane >= 32;
+    const uint32_t side = b.meta & 1u;
+    const uint32_t own = side ? b.p2 : b.p1;
+    const uint32_t mine = kinglane ? (own & b.kings) : (own & ~b.kings);
+    const bool present = (mine >> s) & 1u;
+    const bool jump = (m[4] | m[5] | m[6] | m[7]) != 0u;
+    int d[4]; int nd;
+    if (!jump) {
+        if (kinglane) { d[0] = 0; d[1] = 1; d[2] = 2; d[3] = 3; nd = 4; }
+        else if (side == 0u) { d[0] = 3; d[1] = 2; d[2] = d[3] = 0; nd = 2; }
+        else { d[0] = 1; d[1] = 0; d[2] = d[3] = 0; nd = 2; }
+    } else {
+        if (kinglane) { d[0] = 4; d[1] = 6; d[2] = 5; d[3] = 7; nd = 4; }
+        else if (side == 0u) { d[0] = 6; d[1] = 7; d[2] = d[3] = 0; nd = 2; }
+        else { d[0] = 4; d[1] = 5; d[2] = d[3] = 0; nd = 2; }
+    }
+    bool legal[4];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        legal[i] = present && i < nd && ((sel8(m, d[i]) >> s) & 1u);
+        base += __popcll(__ballot(legal[i]) & lt);
+    }
+    int mine_d = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (legal[i]) { if (base == g) mine_d = d[i]; ++base; }
+    const int src = first_lane(__ballot(mine_d >= 0));
+    d_out = bcast_i32(mine_d, src);
+    s_out = src & 31;
+}
+
+// uniform random playout to the end of the game (MCTS.py:139-143); returns the outcome code
+__device__ uint32_t playout(Wave& w, ckr_board b) {
+    const Dev& D = w.D;
+    const uint32_t ctr = D.g_rng[w.slot];
+    if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
+    for (uint32_t ply = 0;; ++ply) {
+        uint32_t m[8], st;
+        movegen(b, m, st);
+        if (st_outcome(st) != 0u) return st_outcome(st);
+        const uint32_t n = st_nlegal(st);
+        uint32_t k = 0u;
+        if (!D.rollout_first) {                              // np.random.randint(0, len(legal_next_states))
+            const u32x4 r = philox(D.seed_lo, D.seed_hi, (uint32_t)(D.first_worker + w.slot), ctr, ply, 0x52u);
+            k = (uint32_t)(((unsigned long long)r.x * n) >> 32);
+        }
+        int d, s;
+        kth_action(b, m, (int)k, d, s);
+        b = make_child(b, d, s);
+    }
+}
+
+// one simulation of the non-NN tree policy
+__device__ bool rollout_sim(Wave& w, int t) {
+    const Dev& D = w.D;
+    const int ti = w.slot * 2 + t;
+    const size_t tb = w.tb(t);
+    int node = D.t_cursor[ti];
+    for (;;) {
+        const uint32_t st = D.n_status[tb + node];
+        if (st_outcome(st) != 0u) {                          // MCTS.py:97-99 (terminal root)
+            backup_outcome(w, t, node, st_outcome(st));
+            w.count(CNT_TERM);
+            wave_mem_fence();
+            return true;
+        }
+        const uint32_t kids = D.n_kids[tb + node];
+        const int created = (int)(kids >> 24), nleg = (int)st_nlegal(st);
+        int base = (int)(kids & 0xFFFFFFu);
+        if (created < nleg) {                                // MCTS.py:79-81: pop ONE successor from the end of the list
+            if (created == 0) {
+                base = D.t_used[ti];
+                if (base + nleg > D.C) return false;
+                if (w.lane == 0) { D.t_used[ti] = base + nleg; D.n_status[tb + node] = st | ST_EXPANDED; }
+            }
+            const ckr_board b = ld_board(&D.n_board[tb + node]);
+            uint32_t m[8], bst;
+            movegen(b, m, bst);
+            int d, s;
+            kth_action(b, m, nleg - 1 - created, d, s);
+            const ckr_board c = make_child(b, d, s);
+            uint32_t cm[8], cst;
+            movegen(c, cm, cst);
+            const int ci = base + created;
+            if (w.lane == 0) {
+                write_node(D, tb + ci, c, node, 0.0f, cst | ((b.meta & 1u) << 4));
+                D.n_kids[tb + node] = (uint32_t)base | ((uint32_t)(created + 1) << 24);
+            }
+            wave_mem_fence();
+            const uint32_t outcome = playout(w, c);          // MCTS.py:89 child_node.simulation()
+            backup_outcome(w, t, ci, outcome);
+            w.count(CNT_EXP); w.count(CNT_NODES);
+            wave_mem_fence();
+            return true;
+        }
+        // MCTS.select_child, MCTS.py:112-116: q + 2c * (2 ln(N) / n) ** 0.5, first maximum
+        const int np = D.n_N[tb + node];
+        const bool act = w.lane < nleg;
+        const size_t ci = tb + base + (act ? w.lane : 0);
+        const int cn = D.n_N[ci];
+        const float cw = D.n_W[ci];
+        const uint32_t cst = D.n_status[ci];
+        double root;
+        if (np < D.uct_n) root = D.uct_tab[(size_t)np * (size_t)(np + 1) / 2 + (size_t)(act ? cn : 1)];
+        else {
+            const double lnN = np < D.ln_n ? D.ln_tab[np] : log((double)np);
+            root = sqrt((2.0 * lnN) / (double)cn);
+        }
+        const double q = (double)cw / (double)cn;
+        const double score = q + (2.0 * D.uct_c) * root;
+        const int best = wave_argmax_first(score, nleg);
+        const uint32_t bst = (uint32_t)bcast_i32((int)cst, best);
+        const int child = base + best;
+        if (st_outcome(bst) != 0u) {
+            backup_outcome(w, t, child, st_outcome(bst));
+            w.count(CNT_TERM);
+            wave_mem_fence();
+            return true;
         }
         node = child;
     }
@@ -594,6 +731,31 @@ __global__ __launch_bounds__(256) void k_step(const Dev* __restrict__ Dp, const 
     flush_counters(w);
 }
 
+// Random-rollout mode: up to `sims` complete simulations per slot and launch (select, expand one
+// child, playout, backup all in-kernel), including the end-of-ply work when the budget is reached.
+__global__ __launch_bounds__(256) void k_rollout(const Dev* __restrict__ Dp, int sims) {
+    const Dev& D = *Dp;
+    __shared__ WaveLds lds[4];
+    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    if (slot >= D.n_slots) return;
+    Wave w{D, lds[wave], slot, lane_id()};
+    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
+    if (slot == 0) w.count(CNT_STEPS);
+    for (int it = 0; it < sims && D.g_phase[slot] == PH_PLAYING;) {
+        if (D.g_sims[slot] >= D.budget) {
+            if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
+            finish_ply(w);
+            continue;
+        }
+        const int t = (int)(D.g_board[slot].w & 1u);
+        if (rollout_sim(w, t)) { if (w.lane == 0) D.g_sims[slot] += 1; }
+        else { w.count(CNT_OVERFLOW); end_game(w, 0u, 0, 1); }
+        wave_mem_fence();
+        ++it;
+    }
+    flush_counters(w);
+}
+
 // ---- interactive commands (manual_play): Checkers.step / reset and begin_tree_search
 // for the per-tree search interface of the reference (MCTS.py:211-295, Checkers.py:62-75).
 __device__ int apply_action(Wave& w, int action) {
@@ -706,6 +868,8 @@ static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 b
 
 extern "C" {
 
+int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t n);
+
 int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (!c || !out) return fail(CKR_ERR_INVALID, "ckr_engine_create: null argument");
     if (int rc = require_device()) return rc;
@@ -726,6 +890,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 64;
     D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
     D.total_games = c->n_slots * c->games_per_slot;
+    D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
     D.tuples_per_game = (c->tournament || c->manual_play) ? 0 : c->terminate_cnt + 1;
     D.margin = c->budget * 16 + 64; if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
@@ -768,6 +933,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
             ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "queue init failed");
         }
     }
+    if (!D.neural) {
+        if (int rc2 = ckr_engine_set_ln_table(e, nullptr, 0)) { ckr_engine_destroy(e); return rc2; }
+    }
     // results: mark all games unfinished
     if (hipMemset(D.results, 0xFF, (size_t)e->n_games_total * sizeof(ckr_game_result)) != hipSuccess) {
         ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "memset failed");
@@ -798,8 +966,39 @@ int ckr_engine_destroy(ckr_engine* e) {
     return CKR_OK;
 }
 
+int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t n) {
+    if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_set_ln_table: null engine");
+    Dev& D = e->dev;
+    const int LN_N = 1 << 16, UCT_N = 1024;
+    std::vector<double> lnv((size_t)LN_N), uct((size_t)UCT_N * (UCT_N + 1) / 2, 0.0);
+    for (int i = 0; i < LN_N; ++i) lnv[(size_t)i] = (ln && i < n) ? ln[i] : (i ? log((double)i) : 0.0);
+    volatile double half = 0.5;
+    for (int N = 1; N < UCT_N; ++N)
+        for (int c = 1; c <= N; ++c)
+            uct[(size_t)N * (size_t)(N + 1) / 2 + (size_t)c] = pow((2.0 * lnv[(size_t)N]) / (double)c, half);   // np.float64 ** 0.5 == C pow()
+    double* d_ln = nullptr; double* d_uct = nullptr;
+    if (int rc = dalloc(e, &d_ln, lnv.size(), false)) return rc;
+    if (int rc = dalloc(e, &d_uct, uct.size(), false)) return rc;
+    CKR_HIP(hipMemcpy(d_ln, lnv.data(), lnv.size() * sizeof(double), hipMemcpyHostToDevice));
+    CKR_HIP(hipMemcpy(d_uct, uct.data(), uct.size() * sizeof(double), hipMemcpyHostToDevice));
+    D.ln_tab = d_ln; D.uct_tab = d_uct; D.ln_n = LN_N; D.uct_n = UCT_N;
+    if (e->d_dev) CKR_HIP(hipMemcpy(e->d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice));
+    return CKR_OK;
+}
+
+int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) {
+    if (!e || sims <= 0) return fail(CKR_ERR_INVALID, "ckr_engine_rollout: bad argument");
+    if (e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_rollout needs an engine created with neural_net = 0");
+    e->last_stream = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rollout, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
+    CKR_HIP(hipGetLastError());
+    e->steps++;
+    return CKR_OK;
+}
+
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
     if (!e || !d_x) return fail(CKR_ERR_INVALID, "ckr_engine_step: null engine or feature buffer");
+    if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_step drives the NEURAL_NET search; use ckr_engine_rollout");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
     e->last_stream = (hipStream_t)stream;
     hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net);

@@ -23,7 +23,7 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=64, device=0,
-                       manual_play=False, dynamic_queue=False):
+                       manual_play=False, dynamic_queue=False, rollout_first=False):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings."""
     k = mcts_kwargs
@@ -34,8 +34,6 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
         if k["CONSTRAINT"] == "time":
             raise ValueError("CONSTRAINT='time' is not supported by the batched engine (lock-step rollouts)")
         raise ValueError("Invalid MCTS computational constraint!")        # MCTS.py:200
-    if not k["NEURAL_NET"]:
-        raise ValueError("the batched engine implements the NEURAL_NET=True search path")
     budget = int(k["BUDGET"])
     if nodes_per_tree is None:
         nodes_per_tree = max(4096, 48 * budget)
@@ -47,7 +45,8 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        reset_tau_each_game=int(bool(reset_tau_each_game)), nodes_per_tree=int(nodes_per_tree),
                        feature_dtype=FEATURE_DTYPES[feature_dtype], max_sims_per_step=int(max_sims_per_step),
                        record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
-                       device=int(device), dynamic_queue=int(bool(dynamic_queue)), seed=int(seed))
+                       device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
+                       dynamic_queue=int(bool(dynamic_queue)), seed=int(seed))
 
 
 class Engine:
@@ -97,6 +96,27 @@ class Engine:
             pp = vp = None
         _lib.check(self._L.ckr_engine_step(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
+
+    def rollout(self, sims):
+        """Random-rollout mode: up to `sims` complete simulations per slot in one launch."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.ckr_engine_rollout(self._h, int(sims), stream))
+
+    def set_ln_table(self, ln=None, n=4096):
+        """ln(n) exactly as this host's np.log computes it for python ints (the reference's UCT term)."""
+        if ln is None:
+            ln = np.array([0.0] + [float(np.log(i)) for i in range(1, n)], np.float64)
+        ln = np.ascontiguousarray(ln, np.float64)
+        _lib.check(self._L.ckr_engine_set_ln_table(self._h, ln.ctypes.data, len(ln)))
+
+    def run_rollouts(self, sims_per_launch=None, max_launches=1 << 30):
+        """Drive a NEURAL_NET=False engine to completion."""
+        k = sims_per_launch or self.cfg.budget
+        for i in range(max_launches):
+            self.rollout(k)
+            if i % 8 == 7 and self.stats()["active_slots"] == 0:
+                break
+        return self.stats()
 
     def stats(self):
         s = _lib.Stats()

@@ -135,17 +135,26 @@ def _timestamp():
     return datetime.now(tz=None).strftime("%d-%b-%Y(%H:%M:%S)")          # training_pipeline.py:465-469
 
 
-def tuples_to_memory(raw):
+def tuples_to_memory(raw, neural_net=True):
     """Compact tuples -> the reference's list of [state(15,8,8) f64,
     pi(8,8,8) f64, q, z] (training_pipeline.py:369,409,454), ordered by
-    worker, game, ply."""
+    worker, game, ply.  With NEURAL_NET=False the reference's W is a python int,
+    so q = +-W/N is a python float (float64): rebuilt here from the root's W, N."""
     order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
     raw = raw[order]
     states = codec.records_to_planes(raw["board"], raw["mask"], raw["status"])
     memory = []
     for i in range(len(raw)):
         a, n = ckengine.tuple_actions_visits(raw[i])
-        q = int(raw["q"][i]) if raw["q_is_int"][i] else np.float32(raw["q"][i])
+        if raw["q_is_int"][i]:
+            q = int(raw["q"][i])
+        elif neural_net:
+            q = np.float32(raw["q"][i])
+        else:
+            meta = raw["board"][i][3]
+            q = float(raw["root_w"][i]) / int(raw["root_n"][i])
+            if int(codec.meta_mover(meta)) != int(codec.meta_side(meta)):        # training_pipeline.py:365-368
+                q = -q
         memory.append([states[i], codec.pi_planes(a, n), q, int(raw["z"][i])])
     return memory
 
@@ -185,8 +194,12 @@ class generate_Checkers_data:
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first, nodes_per_tree=self.nodes_per_tree,
                 feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
-            runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count), use_graph=self.use_graph)
-            runner.run_to_completion()
+            if self.mcts_kwargs["NEURAL_NET"]:
+                runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count), use_graph=self.use_graph)
+                runner.run_to_completion()
+            else:                                  # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
+                eng.set_ln_table()
+                eng.run_rollouts()
             self.stats = eng.stats()
             self.results = eng.results()
             raw_dev = eng.pack_tuples_device()
@@ -195,7 +208,7 @@ class generate_Checkers_data:
         if rank != 0:
             return None
         raw = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=ckengine.TUPLE_DTYPE)
-        memory = tuples_to_memory(raw)
+        memory = tuples_to_memory(raw, neural_net=bool(self.mcts_kwargs["NEURAL_NET"]))
         filename = self._save_memory(memory, self.TRAINING_ITERATION, _timestamp(), 0)
         return [filename] if self.num_cpus > 1 else filename
 

@@ -167,6 +167,9 @@ typedef struct {
     int32_t  manual_play;        /* 1: interactive search API (MCTS / MCTS_Node facade): slots park after
                                     BUDGET simulations and moves are applied by ckr_engine_command */
     int32_t  device;             /* HIP device ordinal */
+    int32_t  neural_net;         /* NEURAL_NET: 1 = policy/value network search (ckr_engine_step); 0 = random-rollout
+                                    MCTS (MCTS.py:78-89,112-115,132-143; ckr_engine_rollout) */
+    int32_t  rollout_first;      /* test hook: playouts take legal_next_states[0] instead of a random successor */
     int32_t  dynamic_queue;      /* 1: a slot that finishes a game takes the next unplayed one of the engine
                                     (n_slots x games_per_slot in total) instead of a fixed per-worker count */
     uint64_t seed;               /* Philox key for Dirichlet noise / temperature sampling */
@@ -224,6 +227,14 @@ int ckr_engine_destroy(ckr_engine* e);
  * (may be NULL). */
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x,
                     int32_t* d_net, void* stream);
+
+/* Random-rollout mode (neural_net = 0): up to `sims` complete simulations per slot -- UCT descent
+ * (MCTS.py:112-116), one-child expansion (:78-81), uniform random playout (:132-143), backup -- plus
+ * the end-of-ply work, all inside one kernel launch.  No network is involved. */
+int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream);
+/* ln(n) for n < count exactly as the caller's np.log computes it (the UCT term uses np.log); without
+ * this call the C library's log() is used.  HOST array. */
+int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t count);
 
 /* Counters (synchronises the stream the last step ran on). */
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out);

@@ -377,7 +377,7 @@ typedef struct onode {
     uint32_t mask[8];
     uint32_t status;
     struct onode* parent;
-    struct onode** children; int n_children;
+    struct onode** children; int n_children; int n_total;   /* n_total: successors at creation */
     ckro_board* unvisited;  int n_unvisited;  /* successor list, reference order */
     int terminal;
     int n;        /* _number_of_visits */
@@ -458,7 +458,7 @@ static onode* node_new(ckro_worker* w, const ckro_board* b, onode* parent)
     if (CKRO_OUTCOME(n->status) == 0 && cnt > 0) {
         n->unvisited = (ckro_board*)malloc((size_t)cnt * sizeof(ckro_board));
         memcpy(n->unvisited, G.n_jumps ? G.jumps : G.legal, (size_t)cnt * sizeof(ckro_board));
-        n->n_unvisited = cnt;
+        n->n_unvisited = cnt; n->n_total = cnt;
     }
     n->terminal = n->n_unvisited ? 0 : 1;
     w->stats[5]++;
@@ -546,6 +546,72 @@ static int sim_step(ckro_worker* w, onode* root)
             backprop_outcome(node, (int)CKRO_OUTCOME(node->status));
             w->stats[1]++;
             return 0;
+        }
+    }
+}
+
+/* ---- random-rollout mode (NEURAL_NET = False) --------------------------- */
+
+/* MCTS.default_policy, MCTS.py:132-143: uniform random playout to the end of the game */
+static int playout(ckro_worker* w, const onode* from)
+{
+    ckro_board b = from->b;
+    for (;;) {
+        gen_t G; check_moves(&b, &G);
+        int cnt = G.n_jumps ? G.n_jumps : G.n_legal;
+        uint32_t st = outcome_status(&b, cnt, G.n_jumps > 0);
+        if (CKRO_OUTCOME(st)) return (int)CKRO_OUTCOME(st);
+        int k = w->cfg.rollout_first ? 0 : (int)(rng_next(&w->rng) % (uint64_t)cnt);   /* np.random.randint(0, len) */
+        b = G.n_jumps ? G.jumps[k] : G.legal[k];
+    }
+}
+
+/* MCTS.select_child (non-NN branch), MCTS.py:112-116 */
+static onode* select_child_uct(ckro_worker* w, onode* node)
+{
+    double uct[CKRO_MAX_CHILDREN];
+    volatile double half = 0.5;
+    const double lnN = (w->cfg.ln_table && node->n < w->cfg.ln_table_n) ? w->cfg.ln_table[node->n] : log((double)node->n);
+    for (int i = 0; i < node->n_children; ++i) {
+        onode* c = node->children[i];
+        volatile double q = (double)c->w / (double)c->n;                 /* python int / int */
+        volatile double t1 = 2.0 * lnN;
+        volatile double t2 = t1 / (double)c->n;
+        volatile double t3 = pow(t2, half);                              /* np.float64 ** 0.5 -> C pow() */
+        volatile double c2 = 2.0 * w->cfg.uct_c;
+        volatile double t4 = c2 * t3;
+        uct[i] = q + t4;
+    }
+    return node->children[argmax_f64(uct, node->n_children)];
+}
+
+/* MCTS.tree_policy, non-NN branch (MCTS.py:78-89): add ONE child (popped from the end of the
+ * successor list), play it out, back the outcome up from the child */
+static void sim_step_rollout(ckro_worker* w, onode* root)
+{
+    onode* node = root;
+    for (;;) {
+        if (node->n_unvisited) {
+            if (!node->children) node->children = (onode**)calloc((size_t)node->n_total, sizeof(onode*));
+            onode* c = node_new(w, &node->unvisited[node->n_unvisited - 1], node);
+            node->n_unvisited--;
+            node->children[node->n_children++] = c;
+            backprop_outcome(c, playout(w, c));
+            w->stats[0]++;
+            return;
+        }
+        if (!node->terminal) {
+            onode* child = select_child_uct(w, node);
+            if (child->terminal) {
+                backprop_outcome(child, (int)CKRO_OUTCOME(child->status));
+                w->stats[1]++;
+                return;
+            }
+            node = child;
+        } else {
+            backprop_outcome(node, (int)CKRO_OUTCOME(node->status));
+            w->stats[1]++;
+            return;
         }
     }
 }
@@ -728,6 +794,10 @@ int ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf)
             break;
         }
         case PH_SEARCH: {
+            while (!cfg->neural_net && w->rollout_count < cfg->budget) {
+                sim_step_rollout(w, w->root[w->mover]);
+                w->rollout_count++;
+            }
             while (w->rollout_count < cfg->budget) {          /* MCTS.py:219-220, :189-201 */
                 if (sim_step(w, w->root[w->mover])) {
                     ckro_features(&w->pending->b, x896);
@@ -759,6 +829,8 @@ int ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf)
             t->root_n = root->n; t->root_w = root->w; t->chosen = (int)CKRO_ACTION(bc->b.meta);
             float q = node_q(root);
             t->q = (w->parent_player != (int)CKRO_SIDE(root->b.meta)) ? -q : q;
+            { double q64 = root->n ? (double)root->w / (double)root->n : 0.0;
+              t->q64 = (w->parent_player != (int)CKRO_SIDE(root->b.meta)) ? -q64 : q64; }
             w->stats[2]++;
             if (!cfg->tournament && cfg->terminate_cnt > 0 && !w->done && w->move_count >= cfg->terminate_cnt) {
                 /* adjudication, training_pipeline.py:387-405 */

@@ -101,6 +101,10 @@ typedef struct {
     int    num_games;        /* games this worker plays back to back */
     int    tournament;       /* 1: _start_tournament loop (two nets, no tuples) */
     uint64_t seed;           /* RNG for the stochastic paths (not bit-pinned) */
+    int    neural_net;       /* NEURAL_NET: 0 = random-rollout MCTS (MCTS.py:78-89,112-115,132-143) */
+    int    rollout_first;    /* test hook: playouts take legal_next_states[0] instead of a random index */
+    const double* ln_table;  /* optional ln(n) for n < ln_table_n, as the host's np.log computes it */
+    int    ln_table_n;
 } ckro_config;
 
 typedef struct {
@@ -118,6 +122,7 @@ typedef struct {
     float      root_w;
     int        chosen;        /* action code picked by best_child (-1: terminal tuple) */
     float      q;
+    double     q64;           /* rollout mode: q = W/N in float64 (W is a python int there) */
     int        q_is_int;      /* terminal tuple: q is a python int */
     int        z;
 } ckro_tuple;

@@ -29,7 +29,8 @@ class Config(C.Structure):
                 ("alpha", C.c_double), ("epsilon", C.c_double),
                 ("tau", C.c_double), ("tau_decay", C.c_double),
                 ("tau_decay_delay", C.c_int), ("terminate_cnt", C.c_int),
-                ("num_games", C.c_int), ("tournament", C.c_int), ("seed", C.c_uint64)]
+                ("num_games", C.c_int), ("tournament", C.c_int), ("seed", C.c_uint64),
+                ("neural_net", C.c_int), ("rollout_first", C.c_int), ("ln_table", C.c_void_p), ("ln_table_n", C.c_int)]
 
 
 class Tuple(C.Structure):
@@ -38,7 +39,7 @@ class Tuple(C.Structure):
                 ("action", C.c_uint16 * MAX_CHILDREN), ("visits", C.c_uint32 * MAX_CHILDREN),
                 ("wsum", C.c_float * MAX_CHILDREN), ("prior", C.c_float * MAX_CHILDREN),
                 ("root_n", C.c_int), ("root_w", C.c_float), ("chosen", C.c_int),
-                ("q", C.c_float), ("q_is_int", C.c_int), ("z", C.c_int)]
+                ("q", C.c_float), ("q64", C.c_double), ("q_is_int", C.c_int), ("z", C.c_int)]
 
 
 class GameResult(C.Structure):
@@ -142,14 +143,17 @@ def mask_renorm(mask, p512):
     return out
 
 
-def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, seed=0):
+def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, seed=0, rollout_first=False, ln_table=None):
     """Config from the reference's kwargs dict (MCTS.py:43-55)."""
     k = mcts_kwargs
     return Config(uct_c=float(k["UCT_C"]), budget=int(k["BUDGET"]), training=int(bool(k["TRAINING"])),
                   alpha=float(k["DIRICHLET_ALPHA"]), epsilon=float(k["DIRICHLET_EPSILON"]),
                   tau=float(k["TEMPERATURE_TAU"]), tau_decay=float(k["TEMPERATURE_DECAY"]),
                   tau_decay_delay=int(k["TEMP_DECAY_DELAY"]), terminate_cnt=int(terminate_cnt),
-                  num_games=int(num_games), tournament=int(bool(tournament)), seed=int(seed))
+                  num_games=int(num_games), tournament=int(bool(tournament)), seed=int(seed),
+                  neural_net=int(bool(k.get("NEURAL_NET", True))), rollout_first=int(bool(rollout_first)),
+                  ln_table=(ln_table.ctypes.data if ln_table is not None else None),
+                  ln_table_n=(len(ln_table) if ln_table is not None else 0))
 
 
 class Worker:
@@ -202,7 +206,7 @@ class Worker:
                             action=np.array(t.action[:k], np.uint16), visits=np.array(t.visits[:k], np.uint32),
                             wsum=np.array(t.wsum[:k], np.float32), prior=np.array(t.prior[:k], np.float32),
                             root_n=t.root_n, root_w=np.float32(t.root_w), chosen=t.chosen,
-                            q=np.float32(t.q), q_is_int=bool(t.q_is_int), z=int(t.z)))
+                            q=np.float32(t.q), q64=float(t.q64), q_is_int=bool(t.q_is_int), z=int(t.z)))
         return out
 
     def results(self):

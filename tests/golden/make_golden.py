@@ -11,6 +11,7 @@ Fixture families:
                      children (action, N, W, P) and the chosen action
   selfplay_v1.npz    generate_Checkers_data._generate_data output (state, pi, q, z)
   tournament_v1.npz  tournament_Checkers._start_tournament outcomes
+  rollout_v1.npz     NEURAL_NET=False (random-rollout MCTS) self-play tuples with np.random.randint pinned to 0
 The fixtures are data (inputs + the reference's outputs); no reference source
 is stored.
 """
@@ -224,6 +225,39 @@ def gen_selfplay(cases=((30, 40, 2, 0), (20, 1000, 1, 1), (8, 1000, 1, 4), (25, 
     np.savez_compressed(os.path.join(HERE, "selfplay_v1.npz"), **out)
 
 
+# --------------------------------------------------------------------------- random-rollout mode
+def gen_rollout(cases=((60, 20, 1), (100, 10, 1))):
+    """generate_Checkers_data._generate_data with NEURAL_NET=False (MCTS.py:78-89,112-115,132-143).
+    The playout's only randomness, np.random.randint(0, len(legal_next_states)) (MCTS.py:141), is pinned
+    to 0 so the run is reproducible; ln(n) exactly as this host's np.log computes it is stored with
+    the vectors (the UCT term uses np.log)."""
+    out = {}
+    real_randint = np.random.randint
+    np.random.randint = lambda *a, **k: 0
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "training_data"))
+    os.chdir(tmp)
+    try:
+        for ci, (budget, terminate, games) in enumerate(cases):
+            mk = mcts_kwargs(budget)
+            mk["NEURAL_NET"] = False
+            sk = dict(NUM_SELFPLAY_GAMES=games, TRAINING_ITERATION=0, TERMINATE_CNT=terminate, NUM_CPUS=1, NN_FN="unused.h5")
+            mem = pickle.load(open(tp.generate_Checkers_data(sk, mk).generate_data(), "rb"))
+            out["c%d_cfg" % ci] = np.array([budget, terminate, games], np.int64)
+            out["c%d_state" % ci] = np.array([m[0] for m in mem], np.float64)
+            out["c%d_pi" % ci] = np.array([m[1] for m in mem], np.float64)
+            out["c%d_q" % ci] = np.array([float(m[2]) for m in mem], np.float64)
+            out["c%d_q_is_int" % ci] = np.array([type(m[2]) is int for m in mem], np.bool_)
+            out["c%d_z" % ci] = np.array([m[3] for m in mem], np.int64)
+    finally:
+        os.chdir(cwd)
+        np.random.randint = real_randint
+    out["ln_table"] = np.array([0.0] + [float(np.log(n)) for n in range(1, 4096)], np.float64)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "rollout_v1.npz"), **out)
+
+
 # --------------------------------------------------------------------------- tournament
 def gen_tournament(cases=((30, 4, 1, 2), (24, 2, 3, 5), (40, 2, 7, 8))):
     out = {}
@@ -258,12 +292,12 @@ def gen_tournament(cases=((30, 4, 1, 2), (24, 2, 3, 5), (40, 2, 7, 8))):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament"]
+    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:
         fn = globals()["gen_" + w]
-        sys.stdout = devnull if w in ("selfplay", "tournament") else real_stdout   # the reference prints per game
+        sys.stdout = devnull if w in ("selfplay", "tournament", "rollout") else real_stdout   # the reference prints per game
         try:
             fn()
         finally:

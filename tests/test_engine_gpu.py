@@ -300,3 +300,68 @@ def test_dynamic_queue_bookkeeping(E, oracle):
             assert (a == o["action"]).all() and (nv == o["visits"]).all()
     assert eng.stats()["games"] == 24
     eng.close()
+
+
+def test_rollout_mode_matches_reference_golden(E, golden_dir):
+    """NEURAL_NET=False: random-rollout MCTS entirely in the tree kernel, against the reference's
+    own tuples (np.random.randint pinned to 0 on both sides)."""
+    from checkers_mcts_amd import pipeline
+    g = np.load(os.path.join(golden_dir, "rollout_v1.npz"))
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games = (int(v) for v in g["c%d_cfg" % ci])
+        kw = dict(mk(budget), NEURAL_NET=False)
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=3, games_per_slot=games, terminate_cnt=terminate, rollout_first=True))
+        eng.set_ln_table(g["ln_table"])
+        eng.run_rollouts()
+        raw = eng.tuples_raw()
+        n = len(g["c%d_z" % ci])
+        assert len(raw) == 3 * n
+        for wk in range(3):
+            mem = pipeline.tuples_to_memory(raw[raw["worker"] == wk], neural_net=False)
+            for i, (state, pi, q, z) in enumerate(mem):
+                assert (state == g["c%d_state" % ci][i]).all() and (pi == g["c%d_pi" % ci][i]).all()
+                assert float(q) == g["c%d_q" % ci][i] and (type(q) is int) == bool(g["c%d_q_is_int" % ci][i])
+                assert z == g["c%d_z" % ci][i]
+        assert eng.stats()["pool_overflows"] == 0
+        eng.close()
+
+
+def test_rollout_mode_vs_oracle_and_random_playouts(E, oracle, golden_dir):
+    """Deterministic playouts: whole games equal the oracle's (incl. compaction of partially
+    expanded nodes); random playouts: invariants."""
+    g = np.load(os.path.join(golden_dir, "rollout_v1.npz"))
+    ln = np.ascontiguousarray(g["ln_table"])
+    kw = dict(mk(40), NEURAL_NET=False)
+    for npt in (None, 512):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=2, games_per_slot=1, terminate_cnt=45, rollout_first=True,
+                                            nodes_per_tree=npt))
+        eng.set_ln_table(ln)
+        eng.run_rollouts()
+        w = oracle.Worker(oracle.make_config(kw, terminate_cnt=45, num_games=1, rollout_first=True, ln_table=ln))
+        w.run(lambda x, net: None)
+        ot = w.tuples()
+        t = sorted_tuples(eng)
+        assert len(t) == 2 * len(ot)
+        for e, o in zip(t[t["worker"] == 1], ot):
+            assert (e["board"] == o["board"]).all() and e["z"] == o["z"] and e["chosen"] == o["chosen"]
+            a, nv = E.tuple_actions_visits(e)
+            assert (a == o["action"]).all() and (nv == o["visits"]).all()
+            if len(a):
+                assert e["root_n"] == o["root_n"] and e["root_w"] == o["root_w"]
+        if npt:
+            assert eng.stats()["compactions"] > 0
+        assert eng.stats()["reroot_misses"] == w.stats()["reroot_misses"] * 2
+        eng.close()
+    eng = E.Engine(E.config_from_kwargs(dict(mk(30, tau=1.0), NEURAL_NET=False), n_slots=64, games_per_slot=1,
+                                        terminate_cnt=30, seed=5))
+    eng.set_ln_table(ln)
+    st = eng.run_rollouts()
+    assert st["games"] == 64 and st["pool_overflows"] == 0
+    t = sorted_tuples(eng)
+    assert len({tuple(x) for x in t[t["ply"] == 8]["board"][:, :3]}) > 8
+    for e in t:
+        a, nv = E.tuple_actions_visits(e)
+        if e["n_children"]:
+            # a retained root carries the playout of its own creation: sum(child N) = N or N - 1
+            assert nv.sum() in (e["root_n"], e["root_n"] - 1) and (nv >= 1).all() and abs(e["root_w"]) <= e["root_n"]
+    eng.close()

@@ -128,3 +128,24 @@ def test_tournament_outcomes(oracle, golden_dir):
         assert [r["p1_net"] == 0 for r in res] == list(g["c%d_p1_is_new" % ci])
         checked += 1
     assert checked >= 1
+
+
+def test_rollout_mode_tuples_bit_exact(oracle, golden_dir):
+    """NEURAL_NET=False (random-rollout MCTS) with the playout index pinned to 0."""
+    g = _load(golden_dir, "rollout_v1.npz")
+    ln = np.ascontiguousarray(g["ln_table"])
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games = (int(v) for v in g["c%d_cfg" % ci])
+        kw = dict(_mk(budget), NEURAL_NET=False)
+        w = oracle.Worker(oracle.make_config(kw, terminate_cnt=terminate, num_games=games, rollout_first=True, ln_table=ln))
+        w.run(lambda x, net: None)
+        tu = w.tuples()
+        assert len(tu) == len(g["c%d_z" % ci])
+        st = codec.records_to_planes(np.array([t["board"] for t in tu]), np.array([t["mask"] for t in tu]),
+                                     np.array([t["status"] for t in tu], np.uint32))
+        assert (st == g["c%d_state" % ci]).all()
+        for i, t in enumerate(tu):
+            assert (codec.pi_planes(t["action"], t["visits"]) == g["c%d_pi" % ci][i]).all()
+            q = float(int(t["q"])) if t["q_is_int"] else t["q64"]
+            assert q == g["c%d_q" % ci][i] and t["q_is_int"] == bool(g["c%d_q_is_int" % ci][i])
+            assert t["z"] == g["c%d_z" % ci][i]
