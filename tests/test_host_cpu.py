@@ -69,7 +69,9 @@ def test_config_from_kwargs_maps_reference_keys():
     with pytest.raises(ValueError, match="Invalid MCTS computational constraint"):
         E.config_from_kwargs(dict(kw, CONSTRAINT="x"), n_slots=1, games_per_slot=1)
     with pytest.raises(ValueError):
-        E.config_from_kwargs(dict(kw, NEURAL_NET=False), n_slots=1, games_per_slot=1)
+        E.config_from_kwargs(dict(kw, CONSTRAINT="time"), n_slots=1, games_per_slot=1)
+    c = E.config_from_kwargs(dict(kw, NEURAL_NET=False), n_slots=1, games_per_slot=1)
+    assert c.neural_net == 0 and c.rollout_first == 0
 
 
 def test_engine_requires_gpu():
