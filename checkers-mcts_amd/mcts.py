@@ -169,8 +169,11 @@ class MCTS:
             cls._engine.close()
         cfg = ckengine.config_from_kwargs(kwargs, n_slots=1, games_per_slot=1, manual_play=True,
                                           seed=int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))),
-                                          max_sims_per_step=1 << 30, nodes_per_tree=kwargs.get("NODES_PER_TREE"))
+                                          max_sims_per_step=1 << 30, nodes_per_tree=kwargs.get("NODES_PER_TREE"),
+                                          rollout_first=bool(kwargs.get("ROLLOUT_FIRST", False)))   # test hook
         cls._engine = ckengine.Engine(cfg)
+        if not cls.neural_net:
+            cls._engine.set_ln_table(kwargs.get("LN_TABLE"))     # np.log of this host for the UCT term (MCTS.py:114)
         cls._applied = []                  # board records of the plies the engine has been told about
         cls.rollout_count = 0
         cls.reroot_misses = 0
@@ -207,14 +210,20 @@ class MCTS:
         cls._sync()
         if cls._engine.command(CMD_SEARCH)[0]:
             raise ValueError("begin_tree_search on a finished game")
-        ev = cls._evaluator()
-        dev = cls._engine.device                             # nothing is pending when a search starts: p, v unused
-        p, v = torch.zeros((1, 512), device=dev), torch.zeros((1,), device=dev)
-        while True:
-            cls._engine.step(p, v)
-            if not cls._engine.game(0)[3]:
-                break
-            p, v = ev(cls._engine)
+        if not cls.neural_net:                               # random playouts (MCTS.py:78-89,132-143), all in-kernel
+            while True:
+                cls._engine.rollout(cls.budget)
+                if not cls._engine.game(0)[3]:
+                    break
+        else:
+            ev = cls._evaluator()
+            dev = cls._engine.device                         # nothing is pending when a search starts: p, v unused
+            p, v = torch.zeros((1, 512), device=dev), torch.zeros((1,), device=dev)
+            while True:
+                cls._engine.step(p, v)
+                if not cls._engine.game(0)[3]:
+                    break
+                p, v = ev(cls._engine)
         cls.rollout_count = cls.budget
         root_node._load()
         if cls.verbose:
@@ -223,7 +232,11 @@ class MCTS:
     @classmethod
     def best_child(cls, node, criterion="robust"):
         """Most-visited child, or a temperature sample while training (MCTS.py:227-248)."""
-        if not cls.neural_net and criterion not in ("robust",):
+        if cls.neural_net:
+            criterion = "robust"
+        if criterion == "max":                               # highest total reward (the reference's branch at
+            return node.children[int(np.argmax([child.w for child in node.children]))]   # MCTS.py:231-233 is not callable)
+        if criterion != "robust":
             raise ValueError("Invalid winner selection criterion!")
         visits = [child.n for child in node.children]
         if not cls.training or cls.tau <= 0:

@@ -304,3 +304,124 @@ class tournament_Checkers:
                                 headers=["Game Number", "Player 1", "Player 2", "Outcome", "Turn Count"]))
         self.summary = dict(new=fn1, old=fn2, new_wins=int(fn1_wins), old_wins=int(fn2_wins), draws=int(draws))
         return filename
+
+
+class RoundRobinEvaluator:
+    """engine -> (p, v) for an arena in which every slot has its own pair of networks:
+    `model_of[slot, net_id]` names the network that owns the slot's pending leaf."""
+
+    def __init__(self, nets, model_of):
+        self.nets, self.model_of = nets, model_of
+
+    @torch.no_grad()
+    def __call__(self, engine):
+        x = engine.x_nchw
+        which = self.model_of.gather(1, engine.net_id.clamp(min=0).long()[:, None])[:, 0]
+        p, v = self.nets[0](x)
+        for m in range(1, len(self.nets)):
+            pm, vm = self.nets[m](x)
+            sel = which == m
+            p = torch.where(sel[:, None], pm, p)
+            v = torch.where(sel, vm, v)
+        return p.contiguous(), v.contiguous()
+
+
+class final_evaluation:
+    """Round-robin between the models of several training iterations: every pair plays
+    two games, one with each colour (reference: training_pipeline.py:603-718).  All pairs
+    run concurrently, one engine slot per pair, instead of one process pool per round."""
+
+    def __init__(self, model_iter_list, tourney_kwargs, mcts_kwargs):
+        self.model_iter_list = list(model_iter_list)
+        self.model_fn_list = []
+        self.tourney_kwargs = tourney_kwargs
+        self.mcts_kwargs = mcts_kwargs
+        self.num_cpus = tourney_kwargs["NUM_CPUS"]
+        self.tourney_kwargs["TOURNEY_GAMES"] = 2
+        if "MODEL_SPECS" in tourney_kwargs:               # explicit network specifications, e.g. "random:3"
+            self.model_fn_list = [str(s) for s in tourney_kwargs["MODEL_SPECS"]]
+        else:
+            fns = os.listdir("data/model")
+            for iter_num in self.model_iter_list:
+                for fn in fns:
+                    if "Model" + str(iter_num) + "_" in fn and fn.endswith((".h5", ".pt", ".pth")):
+                        self.model_fn_list.append(fn)
+                        break
+        if len(self.model_fn_list) != len(self.model_iter_list):
+            raise ValueError("Model(s) not found!")
+        self.table = np.zeros((len(self.model_iter_list), len(self.model_iter_list)))
+        self.game_outcomes = []
+        self.stats = None
+
+    def _spec(self, fn):
+        return fn if fn.startswith("random:") or os.path.isabs(fn) else "data/model/" + fn
+
+    def start_evaluation(self, num_cpus=None):
+        M = len(self.model_fn_list)
+        pairs = [(new, old) for new in range(M - 1, 0, -1) for old in range(new)]      # the reference's pop() order
+        tk = self.tourney_kwargs
+        dtype = tk.get("NN_DTYPE", torch.float32)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cfg = ckengine.config_from_kwargs(
+            self.mcts_kwargs, n_slots=len(pairs), games_per_slot=2, tournament=True, feature_dtype=dtype,
+            nodes_per_tree=tk.get("NODES_PER_TREE"), seed=tk.get("SEED", int.from_bytes(os.urandom(4), "little")),
+            device=dev.index)
+        eng = ckengine.Engine(cfg, feature_dtype=dtype)
+        nets = [load_network(self._spec(fn), device=dev, dtype=dtype) for fn in self.model_fn_list]
+        model_of = torch.tensor(pairs, dtype=torch.long, device=dev)
+        StepRunner(eng, RoundRobinEvaluator(nets, model_of), use_graph=tk.get("USE_GRAPH", True)).run_to_completion()
+        self.stats = eng.stats()
+        res = eng.results()
+        eng.close()
+        by_new = {}
+        for r in sorted(res, key=lambda r: (r["worker"], r["game"])):
+            new, old = pairs[r["worker"]]
+            fn_new, fn_old = self.model_fn_list[new], self.model_fn_list[old]
+            p1_fn, p2_fn = (fn_new, fn_old) if r["p1_net"] == 0 else (fn_old, fn_new)
+            by_new.setdefault(new, []).append([r["game"] + 1, p1_fn, p2_fn, codec.OUTCOME_NAMES[r["outcome"]], r["move_count"]])
+        self.game_outcomes = [by_new[new] for new in range(M - 1, 0, -1)]
+        filename = self._parse_tourney_results()
+        print("Final evaluation over!  View results in final_eval folder!")
+        return filename
+
+    def _parse_tourney_results(self):
+        """Score table (+1 win, -1 loss per game) and total-score plot in data/final_eval (:668-711)."""
+        from tabulate import tabulate
+        self.table[:] = 0
+        for game_outcomes in self.game_outcomes:
+            for _game_num, p1_fn, p2_fn, outcome, _move_count in game_outcomes:
+                p1_idx, p2_idx = self.model_fn_list.index(p1_fn), self.model_fn_list.index(p2_fn)
+                if outcome == "player1_wins":
+                    self.table[p1_idx, p2_idx] += 1
+                    self.table[p2_idx, p1_idx] -= 1
+                elif outcome == "player2_wins":
+                    self.table[p1_idx, p2_idx] -= 1
+                    self.table[p2_idx, p1_idx] += 1
+        model_scores = np.sum(self.table, axis=1)
+        os.makedirs("data/final_eval", exist_ok=True)
+        self._plot_model_scores(model_scores)
+        col_headers = self.model_iter_list + ["Total"]
+        table = np.hstack((self.table, np.transpose(model_scores[np.newaxis])))
+        filename = "data/final_eval/Checkers_Final_Evaluation_" + _timestamp() + ".txt"
+        with open(filename, "w") as file:
+            file.write(tabulate(table, headers=col_headers, showindex=self.model_iter_list, tablefmt="fancy_grid"))
+        return filename
+
+    def _plot_model_scores(self, model_scores):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:                                   # plotting is optional on a headless node
+            return None
+        plt.figure()
+        plt.plot(self.model_iter_list, model_scores, marker="o")
+        plt.title("Final Evaluation")
+        plt.ylabel("Points")
+        plt.xlabel("Model Iteration Number")
+        plt.grid()
+        filename = "data/final_eval/Checkers_Final_Evaluation_" + _timestamp() + ".png"
+        plt.gcf().set_dpi(200)
+        plt.savefig(filename)
+        plt.close()
+        return filename

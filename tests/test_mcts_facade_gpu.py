@@ -19,11 +19,11 @@ def action_of(state):
     return (int(state[14, 0, 0]) - 6) * 64 + 8 * int(state[14, 0, 1]) + int(state[14, 0, 2])
 
 
-def play(budget, net, max_plies):
+def play(budget, net, max_plies, **extra):
     """The reference's own loop (training_pipeline.py:353-386) on the facade."""
     from checkers_mcts_amd.mcts import MCTS, MCTS_Node, Checkers
     env = Checkers(net)
-    MCTS(**kwargs(budget, env))
+    MCTS(**dict(kwargs(budget, env), **extra))
     initial = env.state
     root1 = MCTS_Node(initial, parent=None)
     best1 = best2 = None
@@ -132,3 +132,23 @@ def test_human_move_then_search(golden_dir):
     root = MCTS.new_root_node(best)
     MCTS.begin_tree_search(root)
     assert root.n >= 20 and abs(root.q) <= 1
+
+
+def test_facade_random_rollout_mode_matches_reference(golden_dir):
+    """NEURAL_NET=False through the per-tree interface: visit counts at every root equal the
+    reference's recorded pi planes (playout randomness pinned to 'first move' on both sides)."""
+    g = np.load(os.path.join(golden_dir, "rollout_v1.npz"))
+    budget, terminate, _ = (int(v) for v in g["c0_cfg"])
+    env, log = play(budget, None, terminate, NEURAL_NET=False, TRAINING=True, ROLLOUT_FIRST=True,
+                    LN_TABLE=np.ascontiguousarray(g["ln_table"]))
+    assert len(log) == terminate == len(g["c0_pi"])
+    for i, e in enumerate(log):
+        pi = np.zeros(512)
+        tot = sum(e["n"])
+        for a, n in zip(e["action"], e["n"]):
+            pi[a] = n / tot
+        assert (pi.reshape(8, 8, 8) == g["c0_pi"][i]).all(), i
+        assert e["root_n"] in (tot, tot + 1)
+        assert all(float(w).is_integer() for w in e["w"])
+    from checkers_mcts_amd.mcts import MCTS
+    assert MCTS.reroot_misses == 0

@@ -159,3 +159,29 @@ def test_pipeline_bf16_uses_fused_kernels(tmp_path, monkeypatch):
     t = tournament_Checkers(tk, mk)
     t.start_tournament()
     assert t.summary["new_wins"] + t.summary["old_wins"] + t.summary["draws"] == 6
+
+
+def test_final_evaluation_round_robin(tmp_path, monkeypatch):
+    """final_evaluation (training_pipeline.py:603-718): every pair plays two games with the
+    colours swapped; without noise each pair's games equal a direct two-game arena between
+    the same networks."""
+    from checkers_mcts_amd.pipeline import final_evaluation, tournament_Checkers
+    monkeypatch.chdir(tmp_path)
+    mk = dict(KW, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0, BUDGET=12,
+              DIRICHLET_EPSILON=0.0)
+    specs = ["random:1", "random:2", "random:3"]
+    fe = final_evaluation([0, 5, 10], dict(NUM_CPUS=4, SEED=3, MODEL_SPECS=specs), mk)
+    fn = fe.start_evaluation(4)
+    assert os.path.exists(fn) and "Total" in open(fn, encoding="utf-8").read()
+    assert [len(g) for g in fe.game_outcomes] == [4, 2]               # new = model 2 vs {0, 1}; new = model 1 vs {0}
+    assert (fe.table == -fe.table.T).all() and abs(fe.table).max() <= 2
+    for rows in fe.game_outcomes:
+        for i in range(0, len(rows), 2):
+            assert rows[i][1] == rows[i + 1][2] and rows[i][2] == rows[i + 1][1]   # colours swapped
+    direct = tournament_Checkers(dict(NEW_NN_FN="random:3", OLD_NN_FN="random:1", TOURNEY_GAMES=2, NUM_CPUS=1, SEED=3),
+                                 mk)._start_tournament()
+    mine = [r for r in fe.game_outcomes[0] if "random:1" in (r[1], r[2])]
+    assert [r[1:] for r in mine] == [r[1:] for r in direct]
+    with pytest.raises(ValueError, match="Model"):
+        os.makedirs("data/model", exist_ok=True)
+        final_evaluation([0, 5], dict(NUM_CPUS=1), mk)
