@@ -52,6 +52,8 @@ def parse():
                     help="fused: conv stack in the hand-written MFMA kernel (bf16 only); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
+    ap.add_argument("--parity-steps", type=int, default=200,
+                    help="timed steps of the extra float32-grade leg (ckr_conv_stack_f16x3; N = 1 only, 0 = skip)")
     return ap.parse_args()
 
 
@@ -126,6 +128,58 @@ def movegen_probe(device):
             "frac": 52.0 * n / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": 52}
 
 
+def split_roofline(conv_flops, slots, t_conv):
+    """Roofline entry of k_conv_stack_x3: algorithmic flops (one multiply-add per weight and
+    position, as for any float32 convolution) over the launch time; the kernel EXECUTES three
+    fp16 MFMAs per multiply-add, so the matrix pipe's own utilisation is 3x `frac`."""
+    tf = conv_flops * slots / t_conv / 1e12 if t_conv else None
+    return {"bound": "mfma", "kernel": "k_conv_stack_x3 (the same fused stack with split-fp16 operands: float32-grade "
+                                       "results, 3 fp16 MFMAs per multiply-add; one launch per step)",
+            "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
+            "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None, "traffic": None,
+            "executed_tflops": 3.0 * tf if tf else None,
+            "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
+            "vs_fp32_matrix_peak": tf / MFMA_PEAK_TFLOPS["fp32"] if tf else None,
+            "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": slots}
+
+
+def parity_leg(a, dev):
+    """The same workload with the network at float32-grade accuracy (pi / v within 1e-5 of a
+    float64 evaluation, BASELINE's parity bar): engine features in float32, conv stack in
+    ckr_conv_stack_f16x3.  Shorter timed region than the main leg; N = 1 only."""
+    from checkers_mcts_amd import engine as ckengine
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.net import make_net
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(MCTS_KWARGS, BUDGET=a.budget)
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=4, terminate_cnt=TERMINATE_CNT,
+                                      feature_dtype=torch.float32, seed=20260929, device=dev.index)
+    eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
+    ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots, mode="f16x3")
+    runner = StepRunner(eng, ev, use_graph=not a.no_graph)
+    runner.warmup(3)
+    runner.step(30)
+    torch.cuda.synchronize(dev)
+    s0 = eng.stats()
+    t0 = time.perf_counter()
+    runner.step(a.parity_steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    cev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(10)]
+    for e0, e1 in cev:
+        e0.record()
+        ev.conv_only(eng.x)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    t_conv = float(np.median([e0.elapsed_time(e1) for e0, e1 in cev])) / 1e3
+    eng.close()
+    return {"value": (s1["expansions"] - s0["expansions"]) / dt, "unit": "node-expansions/s", "steps": a.parity_steps,
+            "ms_per_step": dt / a.parity_steps * 1e3, "dtype": "fp16x2-split operands, fp32 accumulate (fp32-grade)",
+            "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py)",
+            "roofline": split_roofline(ev.CONV_FLOPS_PER_BOARD, a.slots, t_conv)}
+
+
 def main():
     a = parse()
     from checkers_mcts_amd import build as ckbuild, dist as ckdist, engine as ckengine
@@ -149,12 +203,13 @@ def main():
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
                                       first_worker_id=first, feature_dtype=dtype, seed=20260929, device=local_rank)
     eng = ckengine.Engine(cfg, feature_dtype=dtype)
-    which = a.evaluator or ("fused" if a.nn_dtype == "bf16" else "torch")
+    which = a.evaluator or ("fused" if a.nn_dtype in ("bf16", "fp32") else "torch")
     if which == "fused":
-        if a.nn_dtype != "bf16":
-            raise SystemExit("--evaluator fused needs --nn-dtype bf16")
+        if a.nn_dtype not in ("bf16", "fp32"):
+            raise SystemExit("--evaluator fused needs --nn-dtype bf16 or fp32")
         from checkers_mcts_amd.fused import FusedEvaluator
-        evaluator = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots)
+        evaluator = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
+                                   mode="bf16" if a.nn_dtype == "bf16" else "f16x3")
     else:
         evaluator = NetEvaluator(make_net(128, seed=0, device=dev, dtype=dtype))
     runner = StepRunner(eng, evaluator, use_graph=not a.no_graph)
@@ -214,7 +269,11 @@ def main():
         nn_tflops = FLOPS_PER_EVAL * a.slots / t_nn / 1e12 if t_nn else None
         tree = {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "bound": "latency", "algorithmic_bytes_per_sim": 536,
                 "achieved_GBps": 536.0 * a.slots / t_tree / 1e9 if t_tree else None}
-        if which == "fused":
+        if which == "fused" and a.nn_dtype == "fp32":
+            roofline = split_roofline(evaluator.CONV_FLOPS_PER_BOARD, a.slots, t_conv)
+            roofline.update({"network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
+                             "tree_kernel": tree})
+        elif which == "fused":
             conv_flops = evaluator.CONV_FLOPS_PER_BOARD
             conv_tflops = conv_flops * a.slots / t_conv / 1e12 if t_conv else None
             roofline = {"bound": "mfma", "kernel": "k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, "
@@ -236,6 +295,8 @@ def main():
                         "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots,
                         "tree_kernel": tree}
         extra = {"movegen_k1": movegen_probe(dev)}
+        if world == 1 and a.parity_steps > 0 and not (which == "fused" and a.nn_dtype == "fp32"):
+            extra["fp32_grade_mode"] = parity_leg(a, dev)
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(a.budget, a.cpu_seconds)

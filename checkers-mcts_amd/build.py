@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["ckr_rules.hip", "ckr_engine.hip", "ckr_conv.hip"]
+SOURCES = ["ckr_rules.hip", "ckr_engine.hip", "ckr_conv.hip", "ckr_conv_x3.hip"]
 LIB = os.path.join(HERE, "libckr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -39,6 +39,27 @@ def pack_conv_weights(w, cin_pad):
     return t.to(torch.bfloat16).contiguous()
 
 
+XS, WS = 64.0, 1024.0        # power-of-two operand scales of the split-fp16 path (ckr_conv_x3.hip)
+
+
+def pack_split_weights(w, first):
+    """torch conv weight [128, cin, 3, 3] (float32) -> the ring-slot image of
+    ckr_conv_stack_f16x3: fp16 [n_slots][128 out][32 hi | 32 lo | 8 pad] of w * WS, where
+    hi = fp16(w*WS), lo = fp16(w*WS - hi); slot = tap (first layer, 14 planes zero-padded
+    to 32) or tap*4 + quarter (32 of the 128 input channels per slot)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout == 128 and w.shape[2:] == (3, 3) and cin <= (32 if first else 128)
+    q = 1 if first else 4
+    t = torch.zeros((9, cout, 32 * q), dtype=torch.float32, device=w.device)
+    t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin) * WS
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    img = torch.zeros((9, q, cout, 72), dtype=torch.float16, device=w.device)
+    img[..., 0:32] = hi.reshape(9, cout, q, 32).permute(0, 2, 1, 3)
+    img[..., 32:64] = lo.reshape(9, cout, q, 32).permute(0, 2, 1, 3)
+    return img.reshape(9 * q, cout, 72).contiguous()
+
+
 def bn_affine(bn):
     scale = (bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps))
     shift = bn.bias.float() - bn.running_mean.float() * scale
@@ -54,10 +75,17 @@ class FusedEvaluator:
     the device; `debug_outputs` additionally keeps the bf16 body / policy-conv
     activations in HBM (tests)."""
 
-    def __init__(self, net, n_slots, net_old=None, debug_outputs=False):
+    def __init__(self, net, n_slots, net_old=None, debug_outputs=False, mode="bf16"):
+        """mode "bf16": ckr_conv_stack_bf16 (throughput mode, bf16 operands);
+        mode "f16x3": ckr_conv_stack_f16x3 (float32-grade: split-fp16 operands, float32 features)."""
+        if mode not in ("bf16", "f16x3"):
+            raise ValueError("FusedEvaluator mode must be 'bf16' or 'f16x3'")
+        self.mode = mode
         self._L = _lib.load()
         vp = C.c_void_p
         self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp]
+        self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
+                                                 C.c_float, vp]
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
@@ -72,13 +100,19 @@ class FusedEvaluator:
         blocks = list(net.body) + [net.pol1]
         keep = []                                                          # keep device tensors alive
         layers = (ConvLayer * len(blocks))()
-        y_body = torch.empty((S, 8, 8, 128), dtype=torch.bfloat16, device=dev) if self.debug else None
-        y_pol = torch.empty((S, 8, 8, 128), dtype=torch.bfloat16, device=dev) if self.debug else None
+        split = self.mode == "f16x3"
+        odt = torch.float32 if split else torch.bfloat16
+        y_body = torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if self.debug else None
+        y_pol = torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if self.debug else None
         for i, blk in enumerate(blocks):
             cin_pad = 32 if i == 0 else 128
-            w = pack_conv_weights(_f32(blk["conv"].weight), cin_pad)
             b = _f32(blk["conv"].bias)
             sc, sh = bn_affine(blk["bn"])
+            if split:                                                      # power-of-two scalings: exact
+                w = pack_split_weights(_f32(blk["conv"].weight), i == 0)
+                b, sc, sh = (b * (XS * WS)).contiguous(), (sc / WS).contiguous(), (sh * XS).contiguous()
+            else:
+                w = pack_conv_weights(_f32(blk["conv"].weight), cin_pad)
             keep += [w, b, sc, sh]
             out = y_body if i == len(blocks) - 2 else (y_pol if i == len(blocks) - 1 else None)
             layers[i] = ConvLayer(w.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
@@ -102,9 +136,15 @@ class FusedEvaluator:
                     p=torch.empty((S, 512), dtype=torch.float32, device=dev),
                     v=torch.empty((S,), dtype=torch.float32, device=dev))
 
+    def _conv(self, n, x, stream):
+        if self.mode == "f16x3":
+            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, stream))
+        else:
+            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), stream))
+
     def _forward(self, n, x):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), stream))
+        self._conv(n, x, stream)
         t = n["tail"]
         torch.addmm(t["fc_b"], n["pol_feat"], t["fc_w"], out=n["logits"])              # Dense(512)
         torch.softmax(n["logits"], dim=1, out=n["p"])
@@ -116,8 +156,9 @@ class FusedEvaluator:
     @torch.no_grad()
     def __call__(self, engine):
         x = engine.x
-        if x.dtype != torch.bfloat16:
-            raise ValueError("FusedEvaluator needs the engine's features in bfloat16")
+        if x.dtype != (torch.float32 if self.mode == "f16x3" else torch.bfloat16):
+            raise ValueError("FusedEvaluator(%s) needs the engine's features in %s" %
+                             (self.mode, "float32" if self.mode == "f16x3" else "bfloat16"))
         p, v = self._forward(self.nets[0], x)
         if len(self.nets) > 1:
             p2, v2 = self._forward(self.nets[1], x)
@@ -130,9 +171,7 @@ class FusedEvaluator:
 
     def conv_only(self, x_bf16):
         """Launch just the conv-stack kernel (bench.py times it with HIP events)."""
-        n = self.nets[0]
-        stream = torch.cuda.current_stream(x_bf16.device).cuda_stream
-        _lib.check(self._L.ckr_conv_stack_bf16(x_bf16.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), stream))
+        self._conv(self.nets[0], x_bf16, torch.cuda.current_stream(x_bf16.device).cuda_stream)
 
     @torch.no_grad()
     def forward_features(self, x_bf16):

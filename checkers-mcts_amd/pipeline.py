@@ -55,18 +55,31 @@ def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128):
     raise ValueError("unsupported network specification: %r" % (spec,))
 
 
-def make_evaluator(spec, device, dtype, n_slots, spec_old=None):
-    """Evaluator for the engine: bfloat16 runs the hand-written MFMA conv stack
-    (fused.FusedEvaluator, weights taken from the float32 network); float32 /
-    float16 run the PyTorch module."""
-    if dtype == torch.bfloat16:
+def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None):
+    """Evaluator for the engine.  The hand-written MFMA conv stack (fused.FusedEvaluator,
+    weights taken from the float32 network) serves bfloat16 (throughput mode, bf16 operands)
+    and float32 (split-fp16 operands with float32 accumulation: float32-grade results, the
+    parity mode); float16, or kind="torch", runs the PyTorch module instead."""
+    if kind not in (None, "fused", "torch"):
+        raise ValueError("evaluator kind must be 'fused' or 'torch'")
+    if kind != "torch" and dtype in (torch.bfloat16, torch.float32) and _is_128_wide(spec, spec_old):
         from .fused import FusedEvaluator
         new = load_network(spec, device=device, dtype=torch.float32)
         old = load_network(spec_old, device=device, dtype=torch.float32) if spec_old is not None else None
-        return FusedEvaluator(new, n_slots, net_old=old)
+        return FusedEvaluator(new, n_slots, net_old=old, mode="bf16" if dtype == torch.bfloat16 else "f16x3")
+    if kind == "fused":
+        raise ValueError("the fused conv stack needs NN_DTYPE bfloat16 or float32 and a 128-kernel network")
     new = load_network(spec, device=device, dtype=dtype)
     old = load_network(spec_old, device=device, dtype=dtype) if spec_old is not None else None
     return NetEvaluator(new, old)
+
+
+def _is_128_wide(*specs):
+    """The fused kernels are built for NUM_KERNELS = 128 (training_pipeline.py:61)."""
+    for sp in specs:
+        if isinstance(sp, torch.nn.Module) and sp.body[0]["conv"].weight.shape[0] != 128:
+            return False
+    return True
 
 
 class StepRunner:

@@ -136,6 +136,18 @@ typedef struct {
 int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers,
                         int32_t n_layers, const ckr_conv_heads* heads, void* stream);
 
+/* The same stack at float32-grade accuracy (the reference evaluates its network in
+ * float32, Checkers.py:433; BASELINE's parity bar for pi / v is 1e-5): every operand is
+ * split into two fp16 terms and wh*xh + wh*xl + wl*xh is accumulated in the float32
+ * accumulators of the 16-bit MFMA (csrc/ckr_conv_x3.hip).
+ * d_x: float32 NHWC [n_boards][8][8][14].  layers[i].weights: the split image
+ * [n_slots][128][32 hi | 32 lo | 8 pad] fp16 of (w * WS); bias / scale / shift pre-scaled
+ * by the host (bias*XS*WS, scale/WS, shift*XS) so that the stored activation is
+ * y * XS = hi + lo; x_scale = XS (a power of two).  layers[i].out (tests): float32
+ * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32. */
+int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers,
+                         int32_t n_layers, const ckr_conv_heads* heads, float x_scale, void* stream);
+
 /* Value head tail (training_pipeline.py:106-112): Dense(64)+ReLU -> BatchNorm ->
  * Dense(1) -> tanh on d_in[n][64] (the fused value conv's output).
  * w1t: [64 in][64 out] (transposed Dense kernel), b1/scale/shift/w2: [64]. */

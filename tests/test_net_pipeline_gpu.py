@@ -185,3 +185,56 @@ def test_final_evaluation_round_robin(tmp_path, monkeypatch):
     with pytest.raises(ValueError, match="Model"):
         os.makedirs("data/model", exist_ok=True)
         final_evaluation([0, 5], dict(NUM_CPUS=1), mk)
+
+
+def test_split_fp16_conv_stack_within_1e5_of_float64(oracle):
+    """The float32-grade HIP path (ckr_conv_stack_f16x3: split-fp16 operands on the 16-bit MFMA,
+    float32 accumulation) against the float64 restatement: pi and v within 1e-5 (north_star
+    tolerance), incl. ragged tails (board counts that are not a multiple of the 3-board tile)."""
+    import torch
+    import net_ref
+    from checkers_mcts_amd import net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator, XS
+    for n_boards, seed, perturb in ((96, 0, False), (191, 3, True), (7, 4, True), (1, 5, True), (770, 6, True)):
+        m = N.PolicyValueNet(128).keras_init(seed)
+        if perturb:
+            m.perturb_bn(seed)
+        m = m.eval().cuda()
+        x = rules.features(rules.boards_to_device(_positions(n_boards, 77 + seed))).contiguous()
+        fe = FusedEvaluator(m, n_boards, debug_outputs=True, mode="f16x3")
+        p, v = fe.forward_features(x)
+        sd = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
+        rp, rv = net_ref.forward(sd, x.cpu().numpy())
+        assert np.abs(p.cpu().numpy() - rp).max() < 1e-5
+        assert np.abs(v.cpu().numpy() - rv).max() < 1e-5
+        with torch.no_grad():
+            h = x.permute(0, 3, 1, 2)
+            for blk in m.body:
+                h = m._block(blk, h)
+            body_ref = h.permute(0, 2, 3, 1)
+        body = fe.nets[0]["y_body"] / XS
+        assert float((body - body_ref).abs().max()) < 1e-5 * max(1.0, float(body_ref.abs().max()))
+
+
+def test_float32_pipeline_runs_the_split_fp16_kernel():
+    """NN_DTYPE float32 (the default) is served by the hand-written kernel, not by PyTorch;
+    on the engine's own leaf features it agrees with the PyTorch float32 module to 1e-5."""
+    import torch
+    from checkers_mcts_amd import engine as E, pipeline
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.net import NetEvaluator
+    dev = torch.device("cuda", torch.cuda.current_device())
+    fe = pipeline.make_evaluator("random:4", dev, torch.float32, 64)
+    assert isinstance(fe, FusedEvaluator) and fe.mode == "f16x3"
+    te = pipeline.make_evaluator("random:4", dev, torch.float32, 64, kind="torch")
+    assert isinstance(te, NetEvaluator)
+    eng = E.Engine(E.config_from_kwargs(dict(KW, BUDGET=30), n_slots=64, games_per_slot=1, terminate_cnt=40))
+    p = v = None
+    for _ in range(60):
+        eng.step(p, v)
+        p, v = te(eng)
+        p2, v2 = fe(eng)
+        assert float((p - p2).abs().max()) < 1e-5 and float((v - v2).abs().max()) < 1e-5
+    eng.close()
+    with pytest.raises(ValueError):
+        pipeline.make_evaluator("random:4", dev, torch.float16, 64, kind="fused")
