@@ -18,10 +18,11 @@
 // Layout (MI355X-first, cf. ckr_conv.hip): a workgroup keeps THREE boards (192 positions)
 // resident in LDS through all layers as rows of [128 hi | 128 lo] fp16 (528-B pitch: one pad
 // slot, conflict-free ds_read_b128); weights stream from L2 through a 3-slot LDS ring filled
-// by global_load_lds DMA two slots ahead; a slot is 128 output rows x 32 input channels
-// x [hi | lo] (18 KB, 144-B pitch).  The L2->LDS stream is what bounds these kernels
+// by global_load_lds DMA two slots ahead, issued by a FIFTH wave that does nothing else (a DMA
+// piece costs its issuing wave ~60 cycles, which would idle that wave's matrix pipe); a slot is
+// 128 output rows x 32 input channels x [hi | lo] (18 KB, 144-B pitch).  The L2->LDS stream is what bounds these kernels
 // (~25 GB/s per CU), hence the largest position tile that fits 160 KB of LDS.
-// 4 waves: wave (wc, wp) owns channels [64wc,+64) x positions [96wp,+96) = 2 x 3 MFMA tiles;
+// 4 MFMA waves: wave (wc, wp) owns channels [64wc,+64) x positions [96wp,+96) = 2 x 3 MFMA tiles;
 // per 16-deep k-chunk 10 fragment reads feed 18 MFMAs.
 #include "ckr_host.h"
 #include <hip/hip_runtime.h>
@@ -66,13 +67,11 @@ struct Args {
     LayerDev L[MAX_LAYERS];
 };
 
-__device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int wave, int lane) {
+// the loader wave DMAs one ring slot: 18 wave-instructions of 64 lanes x 16 B to a wave-uniform LDS base
+__device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int lane) {
 #pragma unroll
-    for (int i = 0; i < (SLOT_PIECES + 3) / 4; ++i) {
-        const int c = wave + 4 * i;
-        if (c < SLOT_PIECES)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
-    }
+    for (int c = 0; c < SLOT_PIECES; ++c)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
 }
 
 struct Frags { f16x8 ah[2], al[2], bh[3], bl[3]; };
@@ -170,7 +169,7 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
                                          const float* __restrict__ sh, float* __restrict__ out,
                                          long long board0, int rows_valid, int tid, float inv_xs) {
 #pragma clang fp contract(fast)
-    for (int i = tid; i < NOUT * 128; i += 256) stage[i] = w[i];
+    for (int i = tid; i < NOUT * 128; i += 320) stage[i] = w[i];
     if (tid < NOUT) { stage[NOUT * 128 + tid] = b[tid]; stage[NOUT * 129 + tid] = sc[tid]; stage[NOUT * 130 + tid] = sh[tid]; }
     __syncthreads();
     if (tid < rows_valid) {
@@ -236,12 +235,9 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char*
             load_frags(act, cur, 1, 64 * q, half, wrow0, brow, f1);
             mfma_block(f0, acc);
             interleave_reads_with_mfma();
-            // slot s+1 has landed for every wave (slot s+2 may still be in flight: <= 4-5 pieces per wave);
-            // every wave has issued its last reads of `cur`, which is re-filled with slot s+3 right away
-            // (a bare s_barrier: __syncthreads() would also wait vmcnt(0) and drain the look-ahead)
-            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            if (s + 3 < NSLOTS) issue_slot(L.w + (size_t)(s + 3) * SLOT_U4, cur, wave, lane);
-            else if (l + 1 < A.n_layers) issue_slot(A.L[l + 1].w + (size_t)(s + 3 - NSLOTS) * SLOT_U4, cur, wave, lane);
+            // slot boundary (pairs with load_layer): the loader wave arrives once slot s+1 has landed;
+            // every MFMA wave has issued its last reads of `cur`, which the loader re-fills with slot s+3
+            asm volatile("s_barrier" ::: "memory");
             if (s + 1 < NSLOTS) {
                 if (q == QPT - 1) tap_rows(prow0, tap + 1, brow);
                 load_frags(act, wring + nring * SLOT_BYTES, 0, q == QPT - 1 ? 0 : 64 * (q + 1), half, wrow0, brow, f0);
@@ -254,21 +250,38 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char*
         }
     }
     epilogue(act, prm, wc, lane, prow0, acc);
-    __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 1) void k_conv_stack_x3(const Args A) {
+// The loader wave's side of one layer: keeps the weight ring two slots ahead of the MFMA waves.
+// The DMA issue (~60 cycles per 1-KB piece) would otherwise stall the matrix pipe of the issuing wave.
+__device__ __forceinline__ void load_layer(const Args& A, int l, char* wring, int lane, int& ring) {
+    const LayerDev& L = A.L[l];
+    const int nslots = L.n_slots;
+    for (int s = 0; s < nslots; ++s) {
+        // in flight: slots s+1 and s+2 (18 pieces each, in order) -> slot s+1 has landed
+        asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+        char* cur = wring + ring * SLOT_BYTES;
+        if (s + 3 < nslots) issue_slot(L.w + (size_t)(s + 3) * SLOT_U4, cur, lane);
+        else if (l + 1 < A.n_layers) issue_slot(A.L[l + 1].w + (size_t)(s + 3 - nslots) * SLOT_U4, cur, lane);
+        ring = ring == NRING - 1 ? 0 : ring + 1;
+    }
+}
+
+// 4 MFMA waves (one per SIMD) + 1 loader wave
+__global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* act = smem;
     char* wring = smem + ACT_BYTES;
     float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + NRING * SLOT_BYTES);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wc = wave >> 1, wp = wave & 1;
+    const bool loader = wave == 4;
+    const int wc = (wave >> 1) & 1, wp = wave & 1;
     const long long board0 = (long long)blockIdx.x * 3;
     const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
 
-    for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, wave, lane);
-    for (int i = tid; i < ACT_BYTES / 16; i += 256) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
+    if (loader)
+        for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, lane);
+    for (int i = tid; i < ACT_BYTES / 16; i += 320) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (tid < rows_valid) {                                       // 14 float32 planes per position -> hi / lo
         const float2* src = reinterpret_cast<const float2*>(A.x + (board0 * 64 + tid) * 14);
@@ -294,12 +307,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_stack_x3(const Args A) {
     const int wrow0 = 64 * wc + (lane & 31);
     int ring = 0;
     for (int l = 0; l < A.n_layers; ++l) {
-        if (l == 0) run_layer<1>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
+        if (loader) load_layer(A, l, wring, lane, ring);
+        else if (l == 0) run_layer<1>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
         else run_layer<4>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
+        __syncthreads();                                          // epilogue stores visible to every wave
         float* out = A.L[l].out;
         if (out) {                                                // (tests) activation * XS as float32
             float* dst = out + board0 * 64 * 128;
-            for (int q = tid; q < rows_valid * 128; q += 256) {
+            for (int q = tid; q < rows_valid * 128; q += 320) {
                 const int r = q >> 7, c = q & 127;
                 dst[q] = (float)*reinterpret_cast<const _Float16*>(act + r * APITCH + 2 * c) +
                          (float)*reinterpret_cast<const _Float16*>(act + r * APITCH + LO + 2 * c);
@@ -348,7 +363,7 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
         A.L[i] = LayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (float*)s.out, i == 0 ? 9 : 36};
     }
     const int grid = (int)((n_boards + 2) / 3);
-    hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(320), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
