@@ -1,138 +1,126 @@
-// ckr_conv.hip -- the network body as ONE fused MFMA kernel for gfx950.
+// ckr_conv.hip -- the network body as ONE fused bf16 MFMA kernel for gfx950 (six boards per CU).
 //
 // Reference semantics: the 3x3 'same' convolutions of training_pipeline.create_nn
 // (training_pipeline.py:60-92): y = BatchNorm(ReLU(conv3x3(x) + bias)), 7 body layers
-// + the first policy-head conv, all 128 kernels wide.  This is the only MFMA user of
-// the path (BASELINE north_star).
+// + the first policy-head conv, all 128 kernels wide.
 //
-// Design (MI355X-first): an 8x8 board's activations are only 16 KB in bf16, so a
-// workgroup keeps FOUR boards (256 positions x 128 channels = 64 KB) resident in LDS
-// through ALL layers -- activations never round-trip through HBM between layers; only
-// the weights stream (L2-resident, 288 KB per layer, pre-swizzled on the host so the
-// global image IS the LDS image) through a double-buffered LDS ring filled by
-// global_load_lds DMA (no staging registers) one tap ahead of the MFMAs.
-// Per layer the workgroup computes the implicit GEMM
-//   C'[channel][position] = sum_{tap,k} W[tap][channel][k] * X[position + tap][k]
-// with v_mfma_f32_32x32x16_bf16: A = weights (rows = out channels), B = activations
-// (columns = positions), so each lane ends up with 4 consecutive channels of ONE
-// position -- an 8-byte store back into the NHWC LDS image (in place: accumulators
-// hold the whole 128 x 256 output tile, 128 VGPRs per lane).  Zero padding = a zero
-// row in LDS.  Rows are padded by one 16-B slot (pitch 272 B; 80 B for the 32-channel
-// first layer) so every ds_read_b128 lane group touches 16 distinct slots (conflict-free)
-// while the k-offset stays an instruction immediate (no per-read address arithmetic).
-// 4 waves (one per SIMD): wave (wc, wp) owns channels [64wc,+64) x positions [128wp,+128)
-// = 2 x 4 MFMA tiles; per 16-deep k-step 6 fragment reads feed 8 MFMAs, fragments
-// double-buffered in registers one k-step ahead.
+// What bounds this kernel is the L2 -> LDS weight stream (~20-25 GB/s per CU, the LDS-DMA
+// cadence), and every workgroup has to stream the whole network (2.5 MB) once.  So the
+// position tile is as large as 160 KB of LDS allows: SIX boards (384 positions x 128 channels
+// bf16 = 102 KB, rows padded to 272 B) stay resident through all layers, and the weights pass
+// through a 3-slot ring of half taps (128 output rows x 64 input channels, 18 KB, 144-B pitch)
+// filled by global_load_lds two slots ahead.  8 waves (two per SIMD, so one wave's DMA issue /
+// barrier / epilogue stalls are covered by the other's MFMAs): wave (wc, wp) owns channels
+// [64wc,+64) x positions [96wp,+96) = 2 x 3 tiles of v_mfma_f32_32x32x16_bf16; per 16-deep
+// k-step 5 fragment reads feed 6 MFMAs.  A = weights (rows = out channels), B = activations
+// (columns = positions): each lane ends with 4 consecutive channels of one position, an 8-byte
+// store back into the NHWC LDS image in place.  Zero padding = a small zero region in LDS.
 #include "ckr_host.h"
 #include <hip/hip_runtime.h>
 
-namespace ckr {
+namespace ckrc {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef int int4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-constexpr int CONV_MAX_LAYERS = 9;
-constexpr int ACT_ROWS = 256, ACT_PITCH = 272;                   // bytes (256 + one pad slot)
-constexpr int ACT_BYTES = (ACT_ROWS + 1) * ACT_PITCH;            // + zero row
-constexpr int W_BYTES = 128 * 272;                               // one tap, cin = 128 (padded rows)
+constexpr int MAX_LAYERS = 9;
+constexpr int NT = 512;                                          // threads per workgroup
+constexpr int XP = 384;                                          // positions per workgroup
+constexpr int APITCH = 272;                                      // 128 bf16 + 16 B
+constexpr int ZBASE = XP * APITCH;                               // zero region for out-of-board taps (see tap_rows)
+constexpr int ACT_BYTES = ZBASE + 15 * 16 + APITCH;              // 104 960
+constexpr int SLOT_BYTES = 128 * 144;                            // half tap: 64 bf16 + 16 B per row
+constexpr int NRING = 3;
 constexpr int PRM_BYTES = 3 * 128 * 4;
-constexpr int LDS_BYTES = ACT_BYTES + 2 * W_BYTES + PRM_BYTES;   // 141 072 B: one workgroup per CU
+constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 161 792 B
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(ZBASE % 256 == 0 && APITCH % 32 == 16, "bank-group arithmetic of tap_rows");
 
-struct ConvLayerDev {
-    const uint4* w;            // [9][128 rows][cin_pad*2 + 16 bytes] (row-padded LDS image)
+struct LayerDev {
+    const uint4* w;            // first layer [9][128][80 B] (32 padded channels), else [18][128][144 B]
     const float* bias; const float* scale; const float* shift;
     uint16_t* out;             // optional [B,8,8,128] bf16 NHWC
-    int cin_pad;               // 32 or 128
 };
-struct ConvArgs {
+struct Args {
     const uint16_t* x;         // [B,8,8,14] bf16 NHWC
     long long n_boards;
     int n_layers;
     int has_heads;
     ckr_conv_heads H;
-    ConvLayerDev L[CONV_MAX_LAYERS];
+    LayerDev L[MAX_LAYERS];
 };
 
-__device__ __forceinline__ uint32_t f2bf(float f) {              // round to nearest even
-    const uint32_t u = __float_as_uint(f);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
-// DMA one tap of weights (128 padded rows) from global memory into an LDS buffer:
-// every wave-instruction moves 64 lanes x 16 B = 1 KB to a wave-uniform LDS base.
-template <int CIN>
-__device__ __forceinline__ void issue_tap(const uint4* __restrict__ src, char* dst, int wave, int lane) {
-    constexpr int CHUNKS = 128 * (CIN * 2 + 16) / 1024;           // 10 or 34
+// one ring slot = PIECES wave-instructions of 64 lanes x 16 B, dealt round-robin to the 8 waves
+template <int PIECES>
+__device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < (CHUNKS + 3) / 4; ++i) {
-        const int c = wave + 4 * i;
-        if (c < CHUNKS)
+    for (int i = 0; i < (PIECES + 7) / 8; ++i) {
+        const int c = wave + 8 * i;
+        if (c < PIECES)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
     }
 }
 
-template <int CIN>
-__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int kk, int hi,
-                                           int wrow0, int4v brow, bf16x8 (&a)[2], bf16x8 (&b)[4]) {
-    constexpr int WPITCH = CIN * 2 + 16;
-    const int koff = 32 * kk + 16 * hi;                           // byte offset of this lane's 8 k-values
+struct Frags { bf16x8 a[2], b[3]; };
+
+template <int WPITCH>
+__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int kk, int koffb,
+                                           int half, int wrow0, const int (&brow)[3], Frags& f) {
+    const int ka = 32 * kk + 16 * half;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
-        a[ct] = *reinterpret_cast<const bf16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + koff);
+        f.a[ct] = *reinterpret_cast<const bf16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + ka);
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
-        b[pt] = *reinterpret_cast<const bf16x8*>(act + brow[pt] + koff);
+    for (int pt = 0; pt < 3; ++pt)
+        f.b[pt] = *reinterpret_cast<const bf16x8*>(act + brow[pt] + koffb + ka);
 }
 
-__device__ __forceinline__ void mfma_block(const bf16x8 (&a)[2], const bf16x8 (&b)[4], f32x16 (&acc)[2][4]) {
+__device__ __forceinline__ void mfma_block(const Frags& f, f32x16 (&acc)[2][3]) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ct], b[pt], acc[ct][pt], 0, 0, 0);
+        for (int pt = 0; pt < 3; ++pt)
+            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ct], f.b[pt], acc[ct][pt], 0, 0, 0);
 }
 
-// Scheduling directive for one pipelined k-step: issue the 6 ds_read_b128 of the NEXT
-// k-step between the first MFMAs of the CURRENT one (one wave per SIMD: the matrix pipe
-// only stays busy if LDS latency is covered inside the wave).  Without it hipcc re-uses
-// the fragment registers and waits lgkmcnt(0) in front of every MFMA block.
 __device__ __forceinline__ void interleave_reads_with_mfma() {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // 2 DS reads
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);            // remaining 5 MFMAs cover the LDS latency
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 }
 
-// byte offsets of the four B-tile rows this lane reads for tap (dy, dx); out-of-board taps
-// (zero padding of the 'same' convolution) read the zero row
-__device__ __forceinline__ int4v tap_rows(int prow0, int tap) {
+// Byte offsets of the three B-tile rows this lane reads for tap (dy, dx).  Out-of-board taps (the
+// zero padding of the 'same' convolution) read zeros from the zero region, at the 16-byte slot
+// whose LDS bank group equals that of the row the tap would have addressed (row pitch = 17 slots,
+// so bank group = (row + k-slot) mod 16; ZBASE is a multiple of 256 B): the 16 lanes that one
+// ds_read_b128 cycle serves keep 16 distinct bank groups, as for in-board taps (a single shared
+// zero row costs a 2-way conflict on most border reads; measured time is the same either way --
+// the LDS array is ~30 % busy -- so this only keeps SQ_LDS_BANK_CONFLICT clean).
+__device__ __forceinline__ void tap_rows(int prow0, int tap, int (&brow)[3]) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    int4v brow;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7;
+    for (int pt = 0; pt < 3; ++pt) {
+        const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7, r = p + 8 * dy + dx;
         const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
-        brow[pt] = (ok ? p + 8 * dy + dx : ACT_ROWS) * ACT_PITCH;
+        brow[pt] = ok ? r * APITCH : ZBASE + 16 * (r & 15);
     }
-    return brow;
 }
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (round to nearest even)
     const f32x2 v = {a, b};
     const bf16x2 r = __builtin_convertvector(v, bf16x2);
     return *reinterpret_cast<const uint32_t*>(&r);
 }
 
-// fused epilogue: ReLU + BatchNorm affine (the conv bias is already in the accumulators),
-// bf16, back into the LDS image in place
-__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][4]) {
+// fused epilogue: ReLU + BatchNorm affine (the conv bias is already in the accumulators), bf16, in place
+__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][3]) {
 #pragma clang fp contract(fast)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -142,48 +130,47 @@ __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, in
             const float4 sc = *reinterpret_cast<const float4*>(prm + c0);
             const float4 sh = *reinterpret_cast<const float4*>(prm + 128 + c0);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
+            for (int pt = 0; pt < 3; ++pt) {
                 const float y0 = sc.x * fmaxf(acc[ct][pt][4 * g + 0], 0.0f) + sh.x;
                 const float y1 = sc.y * fmaxf(acc[ct][pt][4 * g + 1], 0.0f) + sh.y;
                 const float y2 = sc.z * fmaxf(acc[ct][pt][4 * g + 2], 0.0f) + sh.z;
                 const float y3 = sc.w * fmaxf(acc[ct][pt][4 * g + 3], 0.0f) + sh.w;
-                const int r = prow0 + 32 * pt;
-                *reinterpret_cast<uint2*>(act + r * ACT_PITCH + (c0 << 1)) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+                *reinterpret_cast<uint2*>(act + (prow0 + 32 * pt) * APITCH + (c0 << 1)) =
+                    make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
             }
         }
 }
 
 // 1x1 convolution head on the LDS-resident activations: thread = position, NOUT kernels,
 // + bias + ReLU + BatchNorm affine, float32 out in Keras Flatten order (pos*NOUT + c).
-// Weights are staged in `stage` (an idle half of the weight ring) and read as broadcasts.
 template <int NOUT>
 __device__ __forceinline__ void head_1x1(const char* act, float* stage, const float* __restrict__ w,
                                          const float* __restrict__ b, const float* __restrict__ sc,
                                          const float* __restrict__ sh, float* __restrict__ out,
                                          long long board0, int rows_valid, int tid) {
 #pragma clang fp contract(fast)
-    for (int i = tid; i < NOUT * 128; i += 256) stage[i] = w[i];
+    for (int i = tid; i < NOUT * 128; i += NT) stage[i] = w[i];
     if (tid < NOUT) { stage[NOUT * 128 + tid] = b[tid]; stage[NOUT * 129 + tid] = sc[tid]; stage[NOUT * 130 + tid] = sh[tid]; }
     __syncthreads();
-    float acc[NOUT];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) acc[o] = 0.0f;
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-        const uint4 q = *reinterpret_cast<const uint4*>(act + tid * ACT_PITCH + (s << 4));
-        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
-        float xv[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { xv[2 * j] = __uint_as_float(u[j] << 16); xv[2 * j + 1] = __uint_as_float(u[j] & 0xFFFF0000u); }
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            const float4 w0 = *reinterpret_cast<const float4*>(stage + o * 128 + 8 * s);
-            const float4 w1 = *reinterpret_cast<const float4*>(stage + o * 128 + 8 * s + 4);
-            acc[o] += xv[0] * w0.x + xv[1] * w0.y + xv[2] * w0.z + xv[3] * w0.w +
-                      xv[4] * w1.x + xv[5] * w1.y + xv[6] * w1.z + xv[7] * w1.w;
-        }
-    }
     if (tid < rows_valid) {
+        float acc[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[o] = 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const uint4 q = *reinterpret_cast<const uint4*>(act + tid * APITCH + (s << 4));
+            const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[2 * j] = __uint_as_float(u[j] << 16); xv[2 * j + 1] = __uint_as_float(u[j] & 0xFFFF0000u); }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float4 w0 = *reinterpret_cast<const float4*>(stage + o * 128 + 8 * s);
+                const float4 w1 = *reinterpret_cast<const float4*>(stage + o * 128 + 8 * s + 4);
+                acc[o] += xv[0] * w0.x + xv[1] * w0.y + xv[2] * w0.z + xv[3] * w0.w +
+                          xv[4] * w1.x + xv[5] * w1.y + xv[6] * w1.z + xv[7] * w1.w;
+            }
+        }
         float* dst = out + (board0 * 64 + tid) * NOUT;
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
@@ -192,120 +179,115 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
     __syncthreads();
 }
 
-// One layer for the workgroup's 256 positions.  `g` counts taps globally (LDS ring parity);
-// the tap for step g is already in flight / landed in wring[g & 1] when the layer starts.
-template <int CIN>
-__device__ __forceinline__ void run_layer(const ConvArgs& A, int l, char* act, char* wring, float* prm, int tid, int wave,
-                                          int lane, int wc, int prow0, int wrow0, int& g) {
-    constexpr int TAP_U4 = 128 * (CIN * 2 + 16) / 16;             // uint4 per tap (640 or 2176)
-    constexpr int TAP_U4_NEXT = 128 * (128 * 2 + 16) / 16;        // taps of every later layer
-    constexpr int KSTEPS = CIN / 16;
-    const ConvLayerDev& L = A.L[l];
-    const int hi = lane >> 5;
-    f32x16 acc[2][4];                                             // accumulators start at the conv bias
+// One layer.  `ring` = ring index of the layer's slot 0; slots s, s+1, s+2 are landed / in flight
+// when step s starts.  FIRST: 9 slots of one whole tap each (32 padded input channels, 80-B rows,
+// 2 k-steps); otherwise 18 slots of half a tap (64 channels, 144-B rows, 4 k-steps).
+template <bool FIRST>
+__device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char* wring, float* prm, int tid, int wave,
+                                          int lane, int wc, int prow0, int wrow0, int& ring) {
+    constexpr int SPT = FIRST ? 1 : 2, NSLOTS = 9 * SPT, KSTEPS = FIRST ? 2 : 4, WPITCH = FIRST ? 80 : 144;
+    constexpr int PIECES = 128 * WPITCH / 1024, SLOT_U4 = 128 * WPITCH / 16;       // 10 / 18 pieces
+    constexpr int NEXT_U4 = SLOT_BYTES / 16;
+    const LayerDev& L = A.L[l];
+    const int half = lane >> 5;
+    f32x16 acc[2][3];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bi = *reinterpret_cast<const float4*>(L.bias + 64 * wc + 32 * ct + 8 * q + 4 * hi);
+            const float4 bi = *reinterpret_cast<const float4*>(L.bias + 64 * wc + 32 * ct + 8 * q + 4 * half);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
+            for (int pt = 0; pt < 3; ++pt) {
                 acc[ct][pt][4 * q + 0] = bi.x; acc[ct][pt][4 * q + 1] = bi.y;
                 acc[ct][pt][4 * q + 2] = bi.z; acc[ct][pt][4 * q + 3] = bi.w;
             }
         }
     if (tid < 128) { prm[tid] = L.scale[tid]; prm[128 + tid] = L.shift[tid]; }
-    // Flattened k-step pipeline over the 9 taps: fragments are always one k-step ahead of the
-    // MFMAs, also across tap boundaries.  The boundary (DMA landed + barrier) sits in front of a
-    // tap's LAST k-step: by then every wave has read all it needs from this tap's ring buffer,
-    // so the buffer is re-filled (tap g+2) immediately and the first fragments of tap g+1 load
-    // under the last MFMAs of tap g.
-    bf16x8 a0[2], b0[4], a1[2], b1[4];
-    int4v brow = tap_rows(prow0, 0);
-    load_frags<CIN>(act, wring + (g & 1) * W_BYTES, 0, hi, wrow0, brow, a0, b0);
+    Frags f0, f1;
+    int brow[3];
+    tap_rows(prow0, 0, brow);
+    load_frags<WPITCH>(act, wring + ring * SLOT_BYTES, 0, 0, half, wrow0, brow, f0);
     __builtin_amdgcn_sched_barrier(0);
+    int s = 0;
     for (int tap = 0; tap < 9; ++tap) {
-        char* cur = wring + (g & 1) * W_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS - 2; kk += 2) {
-            load_frags<CIN>(act, cur, kk + 1, hi, wrow0, brow, a1, b1);
-            mfma_block(a0, b0, acc);
+        for (int h = 0; h < SPT; ++h, ++s) {
+            char* cur = wring + ring * SLOT_BYTES;
+            const int nring = ring == NRING - 1 ? 0 : ring + 1;
+            const int koffb = 128 * h;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS - 2; kk += 2) {
+                load_frags<WPITCH>(act, cur, kk + 1, koffb, half, wrow0, brow, f1);
+                mfma_block(f0, acc);
+                interleave_reads_with_mfma();
+                load_frags<WPITCH>(act, cur, kk + 2, koffb, half, wrow0, brow, f0);
+                mfma_block(f1, acc);
+                interleave_reads_with_mfma();
+            }
+            load_frags<WPITCH>(act, cur, KSTEPS - 1, koffb, half, wrow0, brow, f1);
+            mfma_block(f0, acc);
             interleave_reads_with_mfma();
-            load_frags<CIN>(act, cur, kk + 2, hi, wrow0, brow, a0, b0);
-            mfma_block(a1, b1, acc);
-            interleave_reads_with_mfma();
+            // slot s+1 has landed for every wave (slot s+2 may be in flight: >= 1 (first layer) / 2 pieces
+            // per wave); all reads of `cur` are issued, it is re-filled with slot s+3 right away.
+            // A bare s_barrier: __syncthreads() would also wait vmcnt(0) and drain the look-ahead.
+            if (FIRST) asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            if (s + 3 < NSLOTS) issue_slot<PIECES>(L.w + (size_t)(s + 3) * SLOT_U4, cur, wave, lane);
+            else if (l + 1 < A.n_layers) issue_slot<18>(A.L[l + 1].w + (size_t)(s + 3 - NSLOTS) * NEXT_U4, cur, wave, lane);
+            if (s + 1 < NSLOTS) {
+                if (h == SPT - 1) tap_rows(prow0, tap + 1, brow);
+                load_frags<WPITCH>(act, wring + nring * SLOT_BYTES, 0, h == SPT - 1 ? 0 : 128 * (h + 1), half, wrow0, brow, f0);
+                mfma_block(f1, acc);
+                interleave_reads_with_mfma();
+            } else {
+                mfma_block(f1, acc);
+            }
+            ring = nring;
         }
-        load_frags<CIN>(act, cur, KSTEPS - 1, hi, wrow0, brow, a1, b1);
-        mfma_block(a0, b0, acc);
-        interleave_reads_with_mfma();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tap g+1 has landed (it had a whole tap of MFMAs)
-#ifndef CKR_CONV_NO_BARRIER                                       // (timing experiments only)
-        __syncthreads();                                          // ... for every wave; all reads of `cur` are done
-#endif
-#ifndef CKR_CONV_NO_STREAM
-        if (tap + 2 < 9) issue_tap<CIN>(L.w + (size_t)(tap + 2) * TAP_U4, cur, wave, lane);
-        else if (l + 1 < A.n_layers) issue_tap<128>(A.L[l + 1].w + (size_t)(tap + 2 - 9) * TAP_U4_NEXT, cur, wave, lane);
-#endif
-        if (tap < 8) {
-            brow = tap_rows(prow0, tap + 1);
-            load_frags<CIN>(act, wring + ((g + 1) & 1) * W_BYTES, 0, hi, wrow0, brow, a0, b0);
-            mfma_block(a1, b1, acc);
-            interleave_reads_with_mfma();
-        } else {
-            mfma_block(a1, b1, acc);
-        }
-        ++g;
     }
-#ifndef CKR_CONV_NO_EPILOGUE
     epilogue(act, prm, wc, lane, prow0, acc);
-#else
-    { float s = 0.0f;
-      for (int ct = 0; ct < 2; ++ct) for (int pt = 0; pt < 4; ++pt) for (int i = 0; i < 16; ++i) s += acc[ct][pt][i];
-      if (s == 12345.0f) act[0] = 1; }
-#endif
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 1) void k_conv_stack(const ConvArgs A) {
+__global__ __launch_bounds__(NT, 1) void k_conv_stack(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* act = smem;
     char* wring = smem + ACT_BYTES;
-    float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + 2 * W_BYTES);
+    float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + NRING * SLOT_BYTES);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wc = wave >> 1, wp = wave & 1;
-    const long long board0 = (long long)blockIdx.x * 4;
-    const int rows_valid = (int)min((long long)ACT_ROWS, (A.n_boards - board0) * 64);
+    const int wc = wave >> 2, wp = wave & 3;
+    const long long board0 = (long long)blockIdx.x * 6;
+    const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
 
-    issue_tap<32>(A.L[0].w, wring, wave, lane);                   // first two taps of the first layer
-    issue_tap<32>(A.L[0].w + 128 * (32 * 2 + 16) / 16, wring + W_BYTES, wave, lane);
-    // zero the activation image (channel padding of layer 0, tail boards, zero row)
-    for (int i = tid; i < ACT_BYTES / 16; i += 256) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < NRING; ++i)                               // first three taps of the first layer
+        issue_slot<10>(A.L[0].w + (size_t)i * (128 * 80 / 16), wring + i * SLOT_BYTES, wave, lane);
+    for (int i = tid; i < ACT_BYTES / 16; i += NT) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (tid < rows_valid) {                                       // 14 bf16 = 28 B per position
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.x + (board0 * 64 + tid) * 14);
         const uint32_t v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
-        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH) = make_uint4(v0, v1, v2, v3);
-        *reinterpret_cast<uint4*>(act + tid * ACT_PITCH + 16) = make_uint4(v4, v5, v6, 0u);
+        *reinterpret_cast<uint4*>(act + tid * APITCH) = make_uint4(v0, v1, v2, v3);
+        *reinterpret_cast<uint4*>(act + tid * APITCH + 16) = make_uint4(v4, v5, v6, 0u);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int prow0 = 128 * wp + (lane & 31);                     // this lane's position in B tile 0 (+32 per tile)
+    const int prow0 = 96 * wp + (lane & 31);
     const int wrow0 = 64 * wc + (lane & 31);
-    int g = 0;
+    int ring = 0;
     for (int l = 0; l < A.n_layers; ++l) {
-        if (l == 0) run_layer<32>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, g);
-        else run_layer<128>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, g);
+        if (l == 0) run_layer<true>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
+        else run_layer<false>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
         uint16_t* out = A.L[l].out;
-        if (out) {                                                // coalesced un-swizzled copy-out
+        if (out) {                                                // (tests) coalesced copy-out
             uint4* dst = reinterpret_cast<uint4*>(out + board0 * 64 * 128);
-            for (int q = tid; q < rows_valid * 16; q += 256) {
-                const int r = q >> 4, s = q & 15;
-                dst[q] = *reinterpret_cast<const uint4*>(act + r * ACT_PITCH + (s << 4));
+            for (int q = tid; q < rows_valid * 16; q += NT) {
+                const int r = q >> 4, sl = q & 15;
+                dst[q] = *reinterpret_cast<const uint4*>(act + r * APITCH + (sl << 4));
             }
         }
-        if (A.has_heads) {                                        // heads' 1x1 convs while the activations are in LDS
-            // staging: the value head (131 floats) fits the per-layer parameter block, which is idle
-            // between layers; the policy head runs after the last layer, when the weight ring is idle
+        if (A.has_heads) {
+            // staging: the value head (131 floats) fits the per-layer parameter block, idle between layers;
+            // the policy head runs after the last layer, when the weight ring is idle
             if (l == A.n_layers - 2 && A.H.val_out)
                 head_1x1<1>(act, prm, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid);
             if (l == A.n_layers - 1 && A.H.pol_out)
@@ -340,54 +322,53 @@ __global__ __launch_bounds__(256) void k_value_mlp(const float* __restrict__ in,
     }
 }
 
-}  // namespace ckr
+}  // namespace ckrc
 
-using namespace ckr;
+using namespace ckrc;
 
 extern "C" {
 
-/* Layer descriptor of the C-ABI (include/ckr.h): device pointers. */
 int ckr_value_mlp(const float* d_in, int64_t n, const float* w1t, const float* b1, const float* scale, const float* shift,
                   const float* w2, float b2, float* d_v, void* stream) {
-    if (n < 0) return fail(CKR_ERR_INVALID, "ckr_value_mlp: n < 0");
-    if (int rc = require_device()) return rc;
+    if (n < 0) return ckr::fail(CKR_ERR_INVALID, "ckr_value_mlp: n < 0");
+    if (int rc = ckr::require_device()) return rc;
     if (n == 0) return CKR_OK;
-    if (!d_in || !w1t || !b1 || !scale || !shift || !w2 || !d_v) return fail(CKR_ERR_INVALID, "ckr_value_mlp: null pointer");
+    if (!d_in || !w1t || !b1 || !scale || !shift || !w2 || !d_v) return ckr::fail(CKR_ERR_INVALID, "ckr_value_mlp: null pointer");
     int grid = (int)((n + 3) / 4); if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_value_mlp, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in, (long long)n, w1t, b1, scale, shift, w2, b2, d_v);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
 
-int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers, int n_layers,
-                        const ckr_conv_heads* heads, void* stream) {
-    if (n_boards < 0 || n_layers < 1 || n_layers > CONV_MAX_LAYERS || !layers)
-        return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: bad n_boards / n_layers");
-    if (int rc = require_device()) return rc;
+int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
+                                      const ckr_conv_heads* heads, void* stream) {
+    if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: bad n_boards / n_layers");
+    if (int rc = ckr::require_device()) return rc;
     if (n_boards == 0) return CKR_OK;
-    if (!d_x) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null input");
-    ConvArgs A;
+    if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null input");
+    Args A;
     A.x = (const uint16_t*)d_x; A.n_boards = n_boards; A.n_layers = n_layers;
     A.has_heads = heads ? 1 : 0;
     if (heads) {
         A.H = *heads;
-        if (n_layers < 2) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: heads need at least two layers");
+        if (n_layers < 2) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: heads need at least two layers");
         if (A.H.pol_out && !(A.H.pol_w && A.H.pol_b && A.H.pol_scale && A.H.pol_shift))
-            return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null policy-head pointer");
+            return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null policy-head pointer");
         if (A.H.val_out && !(A.H.val_w && A.H.val_b && A.H.val_scale && A.H.val_shift))
-            return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null value-head pointer");
+            return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null value-head pointer");
     } else {
         A.H = ckr_conv_heads{};
     }
     for (int i = 0; i < n_layers; ++i) {
         const ckr_conv_layer& s = layers[i];
-        if (!s.weights || !s.bias || !s.scale || !s.shift) return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null layer pointer");
+        if (!s.weights || !s.bias || !s.scale || !s.shift) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null layer pointer");
         if ((i == 0 && s.cin_pad != 32) || (i > 0 && s.cin_pad != 128))
-            return fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: layer 0 must have cin_pad 32, later layers 128");
-        A.L[i] = ConvLayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (uint16_t*)s.out, s.cin_pad};
+            return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: layer 0 must have cin_pad 32, later layers 128");
+        A.L[i] = LayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (uint16_t*)s.out};
     }
-    const int grid = (int)((n_boards + 3) / 4);
-    hipLaunchKernelGGL(k_conv_stack, dim3(grid), dim3(256), 0, (hipStream_t)stream, A);
+    const int grid = (int)((n_boards + 5) / 6);
+    hipLaunchKernelGGL(k_conv_stack, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -39,7 +39,8 @@ constexpr int MAX_LAYERS = 9;
 constexpr int XP = 192;                                          // positions per workgroup
 constexpr int APITCH = 528;                                      // [128 hi | 128 lo] fp16 + 16 B
 constexpr int LO = 256;                                          // byte offset of the lo half of a row
-constexpr int ACT_BYTES = (XP + 1) * APITCH;                     // + zero row
+constexpr int ZBASE = XP * APITCH;                               // zero region for out-of-board taps (see tap_rows)
+constexpr int ACT_BYTES = ZBASE + 15 * 16 + APITCH;
 constexpr int SLOT_K = 32;                                       // input channels per ring slot
 constexpr int WPITCH = SLOT_K * 4 + 16;                          // [32 hi | 32 lo] fp16 + 16 B = 144
 constexpr int WLO = SLOT_K * 2;
@@ -48,8 +49,9 @@ constexpr int SLOT_U4 = SLOT_BYTES / 16;
 constexpr int SLOT_PIECES = SLOT_BYTES / 1024;
 constexpr int NRING = 3;
 constexpr int PRM_BYTES = 3 * 128 * 4;
-constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 158 736 B
+constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 158 976 B
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(ZBASE % 256 == 0 && APITCH % 32 == 16, "bank-group arithmetic of tap_rows");
 
 struct LayerDev {
     const uint4* w;            // [n_slots][128 rows][144 B]
@@ -120,13 +122,16 @@ __device__ __forceinline__ void interleave_reads_with_mfma() {
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 }
 
+// Out-of-board taps read zeros from the zero region at the 16-byte slot whose bank group equals
+// that of the row the tap would have addressed (pitch = 33 slots: bank group = (row + k-slot) mod 16),
+// so border reads stay conflict-free (cf. ckr_conv.hip).
 __device__ __forceinline__ void tap_rows(int prow0, int tap, int (&brow)[3]) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
     for (int pt = 0; pt < 3; ++pt) {
-        const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7;
+        const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7, r = p + 8 * dy + dx;
         const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
-        brow[pt] = (ok ? p + 8 * dy + dx : XP) * APITCH;
+        brow[pt] = ok ? r * APITCH : ZBASE + 16 * (r & 15);
     }
 }
 

@@ -28,15 +28,24 @@ class ConvHeads(C.Structure):
                                           "val_w", "val_b", "val_scale", "val_shift", "val_out")]
 
 
-def pack_conv_weights(w, cin_pad):
-    """torch conv weight [128, cin, 3, 3] -> bf16 [9 taps][128 out][cin_pad + 8]:
-    the kernel's LDS image (k contiguous per output channel, every row padded by
-    one 16-byte slot so that ds_read_b128 is bank-conflict free)."""
+def pack_conv_weights(w, first):
+    """torch conv weight [128, cin, 3, 3] -> the weight-ring image of ckr_conv_stack_bf16
+    (k contiguous per output channel, every row padded by one 16-byte slot so that
+    ds_read_b128 is bank-conflict free): first layer bf16 [9 taps][128 out][32 + 8]
+    (14 planes zero-padded to 32), later layers [18 half taps][128 out][64 + 8]
+    (slot = tap*2 + half of the 128 input channels; tap = ky*3 + kx)."""
     cout, cin = w.shape[0], w.shape[1]
-    assert cout == 128 and w.shape[2:] == (3, 3) and cin <= cin_pad
-    t = torch.zeros((9, cout, cin_pad + 8), dtype=torch.float32, device=w.device)
-    t[:, :, :cin] = w.permute(2, 3, 0, 1).reshape(9, cout, cin)           # tap = ky*3 + kx
-    return t.to(torch.bfloat16).contiguous()
+    assert cout == 128 and w.shape[2:] == (3, 3)
+    if first:
+        assert cin <= 32
+        t = torch.zeros((9, cout, 40), dtype=torch.float32, device=w.device)
+        t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin)
+        return t.to(torch.bfloat16).contiguous()
+    assert cin == 128
+    t = w.float().permute(2, 3, 0, 1).reshape(9, cout, 2, 64).permute(0, 2, 1, 3)    # [tap][half][out][64]
+    img = torch.zeros((9, 2, cout, 72), dtype=torch.float32, device=w.device)
+    img[..., :64] = t
+    return img.reshape(18, cout, 72).to(torch.bfloat16).contiguous()
 
 
 XS, WS = 64.0, 1024.0        # power-of-two operand scales of the split-fp16 path (ckr_conv_x3.hip)
@@ -112,7 +121,7 @@ class FusedEvaluator:
                 w = pack_split_weights(_f32(blk["conv"].weight), i == 0)
                 b, sc, sh = (b * (XS * WS)).contiguous(), (sc / WS).contiguous(), (sh * XS).contiguous()
             else:
-                w = pack_conv_weights(_f32(blk["conv"].weight), cin_pad)
+                w = pack_conv_weights(_f32(blk["conv"].weight), i == 0)
             keep += [w, b, sc, sh]
             out = y_body if i == len(blocks) - 2 else (y_pol if i == len(blocks) - 1 else None)
             layers[i] = ConvLayer(w.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(),

@@ -9,7 +9,7 @@ from checkers_mcts_amd.fused import FusedEvaluator
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = N.PolicyValueNet(128).keras_init(0).eval().cuda()
-fe = FusedEvaluator(m, S)
+fe = FusedEvaluator(m, S, mode=os.environ.get("CONV_MODE", "bf16"))
 x = (torch.rand(S, 8, 8, 14, device="cuda") < 0.2).to(torch.bfloat16).contiguous()
 n = fe.nets[0]
 import ctypes as C
@@ -17,7 +17,7 @@ from checkers_mcts_amd import _lib
 L = _lib.load()
 stream = torch.cuda.current_stream().cuda_stream
 def conv_only():
-    L.ckr_conv_stack_bf16(x.data_ptr(), S, n["layers"], n["n"], C.byref(n["heads"]), stream)
+    fe.conv_only(x)
 for name, fn in (("conv_stack", conv_only), ("full_forward", lambda: fe.forward_features(x))):
     for _ in range(5): fn()
     torch.cuda.synchronize()
