@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--nn-dtype", choices=list(DTYPES), default="bf16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--evaluator", choices=["fused", "torch"], default=None,
-                    help="fused: conv stack in the hand-written MFMA kernel (bf16 only); torch: MIOpen via PyTorch")
+                    help="fused: conv stack in the hand-written MFMA kernels (bf16, or fp32 = split-fp16 operands); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
     ap.add_argument("--parity-steps", type=int, default=200,
@@ -136,7 +136,12 @@ def split_roofline(conv_flops, slots, t_conv):
     return {"bound": "mfma", "kernel": "k_conv_stack_x3 (the same fused stack with split-fp16 operands: float32-grade "
                                        "results, 3 fp16 MFMAs per multiply-add; one launch per step)",
             "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
-            "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None, "traffic": None,
+            "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
+            # profiles/r01_pmc_conv_kernels.csv: FETCH_SIZE 120 537 KB (doubled, gfx950), WRITE_SIZE 9 216 KB at 4 096
+            # boards -- the 4.7 MB split-weight image exceeds one XCD's 4 MB L2, so part of the stream is served
+            # by the Infinity Cache (3.7 % of the 6.4 GB the workgroups stream per launch)
+            "traffic": (2 * 120537.5 + 9216.0) * 1024.0 * slots / 4096.0,
+            "traffic_source": "profiles/r01_pmc_conv_kernels.csv (separate --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)",
             "executed_tflops": 3.0 * tf if tf else None,
             "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
             "vs_fp32_matrix_peak": tf / MFMA_PEAK_TFLOPS["fp32"] if tf else None,
@@ -277,14 +282,16 @@ def main():
             conv_flops = evaluator.CONV_FLOPS_PER_BOARD
             conv_tflops = conv_flops * a.slots / t_conv / 1e12 if t_conv else None
             roofline = {"bound": "mfma", "kernel": "k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, "
-                                                   "LDS-resident activations; one launch per step)",
+                                                   "6 boards per workgroup LDS-resident through all layers; one launch per step)",
                         "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
                         "frac": conv_tflops / peak if conv_tflops else None,
-                        # HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/
-                        # (r01_pmc_summary.csv: FETCH_SIZE 12 831 KB + WRITE_SIZE 9 216 KB at 4 096 boards),
-                        # scaled to this launch size; not re-measured by this script
-                        "traffic": (12831.067 + 9216.0) * 1024.0 * a.slots / 4096.0,
-                        "traffic_source": "profiles/r01_pmc_summary.csv (separate --pmc passes)",
+                        # HBM-side bytes per launch from the rocprofv3 --pmc passes committed under profiles/
+                        # (r01_pmc_conv_kernels.csv, final rows: FETCH_SIZE 14 713 KB, WRITE_SIZE 9 216 KB at 4 096
+                        # boards; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch
+                        # size; not re-measured by this script.  Algorithmic: 7.3 MB planes in + 9.4 MB head
+                        # features out + the 2.5 MB of weights once per XCD L2.
+                        "traffic": (2 * 14713.4 + 9216.0) * 1024.0 * a.slots / 4096.0,
+                        "traffic_source": "profiles/r01_pmc_conv_kernels.csv (separate --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)",
                         "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": a.slots,
                         "network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
                         "tree_kernel": tree}

@@ -55,13 +55,16 @@ struct Args {
 };
 
 // one ring slot = PIECES wave-instructions of 64 lanes x 16 B, dealt round-robin to the 8 waves
+// (buffer addressing: resource + piece offset in SGPRs, one shared lane-offset VGPR -- no per-lane
+// 64-bit addresses to keep alive across the kernel)
 template <int PIECES>
 __device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, PIECES * 1024, 0x00020000);
 #pragma unroll
     for (int i = 0; i < (PIECES + 7) / 8; ++i) {
         const int c = wave + 8 * i;
         if (c < PIECES)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + c * 1024), 16, lane * 16, c * 1024, 0, 0);
     }
 }
 
@@ -149,6 +152,7 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
                                          const float* __restrict__ sh, float* __restrict__ out,
                                          long long board0, int rows_valid, int tid) {
 #pragma clang fp contract(fast)
+    asm volatile("" : "+v"(tid));      // keep the per-lane head addresses from being hoisted to kernel entry (spills)
     for (int i = tid; i < NOUT * 128; i += NT) stage[i] = w[i];
     if (tid < NOUT) { stage[NOUT * 128 + tid] = b[tid]; stage[NOUT * 129 + tid] = sc[tid]; stage[NOUT * 130 + tid] = sh[tid]; }
     __syncthreads();

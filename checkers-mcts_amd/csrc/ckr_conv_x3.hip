@@ -70,10 +70,12 @@ struct Args {
 };
 
 // the loader wave DMAs one ring slot: 18 wave-instructions of 64 lanes x 16 B to a wave-uniform LDS base
+// (buffer addressing: resource + piece offset in SGPRs, one lane-offset VGPR)
 __device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int lane) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, SLOT_BYTES, 0x00020000);
 #pragma unroll
     for (int c = 0; c < SLOT_PIECES; ++c)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + c * 64 + lane), (lds_ptr_t)(dst + c * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + c * 1024), 16, lane * 16, c * 1024, 0, 0);
 }
 
 struct Frags { f16x8 ah[2], al[2], bh[3], bl[3]; };
@@ -174,6 +176,7 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
                                          const float* __restrict__ sh, float* __restrict__ out,
                                          long long board0, int rows_valid, int tid, float inv_xs) {
 #pragma clang fp contract(fast)
+    asm volatile("" : "+v"(tid));      // keep the per-lane head addresses from being hoisted to kernel entry (spills)
     for (int i = tid; i < NOUT * 128; i += 320) stage[i] = w[i];
     if (tid < NOUT) { stage[NOUT * 128 + tid] = b[tid]; stage[NOUT * 129 + tid] = sc[tid]; stage[NOUT * 130 + tid] = sh[tid]; }
     __syncthreads();
