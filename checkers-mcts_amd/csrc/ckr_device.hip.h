@@ -175,6 +175,11 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     v = max(v, xchg_i32<8>(v));  v = max(v, xchg_i32<16>(v)); v = max(v, xchg_i32<32>(v));
     return v;
 }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += xchg_i32<1>(v); v += xchg_i32<2>(v); v += xchg_i32<4>(v);
+    v += xchg_i32<8>(v); v += xchg_i32<16>(v); v += xchg_i32<32>(v);
+    return v;
+}
 __device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ int first_lane(unsigned long long m) { return (int)__ffsll((long long)m) - 1; }
 // order global memory traffic between the lanes of this wave (same CU, shared L1)

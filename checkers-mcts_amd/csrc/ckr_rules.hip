@@ -87,6 +87,47 @@ __global__ __launch_bounds__(256) void k_features(const uint4* __restrict__ boar
     }
 }
 
+// Training batch straight from compact tuples (the work of Keras_Generator.__getitem__,
+// training_pipeline.py:296-307, without the pickle round trip): x = planes 0-13 channels-last,
+// pi = visit counts / their sum at the action codes (float64 division, then float32 as Keras
+// casts it), value target = (q + z) / 2.  One wavefront per sample; rows staged in LDS so that
+// every global store is a coalesced 16-byte chunk.
+__global__ __launch_bounds__(256) void k_training_batch(const ckr_tuple* __restrict__ tuples, int64_t n_tuples,
+                                                        const int64_t* __restrict__ index, int64_t batch,
+                                                        float* __restrict__ x, float* __restrict__ pi, float* __restrict__ tv) {
+    __shared__ __attribute__((aligned(16))) float feat[4][896];
+    __shared__ __attribute__((aligned(16))) float prob[4][512];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < batch; r += nwaves) {
+        const int64_t t = index ? index[r] : r;
+        const bool ok = t >= 0 && t < n_tuples;
+        const ckr_tuple* T = tuples + (ok ? t : 0);
+        const uint4 bv = *reinterpret_cast<const uint4*>(&T->board);
+        const ckr_board b{bv.x, bv.y, bv.z, bv.w};
+        uint32_t m[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) m[d] = T->mask[d];
+        wave_features(b, m, T->status, feat[wave]);
+        for (int k = lane; k < 512; k += 64) prob[wave][k] = 0.0f;
+        const int nc = ok ? T->n_children : 0;
+        const uint32_t e = lane < nc ? T->pi[lane] : 0u;
+        const int visits = (int)(e & 0x7FFFFFu);
+        const int total = wave_sum_i32(visits);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nc && total > 0) prob[wave][e >> 23] = (float)((double)visits / (double)total);
+        __builtin_amdgcn_wave_barrier();
+        float4* dx = reinterpret_cast<float4*>(x + r * 896);
+        const float4* sx = reinterpret_cast<const float4*>(feat[wave]);
+        for (int k = lane; k < 224; k += 64) dx[k] = ok ? sx[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* dp = reinterpret_cast<float4*>(pi + r * 512);
+        const float4* sp = reinterpret_cast<const float4*>(prob[wave]);
+        for (int k = lane; k < 128; k += 64) dp[k] = sp[k];
+        if (lane == 0) tv[r] = ok ? (float)(((double)T->q + (double)T->z) / 2.0) : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mask_renorm(const uint4* __restrict__ boards, int64_t n,
                                                      const float* __restrict__ p, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float pl[4][512];
@@ -211,6 +252,18 @@ int ckr_mask_renorm_batch(const ckr_board* d_boards, int64_t n, const float* d_p
     CKR_CHECK_ARGS(d_boards && d_p && d_out, "null device pointer");
     hipLaunchKernelGGL(k_mask_renorm, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)d_boards, n, d_p, d_out);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_training_batch(const ckr_tuple* d_tuples, int64_t n_tuples, const int64_t* d_index, int64_t batch,
+                       float* d_x, float* d_pi, float* d_value, void* stream) {
+    CKR_CHECK_ARGS(n_tuples >= 0 && batch >= 0, "negative size");
+    if (int rc = require_device()) return rc;
+    if (batch == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_tuples && d_x && d_pi && d_value, "null device pointer");
+    hipLaunchKernelGGL(k_training_batch, dim3(grid_for(batch, 4)), dim3(256), 0, (hipStream_t)stream,
+                       d_tuples, n_tuples, d_index, batch, d_x, d_pi, d_value);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -193,10 +193,10 @@ class generate_Checkers_data:
         self.stats = None
         self.results = None
 
-    def generate_data(self):
-        """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
-        name (a str for one worker, a one-element list otherwise, mirroring
-        training_pipeline.py:325-332); None on ranks other than 0."""
+    def generate_tuples(self):
+        """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games and returns the compact tuples as a DEVICE
+        tensor [n, 288] uint8 on rank 0 (None elsewhere): the input of train.TrainingData, i.e.
+        self-play -> training without the pickle round trip."""
         rank, local_rank, world = ckdist.init_from_env()
         first, count = ckdist.shard_range(self.num_cpus, rank, world)
         dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
@@ -217,8 +217,14 @@ class generate_Checkers_data:
             self.results = eng.results()
             raw_dev = eng.pack_tuples_device()
             eng.close()
-        gathered = ckdist.gather_rows(raw_dev, dst=0)       # the ONE collective of the job
-        if rank != 0:
+        return ckdist.gather_rows(raw_dev, dst=0)           # the ONE collective of the job
+
+    def generate_data(self):
+        """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
+        name (a str for one worker, a one-element list otherwise, mirroring
+        training_pipeline.py:325-332); None on ranks other than 0."""
+        gathered = self.generate_tuples()
+        if gathered is None:
             return None
         raw = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=ckengine.TUPLE_DTYPE)
         memory = tuples_to_memory(raw, neural_net=bool(self.mcts_kwargs["NEURAL_NET"]))

@@ -1,0 +1,286 @@
+"""Training phase next to the hot path: `create_nn`, `train_nn`, the
+cyclical learning-rate schedule and the small bookkeeping helpers of
+training_pipeline.py:40-244 / CLR/clr_callback.py, on the same GPU as self-play.
+
+What is new relative to the reference is the data path: a training batch is built ON THE
+DEVICE from the compact tuples the engine emits (`ckr_training_batch`, the work of
+`Keras_Generator.__getitem__`, training_pipeline.py:296-307) -- no 11.8-KB-per-tuple pickle,
+no host round trip between self-play and training.  The reference's pickled list format is
+accepted as well.  The optimisation itself (autograd, Adam, MIOpen backward kernels) is
+PyTorch: plumbing around the path, not part of it.
+
+Keras semantics kept: loss = w_p * categorical cross-entropy(pi, p) + w_v * MSE((q+z)/2, v)
++ l2 penalties CONV_REG / DENSE_REG * sum(w^2) on every kernel AND bias of the conv / dense
+layers (training_pipeline.py:49-114); Adam with Keras defaults (epsilon 1e-7); BatchNorm
+momentum 0.99, eps 1e-3; fixed batches re-ordered every epoch (Sequence + shuffle=True);
+validation on the last VAL_SPLIT fraction after one shuffle; EarlyStopping(val_loss,
+PATIENCE, MIN_DELTA); the best val_loss model is the one saved.
+"""
+import ctypes as C
+import os
+import pickle
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .net import PolicyValueNet
+
+TUPLE_BYTES = 288
+
+
+def create_timestamp():
+    return datetime.now(tz=None).strftime("%d-%b-%Y(%H:%M:%S)")                  # training_pipeline.py:192-196
+
+
+def record_params(phase, **kwargs):
+    """Parameter dump of one pipeline phase (training_pipeline.py:225-244): same file names, same text."""
+    names = {"selfplay": "data/training_data/Checkers_SelfPlay_Params_", "training": "data/model/Checkers_Training_Params_",
+             "evaluation": "data/tournament_results/Checkers_Evaluation_Params_",
+             "final": "data/final_eval/Checkers_Final_Evaluation_Params_"}
+    if phase not in names:
+        raise ValueError("Invalid phase!")
+    filename = names[phase] + create_timestamp() + ".txt"
+    os.makedirs(os.path.dirname(filename), exist_ok=True)
+    with open(filename, "w") as file:
+        for key, val in kwargs.items():
+            file.write("{} = {}\n".format(key, val))
+    return filename
+
+
+def load_training_data(filename):
+    with open(filename, "rb") as file:                                            # training_pipeline.py:218-222
+        return pickle.load(file)
+
+
+def save_merged_files(memory, iteration, timestamp):
+    filename = "data/training_data/Checkers_Data" + str(iteration) + "_" + timestamp + ".pkl"
+    os.makedirs("data/training_data", exist_ok=True)
+    with open(filename, "wb") as file:                                            # training_pipeline.py:269-275
+        pickle.dump(memory, file)
+    return filename
+
+
+def merge_data(data_fns, iteration):
+    training_data = []                                                            # training_pipeline.py:277-284
+    for fn in data_fns:
+        training_data.extend(load_training_data("data/training_data/" + fn))
+    save_merged_files(training_data, iteration, create_timestamp())
+    return training_data
+
+
+def create_nn(**kwargs):
+    """Freshly initialised network (Keras defaults: Glorot-uniform kernels, zero biases, BN 1/0/0/1)
+    carrying the regularisation and loss weights of training_pipeline.create_nn (:40-114)."""
+    net = PolicyValueNet(kwargs["NUM_KERNELS"]).keras_init(int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))))
+    net.conv_reg, net.dense_reg = float(kwargs["CONV_REG"]), float(kwargs["DENSE_REG"])
+    net.policy_loss_weight, net.value_loss_weight = float(kwargs["POLICY_LOSS_WEIGHT"]), float(kwargs["VALUE_LOSS_WEIGHT"])
+    return net
+
+
+def save_nn_to_disk(neural_network, iteration, timestamp):
+    filename = "data/model/Checkers_Model" + str(iteration) + "_" + timestamp + ".pt"     # .h5 in the reference (:186-190)
+    os.makedirs("data/model", exist_ok=True)
+    torch.save({k: v.detach().cpu() for k, v in neural_network.state_dict().items()}, filename)
+    return filename
+
+
+class CyclicLR:
+    """Cyclical learning rate, the arithmetic of CLR/clr_callback.py:60-139 (triangular,
+    triangular2, exp_range), stepped once per batch."""
+
+    def __init__(self, base_lr=0.001, max_lr=0.006, step_size=2000., mode="triangular", gamma=1., scale_fn=None,
+                 scale_mode="cycle"):
+        self.base_lr, self.max_lr, self.step_size, self.mode, self.gamma = base_lr, max_lr, step_size, mode, gamma
+        if scale_fn is None:
+            if mode == "triangular":
+                self.scale_fn, self.scale_mode = (lambda x: 1.), "cycle"
+            elif mode == "triangular2":
+                self.scale_fn, self.scale_mode = (lambda x: 1 / (2. ** (x - 1))), "cycle"
+            elif mode == "exp_range":
+                self.scale_fn, self.scale_mode = (lambda x: gamma ** (x)), "iterations"
+            else:
+                raise ValueError("Invalid CLR mode!")
+        else:
+            self.scale_fn, self.scale_mode = scale_fn, scale_mode
+        self.clr_iterations = 0.
+        self.trn_iterations = 0.
+        self.history = {}
+
+    def clr(self):
+        cycle = np.floor(1 + self.clr_iterations / (2 * self.step_size))
+        x = np.abs(self.clr_iterations / self.step_size - 2 * cycle + 1)
+        arg = cycle if self.scale_mode == "cycle" else self.clr_iterations
+        return self.base_lr + (self.max_lr - self.base_lr) * np.maximum(0, (1 - x)) * self.scale_fn(arg)
+
+    def on_train_begin(self):
+        return self.base_lr if self.clr_iterations == 0 else self.clr()
+
+    def on_batch_end(self, lr_used):
+        self.trn_iterations += 1
+        self.clr_iterations += 1
+        self.history.setdefault("lr", []).append(lr_used)
+        self.history.setdefault("iterations", []).append(self.trn_iterations)
+        return self.clr()
+
+
+class TrainingData:
+    """Training examples resident on the device: either the engine's compact tuples ([n, 288]
+    uint8, batches built by `ckr_training_batch`) or dense tensors made from the reference's
+    pickled list of [state(15,8,8), pi(8,8,8), q, z]."""
+
+    def __init__(self, tuples=None, dense=None):
+        self.tuples, self.dense = tuples, dense
+        self.n = int(tuples.shape[0]) if tuples is not None else int(dense[0].shape[0])
+        if tuples is not None:
+            if tuples.dtype != torch.uint8 or tuples.dim() != 2 or tuples.shape[1] != TUPLE_BYTES or not tuples.is_cuda:
+                raise ValueError("compact tuples must be a CUDA uint8 tensor [n, 288]")
+            self._L = _lib.load()
+            vp = C.c_void_p
+            self._L.ckr_training_batch.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp]
+
+    @classmethod
+    def from_memory(cls, memory, device="cuda"):
+        """The reference's list format, with Keras_Generator's arithmetic (training_pipeline.py:296-307)."""
+        states = np.array([e[0][:14] for e in memory])
+        states = np.moveaxis(states, 1, -1)
+        probs = np.array([np.array(e[1]).flatten() for e in memory])
+        qvals = np.array([e[2] for e in memory])
+        zvals = np.array([e[3] for e in memory])
+        target = (qvals + zvals) / 2
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
+        return cls(dense=(t(states), t(probs), t(target)))
+
+    def __len__(self):
+        return self.n
+
+    def batch(self, index):
+        """index: int64 device tensor -> (x [B,8,8,14], pi [B,512], value target [B]) float32."""
+        if self.dense is not None:
+            return tuple(a.index_select(0, index) for a in self.dense)
+        B, dev = int(index.shape[0]), self.tuples.device
+        x = torch.empty((B, 8, 8, 14), dtype=torch.float32, device=dev)
+        pi = torch.empty((B, 512), dtype=torch.float32, device=dev)
+        tv = torch.empty((B,), dtype=torch.float32, device=dev)
+        index = index.to(torch.int64).contiguous()
+        _lib.check(self._L.ckr_training_batch(self.tuples.data_ptr(), self.n, index.data_ptr(), B, x.data_ptr(),
+                                              pi.data_ptr(), tv.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        return x, pi, tv
+
+
+def l2_penalty(net):
+    """Keras kernel_regularizer / bias_regularizer = l2(CONV_REG | DENSE_REG) on every conv and dense layer."""
+    conv = sum((m.weight.square().sum() + m.bias.square().sum()) for m in net.modules() if isinstance(m, torch.nn.Conv2d))
+    dense = sum((m.weight.square().sum() + m.bias.square().sum()) for m in net.modules() if isinstance(m, torch.nn.Linear))
+    return net.conv_reg * conv + net.dense_reg * dense
+
+
+def losses(net, x, pi, tv):
+    """(total, policy CE, value MSE) with Keras' definitions: CE = -sum(t * log(clip(p / sum p, 1e-7, 1 - 1e-7)))."""
+    p, v = net(x.permute(0, 3, 1, 2))
+    p = p / p.sum(dim=1, keepdim=True)
+    ce = -(pi * torch.log(p.clamp(1e-7, 1 - 1e-7))).sum(dim=1).mean()
+    mse = F.mse_loss(v, tv)
+    return net.policy_loss_weight * ce + net.value_loss_weight * mse + l2_penalty(net), ce, mse
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+
+    def add(self, **kw):
+        for k, v in kw.items():
+            self.history.setdefault(k, []).append(float(v))
+
+
+def _as_training_data(training_data, device):
+    if isinstance(training_data, TrainingData):
+        return training_data
+    if isinstance(training_data, torch.Tensor):
+        return TrainingData(tuples=training_data.to(device))
+    return TrainingData.from_memory(training_data, device)
+
+
+def train_nn(training_data, neural_network, **kwargs):
+    """Trains the network (training_pipeline.py:123-179).  training_data: the reference's list, a
+    device tensor of compact tuples (generate_Checkers_data.generate_tuples()), or a TrainingData.
+    Returns (history, filepath of the best model: a torch state_dict readable by NN_FN)."""
+    PATIENCE, MIN_DELTA, VAL_SPLIT = kwargs["PATIENCE"], kwargs["MIN_DELTA"], kwargs["VAL_SPLIT"]
+    TRAINING_ITERATION, BATCH_SIZE = kwargs["TRAINING_ITERATION"], kwargs["BATCH_SIZE"]
+    CLR_SS_COEFF, NN_BASE_LR, NN_MAX_LR, EPOCHS = kwargs["CLR_SS_COEFF"], kwargs["NN_BASE_LR"], kwargs["NN_MAX_LR"], kwargs["EPOCHS"]
+    dev = torch.device(kwargs.get("DEVICE", "cuda"))
+    for name, dflt in (("conv_reg", kwargs.get("CONV_REG", 0.0)), ("dense_reg", kwargs.get("DENSE_REG", 0.0)),
+                       ("policy_loss_weight", kwargs.get("POLICY_LOSS_WEIGHT", 1.0)),
+                       ("value_loss_weight", kwargs.get("VALUE_LOSS_WEIGHT", 1.0))):
+        if not hasattr(neural_network, name):
+            setattr(neural_network, name, float(dflt))
+    net = neural_network.to(device=dev, dtype=torch.float32)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    data = _as_training_data(training_data, dev)
+    g = torch.Generator(device="cpu").manual_seed(int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))))
+    order = torch.randperm(len(data), generator=g)                              # np.random.shuffle(training_data), :149
+    n_val = int(len(data) * VAL_SPLIT) if VAL_SPLIT > 0 else 0
+    train_idx, val_idx = order[:len(data) - n_val].to(dev), order[len(data) - n_val:].to(dev)
+    n_train = int(train_idx.shape[0])
+    steps_per_epoch = int(np.ceil(n_train / float(BATCH_SIZE)))
+    clr = CyclicLR(base_lr=NN_BASE_LR, max_lr=NN_MAX_LR, step_size=int(CLR_SS_COEFF * (n_train / BATCH_SIZE)), mode="triangular")
+    opt = torch.optim.Adam(net.parameters(), lr=clr.on_train_begin(), betas=(0.9, 0.999), eps=1e-7)
+    filepath = "data/model/Checkers_Model" + str(TRAINING_ITERATION + 1) + "_" + create_timestamp() + ".pt"
+    os.makedirs("data/model", exist_ok=True)
+    history, best, es_best, wait, saved = History(), np.inf, np.inf, 0, False
+    lr = clr.on_train_begin()
+
+    def run(idx, train):
+        tot = ce_s = mse_s = 0.0
+        nb = int(np.ceil(idx.shape[0] / float(BATCH_SIZE)))
+        batches = torch.randperm(nb, generator=g).tolist() if train else range(nb)
+        nonlocal lr
+        for b in batches:
+            sel = idx[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
+            x, pi, tv = data.batch(sel)
+            if train:
+                for grp in opt.param_groups:
+                    grp["lr"] = float(lr)
+                opt.zero_grad(set_to_none=True)
+                loss, ce, mse = losses(net, x, pi, tv)
+                loss.backward()
+                opt.step()
+                lr = clr.on_batch_end(float(lr))
+            else:
+                with torch.no_grad():
+                    loss, ce, mse = losses(net, x, pi, tv)
+            w = float(sel.shape[0])
+            tot += float(loss.detach()) * w; ce_s += float(ce.detach()) * w; mse_s += float(mse.detach()) * w
+        n = float(idx.shape[0])
+        return tot / n, ce_s / n, mse_s / n
+
+    for epoch in range(EPOCHS):
+        net.train()
+        tl, tce, tmse = run(train_idx, True)
+        history.add(loss=tl, policy_head_loss=tce, value_head_loss=tmse)
+        if n_val:
+            net.eval()
+            vl, vce, vmse = run(val_idx, False)
+            history.add(val_loss=vl, val_policy_head_loss=vce, val_value_head_loss=vmse)
+            if kwargs.get("VERBOSE", False):
+                print("Epoch %d/%d loss %.4f val_loss %.4f lr %.2e" % (epoch + 1, EPOCHS, tl, vl, lr))
+            if vl < best:                                                      # ModelCheckpoint(save_best_only), :139-145
+                torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, filepath)
+                saved = True
+            best = min(best, vl)
+            if vl - MIN_DELTA < es_best:                                        # EarlyStopping(min_delta, patience), :133-135
+                es_best, wait = vl, 0
+            else:
+                wait += 1
+            if wait >= PATIENCE:
+                break
+    if not saved:
+        torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, filepath)
+    net.eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    history.clr = clr.history
+    return history, filepath

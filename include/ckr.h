@@ -255,6 +255,17 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out);
  * Pass NULL buffers to query counts. */
 int ckr_engine_results(ckr_engine* e, ckr_game_result* out, int64_t cap, int64_t* n);
 int ckr_engine_tuples(ckr_engine* e, ckr_tuple* out, int64_t cap, int64_t* n);
+/* Training batch built on the device from compact tuples: replaces
+ * Keras_Generator.__getitem__ (training_pipeline.py:296-307) and the pickle
+ * round trip between self-play and training.  d_tuples: n_tuples packed records
+ * (ckr_engine_pack_tuples); d_index: batch row -> tuple index (NULL = identity).
+ * Outputs (DEVICE): d_x [batch][8][8][14] float32 (planes 0-13, channels last),
+ * d_pi [batch][512] float32 (visit fractions at the action codes, zeros for a
+ * terminal tuple), d_value [batch] float32 = (q + z) / 2.  Rows whose index is
+ * out of range are zero-filled. */
+int ckr_training_batch(const ckr_tuple* d_tuples, int64_t n_tuples, const int64_t* d_index, int64_t batch,
+                       float* d_x, float* d_pi, float* d_value, void* stream);
+
 /* Device-side compaction of the finished tuples into a caller-provided
  * contiguous DEVICE buffer (what the multi-GPU gather ships). */
 int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t* n, void* stream);

@@ -291,8 +291,52 @@ def gen_tournament(cases=((30, 4, 1, 2), (24, 2, 3, 5), (40, 2, 7, 8))):
     np.savez_compressed(os.path.join(HERE, "tournament_v1.npz"), **out)
 
 
+# --------------------------------------------------------------------------- training-side helpers (N2)
+def gen_training():
+    """Keras_Generator batches (training_pipeline.py:288-307) over the tuples of selfplay case 0 (the same
+    game the engine reproduces bit for bit), and learning-rate sequences of the reference's CyclicLR.clr()
+    (CLR/clr_callback.py:105-111)."""
+    sys.path.insert(0, os.path.join(ref_shim.REFERENCE, "CLR"))
+    import clr_callback
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "training_data"))
+    os.chdir(tmp)
+    try:
+        budget, terminate, games, salt = 30, 40, 2, 0                      # selfplay_v1 case 0
+        sk = dict(NUM_SELFPLAY_GAMES=games, TRAINING_ITERATION=0, TERMINATE_CNT=terminate, NUM_CPUS=1,
+                  NN_FN="hash_salt%d.h5" % salt)
+        real_stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+        try:
+            mem = pickle.load(open(tp.generate_Checkers_data(sk, mcts_kwargs(budget)).generate_data(), "rb"))
+        finally:
+            sys.stdout = real_stdout
+    finally:
+        os.chdir(cwd)
+    gen = tp.Keras_Generator(mem, 32)
+    xs, ps, vs = [], [], []
+    for b in range((len(mem) + 31) // 32):
+        states, (probs, target) = gen[b]
+        xs.append(states); ps.append(probs); vs.append(target)
+    out["cfg"] = np.array([budget, terminate, games, salt], np.int64)
+    out["x"] = np.concatenate(xs).astype(np.float32)                       # what Keras feeds the float32 model
+    out["pi"] = np.concatenate(ps).astype(np.float32)
+    out["value_target"] = np.concatenate(vs).astype(np.float32)
+    for name, kw in (("triangular", dict(mode="triangular")), ("triangular2", dict(mode="triangular2")),
+                     ("exp_range", dict(mode="exp_range", gamma=0.999))):
+        c = clr_callback.CyclicLR(base_lr=5e-5, max_lr=0.01, step_size=37., **kw)
+        seq = []
+        for it in range(400):
+            c.clr_iterations = float(it)
+            seq.append(float(c.clr()))
+        out["clr_" + name] = np.array(seq, np.float64)
+    np.savez_compressed(os.path.join(HERE, "training_v1.npz"), **out)
+    print("training: %d tuples" % len(mem))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout"]
+    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout", "training"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:
