@@ -1,0 +1,116 @@
+"""GPU: BASELINE.json's full-size configurations through size-independent properties
+(cfg3: 4 096 concurrent games at 100 sims/move; cfg4's shape: 400 sims/move, games sharded by
+worker id with the tuples gathered; cfg5: arena at 800 sims/move played to the natural end)."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import checkers_mcts_amd.codec as codec
+from test_engine_gpu import E, mk          # noqa: F401
+
+
+def play(E, kwargs, n_slots, first=0, evaluator=None, **cfg_kw):
+    cfg = E.config_from_kwargs(kwargs, n_slots=n_slots, first_worker_id=first, **cfg_kw)
+    eng = E.Engine(cfg)
+    eng.run(evaluator or E.hashnet_evaluator(7))
+    raw = eng.tuples_raw()
+    raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
+    res, st = eng.results(), eng.stats()
+    eng.close()
+    return raw, res, st
+
+
+def checksum(raw):
+    """Checksum of per-tuple checksums (order-independent within a worker block is not needed: rows are sorted)."""
+    return zlib.crc32(np.ascontiguousarray(raw[["board", "mask", "status", "worker", "game", "ply", "n_children", "q", "z",
+                                                "root_n", "root_w", "chosen", "pi"]]).tobytes())
+
+
+def check_tuples(E, raw, budget):
+    nc = raw["n_children"]
+    live = nc > 0
+    visits = (raw["pi"] & 0x7FFFFF).astype(np.int64)
+    actions = (raw["pi"] >> 23).astype(np.int64)
+    lane = np.arange(raw["pi"].shape[1])[None, :]
+    used = lane < nc[:, None]
+    vsum = (visits * used).sum(1)
+    assert (vsum[live] == raw["root_n"][live] - 1).all()                    # every simulation after the expansion picks a child
+    assert (raw["root_n"][live] >= budget).all()
+    assert ((raw["z"] >= -1) & (raw["z"] <= 1)).all() and (np.abs(raw["q"]) <= 1.0).all()
+    # pi mass only on legal actions: action code = layer*64 + 8x + y, legal bit = mask[layer] bit (4x + y//2)
+    layer, x, y = actions >> 6, (actions >> 3) & 7, actions & 7
+    bit = (np.take_along_axis(raw["mask"], np.minimum(layer, 7), axis=1) >> (4 * x + (y >> 1))) & 1
+    assert (bit[used] == 1).all()
+    legal_count = np.zeros(len(raw), np.int64)
+    for d in range(8):
+        legal_count += np.array([bin(int(m)).count("1") for m in raw["mask"][:, d]])
+    assert (legal_count[live] == nc[live]).all()                            # one child per legal action
+    assert (raw["chosen"][~live] == -1).all()
+    pi_sum = (visits * used).astype(np.float64) / np.maximum(vsum, 1)[:, None]
+    assert np.allclose(pi_sum.sum(1)[live], 1.0, atol=1e-12)
+
+
+def test_cfg3_full_size_selfplay_properties(E):
+    """4 096 concurrent games, 100 sims/move, TERMINATE_CNT 200, noise + temperature as in
+    train_Checkers.py:88-102, played to the end: accounting identities, well-formed tuples,
+    seed-reproducible, and independent of how the workers are sharded across engines (= GPUs)."""
+    kw = mk(100, eps=0.25, tau=1.0)
+    raw, res, st = play(E, kw, 4096, games_per_slot=1, terminate_cnt=200, seed=20260929)
+    assert len(res) == 4096 and all(r["failed"] == 0 for r in res) and st["pool_overflows"] == 0
+    assert st["games"] == 4096 and st["active_slots"] == 0
+    plies = sum(r["move_count"] for r in res)
+    assert st["plies"] == plies
+    assert st["expansions"] + st["terminal_visits"] == 100 * plies           # sims = BUDGET x plies
+    assert all(r["move_count"] <= 200 and r["outcome"] in (1, 2, 3) for r in res)
+    assert all(r["move_count"] == 200 for r in res if r["adjudicated"])      # training_pipeline.py:387-405
+    n_tuples = sum(r["n_tuples"] for r in res)
+    n_adj = sum(r["adjudicated"] for r in res)
+    assert len(raw) == n_tuples == plies + 4096 - n_adj                      # one per ply + the final state of games that end by the rules
+    check_tuples(E, raw, 100)
+    z_by_game = {}
+    for r in res:
+        z_by_game[(r["worker"], r["game"])] = r["outcome"]
+    first = raw[raw["ply"] == 0]
+    assert len(first) == 4096 and (first["board"][:, 0] == 0x00000FFF).all()
+    # reproducible, and sharding-invariant: workers [0,2048) and [2048,4096) on separate engines
+    a, _, _ = play(E, kw, 2048, first=0, games_per_slot=1, terminate_cnt=200, seed=20260929)
+    b, _, _ = play(E, kw, 2048, first=2048, games_per_slot=1, terminate_cnt=200, seed=20260929)
+    assert checksum(np.concatenate([a, b])) == checksum(raw)
+
+
+def test_cfg4_shape_400_sims_sharded(E):
+    """cfg4's per-game shape (400 sims/move) on 512 games: two shards + concatenation (what the
+    RCCL gather ships) equal the single-engine run; dynamic queue plays the same number of games."""
+    kw = mk(400, eps=0.25, tau=1.0)
+    raw, res, st = play(E, kw, 512, games_per_slot=1, terminate_cnt=200, seed=11)
+    assert st["expansions"] + st["terminal_visits"] == 400 * st["plies"] and st["pool_overflows"] == 0
+    check_tuples(E, raw, 400)
+    parts = [play(E, kw, 256, first=f, games_per_slot=1, terminate_cnt=200, seed=11)[0] for f in (0, 256)]
+    assert checksum(np.concatenate(parts)) == checksum(raw)
+    _, res_dq, st_dq = play(E, kw, 128, games_per_slot=4, terminate_cnt=200, seed=11, dynamic_queue=True)
+    assert st_dq["games"] == 512 and len(res_dq) == 512 and st_dq["pool_overflows"] == 0
+
+
+def test_cfg5_arena_800_sims_natural_end(E):
+    """Arena (train_Checkers.py:188-202: TRAINING False, tau 0, eps 0.25), 800 sims/move, two
+    networks, colours swapped for the second half of each worker's games, no TERMINATE_CNT:
+    every game ends by the rules (win or the 80-state draw rule)."""
+    kw = dict(mk(800, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    cfg = E.config_from_kwargs(kw, n_slots=256, games_per_slot=2, tournament=True, seed=5)
+    eng = E.Engine(cfg)
+    eng.run(E.hashnet_evaluator(3, 4))
+    res, st = eng.results(), eng.stats()
+    eng.close()
+    assert len(res) == 512 and st["pool_overflows"] == 0 and all(r["failed"] == 0 for r in res)
+    assert all(r["outcome"] in (1, 2, 3) and r["adjudicated"] == 0 and r["n_tuples"] == 0 for r in res)
+    assert all(r["p1_net"] == (0 if r["game"] == 0 else 1) for r in res)      # training_pipeline.py:523-528
+    assert st["expansions"] + st["terminal_visits"] == 800 * st["plies"]
+    assert sum(r["move_count"] for r in res) == st["plies"]
+    # win / loss / draw bookkeeping as _save_tourney_results does it
+    new = sum((r["outcome"] == 1 and r["p1_net"] == 0) or (r["outcome"] == 2 and r["p1_net"] == 1) for r in res)
+    old = sum((r["outcome"] == 1 and r["p1_net"] == 1) or (r["outcome"] == 2 and r["p1_net"] == 0) for r in res)
+    draws = sum(r["outcome"] == 3 for r in res)
+    assert new + old + draws == 512
