@@ -50,6 +50,7 @@ struct Args {
     long long n_boards;
     int n_layers;
     int has_heads;
+    const int32_t* range;      // optional DEVICE [lo, hi): only tiles overlapping these boards are computed
     ckr_conv_heads H;
     LayerDev L[MAX_LAYERS];
 };
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(NT, 1) void k_conv_stack(const Args A) {
     const int wc = wave >> 2, wp = wave & 3;
     const long long board0 = (long long)blockIdx.x * 6;
     const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
+    if (A.range && (board0 >= A.range[1] || board0 + 6 <= A.range[0])) return;   // arena: this tile belongs to the other network
 
     for (int i = 0; i < NRING; ++i)                               // first three taps of the first layer
         issue_slot<10>(A.L[0].w + (size_t)i * (128 * 80 / 16), wring + i * SLOT_BYTES, wave, lane);
@@ -345,14 +347,14 @@ int ckr_value_mlp(const float* d_in, int64_t n, const float* w1t, const float* b
 }
 
 int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
-                                      const ckr_conv_heads* heads, void* stream) {
+                        const ckr_conv_heads* heads, const int32_t* d_board_range, void* stream) {
     if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: bad n_boards / n_layers");
     if (int rc = ckr::require_device()) return rc;
     if (n_boards == 0) return CKR_OK;
     if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_bf16: null input");
     Args A;
-    A.x = (const uint16_t*)d_x; A.n_boards = n_boards; A.n_layers = n_layers;
+    A.x = (const uint16_t*)d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.range = d_board_range;
     A.has_heads = heads ? 1 : 0;
     if (heads) {
         A.H = *heads;

@@ -64,6 +64,7 @@ struct Args {
     long long n_boards;
     int n_layers;
     int has_heads;
+    const int32_t* range;      // optional DEVICE [lo, hi): only tiles overlapping these boards are computed
     float xs, inv_xs;
     ckr_conv_heads H;
     LayerDev L[MAX_LAYERS];
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
     const int wc = (wave >> 1) & 1, wp = wave & 1;
     const long long board0 = (long long)blockIdx.x * 3;
     const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
+    if (A.range && (board0 >= A.range[1] || board0 + 3 <= A.range[0])) return;   // arena: this tile belongs to the other network
 
     if (loader)
         for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, lane);
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
 using namespace ckrx;
 
 extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
-                                    const ckr_conv_heads* heads, float x_scale, void* stream) {
+                                    const ckr_conv_heads* heads, float x_scale, const int32_t* d_board_range, void* stream) {
     if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: bad n_boards / n_layers");
     if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: x_scale must be positive");
@@ -351,7 +353,7 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     if (n_boards == 0) return CKR_OK;
     if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
     Args A;
-    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale;
+    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale; A.range = d_board_range;
     A.has_heads = heads ? 1 : 0;
     if (heads) {
         A.H = *heads;

@@ -92,9 +92,9 @@ class FusedEvaluator:
         self.mode = mode
         self._L = _lib.load()
         vp = C.c_void_p
-        self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp]
+        self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp, vp]
         self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
-                                                 C.c_float, vp]
+                                                 C.c_float, vp, vp]
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
@@ -145,15 +145,16 @@ class FusedEvaluator:
                     p=torch.empty((S, 512), dtype=torch.float32, device=dev),
                     v=torch.empty((S,), dtype=torch.float32, device=dev))
 
-    def _conv(self, n, x, stream):
+    def _conv(self, n, x, stream, board_range=None):
+        rng = board_range.data_ptr() if board_range is not None else None
         if self.mode == "f16x3":
-            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, stream))
+            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, rng, stream))
         else:
-            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), stream))
+            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
 
-    def _forward(self, n, x):
+    def _forward(self, n, x, board_range=None):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        self._conv(n, x, stream)
+        self._conv(n, x, stream, board_range)
         t = n["tail"]
         torch.addmm(t["fc_b"], n["pol_feat"], t["fc_w"], out=n["logits"])              # Dense(512)
         torch.softmax(n["logits"], dim=1, out=n["p"])
@@ -168,13 +169,31 @@ class FusedEvaluator:
         if x.dtype != (torch.float32 if self.mode == "f16x3" else torch.bfloat16):
             raise ValueError("FusedEvaluator(%s) needs the engine's features in %s" %
                              (self.mode, "float32" if self.mode == "f16x3" else "bfloat16"))
-        p, v = self._forward(self.nets[0], x)
-        if len(self.nets) > 1:
-            p2, v2 = self._forward(self.nets[1], x)
-            sel = engine.net_id == 1
-            p = torch.where(sel[:, None], p2, p)
-            v = torch.where(sel, v2, v)
-        return p, v
+        if len(self.nets) == 1:
+            return self._forward(self.nets[0], x)
+        # Arena: every leaf belongs to exactly one of the two networks.  Sort the batch by network id
+        # (static shapes: HIP-graph safe) so that each network owns one contiguous share, hand the split
+        # point to the conv kernels ON THE DEVICE -- tiles of the other share exit at once -- and
+        # scatter the rows back: one batch worth of convolutions per step instead of two.
+        S, dev = self.S, x.device
+        if not hasattr(self, "_pos"):
+            self._pos = torch.arange(S, device=dev)
+            self._rng_new = torch.zeros(2, dtype=torch.int32, device=dev)          # [0, n_new)
+            self._rng_old = torch.full((2,), S, dtype=torch.int32, device=dev)     # [n_new, S)
+        old = engine.net_id == 1
+        c = old.cumsum(0)
+        n_new = S - c[-1]
+        dest = torch.where(old, n_new + c - 1, self._pos - c)       # stable partition: new rows first
+        xg = torch.empty_like(x)
+        xg.index_copy_(0, dest, x)
+        self._rng_new[1] = n_new
+        self._rng_old[0] = n_new
+        p, v = self._forward(self.nets[0], xg, self._rng_new)
+        p2, v2 = self._forward(self.nets[1], xg, self._rng_old)
+        mine = self._pos < n_new
+        pg = torch.where(mine[:, None], p, p2)
+        vg = torch.where(mine, v, v2)
+        return pg.index_select(0, dest), vg.index_select(0, dest)
 
     CONV_FLOPS_PER_BOARD = 2 * (64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128)      # the 8 convs of the stack
 

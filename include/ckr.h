@@ -132,9 +132,13 @@ typedef struct {
 /* Runs n_layers (<= 9) such layers back to back for n_boards positions with the
  * activations resident in LDS (never written to HBM between layers).
  * d_x: bf16 NHWC [n_boards][8][8][14], the engine's feature buffer.
- * heads may be NULL. */
+ * heads may be NULL.  d_board_range (may be NULL): DEVICE int32[2] = [lo, hi); only the
+ * workgroup tiles that overlap these boards are computed (the arena evaluates each
+ * network on its own contiguous share of a batch sorted by network id, with the split
+ * point known only on the device); outputs of the other rows are left untouched. */
 int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer* layers,
-                        int32_t n_layers, const ckr_conv_heads* heads, void* stream);
+                        int32_t n_layers, const ckr_conv_heads* heads, const int32_t* d_board_range,
+                        void* stream);
 
 /* The same stack at float32-grade accuracy (the reference evaluates its network in
  * float32, Checkers.py:433; BASELINE's parity bar for pi / v is 1e-5): every operand is
@@ -146,7 +150,8 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
  * y * XS = hi + lo; x_scale = XS (a power of two).  layers[i].out (tests): float32
  * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32. */
 int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers,
-                         int32_t n_layers, const ckr_conv_heads* heads, float x_scale, void* stream);
+                         int32_t n_layers, const ckr_conv_heads* heads, float x_scale,
+                         const int32_t* d_board_range, void* stream);
 
 /* Value head tail (training_pipeline.py:106-112): Dense(64)+ReLU -> BatchNorm ->
  * Dense(1) -> tanh on d_in[n][64] (the fused value conv's output).

@@ -238,3 +238,32 @@ def test_float32_pipeline_runs_the_split_fp16_kernel():
     eng.close()
     with pytest.raises(ValueError):
         pipeline.make_evaluator("random:4", dev, torch.float16, 64, kind="fused")
+
+
+def test_arena_evaluates_each_leaf_with_one_network_only():
+    """Two-network FusedEvaluator: the batch is sorted by network id and each conv launch covers only
+    its own share (device-side split point).  Results equal evaluating both networks on every leaf
+    and selecting, bit for bit, in both precisions."""
+    import torch
+    from checkers_mcts_amd import engine as E, net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    kw = dict(KW, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0, BUDGET=24)
+    new, old = N.make_net(128, seed=1), N.make_net(128, seed=2)
+    for mode, dt in (("bf16", torch.bfloat16), ("f16x3", torch.float32)):
+        S = 77
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=S, games_per_slot=2, tournament=True, feature_dtype=dt, seed=9,
+                                            dynamic_queue=True), feature_dtype=dt)      # colours alternate from slot to slot
+        both = FusedEvaluator(new, S, net_old=old, mode=mode)
+        only_new, only_old = FusedEvaluator(new, S, mode=mode), FusedEvaluator(old, S, mode=mode)
+        p = v = None
+        seen = set()
+        for _ in range(80):
+            eng.step(p, v)
+            p, v = both(eng)
+            pa, va = only_new.forward_features(eng.x)
+            pb, vb = only_old.forward_features(eng.x)
+            sel = eng.net_id == 1
+            assert torch.equal(p, torch.where(sel[:, None], pb, pa)) and torch.equal(v, torch.where(sel, vb, va))
+            seen.add(int(sel.sum()))
+        assert len(seen) >= 2 and not seen <= {0, S}           # mixed batches: both networks own a share
+        eng.close()

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tournament", action="store_true")
     ap.add_argument("--dynamic", action="store_true", help="dynamic game queue instead of a fixed count per slot")
+    ap.add_argument("--max-steps", type=int, default=0, help="stop after this many steps (throughput sample of a long run)")
     a = ap.parse_args()
     from checkers_mcts_amd import dist as ckdist, engine as E
     from checkers_mcts_amd.net import NetEvaluator, make_net
@@ -41,7 +42,10 @@ def main():
     runner = StepRunner(eng, make_evaluator("random:0", dev, dt, a.slots, spec_old="random:1" if a.tournament else None))
     ckdist.barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    steps = runner.run_to_completion(check_every=200)
+    if a.max_steps:
+        runner.warmup(); runner.step(a.max_steps); steps = runner.steps
+    else:
+        steps = runner.run_to_completion(check_every=200)
     torch.cuda.synchronize(dev)
     t_play = time.perf_counter() - t0
     st = eng.stats()
@@ -55,10 +59,11 @@ def main():
     exp = ckdist.sum_over_ranks(st["expansions"], dev)
     games = ckdist.sum_over_ranks(st["games"], dev)
     if rank == 0:
-        moves = np.array([r["move_count"] for r in res])
+        moves = np.array([r["move_count"] for r in res] or [0])
         out = dict(n_gpus=world, slots_per_gpu=a.slots, games_per_slot=a.games_per_slot, dynamic_queue=a.dynamic, budget=a.budget, nn_dtype=a.nn_dtype, steps=steps,
                    seconds=t_all, play_seconds=t_play, gather_seconds=t_gather, games=games,
                    games_per_hour=games / t_all * 3600, expansions=exp, expansions_per_s=exp / t_all,
+                   sims_per_s=(exp + ckdist.sum_over_ranks(st["terminal_visits"], dev)) / t_all, ms_per_step=t_play / max(1, steps) * 1e3,
                    tuples_gathered=int(gathered.shape[0]), rank0_stats=st,
                    rank0_game_length=dict(mean=float(moves.mean()), min=int(moves.min()), max=int(moves.max())),
                    rank0_outcomes={str(k): int((np.array([r["outcome"] for r in res]) == k).sum()) for k in (1, 2, 3)},
