@@ -52,6 +52,7 @@ def parse():
                     help="fused: conv stack in the hand-written MFMA kernels (bf16, or fp32 = split-fp16 operands); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
+    ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool per tree and semispace (0 = engine default)")
     ap.add_argument("--parity-steps", type=int, default=200,
                     help="timed steps of the extra float32-grade leg (ckr_conv_stack_f16x3; N = 1 only, 0 = skip)")
     return ap.parse_args()
@@ -206,7 +207,8 @@ def main():
     first, _ = ckdist.shard_range(a.slots * world, rank, world)
     games_per_slot = max(2, (a.steps + a.warmup) // (a.budget * 30) + 2)
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
-                                      first_worker_id=first, feature_dtype=dtype, seed=20260929, device=local_rank)
+                                      first_worker_id=first, feature_dtype=dtype, seed=20260929, device=local_rank,
+                                      nodes_per_tree=a.nodes_per_tree or None)
     eng = ckengine.Engine(cfg, feature_dtype=dtype)
     which = a.evaluator or ("fused" if a.nn_dtype in ("bf16", "fp32") else "torch")
     if which == "fused":

@@ -37,6 +37,8 @@ struct Dev {
     // per slot
     uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
+    uint32_t* g_path;            // [slot][64] root-to-leaf path of the pending simulation: node | mover << 30
+    int32_t* g_plen;             // its length (> 64: not recorded, the backup walks the parent links)
     int32_t* g_gid;              // storage index of the slot's current game (results / tuple region)
     int32_t* next_game;          // dynamic queue: next unclaimed game index
     // per tree (slot*2 + tree)
@@ -80,9 +82,10 @@ __device__ double gamma_sample(const Dev& D, double a, uint32_t c0, uint32_t c1,
         const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0x80000000u);
         boost = pow(u01(r.x, r.y), 1.0 / a); a += 1.0;
     }
-    if (a == 1.0) {
+    if (a == 1.0) {                                        // exponential variate; float32 log (noise, not parity arithmetic)
         const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0u);
-        return -log(u01(r.x, r.y)) * boost;
+        const float uf = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+        return (double)(-logf(uf)) * boost;
     }
     const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
     for (;; ++it) {
@@ -121,6 +124,28 @@ __device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
         if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.D.n_W[tb + n] += reward; }
         if (n == root) break;
         n = w.D.n_parent[tb + n];
+    }
+}
+
+// The same updates along a recorded root-to-node path (entry = node | mover << 30, one entry per
+// lane): every node of a path is distinct, so the read-modify-writes are independent and issue in
+// one round instead of one dependent round trip per tree level.  Per node the order of the float32
+// accumulation over simulations is unchanged.
+__device__ __forceinline__ void backup_value_path(Wave& w, int t, uint32_t entry, int len, float v, uint32_t sim_player) {
+    if (w.lane < len) {
+        const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
+        const float reward = (sim_player != ((entry >> 30) & 1u)) ? -1.0f * v : v;
+        w.D.n_N[i] += 1; w.D.n_W[i] += reward;
+    }
+}
+__device__ __forceinline__ void backup_outcome_path(Wave& w, int t, uint32_t entry, int len, uint32_t outcome) {
+    if (w.lane < len) {
+        const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
+        const uint32_t mover = (entry >> 30) & 1u;
+        float reward = 0.0f;
+        if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
+        else if (outcome == 2u) reward = mover == 1u ? 1.0f : -1.0f;
+        w.D.n_N[i] += 1; w.D.n_W[i] += reward;
     }
 }
 
@@ -261,7 +286,9 @@ __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow,
     }
     w.count(CNT_EXP); w.count(CNT_NODES, (uint32_t)n);
     wave_mem_fence();
-    backup_value(w, t, leaf, v, b.meta & 1u);
+    const int plen = D.g_plen[w.slot];
+    if (plen <= 64) backup_value_path(w, t, D.g_path[(size_t)w.slot * 64 + w.lane], plen, v, b.meta & 1u);
+    else backup_value(w, t, leaf, v, b.meta & 1u);
     wave_mem_fence();
     return true;
 }
@@ -276,23 +303,33 @@ __device__ int descend(Wave& w, int t) {
     const size_t tb = w.tb(t);
     int node = D.t_cursor[w.slot * 2 + t];
     const float one_minus = (float)(1.0 - D.epsilon);
+    // One dependent memory round per tree level: a node's status / child range / visit count come
+    // with its parent's child scan (lanes = children), the noise counter lives in a register, and
+    // the path is kept (lane l = level l) for the backup.
+    uint32_t st = D.n_status[tb + node], kids = D.n_kids[tb + node];
+    int np = D.n_N[tb + node];
+    uint32_t ctr = D.epsilon != 0.0 ? D.g_rng[w.slot] : 0u;
+    uint32_t entry = 0u;
+    int lvl = 0;
     for (;;) {
-        const uint32_t st = D.n_status[tb + node];
-        if (!(st & ST_EXPANDED)) return node;
-        const uint32_t kids = D.n_kids[tb + node];
+        if (w.lane == lvl) entry = (uint32_t)node | (((st >> 4) & 1u) << 30);
+        ++lvl;
+        if (!(st & ST_EXPANDED)) {
+            if (w.lane == 0) { D.g_plen[w.slot] = lvl; if (D.epsilon != 0.0) D.g_rng[w.slot] = ctr; }
+            if (lvl <= 64) D.g_path[(size_t)w.slot * 64 + w.lane] = entry;
+            return node;
+        }
         const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
-        const int np = D.n_N[tb + node];
         const bool act = w.lane < n;
         const size_t ci = tb + base + (act ? w.lane : 0);
         const int cn = D.n_N[ci];
         const float cw = D.n_W[ci], cp = D.n_P[ci];
-        const uint32_t cst = D.n_status[ci];
+        const uint32_t cst = D.n_status[ci], ckids = D.n_kids[ci];
         double dir = 0.0;
         if (D.epsilon != 0.0) {
-            const uint32_t ctr = D.g_rng[w.slot];
             const double g = act ? gamma_sample(D, D.alpha, (uint32_t)(D.first_worker + w.slot), ctr, (uint32_t)w.lane) : 0.0;
             dir = g / wave_sum_f64(g);
-            if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
+            ++ctr;
         }
         const double sqrt_n = np < D.sqrt_n ? D.sqrt_tab[np] : sqrt((double)np);
         const float q = cn ? cw / (float)cn : 0.0f;
@@ -304,12 +341,17 @@ __device__ int descend(Wave& w, int t) {
         const uint32_t bst = (uint32_t)bcast_i32((int)cst, best);
         const int child = base + best;
         if (st_outcome(bst) != 0u) {
-            backup_outcome(w, t, child, st_outcome(bst));
+            if (w.lane == lvl) entry = (uint32_t)child | (((bst >> 4) & 1u) << 30);
+            if (w.lane == 0 && D.epsilon != 0.0) D.g_rng[w.slot] = ctr;
+            if (lvl + 1 <= 64) backup_outcome_path(w, t, entry, lvl + 1, st_outcome(bst));
+            else backup_outcome(w, t, child, st_outcome(bst));
             w.count(CNT_TERM);
             wave_mem_fence();
             return -1;
         }
-        node = child;
+        node = child; st = bst;
+        kids = (uint32_t)bcast_i32((int)ckids, best);
+        np = bcast_i32(cn, best);
     }
 }
 
@@ -681,7 +723,7 @@ __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
 }
 
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
-__global__ __launch_bounds__(256) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
+__global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
                                               const float* __restrict__ v, void* x, int32_t* net_out) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
@@ -903,6 +945,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.n_W, NN, false); A(D.n_P, NN, false); A(D.n_status, NN, false);
     A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
+    A(D.g_path, S * 64, true); A(D.g_plen, S, true);
     A(D.g_gid, S, true); A(D.next_game, (size_t)1, true);
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
