@@ -39,6 +39,8 @@ struct Dev {
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
     uint32_t* g_path;            // [slot][64] root-to-leaf path of the pending simulation: node | mover << 30
     int32_t* g_plen;             // its length (> 64: not recorded, the backup walks the parent links)
+    int32_t* g_row;              // row of the slot in the network batch (x, p, v, net id); identity until
+                                 // ckr_engine_compact_rows moves the active slots to the front
     int32_t* g_gid;              // storage index of the slot's current game (results / tuple region)
     int32_t* next_game;          // dynamic queue: next unclaimed game index
     // per tree (slot*2 + tree)
@@ -661,7 +663,7 @@ __device__ void finish_ply(Wave& w) {
     else start_search(w);
 }
 
-__device__ void write_features(Wave& w, const ckr_board b, void* x) {
+__device__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
     const Dev& D = w.D;
     uint32_t m[8], st;
     movegen(b, m, st);
@@ -669,11 +671,11 @@ __device__ void write_features(Wave& w, const ckr_board b, void* x) {
     wave_features(b, m, st, w.L.u.feat);
     __builtin_amdgcn_wave_barrier();
     if (D.feature_dtype == 0) {
-        float4* dst = reinterpret_cast<float4*>((float*)x + (size_t)w.slot * 896);
+        float4* dst = reinterpret_cast<float4*>((float*)x + (size_t)row * 896);
         const float4* src = reinterpret_cast<const float4*>(w.L.u.feat);
         for (int k = w.lane; k < 224; k += 64) dst[k] = src[k];
     } else {
-        uint4* dst = reinterpret_cast<uint4*>((uint16_t*)x + (size_t)w.slot * 896);
+        uint4* dst = reinterpret_cast<uint4*>((uint16_t*)x + (size_t)row * 896);
         for (int k = w.lane; k < 112; k += 64) {
             uint32_t pk[4];
 #pragma unroll
@@ -714,6 +716,7 @@ __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
     const int gid0 = D.dynamic ? slot : slot * D.games_per_slot;
     if (w.lane == 0) {
         D.g_game[slot] = 0; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; D.g_gid[slot] = gid0;
+        D.g_row[slot] = slot;
         D.g_phase[slot] = gid0 < D.total_games ? PH_PLAYING : PH_FINISHED;
     }
     wave_mem_fence();
@@ -734,9 +737,10 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
     if (slot == 0) w.count(CNT_STEPS);
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
+    const int row = D.g_row[slot];
     if (pending >= 0 && D.g_phase[slot] == PH_PLAYING) {
         const int t = (int)(D.g_board[slot].w & 1u);
-        if (expand(w, t, pending, p + (size_t)slot * 512, v[slot])) {
+        if (expand(w, t, pending, p + (size_t)row * 512, v[row])) {
             if (w.lane == 0) D.g_sims[slot] += 1;
         } else {
             w.count(CNT_OVERFLOW);
@@ -767,9 +771,9 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
     if (w.lane == 0) {
         D.g_pending[slot] = leaf;
         D.leaves[slot] = make_uint4(lb.p1, lb.p2, lb.kings, lb.meta);
-        if (net_out) net_out[slot] = leaf >= 0 ? net : -1;
+        if (net_out) net_out[row] = leaf >= 0 ? net : -1;
     }
-    if (leaf >= 0) write_features(w, lb, x);
+    if (leaf >= 0) write_features(w, lb, x, row);
     flush_counters(w);
 }
 
@@ -867,6 +871,55 @@ __global__ __launch_bounds__(256) void k_command(const Dev* __restrict__ Dp, con
     flush_counters(w);
 }
 
+// ---- batch-row compaction: slots that are still playing move to the front of the network batch so
+// that the conv kernels can stop at the last active row (ckr_engine_compact_rows)
+__global__ __launch_bounds__(1024) void k_rows_scan(const Dev* __restrict__ Dp, int32_t* __restrict__ new_row, int32_t* __restrict__ range) {
+    const Dev& D = *Dp;
+    __shared__ int part[1024];
+    const int S = D.n_slots, tid = threadIdx.x, per = (S + 1023) / 1024;
+    const int lo = min(S, tid * per), hi = min(S, lo + per);
+    int cnt = 0;
+    for (int s = lo; s < hi; ++s) cnt += (D.g_phase[s] == PH_PLAYING);
+    part[tid] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int o = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += o;
+        __syncthreads();
+    }
+    const int total = part[1023];
+    int a = part[tid] - cnt;                     // active slots before this thread's block
+    int i = lo - a;                              // inactive slots before it
+    for (int s = lo; s < hi; ++s) {
+        if (D.g_phase[s] == PH_PLAYING) new_row[s] = a++;
+        else new_row[s] = total + i++;
+    }
+    if (tid == 0) { range[0] = 0; range[1] = total; }
+}
+
+// one wave per slot: move its p row / v / net id to the new row (through temporaries), commit the map
+__global__ __launch_bounds__(256) void k_rows_move(const Dev* __restrict__ Dp, const int32_t* __restrict__ new_row,
+                                                   const float* __restrict__ p_in, const float* __restrict__ v_in,
+                                                   float* __restrict__ p_out, float* __restrict__ v_out, int32_t* __restrict__ net_out) {
+    const Dev& D = *Dp;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (slot >= D.n_slots) return;
+    const int from = D.g_row[slot], to = new_row[slot];
+    const bool live = D.g_phase[slot] == PH_PLAYING;
+    const float4* src = reinterpret_cast<const float4*>(p_in + (size_t)from * 512);
+    float4* dst = reinterpret_cast<float4*>(p_out + (size_t)to * 512);
+    dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
+    if (lane == 0) {
+        v_out[to] = v_in[from];
+        if (net_out && !live) net_out[to] = -1;
+    }
+}
+__global__ __launch_bounds__(256) void k_rows_commit(const Dev* __restrict__ Dp, const int32_t* __restrict__ new_row) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < Dp->n_slots) Dp->g_row[s] = new_row[s];
+}
+
 // tuples of finished games -> contiguous buffer (offsets computed on the host)
 __global__ void k_pack(const ckr_tuple* __restrict__ tuples, const int64_t* __restrict__ src_first,
                        const int64_t* __restrict__ dst_first, int n_games, ckr_tuple* __restrict__ out) {
@@ -893,6 +946,7 @@ struct ckr_engine {
     ckr_tuple* d_pack = nullptr; int64_t pack_cap = 0;
     int64_t* d_off = nullptr; int64_t off_cap = 0;
     int32_t* d_cmd = nullptr;
+    int32_t* d_row_tmp = nullptr; float* d_tmp_p = nullptr; float* d_tmp_v = nullptr;   // ckr_engine_compact_rows
     Dev* d_dev = nullptr;              // device copy of `dev` (owned by allocs)
 };
 
@@ -945,7 +999,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.n_W, NN, false); A(D.n_P, NN, false); A(D.n_status, NN, false);
     A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
-    A(D.g_path, S * 64, true); A(D.g_plen, S, true);
+    A(D.g_path, S * 64, true); A(D.g_plen, S, true); A(D.g_row, S, true); A(e->d_row_tmp, S, true);
     A(D.g_gid, S, true); A(D.next_game, (size_t)1, true);
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
@@ -1047,6 +1101,26 @@ int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x
     hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net);
     CKR_HIP(hipGetLastError());
     e->steps++;
+    return CKR_OK;
+}
+
+int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_net, int32_t* d_range, void* stream) {
+    if (!e || !d_p || !d_v || !d_range) return fail(CKR_ERR_INVALID, "ckr_engine_compact_rows: null argument");
+    if (!e->dev.neural || e->dev.manual) return fail(CKR_ERR_STATE, "ckr_engine_compact_rows: batched NEURAL_NET engines only");
+    const int S = e->cfg.n_slots;
+    if (!e->d_tmp_p) {
+        if (int rc = dalloc(e, &e->d_tmp_p, (size_t)S * 512, false)) return rc;
+        if (int rc = dalloc(e, &e->d_tmp_v, (size_t)S, false)) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    e->last_stream = st;
+    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, st, (const Dev*)e->d_dev, e->d_row_tmp, d_range);
+    hipLaunchKernelGGL(k_rows_move, dim3((S + 3) / 4), dim3(256), 0, st, (const Dev*)e->d_dev, (const int32_t*)e->d_row_tmp,
+                       (const float*)d_p, (const float*)d_v, e->d_tmp_p, e->d_tmp_v, d_net);
+    CKR_HIP(hipMemcpyAsync(d_p, e->d_tmp_p, (size_t)S * 512 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CKR_HIP(hipMemcpyAsync(d_v, e->d_tmp_v, (size_t)S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_rows_commit, dim3((S + 255) / 256), dim3(256), 0, st, (const Dev*)e->d_dev, (const int32_t*)e->d_row_tmp);
+    CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
 

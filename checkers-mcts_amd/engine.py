@@ -66,6 +66,8 @@ class Engine:
         # NHWC network input written by the engine; channels-last view for torch
         self.x = torch.zeros((S, 8, 8, 14), dtype=feature_dtype, device=self.device)
         self.net_id = torch.full((S,), -1, dtype=torch.int32, device=self.device)
+        # board range of the network batch: [0, S) until compact_rows() moves the active slots to the front
+        self.row_range = torch.tensor([0, S], dtype=torch.int32, device=self.device)
         self._first = True
 
     def close(self):
@@ -96,6 +98,15 @@ class Engine:
             pp = vp = None
         _lib.check(self._L.ckr_engine_step(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
+
+    def compact_rows(self, p, v):
+        """Move the slots that are still playing to the front of the network batch (tail of a run):
+        p / v (the pending network outputs) are permuted in place, `self.row_range` (device int32
+        [0, n_active)) is what the conv kernels take as their board range.  Returns n_active."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._L.ckr_engine_compact_rows(self._h, p.data_ptr(), v.data_ptr(), self.net_id.data_ptr(),
+                                                   self.row_range.data_ptr(), stream))
+        return int(self.row_range[1].item())
 
     def rollout(self, sims):
         """Random-rollout mode: up to `sims` complete simulations per slot in one launch."""

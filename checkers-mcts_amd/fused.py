@@ -169,8 +169,8 @@ class FusedEvaluator:
         if x.dtype != (torch.float32 if self.mode == "f16x3" else torch.bfloat16):
             raise ValueError("FusedEvaluator(%s) needs the engine's features in %s" %
                              (self.mode, "float32" if self.mode == "f16x3" else "bfloat16"))
-        if len(self.nets) == 1:
-            return self._forward(self.nets[0], x)
+        if len(self.nets) == 1:                      # engine.row_range: active rows after Engine.compact_rows()
+            return self._forward(self.nets[0], x, engine.row_range)
         # Arena: every leaf belongs to exactly one of the two networks.  Sort the batch by network id
         # (static shapes: HIP-graph safe) so that each network owns one contiguous share, hand the split
         # point to the conv kernels ON THE DEVICE -- tiles of the other share exit at once -- and

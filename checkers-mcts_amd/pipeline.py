@@ -135,13 +135,23 @@ class StepRunner:
             else:
                 self._eager_step()
 
-    def run_to_completion(self, check_every=50):
+    def run_to_completion(self, check_every=50, compact_tail=True):
+        """Steps until every game is over.  Tail handling: once fewer slots are active than the
+        batch has rows (by more than ~3 %), the active slots are moved to the front of the batch
+        (Engine.compact_rows) and the conv kernel stops at the last active row, so the last
+        games of a run cost what they need instead of a full batch per step."""
         if self.steps == 0:
             self.warmup()
+        S = self.eng.cfg.n_slots
+        rows = S
+        can_compact = compact_tail and getattr(self.evaluator, "static_outputs", False)
         while True:
             self.step(check_every)
-            if self.eng.stats()["active_slots"] == 0:
+            active = self.eng.stats()["active_slots"]
+            if active == 0:
                 return self.steps
+            if can_compact and active <= rows - max(6, S // 32):
+                rows = self.eng.compact_rows(self.p, self.v)
 
 
 def _timestamp():

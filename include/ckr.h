@@ -253,6 +253,16 @@ int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream);
  * this call the C library's log() is used.  HOST array. */
 int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t count);
 
+/* Batch-row compaction for the tail of a run: moves the slots that are still playing to the
+ * front of the network batch (rows of d_x / d_p / d_v / d_net are from then on addressed through
+ * an engine-internal slot -> row map, identity before the first call), permutes the pending
+ * network outputs d_p[n_slots][512], d_v[n_slots] in place accordingly, marks the rows behind the
+ * active ones idle in d_net (may be NULL) and writes [0, n_active) to d_range (DEVICE int32[2]):
+ * the value to hand to ckr_conv_stack_*'s d_board_range, so that a step costs what its active
+ * games cost.  Call between steps, on the stream of the steps.  No reference counterpart (the
+ * reference's worker processes simply exit, training_pipeline.py:349-417). */
+int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_net, int32_t* d_range, void* stream);
+
 /* Counters (synchronises the stream the last step ran on). */
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out);
 

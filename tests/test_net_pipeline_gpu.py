@@ -267,3 +267,32 @@ def test_arena_evaluates_each_leaf_with_one_network_only():
             seen.add(int(sel.sum()))
         assert len(seen) >= 2 and not seen <= {0, S}           # mixed batches: both networks own a share
         eng.close()
+
+
+def test_tail_compaction_keeps_results():
+    """Engine.compact_rows (active slots moved to the front of the network batch, conv kernel bounded
+    by a device-side row range) changes nothing but the cost of the last steps: identical tuples and
+    results with and without it, noise and temperature on."""
+    import torch
+    from checkers_mcts_amd import engine as E, net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(KW, BUDGET=8)
+    net = N.make_net(128, seed=3)
+    out = []
+    for compact in (False, True):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=160, games_per_slot=1, terminate_cnt=200, seed=77,
+                                            feature_dtype=torch.bfloat16), feature_dtype=torch.bfloat16)
+        runner = StepRunner(eng, FusedEvaluator(net, 160, mode="bf16"))
+        runner.run_to_completion(check_every=20, compact_tail=compact)
+        raw = eng.tuples_raw()
+        raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
+        res = sorted((r["worker"], r["game"], r["outcome"], r["move_count"], r["n_tuples"]) for r in eng.results())
+        out.append((raw, res, int(eng.row_range[1].item()), eng.stats()))
+        eng.close()
+    (a, ra, rows_a, sa), (b, rb, rows_b, sb) = out
+    assert rows_a == 160 and rows_b < 160                       # the tail was compacted at least once
+    assert ra == rb and len(a) == len(b)
+    for f in ("board", "mask", "status", "worker", "game", "ply", "n_children", "q", "z", "root_n", "root_w", "chosen", "pi"):
+        assert (a[f] == b[f]).all(), f
+    assert sa["expansions"] == sb["expansions"] and sa["plies"] == sb["plies"]
