@@ -174,20 +174,25 @@ class FusedEvaluator:
         # Arena: every leaf belongs to exactly one of the two networks.  Sort the batch by network id
         # (static shapes: HIP-graph safe) so that each network owns one contiguous share, hand the split
         # point to the conv kernels ON THE DEVICE -- tiles of the other share exit at once -- and
-        # scatter the rows back: one batch worth of convolutions per step instead of two.
+        # scatter the rows back: one batch worth of convolutions per step instead of two, and none for
+        # slots whose games are over (the arena's long tail of drawn-out games).
         S, dev = self.S, x.device
         if not hasattr(self, "_pos"):
             self._pos = torch.arange(S, device=dev)
             self._rng_new = torch.zeros(2, dtype=torch.int32, device=dev)          # [0, n_new)
             self._rng_old = torch.full((2,), S, dtype=torch.int32, device=dev)     # [n_new, S)
-        old = engine.net_id == 1
-        c = old.cumsum(0)
-        n_new = S - c[-1]
-        dest = torch.where(old, n_new + c - 1, self._pos - c)       # stable partition: new rows first
+        nid = engine.net_id
+        old, idle = nid == 1, nid < 0                                # idle: the slot's games are over
+        c_old, c_idle = old.cumsum(0), idle.cumsum(0)
+        n_old, n_idle = c_old[-1], c_idle[-1]
+        n_new = S - n_old - n_idle
+        dest = torch.where(old, n_new + c_old - 1,                   # stable 3-way partition: new | old | idle
+                           torch.where(idle, n_new + n_old + c_idle - 1, self._pos - c_old - c_idle))
         xg = torch.empty_like(x)
         xg.index_copy_(0, dest, x)
         self._rng_new[1] = n_new
         self._rng_old[0] = n_new
+        self._rng_old[1] = n_new + n_old
         p, v = self._forward(self.nets[0], xg, self._rng_new)
         p2, v2 = self._forward(self.nets[1], xg, self._rng_old)
         mine = self._pos < n_new

@@ -262,8 +262,9 @@ def test_arena_evaluates_each_leaf_with_one_network_only():
             p, v = both(eng)
             pa, va = only_new.forward_features(eng.x)
             pb, vb = only_old.forward_features(eng.x)
-            sel = eng.net_id == 1
-            assert torch.equal(p, torch.where(sel[:, None], pb, pa)) and torch.equal(v, torch.where(sel, vb, va))
+            sel, live = eng.net_id == 1, eng.net_id >= 0           # rows of finished slots are not evaluated
+            assert torch.equal(p[live], torch.where(sel[:, None], pb, pa)[live])
+            assert torch.equal(v[live], torch.where(sel, vb, va)[live])
             seen.add(int(sel.sum()))
         assert len(seen) >= 2 and not seen <= {0, S}           # mixed batches: both networks own a share
         eng.close()
