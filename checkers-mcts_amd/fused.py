@@ -1,8 +1,10 @@
-"""bf16 inference path with the network in hand-written HIP kernels.
+"""Network inference in hand-written HIP kernels, in two precisions.
 
 The eight 128-wide 3x3 convolutions (7 body layers + the first policy conv,
 training_pipeline.py:60-92) carry 99.5 % of the network's FLOPs; they run inside
-`ckr_conv_stack_bf16` (csrc/ckr_conv.hip) with the activations resident in LDS
+`ckr_conv_stack_f16x3` (csrc/ckr_conv_x3.hip: float32-grade results from split-fp16
+operands, the parity mode and the default for NN_DTYPE float32) or
+`ckr_conv_stack_bf16` (csrc/ckr_conv.hip: throughput mode) with the activations resident in LDS
 from the input planes to the head features, conv bias + ReLU + inference
 BatchNorm fused into the epilogue, and the heads' two 1x1 convolutions
 (training_pipeline.py:93-96,102-105) applied before anything leaves the chip.

@@ -9,8 +9,9 @@ semantics of training_pipeline.create_nn, training_pipeline.py:59-114).
 BatchNorm follows the activation (post-activation BN), eps = 1e-3, and runs on
 its moving statistics at inference.  `keras_init` reproduces a freshly built
 Keras model: Glorot-uniform kernels, zero biases, gamma 1 / beta 0, moving mean
-0 / variance 1.  This is the only MFMA user on the path (MIOpen / hipBLASLt
-kernels underneath); everything else is integer / byte work in libckr.so.
+0 / variance 1.  The module holds the weights and is the cross-check / training forward
+(MIOpen / hipBLASLt underneath); self-play and arena inference run in the hand-written MFMA
+kernels of libckr.so (fused.FusedEvaluator).
 """
 import torch
 import torch.nn as nn
