@@ -64,6 +64,7 @@ struct Args {
     long long n_boards;
     int n_layers;
     int has_heads;
+    int32_t* overflow;         // optional DEVICE flag: set when an activation leaves the fp16 range of the hi terms
     const int32_t* range;      // optional DEVICE [lo, hi): only tiles overlapping these boards are computed
     float xs, inv_xs;
     ckr_conv_heads H;
@@ -139,15 +140,18 @@ __device__ __forceinline__ void tap_rows(int prow0, int tap, int (&brow)[3]) {
 }
 
 // value -> (hi, lo) fp16 pair, saturating at the fp16 range
-__device__ __forceinline__ void split1(float y, _Float16& h, _Float16& l) {
+__device__ __forceinline__ void split1(float y, _Float16& h, _Float16& l, float& amax) {
+    amax = fmaxf(amax, fabsf(y));
     y = fminf(fmaxf(y, -60000.0f), 60000.0f);
     h = (_Float16)y;
     l = (_Float16)(y - (float)h);
 }
 
 // ReLU + BatchNorm affine (bias already in the accumulators, constants pre-scaled), split, store in place
-__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][3]) {
+__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][3],
+                                         int32_t* overflow) {
 #pragma clang fp contract(fast)
+    float amax = 0.0f;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -159,15 +163,16 @@ __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, in
             for (int pt = 0; pt < 3; ++pt) {
                 f16x4 h, l;
                 _Float16 hh, ll;
-                split1(sc.x * fmaxf(acc[ct][pt][4 * g + 0], 0.0f) + sh.x, hh, ll); h[0] = hh; l[0] = ll;
-                split1(sc.y * fmaxf(acc[ct][pt][4 * g + 1], 0.0f) + sh.y, hh, ll); h[1] = hh; l[1] = ll;
-                split1(sc.z * fmaxf(acc[ct][pt][4 * g + 2], 0.0f) + sh.z, hh, ll); h[2] = hh; l[2] = ll;
-                split1(sc.w * fmaxf(acc[ct][pt][4 * g + 3], 0.0f) + sh.w, hh, ll); h[3] = hh; l[3] = ll;
+                split1(sc.x * fmaxf(acc[ct][pt][4 * g + 0], 0.0f) + sh.x, hh, ll, amax); h[0] = hh; l[0] = ll;
+                split1(sc.y * fmaxf(acc[ct][pt][4 * g + 1], 0.0f) + sh.y, hh, ll, amax); h[1] = hh; l[1] = ll;
+                split1(sc.z * fmaxf(acc[ct][pt][4 * g + 2], 0.0f) + sh.z, hh, ll, amax); h[2] = hh; l[2] = ll;
+                split1(sc.w * fmaxf(acc[ct][pt][4 * g + 3], 0.0f) + sh.w, hh, ll, amax); h[3] = hh; l[3] = ll;
                 char* dst = act + (prow0 + 32 * pt) * APITCH + (c0 << 1);
                 *reinterpret_cast<f16x4*>(dst) = h;
                 *reinterpret_cast<f16x4*>(dst + LO) = l;
             }
         }
+    if (overflow && amax > 60000.0f) *overflow = 1;               // results are saturated: the caller must not trust them
 }
 
 // 1x1 convolution head on the LDS-resident activations: thread = position, float32 arithmetic
@@ -258,7 +263,7 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char*
             ring = nring;
         }
     }
-    epilogue(act, prm, wc, lane, prow0, acc);
+    epilogue(act, prm, wc, lane, prow0, acc, A.overflow);
 }
 
 // The loader wave's side of one layer: keeps the weight ring two slots ahead of the MFMA waves.
@@ -299,8 +304,9 @@ __global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const float2 v = src[j];
-            split1(v.x * A.xs, h[2 * j], lo[2 * j]);
-            split1(v.y * A.xs, h[2 * j + 1], lo[2 * j + 1]);
+            float amax = 0.0f;
+            split1(v.x * A.xs, h[2 * j], lo[2 * j], amax);
+            split1(v.y * A.xs, h[2 * j + 1], lo[2 * j + 1], amax);
         }
         h[14] = h[15] = lo[14] = lo[15] = (_Float16)0.0f;
         f16x8 v0, v1, w0, w1;
@@ -345,7 +351,8 @@ __global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
 using namespace ckrx;
 
 extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
-                                    const ckr_conv_heads* heads, float x_scale, const int32_t* d_board_range, void* stream) {
+                                    const ckr_conv_heads* heads, float x_scale, const int32_t* d_board_range, int32_t* d_overflow,
+                                    void* stream) {
     if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: bad n_boards / n_layers");
     if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: x_scale must be positive");
@@ -353,7 +360,7 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     if (n_boards == 0) return CKR_OK;
     if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
     Args A;
-    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale; A.range = d_board_range;
+    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale; A.range = d_board_range; A.overflow = d_overflow;
     A.has_heads = heads ? 1 : 0;
     if (heads) {
         A.H = *heads;

@@ -50,7 +50,7 @@ def pack_conv_weights(w, first):
     return img.reshape(18, cout, 72).to(torch.bfloat16).contiguous()
 
 
-XS, WS = 64.0, 1024.0        # power-of-two operand scales of the split-fp16 path (ckr_conv_x3.hip)
+XS, WS = 8.0, 1024.0         # power-of-two operand scales of the split-fp16 path (ckr_conv_x3.hip): |activation| < 7 500, |w| < 58
 
 
 def pack_split_weights(w, first):
@@ -96,7 +96,8 @@ class FusedEvaluator:
         vp = C.c_void_p
         self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp, vp]
         self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
-                                                 C.c_float, vp, vp]
+                                                 C.c_float, vp, vp, vp]
+        self.overflow = None
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
@@ -150,7 +151,10 @@ class FusedEvaluator:
     def _conv(self, n, x, stream, board_range=None):
         rng = board_range.data_ptr() if board_range is not None else None
         if self.mode == "f16x3":
-            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, rng, stream))
+            if self.overflow is None:
+                self.overflow = torch.zeros(1, dtype=torch.int32, device=x.device)
+            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, rng,
+                                                    self.overflow.data_ptr(), stream))
         else:
             _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
 
@@ -201,6 +205,14 @@ class FusedEvaluator:
         pg = torch.where(mine[:, None], p, p2)
         vg = torch.where(mine, v, v2)
         return pg.index_select(0, dest), vg.index_select(0, dest)
+
+    def check_range(self):
+        """Raises if the float32-grade kernel met an activation outside its range (|a| * XS > 6e4): the
+        split-fp16 terms saturate there, so results since the last check are not to be used."""
+        if self.overflow is not None and int(self.overflow.item()):
+            self.overflow.zero_()
+            raise OverflowError("ckr_conv_stack_f16x3: activation magnitude above %g; use NN_DTYPE bfloat16 or the "
+                                "PyTorch evaluator for this network" % (6e4 / XS))
 
     CONV_FLOPS_PER_BOARD = 2 * (64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128)      # the 8 convs of the stack
 

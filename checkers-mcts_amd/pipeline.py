@@ -148,6 +148,8 @@ class StepRunner:
         while True:
             self.step(check_every)
             active = self.eng.stats()["active_slots"]
+            if hasattr(self.evaluator, "check_range"):
+                self.evaluator.check_range()
             if active == 0:
                 return self.steps
             if can_compact and active <= rows - max(6, S // 32):

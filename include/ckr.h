@@ -148,10 +148,12 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
  * [n_slots][128][32 hi | 32 lo | 8 pad] fp16 of (w * WS); bias / scale / shift pre-scaled
  * by the host (bias*XS*WS, scale/WS, shift*XS) so that the stored activation is
  * y * XS = hi + lo; x_scale = XS (a power of two).  layers[i].out (tests): float32
- * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32. */
+ * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32.
+ * d_overflow (may be NULL): DEVICE int32 set to 1 when an activation * XS exceeds the fp16
+ * range of the hi terms (6e4): such results are saturated and must be discarded. */
 int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers,
                          int32_t n_layers, const ckr_conv_heads* heads, float x_scale,
-                         const int32_t* d_board_range, void* stream);
+                         const int32_t* d_board_range, int32_t* d_overflow, void* stream);
 
 /* Value head tail (training_pipeline.py:106-112): Dense(64)+ReLU -> BatchNorm ->
  * Dense(1) -> tanh on d_in[n][64] (the fused value conv's output).

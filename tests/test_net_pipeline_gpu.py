@@ -214,6 +214,40 @@ def test_split_fp16_conv_stack_within_1e5_of_float64(oracle):
             body_ref = h.permute(0, 2, 3, 1)
         body = fe.nets[0]["y_body"] / XS
         assert float((body - body_ref).abs().max()) < 1e-5 * max(1.0, float(body_ref.abs().max()))
+    # large activations (BatchNorm gains x2.5 per layer: |activation| in the hundreds, toward the fp16 range of the
+    # hi terms) and tiny ones (gains x0.05: lo terms in fp16's subnormal range): relative accuracy holds
+    for gain in (2.5, 0.05):
+        m = N.PolicyValueNet(128).keras_init(11).perturb_bn(11)
+        with torch.no_grad():
+            for blk in list(m.body)[:6]:
+                blk["bn"].weight.mul_(gain)
+        m = m.eval().cuda()
+        x = rules.features(rules.boards_to_device(_positions(48, 5))).contiguous()
+        fe = FusedEvaluator(m, 48, debug_outputs=True, mode="f16x3")
+        p, v = fe.forward_features(x)
+        with torch.no_grad():
+            h = x.double().permute(0, 3, 1, 2)
+            md = N.PolicyValueNet(128).double().cuda()
+            md.load_state_dict({k: t.double() for k, t in m.state_dict().items()})
+            md.eval()
+            for blk in md.body:
+                h = md._block(blk, h)
+            body_ref = h.permute(0, 2, 3, 1)
+            pr, vr = md(x.double().permute(0, 3, 1, 2))
+        body = fe.nets[0]["y_body"].double() / XS
+        scale = float(body_ref.abs().max())
+        assert float((body - body_ref).abs().max()) < 2e-6 * max(scale, 1e-30), (gain, scale)
+        assert float((p.double() - pr).abs().max()) < 1e-5 and float((v.double() - vr).abs().max()) < 1e-5
+        fe.check_range()
+    # out of range (|activation| * XS beyond fp16): flagged, not silently saturated
+    m = N.PolicyValueNet(128).keras_init(11).perturb_bn(11)
+    with torch.no_grad():
+        for blk in list(m.body)[:6]:
+            blk["bn"].weight.mul_(8.0)
+    fe = FusedEvaluator(m.eval().cuda(), 48, mode="f16x3")
+    fe.forward_features(x)
+    with pytest.raises(OverflowError):
+        fe.check_range()
 
 
 def test_float32_pipeline_runs_the_split_fp16_kernel():
