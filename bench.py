@@ -129,6 +129,21 @@ def movegen_probe(device):
             "frac": 52.0 * n / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": 52}
 
 
+def time_conv(evaluator, x, dev, groups=5, per_group=10):
+    """Average launch duration of the conv-stack kernel: HIP events on the launch stream around
+    groups of back-to-back launches (the launch gap of a single eager launch would otherwise add
+    ~5 % to a 0.45 ms kernel); median over the groups.  Seconds per launch."""
+    evaluator.conv_only(x)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(groups)]
+    for e0, e1 in ev:
+        e0.record()
+        for _ in range(per_group):
+            evaluator.conv_only(x)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    return float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])) / 1e3 / per_group
+
+
 def split_roofline(conv_flops, slots, t_conv):
     """Roofline entry of k_conv_stack_x3: algorithmic flops (one multiply-add per weight and
     position, as for any float32 convolution) over the launch time; the kernel EXECUTES three
@@ -172,13 +187,7 @@ def parity_leg(a, dev):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     s1 = eng.stats()
-    cev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(10)]
-    for e0, e1 in cev:
-        e0.record()
-        ev.conv_only(eng.x)
-        e1.record()
-    torch.cuda.synchronize(dev)
-    t_conv = float(np.median([e0.elapsed_time(e1) for e0, e1 in cev])) / 1e3
+    t_conv = time_conv(ev, eng.x, dev)
     eng.close()
     return {"value": (s1["expansions"] - s0["expansions"]) / dt, "unit": "node-expansions/s", "steps": a.parity_steps,
             "ms_per_step": dt / a.parity_steps * 1e3, "dtype": "fp16x2-split operands, fp32 accumulate (fp32-grade)",
@@ -261,13 +270,7 @@ def main():
     # events on the launch stream against the engine's current leaf features
     t_conv = 0.0
     if which == "fused" and a.profile_steps > 0:
-        cev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(a.profile_steps)]
-        for e0, e1 in cev:
-            e0.record()
-            evaluator.conv_only(eng.x)
-            e1.record()
-        torch.cuda.synchronize(dev)
-        t_conv = float(np.median([e0.elapsed_time(e1) for e0, e1 in cev])) / 1e3
+        t_conv = time_conv(evaluator, eng.x, dev, groups=max(3, a.profile_steps // 4))
     stats_end = eng.stats()
 
     out = None

@@ -63,6 +63,8 @@ def pack_split_weights(w, first):
     q = 1 if first else 4
     t = torch.zeros((9, cout, 32 * q), dtype=torch.float32, device=w.device)
     t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin) * WS
+    if float(t.abs().max()) > 6e4:
+        raise OverflowError("conv weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
     hi = t.to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
     img = torch.zeros((9, q, cout, 72), dtype=torch.float16, device=w.device)
