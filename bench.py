@@ -195,6 +195,55 @@ def parity_leg(a, dev):
             "roofline": split_roofline(ev.CONV_FLOPS_PER_BOARD, a.slots, t_conv)}
 
 
+def arena_leg(a, dev):
+    """BASELINE cfg 5's shape on one GPU: arena between two random-init networks, 800 sims/move,
+    TRAINING False / tau 0 / eps 0.25 (train_Checkers.py:188-202), bf16; a short steady-state sample."""
+    from checkers_mcts_amd import engine as ckengine
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.net import make_net
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.bfloat16,
+                                      seed=20260929, device=dev.index, dynamic_queue=True)
+    eng = ckengine.Engine(cfg, feature_dtype=torch.bfloat16)
+    ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
+                        net_old=make_net(128, seed=1, device=dev, dtype=torch.float32), mode="bf16")
+    runner = StepRunner(eng, ev, use_graph=not a.no_graph)
+    runner.warmup(3)
+    runner.step(30)
+    torch.cuda.synchronize(dev)
+    s0, t0 = eng.stats(), time.perf_counter()
+    runner.step(a.parity_steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    s1 = eng.stats()
+    eng.close()
+    sims = s1["expansions"] + s1["terminal_visits"] - s0["expansions"] - s0["terminal_visits"]
+    return {"sims_per_s": sims / dt, "ms_per_step": dt / a.parity_steps * 1e3, "steps": a.parity_steps, "budget": 800,
+            "note": "each leaf is evaluated by its own network only (batch partitioned by network id on the device)"}
+
+
+def rollout_leg(a, dev):
+    """NEURAL_NET=False (iteration-0 data, train_Checkers.py:78, BUDGET 400 as in README:284): whole
+    simulations incl. uniform random playouts to the end of the game inside the tree kernel."""
+    from checkers_mcts_amd import engine as ckengine
+    kw = dict(MCTS_KWARGS, BUDGET=400, NEURAL_NET=False)
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, terminate_cnt=TERMINATE_CNT, seed=20260929,
+                                      device=dev.index)
+    eng = ckengine.Engine(cfg)
+    eng.set_ln_table()
+    eng.rollout(400)
+    torch.cuda.synchronize(dev)
+    s0, t0 = eng.stats(), time.perf_counter()
+    for _ in range(10):
+        eng.rollout(400)
+    s1 = eng.stats()
+    dt = time.perf_counter() - t0
+    eng.close()
+    sims = s1["expansions"] + s1["terminal_visits"] - s0["expansions"] - s0["terminal_visits"]
+    return {"rollouts_per_s": sims / dt, "plies": s1["plies"] - s0["plies"], "seconds": dt, "budget": 400}
+
+
 def main():
     a = parse()
     from checkers_mcts_amd import build as ckbuild, dist as ckdist, engine as ckengine
@@ -309,6 +358,9 @@ def main():
         extra = {"movegen_k1": movegen_probe(dev)}
         if world == 1 and a.parity_steps > 0 and not (which == "fused" and a.nn_dtype == "fp32"):
             extra["fp32_grade_mode"] = parity_leg(a, dev)
+        if world == 1 and a.parity_steps > 0:
+            extra["arena_cfg5_shape"] = arena_leg(a, dev)
+            extra["random_rollout_mode"] = rollout_leg(a, dev)
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(a.budget, a.cpu_seconds)
