@@ -31,11 +31,11 @@ class ConvHeads(C.Structure):
 
 
 def pack_conv_weights(w, first):
-    """torch conv weight [128, cin, 3, 3] -> the weight-ring image of ckr_conv_stack_bf16
-    (k contiguous per output channel, every row padded by one 16-byte slot so that
-    ds_read_b128 is bank-conflict free): first layer bf16 [9 taps][128 out][32 + 8]
-    (14 planes zero-padded to 32), later layers [18 half taps][128 out][64 + 8]
-    (slot = tap*2 + half of the 128 input channels; tap = ky*3 + kx)."""
+    """torch conv weight [128, cin, 3, 3] -> the weight-ring image of ckr_conv_stack_bf16: bf16
+    [n_slots][128 out][32 + 8] (k contiguous per output channel, every row padded by one 16-byte
+    slot so that ds_read_b128 is bank-conflict free).  First layer: one slot per tap (14 planes
+    zero-padded to 32); later layers: slot = tap*4 + quarter of the 128 input channels
+    (tap = ky*3 + kx)."""
     cout, cin = w.shape[0], w.shape[1]
     assert cout == 128 and w.shape[2:] == (3, 3)
     if first:
@@ -44,10 +44,10 @@ def pack_conv_weights(w, first):
         t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin)
         return t.to(torch.bfloat16).contiguous()
     assert cin == 128
-    t = w.float().permute(2, 3, 0, 1).reshape(9, cout, 2, 64).permute(0, 2, 1, 3)    # [tap][half][out][64]
-    img = torch.zeros((9, 2, cout, 72), dtype=torch.float32, device=w.device)
-    img[..., :64] = t
-    return img.reshape(18, cout, 72).to(torch.bfloat16).contiguous()
+    t = w.float().permute(2, 3, 0, 1).reshape(9, cout, 4, 32).permute(0, 2, 1, 3)    # [tap][quarter][out][32]
+    img = torch.zeros((9, 4, cout, 40), dtype=torch.float32, device=w.device)
+    img[..., :32] = t
+    return img.reshape(36, cout, 40).to(torch.bfloat16).contiguous()
 
 
 XS, WS = 8.0, 1024.0         # power-of-two operand scales of the split-fp16 path (ckr_conv_x3.hip): |activation| < 7 500, |w| < 58
