@@ -13,17 +13,16 @@
 // convolution's.  Three 16-bit MFMAs per multiply-add = an effective 833 TFLOP/s peak,
 // 5.3x the float32 matrix peak.  The scale factors keep the low terms out of fp16's
 // subnormal range; they are folded into bias / BatchNorm constants on the host
-// (fused.SplitEvaluator), the kernel never multiplies by them.
+// (fused.pack_split_weights), the kernel never multiplies by them.
 //
-// Layout (MI355X-first, cf. ckr_conv.hip): a workgroup keeps THREE boards (192 positions)
-// resident in LDS through all layers as rows of [128 hi | 128 lo] fp16 (528-B pitch: one pad
-// slot, conflict-free ds_read_b128); weights stream from L2 through a 3-slot LDS ring filled
-// by global_load_lds DMA two slots ahead, issued by a FIFTH wave that does nothing else (a DMA
-// piece costs its issuing wave ~60 cycles, which would idle that wave's matrix pipe); a slot is
-// 128 output rows x 32 input channels x [hi | lo] (18 KB, 144-B pitch).  The L2->LDS stream is what bounds these kernels
-// (~25 GB/s per CU), hence the largest position tile that fits 160 KB of LDS.
-// 4 MFMA waves: wave (wc, wp) owns channels [64wc,+64) x positions [96wp,+96) = 2 x 3 MFMA tiles;
-// per 16-deep k-chunk 10 fragment reads feed 18 MFMAs.
+// Layout (cf. ckr_conv.hip): a workgroup keeps FOUR boards (256 positions) resident in LDS
+// through all layers as unpadded rows of [128 hi | 128 lo] fp16 (512 B) whose 16-byte k-slots are
+// XOR-swizzled with the row number (conflict-free ds_read_b128, one v_xor per read): 128 KB, and
+// 4 096 boards make exactly four rounds of 256 workgroups.  Weights stream through a 3-slot LDS
+// ring of 16-input-channel slices (128 output rows x [16 hi | 16 lo], 10 KB, 80-B pitch) filled
+// by buffer_load ... lds two slots ahead.  8 waves (two per SIMD): wave (wc, wp) owns channels
+// [64wc,+64) x positions [64wp,+64) = 2 x 2 MFMA tiles; per 16-deep k-chunk 8 fragment reads
+// feed 12 MFMAs.
 #include "ckr_host.h"
 #include <hip/hip_runtime.h>
 
@@ -33,109 +32,111 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int MAX_LAYERS = 9;
-constexpr int XP = 192;                                          // positions per workgroup
-constexpr int APITCH = 528;                                      // [128 hi | 128 lo] fp16 + 16 B
+constexpr int NT = 512;                                          // 8 waves
+constexpr int TILE = 4;                                          // boards per workgroup
+constexpr int XP = 64 * TILE;                                    // positions per workgroup
+constexpr int AROW = 512;                                        // [128 hi | 128 lo] fp16, swizzled, no padding
 constexpr int LO = 256;                                          // byte offset of the lo half of a row
-constexpr int ZBASE = XP * APITCH;                               // zero region for out-of-board taps (see tap_rows)
-constexpr int ACT_BYTES = ZBASE + 15 * 16 + APITCH;
-constexpr int SLOT_K = 32;                                       // input channels per ring slot
-constexpr int WPITCH = SLOT_K * 4 + 16;                          // [32 hi | 32 lo] fp16 + 16 B = 144
-constexpr int WLO = SLOT_K * 2;
-constexpr int SLOT_BYTES = 128 * WPITCH;                         // 18 432 = 18 DMA pieces of 1 KB
+constexpr int ZBASE = XP * AROW;                                 // 512-B zero region for out-of-board taps
+constexpr int ACT_BYTES = ZBASE + 512;
+constexpr int WPITCH = 80;                                       // [16 hi | 16 lo] fp16 + 16 B per weight row
+constexpr int WLO = 32;
+constexpr int SLOT_BYTES = 128 * WPITCH;                         // 16 input channels of one tap
 constexpr int SLOT_U4 = SLOT_BYTES / 16;
-constexpr int SLOT_PIECES = SLOT_BYTES / 1024;
+constexpr int PIECES = SLOT_BYTES / 1024;                        // 10 DMA pieces of 1 KB
 constexpr int NRING = 3;
 constexpr int PRM_BYTES = 3 * 128 * 4;
-constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 158 976 B
+constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 163 840 B: all of it
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(ZBASE % 256 == 0 && APITCH % 32 == 16, "bank-group arithmetic of tap_rows");
 
 struct LayerDev {
-    const uint4* w;            // [n_slots][128 rows][144 B]
+    const uint4* w;            // [n_slots][128 rows][80 B]: first layer 9 slots (one per tap), else 72 (tap*8 + slice)
     const float* bias; const float* scale; const float* shift;   // pre-scaled on the host
     float* out;                // optional [B,8,8,128] float32 (activation * XS)
-    int n_slots;               // 9 (first layer: one slot per tap) or 36 (4 per tap)
 };
 struct Args {
     const float* x;            // [B,8,8,14] float32 NHWC
     long long n_boards;
     int n_layers;
     int has_heads;
+    float xs, inv_xs;
     int32_t* overflow;         // optional DEVICE flag: set when an activation leaves the fp16 range of the hi terms
     const int32_t* range;      // optional DEVICE [lo, hi): only tiles overlapping these boards are computed
-    float xs, inv_xs;
     ckr_conv_heads H;
     LayerDev L[MAX_LAYERS];
 };
 
-// the loader wave DMAs one ring slot: 18 wave-instructions of 64 lanes x 16 B to a wave-uniform LDS base
-// (buffer addressing: resource + piece offset in SGPRs, one lane-offset VGPR)
-__device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int lane) {
+// byte address of the hi half's 16-byte k-slot `ks` (8 channels) of activation row `r` (lo: + LO)
+__device__ __forceinline__ int act_addr(int r, int ks) { return r * AROW + ((ks ^ (r & 15)) << 4); }
+
+// one ring slot = 10 wave-instructions of 64 lanes x 16 B, dealt round-robin to the 8 waves
+__device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, SLOT_BYTES, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < SLOT_PIECES; ++c)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + c * 1024), 16, lane * 16, c * 1024, 0, 0);
+    for (int i = 0; i < (PIECES + 7) / 8; ++i) {
+        const int c = wave + 8 * i;
+        if (c < PIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + c * 1024), 16, lane * 16, c * 1024, 0, 0);
+    }
 }
 
-struct Frags { f16x8 ah[2], al[2], bh[3], bl[3]; };
+struct Frags { f16x8 ah[2], al[2], bh[2], bl[2]; };
 
-// chunk c (0/1) of a slot; koffb = byte offset of the slot's 32 input channels in an activation row
-__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int c, int koffb,
-                                           int half, int wrow0, const int (&brow)[3], Frags& f) {
-    const int ka = 32 * c + 16 * half;
+// the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half)
+__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int c8, int half,
+                                           int wrow0, const int (&rowaddr)[2], Frags& f) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        f.ah[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + ka);
-        f.al[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + WLO + ka);
+        f.ah[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + 16 * half);
+        f.al[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + WLO + 16 * half);
     }
+    const int kc = (2 * c8) << 4;
 #pragma unroll
-    for (int pt = 0; pt < 3; ++pt) {
-        f.bh[pt] = *reinterpret_cast<const f16x8*>(act + brow[pt] + koffb + ka);
-        f.bl[pt] = *reinterpret_cast<const f16x8*>(act + brow[pt] + LO + koffb + ka);
+    for (int pt = 0; pt < 2; ++pt) {
+        f.bh[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc));
+        f.bl[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc) + LO);
     }
 }
 
-__device__ __forceinline__ void mfma_block(const Frags& f, f32x16 (&acc)[2][3]) {
+__device__ __forceinline__ void mfma_block(const Frags& f, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
+        for (int pt = 0; pt < 2; ++pt)
             acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
+        for (int pt = 0; pt < 2; ++pt)
             acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bl[pt], acc[ct][pt], 0, 0, 0);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 3; ++pt)
+        for (int pt = 0; pt < 2; ++pt)
             acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
 }
 
-// 10 ds_read_b128 of the next chunk between the first MFMAs of the current one (one wave per SIMD)
+// 8 ds_read_b128 of the next slot between the first MFMAs of the current one
 __device__ __forceinline__ void interleave_reads_with_mfma() {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 }
 
-// Out-of-board taps read zeros from the zero region at the 16-byte slot whose bank group equals
-// that of the row the tap would have addressed (pitch = 33 slots: bank group = (row + k-slot) mod 16),
-// so border reads stay conflict-free (cf. ckr_conv.hip).
-__device__ __forceinline__ void tap_rows(int prow0, int tap, int (&brow)[3]) {
+// Row addresses (k-slot `half`) of the two B-tile rows this lane reads for tap (dy, dx); out-of-board
+// taps read the zero region with the swizzle of the row they replace (conflict-free).
+__device__ __forceinline__ void tap_rows(int prow0, int tap, int half, int (&rowaddr)[2]) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-    for (int pt = 0; pt < 3; ++pt) {
+    for (int pt = 0; pt < 2; ++pt) {
         const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7, r = p + 8 * dy + dx;
         const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
-        brow[pt] = ok ? r * APITCH : ZBASE + 16 * (r & 15);
+        rowaddr[pt] = (ok ? r * AROW : ZBASE) + (((r & 15) ^ half) << 4);
     }
 }
 
@@ -148,9 +149,10 @@ __device__ __forceinline__ void split1(float y, _Float16& h, _Float16& l, float&
 }
 
 // ReLU + BatchNorm affine (bias already in the accumulators, constants pre-scaled), split, store in place
-__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][3],
+__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][2],
                                          int32_t* overflow) {
 #pragma clang fp contract(fast)
+    asm volatile("" : "+v"(prow0), "+v"(lane));    // compute the store addresses here, not at kernel entry
     float amax = 0.0f;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -160,14 +162,14 @@ __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, in
             const float4 sc = *reinterpret_cast<const float4*>(prm + c0);
             const float4 sh = *reinterpret_cast<const float4*>(prm + 128 + c0);
 #pragma unroll
-            for (int pt = 0; pt < 3; ++pt) {
+            for (int pt = 0; pt < 2; ++pt) {
                 f16x4 h, l;
                 _Float16 hh, ll;
                 split1(sc.x * fmaxf(acc[ct][pt][4 * g + 0], 0.0f) + sh.x, hh, ll, amax); h[0] = hh; l[0] = ll;
                 split1(sc.y * fmaxf(acc[ct][pt][4 * g + 1], 0.0f) + sh.y, hh, ll, amax); h[1] = hh; l[1] = ll;
                 split1(sc.z * fmaxf(acc[ct][pt][4 * g + 2], 0.0f) + sh.z, hh, ll, amax); h[2] = hh; l[2] = ll;
                 split1(sc.w * fmaxf(acc[ct][pt][4 * g + 3], 0.0f) + sh.w, hh, ll, amax); h[3] = hh; l[3] = ll;
-                char* dst = act + (prow0 + 32 * pt) * APITCH + (c0 << 1);
+                char* dst = act + act_addr(prow0 + 32 * pt, c0 >> 3) + ((c0 & 7) << 1);
                 *reinterpret_cast<f16x4*>(dst) = h;
                 *reinterpret_cast<f16x4*>(dst + LO) = l;
             }
@@ -183,7 +185,7 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
                                          long long board0, int rows_valid, int tid, float inv_xs) {
 #pragma clang fp contract(fast)
     asm volatile("" : "+v"(tid));      // keep the per-lane head addresses from being hoisted to kernel entry (spills)
-    for (int i = tid; i < NOUT * 128; i += 320) stage[i] = w[i];
+    for (int i = tid; i < NOUT * 128; i += NT) stage[i] = w[i];
     if (tid < NOUT) { stage[NOUT * 128 + tid] = b[tid]; stage[NOUT * 129 + tid] = sc[tid]; stage[NOUT * 130 + tid] = sh[tid]; }
     __syncthreads();
     if (tid < rows_valid) {
@@ -192,8 +194,8 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
         for (int o = 0; o < NOUT; ++o) acc[o] = 0.0f;
 #pragma unroll 4
         for (int s = 0; s < 16; ++s) {
-            const f16x8 qh = *reinterpret_cast<const f16x8*>(act + tid * APITCH + (s << 4));
-            const f16x8 ql = *reinterpret_cast<const f16x8*>(act + tid * APITCH + LO + (s << 4));
+            const f16x8 qh = *reinterpret_cast<const f16x8*>(act + act_addr(tid, s));
+            const f16x8 ql = *reinterpret_cast<const f16x8*>(act + act_addr(tid, s) + LO);
             float xv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[j] = ((float)qh[j] + (float)ql[j]) * inv_xs;
@@ -213,98 +215,94 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
     __syncthreads();
 }
 
-// One layer.  `ring` is the index (0..2) of the ring slot that holds this layer's slot 0; the
-// slots for steps s, s+1, s+2 are landed / in flight when step s starts.
-// QPT = ring slots per tap: 1 (first layer, 32 padded input channels) or 4 (128 channels).
-template <int QPT>
+// One layer.  `ring` = ring index of the layer's slot 0; slots s, s+1, s+2 are landed / in flight when step s
+// starts.  CPT = ring slots (16-channel slices) per tap: 1 (first layer: 14 planes in one slice) or 8.
+// Each step: boundary (slot s+1 landed for every wave; the buffer of slot s -- whose fragments are
+// already in registers -- is re-filled with slot s+3), fragment loads of slot s+1, MFMAs of slot s.
+template <int CPT>
 __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char* wring, float* prm, int tid, int wave,
                                           int lane, int wc, int prow0, int wrow0, int& ring) {
-    constexpr int NSLOTS = 9 * QPT;
+    constexpr int NSLOTS = 9 * CPT;
     const LayerDev& L = A.L[l];
+    asm volatile("" : "+v"(prow0), "+v"(wrow0), "+v"(lane));     // per-layer address arithmetic stays inside the layer
     const int half = lane >> 5;
-    f32x16 acc[2][3];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 bi = *reinterpret_cast<const float4*>(L.bias + 64 * wc + 32 * ct + 8 * q + 4 * half);
 #pragma unroll
-            for (int pt = 0; pt < 3; ++pt) {
+            for (int pt = 0; pt < 2; ++pt) {
                 acc[ct][pt][4 * q + 0] = bi.x; acc[ct][pt][4 * q + 1] = bi.y;
                 acc[ct][pt][4 * q + 2] = bi.z; acc[ct][pt][4 * q + 3] = bi.w;
             }
         }
     if (tid < 128) { prm[tid] = L.scale[tid]; prm[128 + tid] = L.shift[tid]; }
     Frags f0, f1;
-    int brow[3];
-    tap_rows(prow0, 0, brow);
-    load_frags(act, wring + ring * SLOT_BYTES, 0, 0, half, wrow0, brow, f0);
+    int rowaddr[2];
+    tap_rows(prow0, 0, half, rowaddr);
+    load_frags(act, wring + ring * SLOT_BYTES, 0, half, wrow0, rowaddr, f0);
     __builtin_amdgcn_sched_barrier(0);
-    int s = 0;
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-        for (int q = 0; q < QPT; ++q, ++s) {
-            char* cur = wring + ring * SLOT_BYTES;
-            const int nring = ring == NRING - 1 ? 0 : ring + 1;
-            load_frags(act, cur, 1, 64 * q, half, wrow0, brow, f1);
-            mfma_block(f0, acc);
+    // one step: slot s (fragments in fc) is multiplied while the fragments of slot s+1 load into fn
+    auto step = [&](int s, int tap, int c8, Frags& fc, Frags& fn) {
+        char* cur = wring + ring * SLOT_BYTES;
+        const int nring = ring == NRING - 1 ? 0 : ring + 1;
+        // (a bare s_barrier: __syncthreads() would also wait vmcnt(0) and drain the look-ahead; slot s+2 may be
+        // in flight with >= 1 piece per wave)
+        asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+        if (s + 3 < NSLOTS) issue_slot(L.w + (size_t)(s + 3) * SLOT_U4, cur, wave, lane);
+        else if (l + 1 < A.n_layers) issue_slot(A.L[l + 1].w + (size_t)(s + 3 - NSLOTS) * SLOT_U4, cur, wave, lane);
+        if (s + 1 < NSLOTS) {
+            if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
+            load_frags(act, wring + nring * SLOT_BYTES, c8 == CPT - 1 ? 0 : c8 + 1, half, wrow0, rowaddr, fn);
+            mfma_block(fc, acc);
             interleave_reads_with_mfma();
-            // slot boundary (pairs with load_layer): the loader wave arrives once slot s+1 has landed;
-            // every MFMA wave has issued its last reads of `cur`, which the loader re-fills with slot s+3
-            asm volatile("s_barrier" ::: "memory");
-            if (s + 1 < NSLOTS) {
-                if (q == QPT - 1) tap_rows(prow0, tap + 1, brow);
-                load_frags(act, wring + nring * SLOT_BYTES, 0, q == QPT - 1 ? 0 : 64 * (q + 1), half, wrow0, brow, f0);
-                mfma_block(f1, acc);
-                interleave_reads_with_mfma();
-            } else {
-                mfma_block(f1, acc);
+        } else {
+            mfma_block(fc, acc);
+        }
+        ring = nring;
+    };
+    if constexpr (CPT == 1) {
+#pragma unroll
+        for (int s = 0; s < NSLOTS; ++s) {
+            if (s & 1) step(s, s, 0, f1, f0);
+            else step(s, s, 0, f0, f1);
+        }
+    } else {
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int c8 = 0; c8 < CPT; c8 += 2) {
+                step(tap * CPT + c8, tap, c8, f0, f1);
+                step(tap * CPT + c8 + 1, tap, c8 + 1, f1, f0);
             }
-            ring = nring;
         }
     }
     epilogue(act, prm, wc, lane, prow0, acc, A.overflow);
+    __syncthreads();
 }
 
-// The loader wave's side of one layer: keeps the weight ring two slots ahead of the MFMA waves.
-// The DMA issue (~60 cycles per 1-KB piece) would otherwise stall the matrix pipe of the issuing wave.
-__device__ __forceinline__ void load_layer(const Args& A, int l, char* wring, int lane, int& ring) {
-    const LayerDev& L = A.L[l];
-    const int nslots = L.n_slots;
-    for (int s = 0; s < nslots; ++s) {
-        // in flight: slots s+1 and s+2 (18 pieces each, in order) -> slot s+1 has landed
-        asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
-        char* cur = wring + ring * SLOT_BYTES;
-        if (s + 3 < nslots) issue_slot(L.w + (size_t)(s + 3) * SLOT_U4, cur, lane);
-        else if (l + 1 < A.n_layers) issue_slot(A.L[l + 1].w + (size_t)(s + 3 - nslots) * SLOT_U4, cur, lane);
-        ring = ring == NRING - 1 ? 0 : ring + 1;
-    }
-}
-
-// 4 MFMA waves (one per SIMD) + 1 loader wave
-__global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
+__global__ __launch_bounds__(NT, 1) void k_conv_stack_x3(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* act = smem;
     char* wring = smem + ACT_BYTES;
     float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + NRING * SLOT_BYTES);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool loader = wave == 4;
-    const int wc = (wave >> 1) & 1, wp = wave & 1;
-    const long long board0 = (long long)blockIdx.x * 3;
+    const int wc = wave >> 2, wp = wave & 3;
+    const long long board0 = (long long)blockIdx.x * TILE;
     const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
-    if (A.range && (board0 >= A.range[1] || board0 + 3 <= A.range[0])) return;   // arena: this tile belongs to the other network
+    if (A.range && (board0 >= A.range[1] || board0 + TILE <= A.range[0])) return;   // arena / tail: not this launch's share
 
-    if (loader)
-        for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, lane);
-    for (int i = tid; i < ACT_BYTES / 16; i += 320) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, wave, lane);
+    for (int i = tid; i < ACT_BYTES / 16; i += NT) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (tid < rows_valid) {                                       // 14 float32 planes per position -> hi / lo
+    if (tid < rows_valid) {                                       // 14 float32 planes per position -> hi / lo, k-slots 0 and 1
         const float2* src = reinterpret_cast<const float2*>(A.x + (board0 * 64 + tid) * 14);
         _Float16 h[16], lo[16];
+        float amax = 0.0f;
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const float2 v = src[j];
-            float amax = 0.0f;
             split1(v.x * A.xs, h[2 * j], lo[2 * j], amax);
             split1(v.y * A.xs, h[2 * j + 1], lo[2 * j + 1], amax);
         }
@@ -312,28 +310,27 @@ __global__ __launch_bounds__(320, 1) void k_conv_stack_x3(const Args A) {
         f16x8 v0, v1, w0, w1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v0[j] = h[j]; v1[j] = h[8 + j]; w0[j] = lo[j]; w1[j] = lo[8 + j]; }
-        *reinterpret_cast<f16x8*>(act + tid * APITCH) = v0;
-        *reinterpret_cast<f16x8*>(act + tid * APITCH + 16) = v1;
-        *reinterpret_cast<f16x8*>(act + tid * APITCH + LO) = w0;
-        *reinterpret_cast<f16x8*>(act + tid * APITCH + LO + 16) = w1;
+        *reinterpret_cast<f16x8*>(act + act_addr(tid, 0)) = v0;
+        *reinterpret_cast<f16x8*>(act + act_addr(tid, 1)) = v1;
+        *reinterpret_cast<f16x8*>(act + act_addr(tid, 0) + LO) = w0;
+        *reinterpret_cast<f16x8*>(act + act_addr(tid, 1) + LO) = w1;
+        if (A.overflow && amax > 60000.0f) *A.overflow = 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int prow0 = 96 * wp + (lane & 31);
+    const int prow0 = 64 * wp + (lane & 31);
     const int wrow0 = 64 * wc + (lane & 31);
     int ring = 0;
     for (int l = 0; l < A.n_layers; ++l) {
-        if (loader) load_layer(A, l, wring, lane, ring);
-        else if (l == 0) run_layer<1>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
-        else run_layer<4>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
-        __syncthreads();                                          // epilogue stores visible to every wave
+        if (l == 0) run_layer<1>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
+        else run_layer<8>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
         float* out = A.L[l].out;
         if (out) {                                                // (tests) activation * XS as float32
             float* dst = out + board0 * 64 * 128;
-            for (int q = tid; q < rows_valid * 128; q += 320) {
+            for (int q = tid; q < rows_valid * 128; q += NT) {
                 const int r = q >> 7, c = q & 127;
-                dst[q] = (float)*reinterpret_cast<const _Float16*>(act + r * APITCH + 2 * c) +
-                         (float)*reinterpret_cast<const _Float16*>(act + r * APITCH + LO + 2 * c);
+                const char* src = act + act_addr(r, c >> 3) + ((c & 7) << 1);
+                dst[q] = (float)*reinterpret_cast<const _Float16*>(src) + (float)*reinterpret_cast<const _Float16*>(src + LO);
             }
         }
         if (A.has_heads) {
@@ -360,7 +357,8 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     if (n_boards == 0) return CKR_OK;
     if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
     Args A;
-    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale; A.range = d_board_range; A.overflow = d_overflow;
+    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale;
+    A.range = d_board_range; A.overflow = d_overflow;
     A.has_heads = heads ? 1 : 0;
     if (heads) {
         A.H = *heads;
@@ -377,10 +375,10 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
         if (!s.weights || !s.bias || !s.scale || !s.shift) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null layer pointer");
         if ((i == 0 && s.cin_pad != 32) || (i > 0 && s.cin_pad != 128))
             return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: layer 0 must have cin_pad 32, later layers 128");
-        A.L[i] = LayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (float*)s.out, i == 0 ? 9 : 36};
+        A.L[i] = LayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (float*)s.out};
     }
-    const int grid = (int)((n_boards + 2) / 3);
-    hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(320), 0, (hipStream_t)stream, A);
+    const int grid = (int)((n_boards + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -54,23 +54,21 @@ XS, WS = 8.0, 1024.0         # power-of-two operand scales of the split-fp16 pat
 
 
 def pack_split_weights(w, first):
-    """torch conv weight [128, cin, 3, 3] (float32) -> the ring-slot image of
-    ckr_conv_stack_f16x3: fp16 [n_slots][128 out][32 hi | 32 lo | 8 pad] of w * WS, where
-    hi = fp16(w*WS), lo = fp16(w*WS - hi); slot = tap (first layer, 14 planes zero-padded
-    to 32) or tap*4 + quarter (32 of the 128 input channels per slot)."""
+    """Ring-slot image of ckr_conv_stack_f16x3: fp16 [n_slots][128 out][16 hi | 16 lo | 8 pad]
+    of w * WS; slot = tap (first layer: 14 planes in one 16-channel slice) or tap*8 + slice."""
     cout, cin = w.shape[0], w.shape[1]
-    assert cout == 128 and w.shape[2:] == (3, 3) and cin <= (32 if first else 128)
-    q = 1 if first else 4
-    t = torch.zeros((9, cout, 32 * q), dtype=torch.float32, device=w.device)
+    assert cout == 128 and w.shape[2:] == (3, 3) and cin <= (16 if first else 128)
+    q = 1 if first else 8
+    t = torch.zeros((9, cout, 16 * q), dtype=torch.float32, device=w.device)
     t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin) * WS
     if float(t.abs().max()) > 6e4:
         raise OverflowError("conv weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
     hi = t.to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
-    img = torch.zeros((9, q, cout, 72), dtype=torch.float16, device=w.device)
-    img[..., 0:32] = hi.reshape(9, cout, q, 32).permute(0, 2, 1, 3)
-    img[..., 32:64] = lo.reshape(9, cout, q, 32).permute(0, 2, 1, 3)
-    return img.reshape(9 * q, cout, 72).contiguous()
+    img = torch.zeros((9, q, cout, 40), dtype=torch.float16, device=w.device)
+    img[..., 0:16] = hi.reshape(9, cout, q, 16).permute(0, 2, 1, 3)
+    img[..., 16:32] = lo.reshape(9, cout, q, 16).permute(0, 2, 1, 3)
+    return img.reshape(9 * q, cout, 40).contiguous()
 
 
 def bn_affine(bn):
@@ -174,7 +172,7 @@ class FusedEvaluator:
     @torch.no_grad()
     def __call__(self, engine):
         x = engine.x
-        if x.dtype != (torch.float32 if self.mode == "f16x3" else torch.bfloat16):
+        if x.dtype != (torch.bfloat16 if self.mode == "bf16" else torch.float32):
             raise ValueError("FusedEvaluator(%s) needs the engine's features in %s" %
                              (self.mode, "float32" if self.mode == "f16x3" else "bfloat16"))
         if len(self.nets) == 1:                      # engine.row_range: active rows after Engine.compact_rows()

@@ -145,7 +145,7 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
  * split into two fp16 terms and wh*xh + wh*xl + wl*xh is accumulated in the float32
  * accumulators of the 16-bit MFMA (csrc/ckr_conv_x3.hip).
  * d_x: float32 NHWC [n_boards][8][8][14].  layers[i].weights: the split image
- * [n_slots][128][32 hi | 32 lo | 8 pad] fp16 of (w * WS); bias / scale / shift pre-scaled
+ * [n_slots][128][16 hi | 16 lo | 8 pad] fp16 of (w * WS), n_slots = 9 (first layer) or 72; bias / scale / shift pre-scaled
  * by the host (bias*XS*WS, scale/WS, shift*XS) so that the stored activation is
  * y * XS = hi + lo; x_scale = XS (a power of two).  layers[i].out (tests): float32
  * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32.
