@@ -153,10 +153,10 @@ def split_roofline(conv_flops, slots, t_conv):
                                        "results, 3 fp16 MFMAs per multiply-add; one launch per step)",
             "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
             "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
-            # profiles/r01_pmc_conv_kernels.csv: FETCH_SIZE 120 537 KB (doubled, gfx950), WRITE_SIZE 9 216 KB at 4 096
-            # boards -- the 4.7 MB split-weight image exceeds one XCD's 4 MB L2, so part of the stream is served
-            # by the Infinity Cache (3.7 % of the 6.4 GB the workgroups stream per launch)
-            "traffic": (2 * 120537.5 + 9216.0) * 1024.0 * slots / 4096.0,
+            # profiles/r01_pmc_conv_kernels.csv: FETCH_SIZE 89 742 KB (doubled, gfx950), WRITE_SIZE 9 216 KB at 4 096
+            # boards -- the 5.9 MB split-weight image exceeds one XCD's 4 MB L2, so part of the stream is served
+            # by the Infinity Cache (3 % of the 6.0 GB the workgroups stream per launch)
+            "traffic": (2 * 89742.0 + 9216.0) * 1024.0 * slots / 4096.0,
             "traffic_source": "profiles/r01_pmc_conv_kernels.csv (separate --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)",
             "executed_tflops": 3.0 * tf if tf else None,
             "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
@@ -336,15 +336,15 @@ def main():
             conv_flops = evaluator.CONV_FLOPS_PER_BOARD
             conv_tflops = conv_flops * a.slots / t_conv / 1e12 if t_conv else None
             roofline = {"bound": "mfma", "kernel": "k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, "
-                                                   "6 boards per workgroup LDS-resident through all layers; one launch per step)",
+                                                   "8 boards per workgroup LDS-resident through all layers; one launch per step)",
                         "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
                         "frac": conv_tflops / peak if conv_tflops else None,
                         # HBM-side bytes per launch from the rocprofv3 --pmc passes committed under profiles/
-                        # (r01_pmc_conv_kernels.csv, final rows: FETCH_SIZE 14 713 KB, WRITE_SIZE 9 216 KB at 4 096
+                        # (r01_pmc_conv_kernels.csv, final rows: FETCH_SIZE 14 918 KB, WRITE_SIZE 9 216 KB at 4 096
                         # boards; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch
                         # size; not re-measured by this script.  Algorithmic: 7.3 MB planes in + 9.4 MB head
-                        # features out + the 2.5 MB of weights once per XCD L2.
-                        "traffic": (2 * 14713.4 + 9216.0) * 1024.0 * a.slots / 4096.0,
+                        # features out + the 2.9 MB of weights once per XCD L2.
+                        "traffic": (2 * 14918.2 + 9216.0) * 1024.0 * a.slots / 4096.0,
                         "traffic_source": "profiles/r01_pmc_conv_kernels.csv (separate --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)",
                         "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": a.slots,
                         "network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
