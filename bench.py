@@ -130,15 +130,23 @@ def movegen_probe(device):
 
 
 def time_conv(evaluator, x, dev, groups=5, per_group=10):
-    """Average launch duration of the conv-stack kernel: HIP events on the launch stream around
-    groups of back-to-back launches (the launch gap of a single eager launch would otherwise add
-    ~5 % to a 0.45 ms kernel); median over the groups.  Seconds per launch."""
+    """Average launch duration of the conv-stack kernel: HIP events on the launch stream around a HIP
+    graph of `per_group` back-to-back launches (graph dispatch, as in the real step: eager launches
+    add a ~15 us inter-kernel gap to a 0.4 ms kernel); median over `groups` replays.  Seconds per launch."""
     evaluator.conv_only(x)
+    torch.cuda.synchronize(dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(per_group):
+            evaluator.conv_only(x)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g.replay()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(groups)]
     for e0, e1 in ev:
         e0.record()
-        for _ in range(per_group):
-            evaluator.conv_only(x)
+        g.replay()
         e1.record()
     torch.cuda.synchronize(dev)
     return float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])) / 1e3 / per_group
