@@ -128,6 +128,61 @@ __global__ __launch_bounds__(256) void k_training_batch(const ckr_tuple* __restr
     }
 }
 
+// ---- arena batch partition (fused.FusedEvaluator with two networks): rows sorted new | old | idle
+// dest[row] = position of the row in the sorted batch; ranges = {0, n_new, n_new, n_new + n_old}
+__global__ __launch_bounds__(1024) void k_partition(const int32_t* __restrict__ net_id, int n, int32_t* __restrict__ dest,
+                                                    int32_t* __restrict__ ranges) {
+    __shared__ int c_old[1024], c_idle[1024];
+    const int tid = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, tid * per), hi = min(n, lo + per);
+    int no = 0, ni = 0;
+    for (int r = lo; r < hi; ++r) { const int id = net_id[r]; no += id == 1; ni += id < 0; }
+    c_old[tid] = no; c_idle[tid] = ni;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int a = tid >= d ? c_old[tid - d] : 0, b = tid >= d ? c_idle[tid - d] : 0;
+        __syncthreads();
+        c_old[tid] += a; c_idle[tid] += b;
+        __syncthreads();
+    }
+    const int n_old = c_old[1023], n_idle = c_idle[1023], n_new = n - n_old - n_idle;
+    int bo = c_old[tid] - no, bi = c_idle[tid] - ni;          // old / idle rows before this thread's block
+    for (int r = lo; r < hi; ++r) {
+        const int id = net_id[r];
+        if (id == 1) dest[r] = n_new + bo++;
+        else if (id < 0) dest[r] = n_new + n_old + bi++;
+        else dest[r] = r - bo - bi;
+    }
+    if (tid == 0) { ranges[0] = 0; ranges[1] = n_new; ranges[2] = n_new; ranges[3] = n_new + n_old; }
+}
+
+// xg[dest[r]] = x[r]: one wave per row of `row_u4` 16-byte chunks
+__global__ __launch_bounds__(256) void k_gather_rows(const uint4* __restrict__ x, const int32_t* __restrict__ dest, int n,
+                                                     int row_u4, uint4* __restrict__ xg) {
+    const int lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nwaves) {
+        const uint4* src = x + r * row_u4;
+        uint4* dst = xg + (int64_t)dest[r] * row_u4;
+        for (int k = lane; k < row_u4; k += 64) dst[k] = src[k];
+    }
+}
+
+// p[r] = (dest[r] < n_new ? pa : pb)[dest[r]], same for v: the sorted outputs of the two networks back in slot order
+__global__ __launch_bounds__(256) void k_select_scatter(const float* __restrict__ pa, const float* __restrict__ va,
+                                                        const float* __restrict__ pb, const float* __restrict__ vb,
+                                                        const int32_t* __restrict__ dest, const int32_t* __restrict__ ranges,
+                                                        int n, float* __restrict__ p, float* __restrict__ v) {
+    const int lane = lane_id(), n_new = ranges[1];
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += nwaves) {
+        const int d = dest[r];
+        const float4* src = reinterpret_cast<const float4*>((d < n_new ? pa : pb) + (int64_t)d * 512);
+        float4* dst = reinterpret_cast<float4*>(p + r * 512);
+        dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
+        if (lane == 0) v[r] = (d < n_new ? va : vb)[d];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_mask_renorm(const uint4* __restrict__ boards, int64_t n,
                                                      const float* __restrict__ p, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float pl[4][512];
@@ -264,6 +319,31 @@ int ckr_training_batch(const ckr_tuple* d_tuples, int64_t n_tuples, const int64_
     CKR_CHECK_ARGS(d_tuples && d_x && d_pi && d_value, "null device pointer");
     hipLaunchKernelGGL(k_training_batch, dim3(grid_for(batch, 4)), dim3(256), 0, (hipStream_t)stream,
                        d_tuples, n_tuples, d_index, batch, d_x, d_pi, d_value);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_arena_partition(const int32_t* d_net_id, int32_t n, const void* d_x, int32_t row_bytes, int32_t* d_dest,
+                        int32_t* d_ranges, void* d_x_sorted, void* stream) {
+    CKR_CHECK_ARGS(n >= 0 && row_bytes > 0 && row_bytes % 16 == 0, "bad size");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_net_id && d_x && d_dest && d_ranges && d_x_sorted, "null device pointer");
+    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_net_id, (int)n, d_dest, d_ranges);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_x,
+                       (const int32_t*)d_dest, (int)n, (int)(row_bytes / 16), (uint4*)d_x_sorted);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_arena_merge(const float* d_p_new, const float* d_v_new, const float* d_p_old, const float* d_v_old,
+                    const int32_t* d_dest, const int32_t* d_ranges, int32_t n, float* d_p, float* d_v, void* stream) {
+    CKR_CHECK_ARGS(n >= 0, "n < 0");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    CKR_CHECK_ARGS(d_p_new && d_v_new && d_p_old && d_v_old && d_dest && d_ranges && d_p && d_v, "null device pointer");
+    hipLaunchKernelGGL(k_select_scatter, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, d_p_new, d_v_new, d_p_old,
+                       d_v_old, d_dest, d_ranges, (int)n, d_p, d_v);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -104,7 +104,8 @@ class FusedEvaluator:
         self.nets = [self._prepare(net)]
         if net_old is not None:
             self.nets.append(self._prepare(net_old))
-        self.static_outputs = net_old is None   # one net: p / v are always the same device buffers
+        self.static_outputs = True              # p / v are always the same device buffers: no copies in the runner
+        self.supports_row_range = net_old is None   # single network: honours Engine.compact_rows() (tail of a run)
 
     def _prepare(self, net):
         dev = next(net.parameters()).device
@@ -183,28 +184,20 @@ class FusedEvaluator:
         # scatter the rows back: one batch worth of convolutions per step instead of two, and none for
         # slots whose games are over (the arena's long tail of drawn-out games).
         S, dev = self.S, x.device
-        if not hasattr(self, "_pos"):
-            self._pos = torch.arange(S, device=dev)
-            self._rng_new = torch.zeros(2, dtype=torch.int32, device=dev)          # [0, n_new)
-            self._rng_old = torch.full((2,), S, dtype=torch.int32, device=dev)     # [n_new, S)
-        nid = engine.net_id
-        old, idle = nid == 1, nid < 0                                # idle: the slot's games are over
-        c_old, c_idle = old.cumsum(0), idle.cumsum(0)
-        n_old, n_idle = c_old[-1], c_idle[-1]
-        n_new = S - n_old - n_idle
-        dest = torch.where(old, n_new + c_old - 1,                   # stable 3-way partition: new | old | idle
-                           torch.where(idle, n_new + n_old + c_idle - 1, self._pos - c_old - c_idle))
-        xg = torch.empty_like(x)
-        xg.index_copy_(0, dest, x)
-        self._rng_new[1] = n_new
-        self._rng_old[0] = n_new
-        self._rng_old[1] = n_new + n_old
-        p, v = self._forward(self.nets[0], xg, self._rng_new)
-        p2, v2 = self._forward(self.nets[1], xg, self._rng_old)
-        mine = self._pos < n_new
-        pg = torch.where(mine[:, None], p, p2)
-        vg = torch.where(mine, v, v2)
-        return pg.index_select(0, dest), vg.index_select(0, dest)
+        if not hasattr(self, "_dest"):
+            self._dest = torch.zeros(S, dtype=torch.int32, device=dev)
+            self._ranges = torch.zeros(4, dtype=torch.int32, device=dev)      # {0, n_new, n_new, n_new + n_old}
+            self._xg = torch.empty_like(x)
+            self._p = torch.empty((S, 512), dtype=torch.float32, device=dev)
+            self._v = torch.empty((S,), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._L.ckr_arena_partition(engine.net_id.data_ptr(), S, x.data_ptr(), x[0].numel() * x.element_size(),
+                                               self._dest.data_ptr(), self._ranges.data_ptr(), self._xg.data_ptr(), stream))
+        p, v = self._forward(self.nets[0], self._xg, self._ranges[0:2])
+        p2, v2 = self._forward(self.nets[1], self._xg, self._ranges[2:4])
+        _lib.check(self._L.ckr_arena_merge(p.data_ptr(), v.data_ptr(), p2.data_ptr(), v2.data_ptr(), self._dest.data_ptr(),
+                                           self._ranges.data_ptr(), S, self._p.data_ptr(), self._v.data_ptr(), stream))
+        return self._p, self._v
 
     def check_range(self):
         """Raises if the float32-grade kernel met an activation outside its range (|a| * XS > 6e4): the

@@ -144,7 +144,7 @@ class StepRunner:
             self.warmup()
         S = self.eng.cfg.n_slots
         rows = S
-        can_compact = compact_tail and getattr(self.evaluator, "static_outputs", False)
+        can_compact = compact_tail and getattr(self.evaluator, "supports_row_range", False)
         while True:
             self.step(check_every)
             active = self.eng.stats()["active_slots"]

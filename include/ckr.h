@@ -155,6 +155,18 @@ int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_laye
                          int32_t n_layers, const ckr_conv_heads* heads, float x_scale,
                          const int32_t* d_board_range, int32_t* d_overflow, void* stream);
 
+/* Arena batches (tournament_Checkers swaps game_env.neural_net per side, training_pipeline.py:
+ * 529,536,546): every leaf belongs to one of two networks.  ckr_arena_partition sorts the batch
+ * rows new | old | idle by d_net_id (0 / 1 / -1, as ckr_engine_step writes it): d_dest[row] = sorted
+ * position, d_ranges = {0, n_new, n_new, n_new + n_old} (DEVICE int32[4]: the two board ranges for
+ * ckr_conv_stack_*), d_x_sorted[d_dest[row]] = d_x[row] (rows of row_bytes, a multiple of 16).
+ * ckr_arena_merge brings the two networks' outputs (computed on the sorted batch) back to slot
+ * order: d_p[row] / d_v[row] come from the network that owns the row. */
+int ckr_arena_partition(const int32_t* d_net_id, int32_t n, const void* d_x, int32_t row_bytes, int32_t* d_dest,
+                        int32_t* d_ranges, void* d_x_sorted, void* stream);
+int ckr_arena_merge(const float* d_p_new, const float* d_v_new, const float* d_p_old, const float* d_v_old,
+                    const int32_t* d_dest, const int32_t* d_ranges, int32_t n, float* d_p, float* d_v, void* stream);
+
 /* Value head tail (training_pipeline.py:106-112): Dense(64)+ReLU -> BatchNorm ->
  * Dense(1) -> tanh on d_in[n][64] (the fused value conv's output).
  * w1t: [64 in][64 out] (transposed Dense kernel), b1/scale/shift/w2: [64]. */
