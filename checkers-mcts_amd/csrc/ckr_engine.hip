@@ -709,7 +709,7 @@ __device__ __forceinline__ void flush_counters(Wave& w) {
 __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
-    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     Wave w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
                                               const float* __restrict__ v, void* x, int32_t* net_out) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
-    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     Wave w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
@@ -753,6 +753,7 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
     int leaf = -1, net = -1, free_sims = 0;
     ckr_board lb{0u, 0u, 0u, 0u};
     while (D.g_phase[slot] == PH_PLAYING) {
+        asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
         if (D.g_sims[slot] >= D.budget) {                                // MCTS.computational_budget, :189-201
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
             finish_ply(w); continue;
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
 __global__ __launch_bounds__(256) void k_rollout(const Dev* __restrict__ Dp, int sims) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
-    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     Wave w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(256) void k_command(const Dev* __restrict__ Dp, con
                                                  const int32_t* __restrict__ arg, int32_t* __restrict__ err) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
-    const int wave = threadIdx.x >> 6, slot = blockIdx.x * 4 + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     Wave w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
