@@ -156,14 +156,22 @@ class TrainingData:
     def __len__(self):
         return self.n
 
-    def batch(self, index):
-        """index: int64 device tensor -> (x [B,8,8,14], pi [B,512], value target [B]) float32."""
+    def batch(self, index, out=None):
+        """index: int64 device tensor -> (x [B,8,8,14], pi [B,512], value target [B]) float32
+        (written into the tensors of `out` when given: static buffers of a captured training step)."""
         if self.dense is not None:
-            return tuple(a.index_select(0, index) for a in self.dense)
+            if out is None:
+                return tuple(a.index_select(0, index) for a in self.dense)
+            for a, o in zip(self.dense, out):
+                torch.index_select(a, 0, index, out=o)
+            return out
         B, dev = int(index.shape[0]), self.tuples.device
-        x = torch.empty((B, 8, 8, 14), dtype=torch.float32, device=dev)
-        pi = torch.empty((B, 512), dtype=torch.float32, device=dev)
-        tv = torch.empty((B,), dtype=torch.float32, device=dev)
+        if out is None:
+            x = torch.empty((B, 8, 8, 14), dtype=torch.float32, device=dev)
+            pi = torch.empty((B, 512), dtype=torch.float32, device=dev)
+            tv = torch.empty((B,), dtype=torch.float32, device=dev)
+        else:
+            x, pi, tv = out
         index = index.to(torch.int64).contiguous()
         _lib.check(self._L.ckr_training_batch(self.tuples.data_ptr(), self.n, index.data_ptr(), B, x.data_ptr(),
                                               pi.data_ptr(), tv.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
@@ -177,13 +185,44 @@ def l2_penalty(net):
     return net.conv_reg * conv + net.dense_reg * dense
 
 
-def losses(net, x, pi, tv):
-    """(total, policy CE, value MSE) with Keras' definitions: CE = -sum(t * log(clip(p / sum p, 1e-7, 1 - 1e-7)))."""
-    p, v = net(x.permute(0, 3, 1, 2))
+def _reg_groups(net):
+    conv = [t for m in net.modules() if isinstance(m, torch.nn.Conv2d) for t in (m.weight, m.bias)]
+    dense = [t for m in net.modules() if isinstance(m, torch.nn.Linear) for t in (m.weight, m.bias)]
+    return conv, dense
+
+
+def l2_penalty_value(net):
+    """The same penalty as a detached device scalar, in two multi-tensor launches (reporting only)."""
+    conv, dense = _reg_groups(net)
+    with torch.no_grad():
+        c = torch.stack(torch._foreach_norm(conv, 2)).square().sum()
+        d = torch.stack(torch._foreach_norm(dense, 2)).square().sum()
+    return net.conv_reg * c + net.dense_reg * d
+
+
+def add_l2_gradients(net):
+    """d(penalty)/dw = 2 * reg * w added to the gradients in two multi-tensor launches (what autograd through
+    l2_penalty() would add, without ~100 small kernels per batch)."""
+    for group, reg in zip(_reg_groups(net), (net.conv_reg, net.dense_reg)):
+        if reg:
+            torch._foreach_add_([t.grad for t in group], [t.detach() for t in group], alpha=2.0 * reg)
+
+
+def losses(net, x, pi, tv, autocast_dtype=None, with_penalty=True):
+    """(total, policy CE, value MSE) with Keras' definitions: CE = -sum(t * log(clip(p / sum p, 1e-7, 1 - 1e-7))).
+    autocast_dtype (opt-in, TRAIN_DTYPE): run the convolutions / dense layers in that dtype (torch.autocast);
+    BatchNorm, softmax and the losses stay float32."""
+    if autocast_dtype is not None and autocast_dtype != torch.float32:
+        with torch.autocast(device_type=x.device.type, dtype=autocast_dtype):
+            p, v = net(x.permute(0, 3, 1, 2))
+        p, v = p.float(), v.float()
+    else:
+        p, v = net(x.permute(0, 3, 1, 2))
     p = p / p.sum(dim=1, keepdim=True)
     ce = -(pi * torch.log(p.clamp(1e-7, 1 - 1e-7))).sum(dim=1).mean()
     mse = F.mse_loss(v, tv)
-    return net.policy_loss_weight * ce + net.value_loss_weight * mse + l2_penalty(net), ce, mse
+    data_loss = net.policy_loss_weight * ce + net.value_loss_weight * mse
+    return (data_loss + l2_penalty(net)) if with_penalty else data_loss, ce, mse
 
 
 class History:
@@ -211,12 +250,15 @@ def train_nn(training_data, neural_network, **kwargs):
     TRAINING_ITERATION, BATCH_SIZE = kwargs["TRAINING_ITERATION"], kwargs["BATCH_SIZE"]
     CLR_SS_COEFF, NN_BASE_LR, NN_MAX_LR, EPOCHS = kwargs["CLR_SS_COEFF"], kwargs["NN_BASE_LR"], kwargs["NN_MAX_LR"], kwargs["EPOCHS"]
     dev = torch.device(kwargs.get("DEVICE", "cuda"))
+    amp = kwargs.get("TRAIN_DTYPE", torch.float32)          # build-specific: torch.bfloat16 = mixed-precision training
     for name, dflt in (("conv_reg", kwargs.get("CONV_REG", 0.0)), ("dense_reg", kwargs.get("DENSE_REG", 0.0)),
                        ("policy_loss_weight", kwargs.get("POLICY_LOSS_WEIGHT", 1.0)),
                        ("value_loss_weight", kwargs.get("VALUE_LOSS_WEIGHT", 1.0))):
         if not hasattr(neural_network, name):
             setattr(neural_network, name, float(dflt))
     net = neural_network.to(device=dev, dtype=torch.float32)
+    if dev.type == "cuda":
+        net = net.to(memory_format=torch.channels_last)
     for p in net.parameters():
         p.requires_grad_(True)
     data = _as_training_data(training_data, dev)
@@ -227,35 +269,80 @@ def train_nn(training_data, neural_network, **kwargs):
     n_train = int(train_idx.shape[0])
     steps_per_epoch = int(np.ceil(n_train / float(BATCH_SIZE)))
     clr = CyclicLR(base_lr=NN_BASE_LR, max_lr=NN_MAX_LR, step_size=int(CLR_SS_COEFF * (n_train / BATCH_SIZE)), mode="triangular")
-    opt = torch.optim.Adam(net.parameters(), lr=clr.on_train_begin(), betas=(0.9, 0.999), eps=1e-7)
+    # the learning rate lives in a device tensor so that a captured step sees the cyclical schedule
+    lr_t = torch.tensor(float(clr.on_train_begin()), dtype=torch.float32, device=dev)
+    opt = torch.optim.Adam(net.parameters(), lr=lr_t if dev.type == "cuda" else float(lr_t), betas=(0.9, 0.999), eps=1e-7,
+                           **({"fused": True, "capturable": True} if dev.type == "cuda" else {}))
     filepath = "data/model/Checkers_Model" + str(TRAINING_ITERATION + 1) + "_" + create_timestamp() + ".pt"
     os.makedirs("data/model", exist_ok=True)
     history, best, es_best, wait, saved = History(), np.inf, np.inf, 0, False
     lr = clr.on_train_begin()
 
+    use_graph = dev.type == "cuda" and kwargs.get("USE_GRAPH", True)
+    captured = {}                            # "train": (graph, static x / pi / tv, static sums); lr lives in a device tensor
+
+    def train_batch(x, pi, tv, acc, n_rows):
+        opt.zero_grad(set_to_none=False)
+        loss, ce, mse = losses(net, x, pi, tv, amp, with_penalty=False)
+        loss.backward()
+        pen = l2_penalty_value(net)
+        add_l2_gradients(net)
+        opt.step()
+        acc += torch.stack([loss.detach() + pen, ce.detach(), mse.detach()]).double() * float(n_rows)
+
+    def capture_train_step(acc):
+        """The whole training step (forward, backward, penalty gradients, fused Adam, loss sums) of a full
+        batch as ONE HIP graph: at batch 128 the step is launch-bound (~150 small kernels)."""
+        sx = torch.zeros((BATCH_SIZE, 8, 8, 14), dtype=torch.float32, device=dev)
+        spi = torch.zeros((BATCH_SIZE, 512), dtype=torch.float32, device=dev)
+        stv = torch.zeros((BATCH_SIZE,), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            train_batch(sx, spi, stv, acc, BATCH_SIZE)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return graph, (sx, spi, stv)
+
     def run(idx, train):
-        tot = ce_s = mse_s = 0.0
+        # per-batch sums stay on the device (one host read per pass); the l2 penalty enters the gradients
+        # through add_l2_gradients and the reported loss through l2_penalty_value
         nb = int(np.ceil(idx.shape[0] / float(BATCH_SIZE)))
         batches = torch.randperm(nb, generator=g).tolist() if train else range(nb)
         nonlocal lr
+        if train:
+            acc = captured.setdefault("acc", torch.zeros(3, dtype=torch.float64, device=dev))
+            acc.zero_()
+        else:
+            acc = torch.zeros(3, dtype=torch.float64, device=dev)
+        pen_eval = None if train else l2_penalty_value(net)
         for b in batches:
             sel = idx[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
-            x, pi, tv = data.batch(sel)
             if train:
-                for grp in opt.param_groups:
-                    grp["lr"] = float(lr)
-                opt.zero_grad(set_to_none=True)
-                loss, ce, mse = losses(net, x, pi, tv)
-                loss.backward()
-                opt.step()
+                lr_t.fill_(float(lr))
+                if dev.type != "cuda":
+                    for grp in opt.param_groups:
+                        grp["lr"] = float(lr)
+                if use_graph and int(sel.shape[0]) == BATCH_SIZE and captured.get("warm", 0) >= 3:
+                    if "graph" not in captured:
+                        captured["graph"], captured["static"] = capture_train_step(acc)
+                        data.batch(sel, out=captured["static"])
+                        train_batch(*captured["static"], acc, BATCH_SIZE)       # this batch itself runs eagerly
+                    else:
+                        data.batch(sel, out=captured["static"])
+                        captured["graph"].replay()
+                else:
+                    x, pi, tv = data.batch(sel)
+                    train_batch(x, pi, tv, acc, int(sel.shape[0]))
+                    captured["warm"] = captured.get("warm", 0) + 1
                 lr = clr.on_batch_end(float(lr))
             else:
+                x, pi, tv = data.batch(sel)
                 with torch.no_grad():
-                    loss, ce, mse = losses(net, x, pi, tv)
-            w = float(sel.shape[0])
-            tot += float(loss.detach()) * w; ce_s += float(ce.detach()) * w; mse_s += float(mse.detach()) * w
-        n = float(idx.shape[0])
-        return tot / n, ce_s / n, mse_s / n
+                    loss, ce, mse = losses(net, x, pi, tv, amp, with_penalty=False)
+                acc += torch.stack([loss.detach() + pen_eval, ce.detach(), mse.detach()]).double() * float(sel.shape[0])
+        tot, ce_s, mse_s = (acc / float(idx.shape[0])).tolist()
+        return tot, ce_s, mse_s
 
     for epoch in range(EPOCHS):
         net.train()

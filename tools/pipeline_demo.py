@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=6)
     ap.add_argument("--arena-games", type=int, default=512)
     ap.add_argument("--workdir", default="/tmp/ckr_pipeline_demo")
+    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="bf16 = mixed-precision training (opt-in)")
+    ap.add_argument("--skip-arena", action="store_true")
     a = ap.parse_args()
     os.makedirs(a.workdir, exist_ok=True)
     os.chdir(a.workdir)
@@ -23,7 +25,8 @@ def main():
 
     training_kwargs = dict(TRAINING_ITERATION=0, NN_BASE_LR=5e-5, NN_MAX_LR=1e-2, CLR_SS_COEFF=4, BATCH_SIZE=128, EPOCHS=a.epochs,
                            CONV_REG=0.001, DENSE_REG=0.001, NUM_KERNELS=128, VAL_SPLIT=0.2, MIN_DELTA=0.01, PATIENCE=20,
-                           POLICY_LOSS_WEIGHT=1.0, VALUE_LOSS_WEIGHT=1.0, SLIDING_WINDOW=1, SEED=1)
+                           POLICY_LOSS_WEIGHT=1.0, VALUE_LOSS_WEIGHT=1.0, SLIDING_WINDOW=1, SEED=1,
+                           TRAIN_DTYPE=torch.bfloat16 if a.train_dtype == "bf16" else torch.float32)
     nn = T.create_nn(**training_kwargs)
     NN_FN = T.save_nn_to_disk(nn, 0, T.create_timestamp())
     first_fn = NN_FN
@@ -54,7 +57,7 @@ def main():
         tourney_mcts_kwargs = dict(mcts_kwargs, NEURAL_NET=True, BUDGET=200, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0,
                                    TEMP_DECAY_DELAY=0)
         for opp_name, opp in (("previous", NN_FN), ("initial", first_fn)):
-            if opp_name == "initial" and opp == NN_FN:
+            if a.skip_arena or (opp_name == "initial" and opp == NN_FN):
                 continue
             t0 = time.perf_counter()
             tour = tournament_Checkers(dict(TRAINING_ITERATION=it, OLD_NN_FN=opp, NEW_NN_FN=NEW_NN_FN, TOURNEY_GAMES=2,
