@@ -10,7 +10,7 @@ from checkers_mcts_amd.fused import FusedEvaluator
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = N.PolicyValueNet(128).keras_init(0).eval().cuda()
 fe = FusedEvaluator(m, S, mode=os.environ.get("CONV_MODE", "bf16"))
-x = (torch.rand(S, 8, 8, 14, device="cuda") < 0.2).to(torch.bfloat16).contiguous()
+x = (torch.rand(S, 8, 8, 14, device="cuda") < 0.2).to(torch.float32 if os.environ.get("CONV_MODE") == "f16x3" else torch.bfloat16).contiguous()
 n = fe.nets[0]
 import ctypes as C
 from checkers_mcts_amd import _lib
