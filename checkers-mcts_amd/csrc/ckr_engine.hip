@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
 
 // Random-rollout mode: up to `sims` complete simulations per slot and launch (select, expand one
 // child, playout, backup all in-kernel), including the end-of-ply work when the budget is reached.
-__global__ __launch_bounds__(256) void k_rollout(const Dev* __restrict__ Dp, int sims) {
+__global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, int sims) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
