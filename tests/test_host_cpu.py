@@ -33,6 +33,9 @@ def _gather_worker(rank, world, port, q):
     first, count = ckdist.shard_range(11, rank, world)
     rows = torch.arange(first, first + count, dtype=torch.int64).reshape(-1, 1).repeat(1, 36).to(torch.uint8)
     got = ckdist.gather_rows(rows, dst=0)
+    f1, c1 = ckdist.shard_range(1, rank, world)                      # fewer workers than ranks: an empty shard
+    few = ckdist.gather_rows(torch.full((c1, 36), 7, dtype=torch.uint8), dst=0)
+    assert (rank != 0) or (tuple(few.shape) == (1, 36) and int(few[0, 0]) == 7)
     tmax = ckdist.max_over_ranks(1.0 + rank, "cpu")
     tsum = ckdist.sum_over_ranks(count, "cpu")
     ckdist.barrier()
