@@ -255,24 +255,36 @@ __device__ void new_game(Wave& w) {
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
 // Checkers.predict's mask/renormalise (Checkers.py:435-437) and
 // set_prior_probs (:440-452).  Returns false on pool overflow.
-__device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v) {
+// Per-slot values expand() needs, loaded at kernel entry in the same memory round as the slot's
+// phase / pending leaf (one dependent round less per item than loading them where they are used).
+struct ExpandPre { int half, used, plen; uint32_t entry; };
+
+__device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
-    const size_t tb = w.tb(t);
+    const size_t tb = w.tbase(t, pre.half);
+    // second (and last) round of loads: the leaf's board and status, the network's p row, and N / W of
+    // the nodes on the recorded path (their updates are stored at the end; nothing in between touches them)
     const ckr_board b = ld_board(&D.n_board[tb + leaf]);
+    const uint32_t leaf_status = D.n_status[tb + leaf];
+    const float4* src = reinterpret_cast<const float4*>(prow);
+    const float4 p0 = src[w.lane], p1 = src[w.lane + 64];
+    const bool on_path = pre.plen <= 64 && w.lane < pre.plen;
+    const size_t pnode = tb + (pre.entry & 0x3FFFFFFFu);
+    int path_n = 0; float path_w = 0.0f;
+    if (on_path) { path_n = D.n_N[pnode]; path_w = D.n_W[pnode]; }
     uint32_t m[8], st;
     movegen(b, m, st);
     if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
     {
-        const float4* src = reinterpret_cast<const float4*>(prow);
         float4* dl = reinterpret_cast<float4*>(w.L.u.p);
-        dl[w.lane] = src[w.lane]; dl[w.lane + 64] = src[w.lane + 64];
+        dl[w.lane] = p0; dl[w.lane + 64] = p1;
     }
     __builtin_amdgcn_wave_barrier();
     const float total = wave_masked_sum(w.L.u.p, w.L.mask);
     const int n = wave_children(b, m, w.L.kids, true);
     __builtin_amdgcn_wave_barrier();
-    const int used = D.t_used[ti];
+    const int used = pre.used;
     if (used + n > D.C) return false;
     if (w.lane < n) {
         const ckr_board c = w.L.kids[w.lane];
@@ -283,14 +295,20 @@ __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow,
     }
     if (w.lane == 0) {
         D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
-        D.n_status[tb + leaf] |= ST_EXPANDED;
+        D.n_status[tb + leaf] = leaf_status | ST_EXPANDED;
         D.t_used[ti] = used + n;
     }
     w.count(CNT_EXP); w.count(CNT_NODES, (uint32_t)n);
-    wave_mem_fence();
-    const int plen = D.g_plen[w.slot];
-    if (plen <= 64) backup_value_path(w, t, D.g_path[(size_t)w.slot * 64 + w.lane], plen, v, b.meta & 1u);
-    else backup_value(w, t, leaf, v, b.meta & 1u);
+    const uint32_t sim_player = b.meta & 1u;
+    if (pre.plen <= 64) {                                     // backup along the recorded path (cf. backup_value_path)
+        if (on_path) {
+            const float reward = (sim_player != ((pre.entry >> 30) & 1u)) ? -1.0f * v : v;
+            D.n_N[pnode] = path_n + 1; D.n_W[pnode] = path_w + reward;
+        }
+    } else {
+        wave_mem_fence();
+        backup_value(w, t, leaf, v, sim_player);
+    }
     wave_mem_fence();
     return true;
 }
@@ -738,9 +756,15 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
     const int row = D.g_row[slot];
-    if (pending >= 0 && D.g_phase[slot] == PH_PLAYING) {
-        const int t = (int)(D.g_board[slot].w & 1u);
-        if (expand(w, t, pending, p + (size_t)row * 512, v[row])) {
+    const int phase0 = D.g_phase[slot];
+    const int t0 = (int)(D.g_board[slot].w & 1u);
+    ExpandPre pre;                                             // same round of loads (unused if nothing is pending)
+    pre.half = D.t_half[slot * 2 + t0]; pre.used = D.t_used[slot * 2 + t0]; pre.plen = D.g_plen[slot];
+    pre.entry = D.g_path[(size_t)slot * 64 + w.lane];
+    asm volatile("" :: "v"(pre.half), "v"(pre.used), "v"(pre.plen), "v"(pre.entry));   // keep the loads up here
+    if (pending >= 0 && phase0 == PH_PLAYING) {
+        const int t = t0;
+        if (expand(w, t, pending, p + (size_t)row * 512, v[row], pre)) {
             if (w.lane == 0) D.g_sims[slot] += 1;
         } else {
             w.count(CNT_OVERFLOW);
