@@ -8,9 +8,10 @@ operands, the parity mode and the default for NN_DTYPE float32) or
 from the input planes to the head features, conv bias + ReLU + inference
 BatchNorm fused into the epilogue, and the heads' two 1x1 convolutions
 (training_pipeline.py:93-96,102-105) applied before anything leaves the chip.
-What reaches HBM per position is 512 + 64 floats.  The tail is three launches:
-the policy Dense(512) GEMM (fp32, hipBLASLt through torch.addmm) + softmax, and
-`ckr_value_mlp` (Dense(64)+ReLU -> BN -> Dense(1) -> tanh).
+What reaches HBM per position is 512 + 64 floats.  The tail is two launches:
+`ckr_policy_head` (Dense(512) + softmax, float32-grade split-fp16 MFMA) and
+`ckr_value_mlp` (Dense(64)+ReLU -> BN -> Dense(1) -> tanh).  PyTorch holds the memory,
+the streams and the HIP graph; no torch operator runs in the inference step.
 Weights come from a float32 `net.PolicyValueNet`.
 """
 import ctypes as C
@@ -71,6 +72,22 @@ def pack_split_weights(w, first):
     return img.reshape(9 * q, cout, 40).contiguous()
 
 
+def pack_dense_weights(w):
+    """Dense(512) kernel [512 out][512 in] (torch Linear layout) -> the fragment-ordered image of
+    ckr_policy_head: fp16 [32 out-tiles][16 k-steps][hi, lo][64 lanes][8] of w * WS,
+    lane = 16 * ((in % 32) // 8) + out % 16, element = in % 8."""
+    assert tuple(w.shape) == (512, 512)
+    t = w.float() * WS
+    if float(t.abs().max()) > 6e4:
+        raise OverflowError("dense weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+
+    def frag(a):                                            # [T, j, ks, g, e] -> [T, ks, g, j, e]
+        return a.reshape(32, 16, 16, 4, 8).permute(0, 2, 3, 1, 4).reshape(32, 16, 64, 8)
+    return torch.stack([frag(hi), frag(lo)], dim=2).contiguous()          # [32][16][2][64][8]
+
+
 def bn_affine(bn):
     scale = (bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps))
     shift = bn.bias.float() - bn.running_mean.float() * scale
@@ -99,6 +116,7 @@ class FusedEvaluator:
                                                  C.c_float, vp, vp, vp]
         self.overflow = None
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
+        self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
         self.nets = [self._prepare(net)]
@@ -141,6 +159,7 @@ class FusedEvaluator:
                           t["val_shift"].data_ptr(), val_feat.data_ptr())
         vsc, vsh = bn_affine(net.val_bn)
         tail = dict(fc_w=_f32(net.pol_fc.weight).t().contiguous(), fc_b=_f32(net.pol_fc.bias),
+                    fc_packed=pack_dense_weights(_f32(net.pol_fc.weight)),
                     w1t=_f32(net.val_fc1.weight).t().contiguous(), b1=_f32(net.val_fc1.bias), sc=vsc, sh=vsh,
                     w2=_f32(net.val_fc2.weight).reshape(64).contiguous(), b2=float(net.val_fc2.bias.detach().float().item()))
         return dict(layers=layers, n=len(blocks), heads=heads, keep=keep + list(t.values()), y_body=y_body, y_pol=y_pol,
@@ -163,8 +182,8 @@ class FusedEvaluator:
         stream = torch.cuda.current_stream(x.device).cuda_stream
         self._conv(n, x, stream, board_range)
         t = n["tail"]
-        torch.addmm(t["fc_b"], n["pol_feat"], t["fc_w"], out=n["logits"])              # Dense(512)
-        torch.softmax(n["logits"], dim=1, out=n["p"])
+        _lib.check(self._L.ckr_policy_head(n["pol_feat"].data_ptr(), self.S, t["fc_packed"].data_ptr(), t["fc_b"].data_ptr(),
+                                           XS, WS, n["p"].data_ptr(), stream))         # Dense(512) + softmax
         _lib.check(self._L.ckr_value_mlp(n["val_feat"].data_ptr(), self.S, t["w1t"].data_ptr(), t["b1"].data_ptr(),
                                          t["sc"].data_ptr(), t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"],
                                          n["v"].data_ptr(), stream))
