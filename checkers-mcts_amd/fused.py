@@ -158,13 +158,12 @@ class FusedEvaluator:
                           pol_feat.data_ptr(), t["val_w"].data_ptr(), t["val_b"].data_ptr(), t["val_scale"].data_ptr(),
                           t["val_shift"].data_ptr(), val_feat.data_ptr())
         vsc, vsh = bn_affine(net.val_bn)
-        tail = dict(fc_w=_f32(net.pol_fc.weight).t().contiguous(), fc_b=_f32(net.pol_fc.bias),
+        tail = dict(fc_b=_f32(net.pol_fc.bias),
                     fc_packed=pack_dense_weights(_f32(net.pol_fc.weight)),
                     w1t=_f32(net.val_fc1.weight).t().contiguous(), b1=_f32(net.val_fc1.bias), sc=vsc, sh=vsh,
                     w2=_f32(net.val_fc2.weight).reshape(64).contiguous(), b2=float(net.val_fc2.bias.detach().float().item()))
         return dict(layers=layers, n=len(blocks), heads=heads, keep=keep + list(t.values()), y_body=y_body, y_pol=y_pol,
                     pol_feat=pol_feat, val_feat=val_feat, tail=tail,
-                    logits=torch.empty((S, 512), dtype=torch.float32, device=dev),
                     p=torch.empty((S, 512), dtype=torch.float32, device=dev),
                     v=torch.empty((S,), dtype=torch.float32, device=dev))
 
