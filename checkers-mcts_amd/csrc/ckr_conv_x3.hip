@@ -414,7 +414,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 template <int MT>
 __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ feat, long long n, const uint4* __restrict__ wp,
                                                      const float* __restrict__ bias, float x_scale, float inv_scale,
-                                                     float* __restrict__ p) {
+                                                     float* __restrict__ p, int32_t* __restrict__ overflow) {
     __shared__ float red[2][8][16 * MT];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, grp = lane >> 4;
     const long long row0 = (long long)blockIdx.x * (16 * MT);
@@ -430,6 +430,7 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
     constexpr int DEPTH = 3;                                      // register ring: DEPTH - 1 k-steps of loads in flight (2..4: same time)
     uint4 bq[DEPTH][8];
     float4 xq[DEPTH][MT][2];
+    float amax = 0.0f;
     auto fetch = [&](int ks, int slot) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -457,7 +458,9 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
                                  xq[s][mt][1].x, xq[s][mt][1].y, xq[s][mt][1].z, xq[s][mt][1].w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float y = fminf(fmaxf(xv[j] * x_scale, -60000.0f), 60000.0f);
+                const float y0 = xv[j] * x_scale;
+                amax = fmaxf(amax, fabsf(y0));
+                const float y = fminf(fmaxf(y0, -60000.0f), 60000.0f);
                 ah[mt][j] = (_Float16)y;
                 al[mt][j] = (_Float16)(y - (float)ah[mt][j]);
             }
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
             }
         }
     }
+    if (overflow && amax > 60000.0f) *overflow = 1;               // a feature left the fp16 range of the hi terms
     // logits: lane holds rows 16*mt + 4*grp + r (r = 0..3) of column 64*wave + 16*nt + col
     float mx[MT][4], sm[MT][4];
 #pragma unroll
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
 }  // namespace ckrp
 
 extern "C" int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_packed, const float* d_bias, float x_scale,
-                               float w_scale, float* d_p, void* stream) {
+                               float w_scale, float* d_p, int32_t* d_overflow, void* stream) {
     if (n < 0 || !(x_scale > 0.0f) || !(w_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_policy_head: bad argument");
     if (int rc = ckr::require_device()) return rc;
     if (n == 0) return CKR_OK;
@@ -547,7 +551,7 @@ extern "C" int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_p
     // MT = 1: 16 positions per workgroup (measured 22 us per 4 096 positions; MT = 2: 31 us, MT = 4: 53 us -- fewer CUs busy)
     hipLaunchKernelGGL(ckrp::k_policy_head<1>, dim3((unsigned)((n + 15) / 16)), dim3(512), 0,
                        (hipStream_t)stream, d_feat, (long long)n, (const uint4*)d_w_packed, d_bias, x_scale,
-                       1.0f / (x_scale * w_scale), d_p);
+                       1.0f / (x_scale * w_scale), d_p, d_overflow);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -116,7 +116,7 @@ class FusedEvaluator:
                                                  C.c_float, vp, vp, vp]
         self.overflow = None
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
-        self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp]
+        self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
         self.nets = [self._prepare(net)]
@@ -167,13 +167,16 @@ class FusedEvaluator:
                     p=torch.empty((S, 512), dtype=torch.float32, device=dev),
                     v=torch.empty((S,), dtype=torch.float32, device=dev))
 
+    def _overflow_ptr(self, device):
+        if self.overflow is None:
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        return self.overflow.data_ptr()
+
     def _conv(self, n, x, stream, board_range=None):
         rng = board_range.data_ptr() if board_range is not None else None
         if self.mode == "f16x3":
-            if self.overflow is None:
-                self.overflow = torch.zeros(1, dtype=torch.int32, device=x.device)
             _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, rng,
-                                                    self.overflow.data_ptr(), stream))
+                                                    self._overflow_ptr(x.device), stream))
         else:
             _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
 
@@ -182,7 +185,7 @@ class FusedEvaluator:
         self._conv(n, x, stream, board_range)
         t = n["tail"]
         _lib.check(self._L.ckr_policy_head(n["pol_feat"].data_ptr(), self.S, t["fc_packed"].data_ptr(), t["fc_b"].data_ptr(),
-                                           XS, WS, n["p"].data_ptr(), stream))         # Dense(512) + softmax
+                                           XS, WS, n["p"].data_ptr(), self._overflow_ptr(x.device), stream))   # Dense(512) + softmax
         _lib.check(self._L.ckr_value_mlp(n["val_feat"].data_ptr(), self.S, t["w1t"].data_ptr(), t["b1"].data_ptr(),
                                          t["sc"].data_ptr(), t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"],
                                          n["v"].data_ptr(), stream))
@@ -222,8 +225,8 @@ class FusedEvaluator:
         split-fp16 terms saturate there, so results since the last check are not to be used."""
         if self.overflow is not None and int(self.overflow.item()):
             self.overflow.zero_()
-            raise OverflowError("ckr_conv_stack_f16x3: activation magnitude above %g; use NN_DTYPE bfloat16 or the "
-                                "PyTorch evaluator for this network" % (6e4 / XS))
+            raise OverflowError("split-fp16 kernels: activation magnitude above %g; use the PyTorch evaluator "
+                                "(kind='torch') for this network" % (6e4 / XS))
 
     CONV_FLOPS_PER_BOARD = 2 * (64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128)      # the 8 convs of the stack
 

@@ -171,9 +171,10 @@ int ckr_arena_merge(const float* d_p_new, const float* d_v_new, const float* d_p
  * policy conv's output, Keras Flatten order) -> d_p[n][512] (index = layer*64 + x*8 + y,
  * Checkers.py:434), float32-grade (split-fp16 operands, float32 accumulation, float32 softmax).
  * d_w_packed: Dense kernel [512 out][512 in] * w_scale as fp16 hi / lo terms in MFMA lane order:
- * [32 out-tiles][16 k-steps][2: hi, lo][64 lanes][8], lane = 16*((in%32)/8) + out%16, element = in%8. */
+ * [32 out-tiles][16 k-steps][2: hi, lo][64 lanes][8], lane = 16*((in%32)/8) + out%16, element = in%8.
+ * d_overflow (may be NULL): DEVICE int32 set to 1 when |feature| * x_scale exceeds the fp16 range. */
 int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_packed, const float* d_bias, float x_scale,
-                    float w_scale, float* d_p, void* stream);
+                    float w_scale, float* d_p, int32_t* d_overflow, void* stream);
 
 /* Value head tail (training_pipeline.py:106-112): Dense(64)+ReLU -> BatchNorm ->
  * Dense(1) -> tanh on d_in[n][64] (the fused value conv's output).
