@@ -389,13 +389,14 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
 // float32-grade like the stack above: features and weights are split into two fp16 terms and
 // wh*xh + wh*xl + wl*xh accumulates in float32 (v_mfma_f32_16x16x32_f16).  One workgroup = 16
 // positions x all 512 outputs (256 workgroups at 4 096 positions), 8 waves of 4 MFMA tiles;
-// no LDS staging: the A fragments are 32-byte reads of the feature rows, the B
+// the A tile (16 x 512 features) is split once per workgroup into LDS in fragment order, the B
 // fragments arrive from L2 already in MFMA lane order (packed by fused.pack_dense_weights:
 // [32 tiles][16 k-steps][hi, lo][64 lanes] x 16 B), the softmax is reduced in registers (16-lane
 // butterflies) and across the eight waves through 1 KB of LDS.
 namespace ckrp {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float group16_max(float v) {
@@ -416,11 +417,9 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
                                                      const float* __restrict__ bias, float x_scale, float inv_scale,
                                                      float* __restrict__ p, int32_t* __restrict__ overflow) {
     __shared__ float red[2][8][16 * MT];
+    __shared__ uint4 a_hi[16][4][16 * MT], a_lo[16][4][16 * MT];      // A fragments [k-step][k-group][position]: 16 B each
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, grp = lane >> 4;
     const long long row0 = (long long)blockIdx.x * (16 * MT);
-    const float* fa[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) fa[mt] = feat + min(row0 + 16 * mt + col, n - 1) * 512 + 8 * grp;   // ragged tail: clamped reads
     const uint4* wb = wp + ((size_t)(wave * 4) * 16 * 2) * 64 + lane;
     f32x4 acc[MT][4];
 #pragma unroll
@@ -429,23 +428,37 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int DEPTH = 3;                                      // register ring: DEPTH - 1 k-steps of loads in flight (2..4: same time)
     uint4 bq[DEPTH][8];
-    float4 xq[DEPTH][MT][2];
-    float amax = 0.0f;
     auto fetch = [&](int ks, int slot) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             bq[slot][2 * nt] = wb[((size_t)(nt * 16 + ks) * 2 + 0) * 64];
             bq[slot][2 * nt + 1] = wb[((size_t)(nt * 16 + ks) * 2 + 1) * 64];
         }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            xq[slot][mt][0] = *reinterpret_cast<const float4*>(fa[mt] + 32 * ks);
-            xq[slot][mt][1] = *reinterpret_cast<const float4*>(fa[mt] + 32 * ks + 4);
-        }
     };
 #pragma unroll
     for (int i = 0; i < DEPTH - 1; ++i) fetch(i, i);
     __builtin_amdgcn_sched_barrier(0);
+    // the feature tile is split into hi / lo fp16 ONCE per workgroup (coalesced float4 reads) and kept in
+    // LDS in fragment order; every wave then reads its A fragments with two ds_read_b128 per k-step
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4 * MT; ++i) {
+        const int q = tid + 512 * i, r = q >> 7, k = (q & 127) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(feat + min(row0 + r, n - 1) * 512 + k);   // ragged tail: clamped reads
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        f16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float y0 = xv[j] * x_scale;
+            amax = fmaxf(amax, fabsf(y0));
+            const float y = fminf(fmaxf(y0, -60000.0f), 60000.0f);
+            h[j] = (_Float16)y;
+            l[j] = (_Float16)(y - (float)h[j]);
+        }
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&a_hi[k >> 5][(k >> 3) & 3][r]) + (k & 7)) = h;
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(&a_lo[k >> 5][(k >> 3) & 3][r]) + (k & 7)) = l;
+    }
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         if (ks + DEPTH - 1 < 16) fetch(ks + DEPTH - 1, (ks + DEPTH - 1) % DEPTH);
@@ -454,16 +467,8 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
         f16x8 ah[MT], al[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const float xv[8] = {xq[s][mt][0].x, xq[s][mt][0].y, xq[s][mt][0].z, xq[s][mt][0].w,
-                                 xq[s][mt][1].x, xq[s][mt][1].y, xq[s][mt][1].z, xq[s][mt][1].w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float y0 = xv[j] * x_scale;
-                amax = fmaxf(amax, fabsf(y0));
-                const float y = fminf(fmaxf(y0, -60000.0f), 60000.0f);
-                ah[mt][j] = (_Float16)y;
-                al[mt][j] = (_Float16)(y - (float)ah[mt][j]);
-            }
+            ah[mt] = *reinterpret_cast<const f16x8*>(&a_hi[ks][grp][col + 16 * mt]);
+            al[mt] = *reinterpret_cast<const f16x8*>(&a_lo[ks][grp][col + 16 * mt]);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
