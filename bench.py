@@ -7,19 +7,37 @@ policy/value network (Keras-default initialisation), synthetic data.
 
 One "step" = one lock-step simulation for every game slot: the tree kernel
 (expand + backup of the previous leaves, PUCT descent, end-of-ply work, feature
-build) followed by one network forward over the S leaves.  Metric: MCTS
-node-expansions/s (executions of the expand branch, MCTS.py:70-77), whole job.
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; game
-slots are sharded by worker id, there is no per-step collective (weak scaling).
+build) followed by one network forward over the S leaves.  Metric M1: MCTS
+node-expansions/s (executions of the expand branch, MCTS.py:70-77), whole job;
+metric M2: complete self-play games per hour.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two
-extra objects: `roofline` (dominant kernel group, HIP-event timed on the launch
-stream in this run) and `cpu_baseline` (the CPU oracle + PyTorch-CPU network,
-timed on this host's cores on a bounded sample; rank 0, N = 1 only).
+The network runs in the float32-grade mode by default (split-fp16 operands,
+float32 accumulation: pi / v within 1e-5 of a float64 evaluation, the parity bar
+of BASELINE.json; the reference evaluates the network in float32,
+Checkers.py:433).  The bf16 throughput mode is reported under `extra` only.
+
+Sequence on every rank (one rank per GPU; `--gpus N` launches the ranks itself
+when it is not already running under torch.distributed.run):
+  1. untimed PRE-ROLL (`--preroll` steps, default about one mean game length) so
+     that the slots are spread over ply phase and game progress -- the timed
+     window then contains ply ends, terminal visits and game ends like any
+     stretch of a long run;
+  2. W untimed warm-up steps, then EXACTLY K timed steps between
+     barrier + synchronize pairs -> `value` (max over ranks);
+  3. the same engine keeps playing until every game of the run is over ->
+     whole-run wall time, `games_per_hour` (M2) and the whole-run / steady-state
+     ratio; the finished tuples are packed and gathered to rank 0 (the job's one
+     collective).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed
+on the launch stream in this run) and `cpu_baseline` (the CPU oracle + PyTorch-CPU
+network on this host's cores, bounded sample; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,8 +53,15 @@ MCTS_KWARGS = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=100, MUL
                    TEMPERATURE_TAU=1.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
 TERMINATE_CNT = 200
 DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+DTYPE_LABEL = {"fp32": "fp32-grade (fp16x3 split operands, fp32 accumulate)", "bf16": "bf16", "fp16": "fp16"}
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+# HBM-side bytes per launch of 4 096 boards from the committed rocprofv3 --pmc passes (separate passes for
+# FETCH_SIZE and WRITE_SIZE; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950): see profiles/README.md
+PMC_TRAFFIC = {
+    "fp32": dict(bytes=(2 * 89742.0 + 9216.0) * 1024.0, source="profiles/r01_pmc_conv_kernels.csv (2 x FETCH_SIZE + WRITE_SIZE)"),
+    "bf16": dict(bytes=(2 * 14918.2 + 9216.0) * 1024.0, source="profiles/r01_pmc_conv_kernels.csv (2 x FETCH_SIZE + WRITE_SIZE)"),
+}
 
 
 def parse():
@@ -46,36 +71,70 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--slots", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--budget", type=int, default=100)
-    ap.add_argument("--nn-dtype", choices=list(DTYPES), default="bf16")
+    ap.add_argument("--nn-dtype", choices=list(DTYPES), default="fp32",
+                    help="fp32 = float32-grade parity mode (default, the creditable one); bf16 = throughput mode")
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed steps before the warm-up that bring the slots to a desynchronised steady state "
+                         "(-1 = 90 x BUDGET: about one mean game)")
+    ap.add_argument("--games-per-slot", type=int, default=4,
+                    help="games every slot plays back to back in the run (reference semantics: NUM_SELFPLAY_GAMES per worker)")
+    ap.add_argument("--no-complete", action="store_true", help="skip leg 3 (play the run to its end; M2)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--evaluator", choices=["fused", "torch"], default=None,
-                    help="fused: conv stack in the hand-written MFMA kernels (bf16, or fp32 = split-fp16 operands); torch: MIOpen via PyTorch")
+                    help="fused: conv stack in the hand-written MFMA kernels (fp32 = split-fp16 operands, or bf16); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool per tree and semispace (0 = engine default)")
-    ap.add_argument("--parity-steps", type=int, default=200,
-                    help="timed steps of the extra float32-grade leg (ckr_conv_stack_f16x3; N = 1 only, 0 = skip)")
+    ap.add_argument("--extra-steps", type=int, default=300,
+                    help="timed steps of the extra legs (bf16 throughput mode, arena, random rollouts; N = 1 only, 0 = skip)")
     return ap.parse_args()
 
 
-def cpu_baseline(budget, seconds):
-    """CPU oracle (C restatement of the reference search, proven bit-exact to
-    it) + the same network on PyTorch-CPU fp32, W games in lock-step so the
-    network sees a batch of W leaves per step.  Bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as orc
-    from checkers_mcts_amd.net import make_net
-    orc.build()
+def self_launch(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks here."""
+    if torch.cuda.device_count() < a.gpus and os.environ.get("CKR_DIST_BACKEND") != "gloo":   # gloo: ranks may share a GPU (tests)
+        raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (a.gpus, torch.cuda.device_count()))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))        # PyTorch-CPU convs of this size stop scaling (and regress) beyond ~32 threads
-    torch.set_num_threads(cores)
-    W = 8 * cores
+    return model, os.cpu_count() or avail, avail
+
+
+def cpu_baseline(budget, seconds):
+    """CPU oracle (C restatement of the reference search, proven bit-exact to it) + the same
+    network on PyTorch-CPU fp32.  W games advance in lock-step so that the network sees a batch
+    of W leaves per step; the searches run one game per host thread on ALL cores this process
+    may use, the network on the PyTorch thread count that measured fastest here.  Bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    from checkers_mcts_amd.net import make_net
+    orc.build()
+    model, nproc, avail = host_cpu()
+    W = int(min(2048, max(64, 8 * avail)))
     kw = dict(MCTS_KWARGS, BUDGET=budget)
     batch = orc.WorkerBatch([orc.make_config(kw, terminate_cnt=TERMINATE_CNT, num_games=1000, seed=1000 + i)
-                             for i in range(W)])
+                             for i in range(W)], threads=avail)
     net = make_net(128, seed=0, device="cpu", dtype=torch.float32)
 
     def one_step():
@@ -84,9 +143,20 @@ def cpu_baseline(budget, seconds):
         p, v = net(x)
         batch.submit(p.numpy(), v.numpy())
 
-    steps = 0
     with torch.no_grad():
-        one_step()                         # untimed: oneDNN primitive creation
+        # PyTorch-CPU convolutions of this size stop scaling at some thread count: pick the fastest of a few
+        best_t, nn_threads = None, avail
+        for cand in sorted({avail, min(avail, 64), min(avail, 32)}, reverse=True):
+            torch.set_num_threads(cand)
+            one_step()                                   # primitive creation for this thread count
+            t0 = time.perf_counter()
+            one_step()
+            dt = time.perf_counter() - t0
+            if best_t is None or dt < best_t:
+                best_t, nn_threads = dt, cand
+        torch.set_num_threads(nn_threads)
+        one_step()
+        steps = 0
         e0 = batch.stats()["expansions"]
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
@@ -94,9 +164,11 @@ def cpu_baseline(budget, seconds):
             steps += 1
     dt = time.perf_counter() - t0
     done = batch.stats()["expansions"] - e0
-    return {"value": done / dt, "unit": "node-expansions/s", "cores": cores, "kind": "port",
-            "sample": "%d lock-step games x %d steps (%.1f s) of the same workload: C oracle search (1 thread) + "
-                      "PyTorch-CPU fp32 network on %d threads, batch %d" % (W, steps, dt, cores, W)}
+    return {"value": done / dt, "unit": "node-expansions/s", "cores": avail, "kind": "port",
+            "host": {"cpu_model": model, "nproc": nproc, "usable_cores": avail},
+            "sample": "%d lock-step games x %d steps (%.1f s) of the same workload: C oracle search on %d threads (one game per "
+                      "thread at a time) + PyTorch-CPU fp32 network on %d threads, batch %d"
+                      % (W, steps, dt, batch.threads, nn_threads, W)}
 
 
 def movegen_probe(device):
@@ -132,7 +204,7 @@ def movegen_probe(device):
 def time_conv(evaluator, x, dev, groups=5, per_group=10):
     """Average launch duration of the conv-stack kernel: HIP events on the launch stream around a HIP
     graph of `per_group` back-to-back launches (graph dispatch, as in the real step: eager launches
-    add a ~15 us inter-kernel gap to a 0.4 ms kernel); median over `groups` replays.  Seconds per launch."""
+    add a ~15 us inter-kernel gap); median over `groups` replays.  Seconds per launch."""
     evaluator.conv_only(x)
     torch.cuda.synchronize(dev)
     side = torch.cuda.Stream(device=dev)
@@ -152,83 +224,106 @@ def time_conv(evaluator, x, dev, groups=5, per_group=10):
     return float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])) / 1e3 / per_group
 
 
-def split_roofline(conv_flops, slots, t_conv):
-    """Roofline entry of k_conv_stack_x3: algorithmic flops (one multiply-add per weight and
-    position, as for any float32 convolution) over the launch time; the kernel EXECUTES three
-    fp16 MFMAs per multiply-add, so the matrix pipe's own utilisation is 3x `frac`."""
+def conv_roofline(mode, conv_flops, slots, t_conv):
+    """Roofline entry of the dominant kernel.  float32-grade mode: `achieved` counts ALGORITHMIC flops
+    (one multiply-add per weight and position, as for any float32 convolution); the kernel EXECUTES
+    three fp16 MFMAs per multiply-add, reported as executed_*."""
     tf = conv_flops * slots / t_conv / 1e12 if t_conv else None
-    return {"bound": "mfma", "kernel": "k_conv_stack_x3 (the same fused stack with split-fp16 operands: float32-grade "
-                                       "results, 3 fp16 MFMAs per multiply-add; one launch per step)",
-            "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
-            "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
-            # profiles/r01_pmc_conv_kernels.csv: FETCH_SIZE 89 742 KB (doubled, gfx950), WRITE_SIZE 9 216 KB at 4 096
-            # boards -- the 5.9 MB split-weight image exceeds one XCD's 4 MB L2, so part of the stream is served
-            # by the Infinity Cache (3 % of the 6.0 GB the workgroups stream per launch)
-            "traffic": (2 * 89742.0 + 9216.0) * 1024.0 * slots / 4096.0,
-            "traffic_source": "profiles/r01_pmc_conv_kernels.csv (separate --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)",
-            "executed_tflops": 3.0 * tf if tf else None,
-            "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
-            "vs_fp32_matrix_peak": tf / MFMA_PEAK_TFLOPS["fp32"] if tf else None,
-            "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": slots}
+    tr = PMC_TRAFFIC[mode]
+    out = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
+           "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
+           "traffic": tr["bytes"] * slots / 4096.0, "traffic_source": tr["source"],
+           "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": slots}
+    if mode == "fp32":
+        out["kernel"] = ("k_conv_stack_x3 (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, activations LDS-resident; "
+                         "split-fp16 operands: float32-grade results, 3 fp16 MFMAs per multiply-add; one launch per step)")
+        out.update({"executed_tflops": 3.0 * tf if tf else None,
+                    "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
+                    "vs_fp32_matrix_peak": tf / MFMA_PEAK_TFLOPS["fp32"] if tf else None})
+    else:
+        out["kernel"] = ("k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, 8 boards per workgroup "
+                         "LDS-resident through all layers; one launch per step)")
+    return out
 
 
-def parity_leg(a, dev):
-    """The same workload with the network at float32-grade accuracy (pi / v within 1e-5 of a
-    float64 evaluation, BASELINE's parity bar): engine features in float32, conv stack in
-    ckr_conv_stack_f16x3.  Shorter timed region than the main leg; N = 1 only."""
+def make_leg(a, dev, mode, first_worker, games_per_slot):
+    """Engine + evaluator + step runner of one precision mode."""
     from checkers_mcts_amd import engine as ckengine
-    from checkers_mcts_amd.fused import FusedEvaluator
-    from checkers_mcts_amd.net import make_net
+    from checkers_mcts_amd.net import NetEvaluator, make_net
     from checkers_mcts_amd.pipeline import StepRunner
+    dtype = DTYPES[mode]
     kw = dict(MCTS_KWARGS, BUDGET=a.budget)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=4, terminate_cnt=TERMINATE_CNT,
-                                      feature_dtype=torch.float32, seed=20260929, device=dev.index)
-    eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
-    ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots, mode="f16x3")
-    runner = StepRunner(eng, ev, use_graph=not a.no_graph)
-    runner.warmup(3)
-    runner.step(30)
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
+                                      first_worker_id=first_worker, feature_dtype=dtype, seed=20260929, device=dev.index,
+                                      nodes_per_tree=a.nodes_per_tree or None)
+    eng = ckengine.Engine(cfg, feature_dtype=dtype)
+    which = a.evaluator or ("fused" if mode in ("bf16", "fp32") else "torch")
+    if which == "fused":
+        if mode not in ("bf16", "fp32"):
+            raise SystemExit("--evaluator fused needs --nn-dtype bf16 or fp32")
+        from checkers_mcts_amd.fused import FusedEvaluator
+        evaluator = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
+                                   mode="bf16" if mode == "bf16" else "f16x3")
+    else:
+        evaluator = NetEvaluator(make_net(128, seed=0, device=dev, dtype=dtype))
+    return eng, evaluator, StepRunner(eng, evaluator, use_graph=not a.no_graph), which
+
+
+def timed_window(runner, eng, dev, steps, barrier=lambda: None):
     torch.cuda.synchronize(dev)
     s0 = eng.stats()
-    t0 = time.perf_counter()
-    runner.step(a.parity_steps)
+    barrier()
     torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    runner.step(steps)
+    torch.cuda.synchronize(dev)
+    barrier()
     dt = time.perf_counter() - t0
     s1 = eng.stats()
-    t_conv = time_conv(ev, eng.x, dev)
+    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games")}
+
+
+def throughput_leg(a, dev, mode):
+    """extra: the same workload in the other precision mode (steady state after a pre-roll)."""
+    eng, evaluator, runner, which = make_leg(a, dev, mode, 0, 64)
+    runner.warmup(3)
+    runner.step(preroll_steps(a))
+    dt, d = timed_window(runner, eng, dev, a.extra_steps)
+    t_conv = time_conv(evaluator, eng.x, dev) if which == "fused" else 0.0
     eng.close()
-    return {"value": (s1["expansions"] - s0["expansions"]) / dt, "unit": "node-expansions/s", "steps": a.parity_steps,
-            "ms_per_step": dt / a.parity_steps * 1e3, "dtype": "fp16x2-split operands, fp32 accumulate (fp32-grade)",
-            "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py)",
-            "roofline": split_roofline(ev.CONV_FLOPS_PER_BOARD, a.slots, t_conv)}
+    out = {"value": d["expansions"] / dt, "unit": "node-expansions/s", "steps": a.extra_steps,
+           "ms_per_step": dt / a.extra_steps * 1e3, "dtype": DTYPE_LABEL[mode], "plies": d["plies"],
+           "terminal_visits": d["terminal_visits"], "preroll_steps": preroll_steps(a)}
+    if which == "fused":
+        out["roofline"] = conv_roofline(mode, evaluator.CONV_FLOPS_PER_BOARD, a.slots, t_conv)
+    if mode == "bf16":
+        out["note"] = ("throughput mode, NOT a parity mode: bf16 operands (pi within 5e-3, v within 5e-2 of the float32 network); "
+                       "the creditable figure is the float32-grade headline")
+    return out
 
 
 def arena_leg(a, dev):
     """BASELINE cfg 5's shape on one GPU: arena between two random-init networks, 800 sims/move,
-    TRAINING False / tau 0 / eps 0.25 (train_Checkers.py:188-202), bf16; a short steady-state sample."""
+    TRAINING False / tau 0 / eps 0.25 (train_Checkers.py:188-202), float32-grade; a short sample."""
     from checkers_mcts_amd import engine as ckengine
     from checkers_mcts_amd.fused import FusedEvaluator
     from checkers_mcts_amd.net import make_net
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.bfloat16,
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.float32,
                                       seed=20260929, device=dev.index, dynamic_queue=True)
-    eng = ckengine.Engine(cfg, feature_dtype=torch.bfloat16)
+    eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
     ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
-                        net_old=make_net(128, seed=1, device=dev, dtype=torch.float32), mode="bf16")
+                        net_old=make_net(128, seed=1, device=dev, dtype=torch.float32), mode="f16x3")
     runner = StepRunner(eng, ev, use_graph=not a.no_graph)
     runner.warmup(3)
     runner.step(30)
-    torch.cuda.synchronize(dev)
-    s0, t0 = eng.stats(), time.perf_counter()
-    runner.step(a.parity_steps)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    s1 = eng.stats()
+    dt, d = timed_window(runner, eng, dev, a.extra_steps)
     eng.close()
-    sims = s1["expansions"] + s1["terminal_visits"] - s0["expansions"] - s0["terminal_visits"]
-    return {"sims_per_s": sims / dt, "ms_per_step": dt / a.parity_steps * 1e3, "steps": a.parity_steps, "budget": 800,
-            "note": "each leaf is evaluated by its own network only (batch partitioned by network id on the device)"}
+    return {"sims_per_s": (d["expansions"] + d["terminal_visits"]) / dt, "ms_per_step": dt / a.extra_steps * 1e3,
+            "steps": a.extra_steps, "budget": 800, "dtype": DTYPE_LABEL["fp32"],
+            "note": "each leaf is evaluated by its own network only (batch partitioned by network id on the device); "
+                    "sample from the start of the games"}
 
 
 def rollout_leg(a, dev):
@@ -252,140 +347,155 @@ def rollout_leg(a, dev):
     return {"rollouts_per_s": sims / dt, "plies": s1["plies"] - s0["plies"], "seconds": dt, "budget": 400}
 
 
+def preroll_steps(a):
+    return a.preroll if a.preroll >= 0 else 90 * a.budget
+
+
 def main():
     a = parse()
-    from checkers_mcts_amd import build as ckbuild, dist as ckdist, engine as ckengine
-    from checkers_mcts_amd.net import FLOPS_PER_EVAL, NetEvaluator, make_net
-    from checkers_mcts_amd.pipeline import StepRunner
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
+    from checkers_mcts_amd import build as ckbuild, dist as ckdist
+    from checkers_mcts_amd.net import FLOPS_PER_EVAL
 
     rank, local_rank, world = ckdist.init_from_env()
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if rank == 0:
         ckbuild.build()
     ckdist.barrier()
-    dev = torch.device("cuda", local_rank)
+    dev = ckdist.local_device(local_rank)
     torch.cuda.set_device(dev)
-    dtype = DTYPES[a.nn_dtype]
-    kw = dict(MCTS_KWARGS, BUDGET=a.budget)
+    mode = a.nn_dtype
     first, _ = ckdist.shard_range(a.slots * world, rank, world)
-    games_per_slot = max(2, (a.steps + a.warmup) // (a.budget * 30) + 2)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
-                                      first_worker_id=first, feature_dtype=dtype, seed=20260929, device=local_rank,
-                                      nodes_per_tree=a.nodes_per_tree or None)
-    eng = ckengine.Engine(cfg, feature_dtype=dtype)
-    which = a.evaluator or ("fused" if a.nn_dtype in ("bf16", "fp32") else "torch")
-    if which == "fused":
-        if a.nn_dtype not in ("bf16", "fp32"):
-            raise SystemExit("--evaluator fused needs --nn-dtype bf16 or fp32")
-        from checkers_mcts_amd.fused import FusedEvaluator
-        evaluator = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
-                                   mode="bf16" if a.nn_dtype == "bf16" else "f16x3")
-    else:
-        evaluator = NetEvaluator(make_net(128, seed=0, device=dev, dtype=dtype))
-    runner = StepRunner(eng, evaluator, use_graph=not a.no_graph)
+    pre = preroll_steps(a)
+    # enough games per slot that no slot runs dry before the timed window is over when leg 3 is skipped
+    games_per_slot = a.games_per_slot if not a.no_complete else max(2, (pre + a.steps + a.warmup) // (a.budget * 30) + 2)
+    eng, evaluator, runner, which = make_leg(a, dev, mode, first, games_per_slot)
 
+    # ---- 1. pre-roll (untimed for `value`, timed for the whole run)
+    ckdist.barrier()
+    torch.cuda.synchronize(dev)
+    t_run0 = time.perf_counter()
     runner.warmup(3)
-    done = runner.steps
-    if a.warmup > done:
-        runner.step(a.warmup - done)
-    torch.cuda.synchronize(dev)
-    s0 = eng.stats()
-    ckdist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    runner.step(a.steps)
-    torch.cuda.synchronize(dev)
-    ckdist.barrier()
-    dt_local = time.perf_counter() - t0
-    s1 = eng.stats()
+    if pre > runner.steps:
+        runner.step(pre - runner.steps)
+    if hasattr(evaluator, "check_range"):
+        evaluator.check_range()
+    # ---- 2. warm-up + the timed window
+    runner.step(a.warmup)
+    dt_local, d = timed_window(runner, eng, dev, a.steps, ckdist.barrier)
     dt = ckdist.max_over_ranks(dt_local, dev)
-    exp_local = s1["expansions"] - s0["expansions"]
-    exp_total = ckdist.sum_over_ranks(exp_local, dev)
-    term_total = ckdist.sum_over_ranks(s1["terminal_visits"] - s0["terminal_visits"], dev)
-    plies_total = ckdist.sum_over_ranks(s1["plies"] - s0["plies"], dev)
+    exp_total = ckdist.sum_over_ranks(d["expansions"], dev)
+    term_total = ckdist.sum_over_ranks(d["terminal_visits"], dev)
+    plies_total = ckdist.sum_over_ranks(d["plies"], dev)
+    games_window = ckdist.sum_over_ranks(d["games"], dev)
+    active_after_window = eng.stats()["active_slots"]
 
-    # instrumented eager pass (not part of the timed region): HIP events on the launch stream
-    t_tree = t_nn = 0.0
+    # ---- instrumented eager pass (its wall time is taken out of the whole-run figure): HIP events on the launch stream
+    t_probe0 = time.perf_counter()
+    t_tree = t_nn = t_conv = 0.0
     if a.profile_steps > 0:
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.profile_steps)]
-        evaluator = runner.evaluator
         with torch.no_grad():
             for e0, e1, e2 in ev:
                 e0.record()
                 eng.step(runner.p, runner.v)
                 e1.record()
                 p, v = evaluator(eng)
-                runner.p.copy_(p); runner.v.copy_(v)
+                if not getattr(evaluator, "static_outputs", False):
+                    runner.p.copy_(p); runner.v.copy_(v)
                 e2.record()
         torch.cuda.synchronize(dev)
         t_tree = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in ev])) / 1e3
         t_nn = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in ev])) / 1e3
-    # the dominant kernel on its own: k_conv_stack, one launch per step, timed with HIP
-    # events on the launch stream against the engine's current leaf features
-    t_conv = 0.0
-    if which == "fused" and a.profile_steps > 0:
-        t_conv = time_conv(evaluator, eng.x, dev, groups=max(3, a.profile_steps // 4))
-    stats_end = eng.stats()
+        # the dominant kernel on its own: one launch per step, against the engine's current leaf features
+        if which == "fused":
+            t_conv = time_conv(evaluator, eng.x, dev, groups=max(3, a.profile_steps // 4))
+    torch.cuda.synchronize(dev)
+    t_probe = time.perf_counter() - t_probe0
+
+    # ---- 3. play the run to its end: M2 and the whole-run / steady-state ratio; then the job's one collective
+    whole = None
+    if not a.no_complete:
+        trace = []
+        runner.run_to_completion(check_every=100, trace=trace)
+        torch.cuda.synchronize(dev)
+        ckdist.barrier()
+        t_play = ckdist.max_over_ranks(time.perf_counter() - t_run0 - t_probe, dev)
+        st = eng.stats()
+        payload = eng.pack_tuples_device()
+        torch.cuda.synchronize(dev)
+        ckdist.barrier()
+        g0 = time.perf_counter()
+        gathered = ckdist.gather_rows(payload, dst=0)
+        torch.cuda.synchronize(dev)
+        t_gather = ckdist.max_over_ranks(time.perf_counter() - g0, dev)
+        tot = {k: ckdist.sum_over_ranks(st[k], dev) for k in ("expansions", "terminal_visits", "plies", "games", "pool_overflows")}
+        if rank == 0:
+            n_rows = int(gathered.shape[0])
+            whole = {"games": int(tot["games"]), "games_per_slot": games_per_slot, "seconds": t_play + t_gather,
+                     "play_seconds": t_play, "steps": runner.steps,
+                     "expansions": tot["expansions"], "expansions_per_s": tot["expansions"] / (t_play + t_gather),
+                     "plies": tot["plies"], "mean_plies_per_game": tot["plies"] / max(1.0, tot["games"]),
+                     "terminal_visit_fraction": tot["terminal_visits"] / max(1.0, tot["expansions"] + tot["terminal_visits"]),
+                     "pool_overflows": int(tot["pool_overflows"]),
+                     "gather": {"collective": "all_gather(sizes) + gather(padded rows) to rank 0 (%s)"
+                                              % ("RCCL" if world > 1 else "single rank: no collective issued"),
+                                "tuples": n_rows, "bytes": n_rows * 288, "seconds": t_gather},
+                     "active_slots_trace": trace[:: max(1, len(trace) // 40)],
+                     "semantics": "fixed number of games per worker slot, played back to back (training_pipeline.py:349); "
+                                  "includes pre-roll, timed window and the tail in which slots run dry"}
 
     out = None
     if rank == 0:
-        peak = MFMA_PEAK_TFLOPS[a.nn_dtype]
+        peak = MFMA_PEAK_TFLOPS[mode]
         nn_tflops = FLOPS_PER_EVAL * a.slots / t_nn / 1e12 if t_nn else None
         tree = {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "bound": "latency", "algorithmic_bytes_per_sim": 536,
                 "achieved_GBps": 536.0 * a.slots / t_tree / 1e9 if t_tree else None}
-        if which == "fused" and a.nn_dtype == "fp32":
-            roofline = split_roofline(evaluator.CONV_FLOPS_PER_BOARD, a.slots, t_conv)
-            roofline.update({"network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
-                             "tree_kernel": tree})
-        elif which == "fused":
-            conv_flops = evaluator.CONV_FLOPS_PER_BOARD
-            conv_tflops = conv_flops * a.slots / t_conv / 1e12 if t_conv else None
-            roofline = {"bound": "mfma", "kernel": "k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, "
-                                                   "8 boards per workgroup LDS-resident through all layers; one launch per step)",
-                        "achieved": conv_tflops, "peak": peak, "unit": "TFLOP/s",
-                        "frac": conv_tflops / peak if conv_tflops else None,
-                        # HBM-side bytes per launch from the rocprofv3 --pmc passes committed under profiles/
-                        # (r01_pmc_conv_kernels.csv, final rows: FETCH_SIZE 14 918 KB, WRITE_SIZE 9 216 KB at 4 096
-                        # boards; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch
-                        # size; not re-measured by this script.  Algorithmic: 7.3 MB planes in + 9.4 MB head
-                        # features out + the 2.9 MB of weights once per XCD L2.
-                        "traffic": (2 * 14918.2 + 9216.0) * 1024.0 * a.slots / 4096.0,
-                        "traffic_source": "profiles/r01_pmc_conv_kernels.csv (separate --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)",
-                        "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": a.slots,
-                        "network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
-                        "tree_kernel": tree}
+        if which == "fused":
+            roofline = conv_roofline(mode, evaluator.CONV_FLOPS_PER_BOARD, a.slots, t_conv)
         else:
             roofline = {"bound": "mfma", "kernel": "network forward via PyTorch/MIOpen (conv3x3 x8 + heads), launch group per step",
                         "achieved": nn_tflops, "peak": peak, "unit": "TFLOP/s",
                         "frac": (nn_tflops / peak) if nn_tflops else None, "traffic": None,
-                        "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots,
-                        "tree_kernel": tree}
+                        "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots}
+        roofline.update({"network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
+                         "tree_kernel": tree})
+        value = exp_total / dt
+        if whole is not None:
+            whole["efficiency_vs_steady_state"] = whole["expansions_per_s"] / value
         extra = {"movegen_k1": movegen_probe(dev)}
-        if world == 1 and a.parity_steps > 0 and not (which == "fused" and a.nn_dtype == "fp32"):
-            extra["fp32_grade_mode"] = parity_leg(a, dev)
-        if world == 1 and a.parity_steps > 0:
+        if world == 1 and a.extra_steps > 0:
+            other = "bf16" if mode != "bf16" else "fp32"
+            extra["bf16_throughput_mode" if other == "bf16" else "fp32_grade_mode"] = throughput_leg(a, dev, other)
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
             extra["random_rollout_mode"] = rollout_leg(a, dev)
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(a.budget, a.cpu_seconds)
-        value = exp_total / dt
         out = {"metric": "MCTS node-expansions/sec (whole node) at 100 sims/move", "value": value,
                "unit": "node-expansions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": a.nn_dtype, "data": "synthetic",
+               "dtype": DTYPE_LABEL[mode], "data": "synthetic",
                "config": {"workload": "cfg3: batched MCTS %d sims/move, %d concurrent self-play games per GPU, "
                                       "random-init policy/value net (Keras-default init), TERMINATE_CNT 200"
                                       % (a.budget, a.slots),
-                          "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": a.nn_dtype,
-                          "hip_graph": not a.no_graph, "evaluator": which, "parallelism": "games sharded x%d, no per-step collective" % world},
-               "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total,
+                          "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": mode, "preroll_steps": pre,
+                          "hip_graph": not a.no_graph, "evaluator": which,
+                          "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
+               "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py); rules, search, tuples "
+                         "bit-exact vs the reference golden vectors (under NumPy >= 2 promotion rules)" if mode == "fp32" else
+                         "throughput mode (not a parity claim)",
+               "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total, "games_finished_in_window": games_window,
+               "active_slots_after_window": active_after_window,
                "sims_per_s": (exp_total + term_total) / dt,
-               "games_per_hour_est": (plies_total / dt) * 3600.0 / 100.0 if plies_total else None,
-               "engine_stats": stats_end, "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+               "games_per_hour": whole["games"] / whole["seconds"] * 3600.0 if whole else None,
+               "games_per_hour_steady_state_est": (plies_total / dt) * 3600.0 / whole["mean_plies_per_game"] if whole and plies_total else None,
+               "whole_run": whole, "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
     eng.close()
     ckdist.barrier()
     if rank == 0:

@@ -19,8 +19,11 @@
 // through all layers as unpadded rows of [128 hi | 128 lo] fp16 (512 B) whose 16-byte k-slots are
 // XOR-swizzled with the row number (conflict-free ds_read_b128, one v_xor per read): 128 KB, and
 // 4 096 boards make exactly four rounds of 256 workgroups.  Weights stream through a 3-slot LDS
-// ring of 16-input-channel slices (128 output rows x [16 hi | 16 lo], 10 KB, 80-B pitch) filled
-// by buffer_load ... lds two slots ahead.  8 waves (two per SIMD): wave (wc, wp) owns channels
+// ring of 16-input-channel slices (128 output rows x [16 hi | 16 lo] = 8 KB, 64-B rows without
+// padding: the four 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3, which keeps
+// the 16 lanes one ds_read_b128 cycle serves on 16 distinct bank groups; the swizzle is applied
+// by the host packer, so the HBM image is the LDS image) filled by buffer_load ... lds two
+// slots ahead, exactly one 1-KB piece per wave and slot.  8 waves (two per SIMD): wave (wc, wp) owns channels
 // [64wc,+64) x positions [64wp,+64) = 2 x 2 MFMA tiles; per 16-deep k-chunk 8 fragment reads
 // feed 12 MFMAs.
 #include "ckr_host.h"
@@ -41,18 +44,19 @@ constexpr int AROW = 512;                                        // [128 hi | 12
 constexpr int LO = 256;                                          // byte offset of the lo half of a row
 constexpr int ZBASE = XP * AROW;                                 // 512-B zero region for out-of-board taps
 constexpr int ACT_BYTES = ZBASE + 512;
-constexpr int WPITCH = 80;                                       // [16 hi | 16 lo] fp16 + 16 B per weight row
-constexpr int WLO = 32;
+constexpr int WPITCH = 64;                                       // [16 hi | 16 lo] fp16 per weight row, chunks swizzled, no padding
+constexpr int WLO = 32;                                          // logical chunk 2: xor into the swizzled chunk address
 constexpr int SLOT_BYTES = 128 * WPITCH;                         // 16 input channels of one tap
 constexpr int SLOT_U4 = SLOT_BYTES / 16;
-constexpr int PIECES = SLOT_BYTES / 1024;                        // 10 DMA pieces of 1 KB
+constexpr int PIECES = SLOT_BYTES / 1024;                        // 8 DMA pieces of 1 KB: one per wave
+static_assert(PIECES == 8, "one DMA piece per wave and slot");
 constexpr int NRING = 3;
 constexpr int PRM_BYTES = 3 * 128 * 4;
-constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 163 840 B: all of it
+constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 157 696 B
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 struct LayerDev {
-    const uint4* w;            // [n_slots][128 rows][80 B]: first layer 9 slots (one per tap), else 72 (tap*8 + slice)
+    const uint4* w;            // [n_slots][128 rows][64 B, swizzled]: first layer 9 slots (one per tap), else 72 (tap*8 + slice)
     const float* bias; const float* scale; const float* shift;   // pre-scaled on the host
     float* out;                // optional [B,8,8,128] float32 (activation * XS)
 };
@@ -71,26 +75,22 @@ struct Args {
 // byte address of the hi half's 16-byte k-slot `ks` (8 channels) of activation row `r` (lo: + LO)
 __device__ __forceinline__ int act_addr(int r, int ks) { return r * AROW + ((ks ^ (r & 15)) << 4); }
 
-// one ring slot = 10 wave-instructions of 64 lanes x 16 B, dealt round-robin to the 8 waves
+// one ring slot = 8 wave-instructions of 64 lanes x 16 B: wave w moves bytes [1024 w, +1024)
 __device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int wave, int lane) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, SLOT_BYTES, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < (PIECES + 7) / 8; ++i) {
-        const int c = wave + 8 * i;
-        if (c < PIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + c * 1024), 16, lane * 16, c * 1024, 0, 0);
-    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
 }
 
 struct Frags { f16x8 ah[2], al[2], bh[2], bl[2]; };
 
-// the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half)
-__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int c8, int half,
-                                           int wrow0, const int (&rowaddr)[2], Frags& f) {
+// the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half);
+// wa = byte offset of this lane's hi weight chunk (k-half `half`) of row wrow0 inside a slot, swizzled
+__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int c8, int wa,
+                                           const int (&rowaddr)[2], Frags& f) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        f.ah[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + 16 * half);
-        f.al[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wrow0 + 32 * ct) * WPITCH + WLO + 16 * half);
+        f.ah[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wa + 32 * ct * WPITCH));
+        f.al[ct] = *reinterpret_cast<const f16x8*>(wbuf + ((wa + 32 * ct * WPITCH) ^ WLO));
     }
     const int kc = (2 * c8) << 4;
 #pragma unroll
@@ -118,12 +118,17 @@ __device__ __forceinline__ void mfma_block(const Frags& f, f32x16 (&acc)[2][2]) 
             acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
 }
 
-// 8 ds_read_b128 of the next slot between the first MFMAs of the current one
+// 8 ds_read_b128 of the next slot between the first MFMAs of the current one; the ring refill (one
+// buffer_load ... lds per wave) is pinned behind the first MFMA: issued straight after the barrier release
+// it would hold back both waves of a SIMD while the matrix pipe has nothing queued
 __device__ __forceinline__ void interleave_reads_with_mfma() {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // the DMA piece (VMEM read), when the step has one
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
+    for (int i = 1; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 }
@@ -226,6 +231,7 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char*
     const LayerDev& L = A.L[l];
     asm volatile("" : "+v"(prow0), "+v"(wrow0), "+v"(lane));     // per-layer address arithmetic stays inside the layer
     const int half = lane >> 5;
+    const int wa = wrow0 * WPITCH + ((half ^ ((lane >> 2) & 3)) << 4);    // (row >> 2) & 3 == (lane >> 2) & 3: wrow0 = 64 wc + (lane & 31)
     f32x16 acc[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -242,20 +248,20 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char*
     Frags f0, f1;
     int rowaddr[2];
     tap_rows(prow0, 0, half, rowaddr);
-    load_frags(act, wring + ring * SLOT_BYTES, 0, half, wrow0, rowaddr, f0);
+    load_frags(act, wring + ring * SLOT_BYTES, 0, wa, rowaddr, f0);
     __builtin_amdgcn_sched_barrier(0);
     // one step: slot s (fragments in fc) is multiplied while the fragments of slot s+1 load into fn
     auto step = [&](int s, int tap, int c8, Frags& fc, Frags& fn) {
         char* cur = wring + ring * SLOT_BYTES;
         const int nring = ring == NRING - 1 ? 0 : ring + 1;
-        // (a bare s_barrier: __syncthreads() would also wait vmcnt(0) and drain the look-ahead; slot s+2 may be
-        // in flight with >= 1 piece per wave)
+        // (a bare s_barrier: __syncthreads() would also wait vmcnt(0) and drain the look-ahead; every wave has
+        // one piece of slot s+1 and one of slot s+2 outstanding)
         asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
         if (s + 3 < NSLOTS) issue_slot(L.w + (size_t)(s + 3) * SLOT_U4, cur, wave, lane);
         else if (l + 1 < A.n_layers) issue_slot(A.L[l + 1].w + (size_t)(s + 3 - NSLOTS) * SLOT_U4, cur, wave, lane);
         if (s + 1 < NSLOTS) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
-            load_frags(act, wring + nring * SLOT_BYTES, c8 == CPT - 1 ? 0 : c8 + 1, half, wrow0, rowaddr, fn);
+            load_frags(act, wring + nring * SLOT_BYTES, c8 == CPT - 1 ? 0 : c8 + 1, wa, rowaddr, fn);
             mfma_block(fc, acc);
             interleave_reads_with_mfma();
         } else {

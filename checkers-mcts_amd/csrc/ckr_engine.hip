@@ -101,6 +101,39 @@ __device__ double gamma_sample(const Dev& D, double a, uint32_t c0, uint32_t c1,
     }
 }
 
+// np.random.dirichlet([alpha] * n) for the n children of a node, one component per lane: independent
+// gamma(alpha) variates divided by their sum (MCTS.py:107-108).  Philox counters: (worker, draw, lane).
+__device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_t worker, uint32_t ctr, int lane) {
+    const double g = act ? gamma_sample(D, D.alpha, worker, ctr, (uint32_t)lane) : 0.0;
+    return g / wave_sum_f64(g);
+}
+
+// MCTS.best_child with TRAINING and tau > 0 (MCTS.py:240-246): np.random.choice(children, p = N^(1/tau) / sum)
+// as an inverse-CDF pick over the children in tree order; `ev` = 64 doubles of LDS.  All lanes return the pick.
+__device__ __forceinline__ int temperature_pick(const Dev& D, double* ev, int cn, bool act, int n, double tau,
+                                                uint32_t worker, uint32_t ctr, int lane) {
+    ev[lane] = act ? pow((double)cn, 1.0 / tau) : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double cum = 0.0;
+    for (int j = 0; j <= lane && j < n; ++j) cum += ev[j];
+    const double total = __hiloint2double(bcast_i32(__double2hiint(cum), 63), bcast_i32(__double2loint(cum), 63));
+    const u32x4 r = philox(D.seed_lo, D.seed_hi, worker, ctr, 0xFFFFFFFFu, 0x7A0u);
+    const double uu = u01(r.x, r.y) * total;
+    const unsigned long long hit = __ballot(act && uu < cum);
+    __builtin_amdgcn_wave_barrier();
+    return hit ? first_lane(hit) : n - 1;
+}
+
+// temperature schedule (MCTS.py:243-245): after TEMP_DECAY_DELAY moves tau drops by TEMPERATURE_DECAY per
+// sampled move and snaps to 0 when np.isclose(tau, 0) (|tau| <= 1e-8)
+__device__ __forceinline__ double decayed_tau(const Dev& D, double tau, int move_count) {
+    if (move_count > D.tau_decay_delay) {
+        tau -= D.tau_decay;
+        if (fabs(tau) <= 1e-8) tau = 0.0;
+    }
+    return tau;
+}
+
 // ---- backups: MCTS_Node.backpropagation + MCTS.determine_reward (MCTS.py:149-186,419-430)
 __device__ void backup_value(Wave& w, int t, int node, float v, uint32_t sim_player) {
     const size_t tb = w.tb(t);
@@ -347,8 +380,7 @@ __device__ int descend(Wave& w, int t) {
         const uint32_t cst = D.n_status[ci], ckids = D.n_kids[ci];
         double dir = 0.0;
         if (D.epsilon != 0.0) {
-            const double g = act ? gamma_sample(D, D.alpha, (uint32_t)(D.first_worker + w.slot), ctr, (uint32_t)w.lane) : 0.0;
-            dir = g / wave_sum_f64(g);
+            dir = dirichlet_lane(D, act, (uint32_t)(D.first_worker + w.slot), ctr, w.lane);
             ++ctr;
         }
         const double sqrt_n = np < D.sqrt_n ? D.sqrt_tab[np] : sqrt((double)np);
@@ -597,24 +629,13 @@ __device__ void finish_ply(Wave& w) {
         const int mx = wave_max_i32(cn);
         pick = first_lane(__ballot(act && cn == mx));
     } else {
-        const double ev = act ? pow((double)cn, 1.0 / tau) : 0.0;
-        w.L.u.ev[w.lane] = ev;
-        __builtin_amdgcn_wave_barrier();
-        double cum = 0.0;
-        for (int j = 0; j <= w.lane && j < n; ++j) cum += w.L.u.ev[j];
-        const double total = __hiloint2double(bcast_i32(__double2hiint(cum), 63), bcast_i32(__double2loint(cum), 63));
-        if (moves > D.tau_decay_delay) {                   // :243-245
-            tau -= D.tau_decay;
-            if (fabs(tau) <= 1e-8) tau = 0.0;
-            if (w.lane == 0) D.g_tau[w.slot] = tau;
-        }
         const uint32_t ctr = D.g_rng[w.slot];
-        const u32x4 r = philox(D.seed_lo, D.seed_hi, (uint32_t)(D.first_worker + w.slot), ctr, 0xFFFFFFFFu, 0x7A0u);
-        if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
-        const double uu = u01(r.x, r.y) * total;
-        const unsigned long long hit = __ballot(act && uu < cum);
-        pick = hit ? first_lane(hit) : n - 1;
-        __builtin_amdgcn_wave_barrier();
+        pick = temperature_pick(D, w.L.u.ev, cn, act, n, tau, (uint32_t)(D.first_worker + w.slot), ctr, w.lane);
+        if (w.lane == 0) {
+            D.g_rng[w.slot] = ctr + 1u;
+            const double nt = decayed_tau(D, tau, moves);          // the pick used tau BEFORE the decay (:240-245)
+            if (nt != tau) D.g_tau[w.slot] = nt;
+        }
     }
     const int chosen = base + pick;
     const ckr_board cb = ld_board(&D.n_board[tb + chosen]);
@@ -957,9 +978,46 @@ __global__ void k_pack(const ckr_tuple* __restrict__ tuples, const int64_t* __re
     for (int64_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
 }
 
+// ---- test probes of the stochastic paths (ckr_probe_*): the SAME device functions the search uses, driven
+// with explicit inputs so that tests can compare their output distributions with NumPy's
+__global__ __launch_bounds__(256) void k_probe_dirichlet(const Dev* __restrict__ Dp, int n, int samples, double* __restrict__ out) {
+    const Dev& D = *Dp;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (s >= samples) return;
+    const double d = dirichlet_lane(D, lane < n, (uint32_t)(D.first_worker + (s & 1023)), (uint32_t)(s >> 10), lane);
+    if (lane < n) out[(size_t)s * n + lane] = d;
+}
+__global__ __launch_bounds__(256) void k_probe_temperature(const Dev* __restrict__ Dp, const int32_t* __restrict__ visits, int n,
+                                                           double tau, int samples, int32_t* __restrict__ picks) {
+    const Dev& D = *Dp;
+    __shared__ double ev[4][64];
+    const int wv = threadIdx.x >> 6, s = blockIdx.x * 4 + wv, lane = lane_id();
+    if (s >= samples) return;
+    const bool act = lane < n;
+    const int cn = act ? visits[lane] : -1;
+    const int pick = temperature_pick(D, ev[wv], cn, act, n, tau, (uint32_t)(D.first_worker + (s & 1023)), (uint32_t)(s >> 10), lane);
+    if (lane == 0) picks[s] = pick;
+}
+__global__ void k_probe_tau(const Dev* __restrict__ Dp, int moves, double* __restrict__ out) {
+    const Dev& D = *Dp;
+    if (threadIdx.x || blockIdx.x) return;
+    double tau = D.tau0;
+    for (int m = 0; m < moves; ++m) {                     // every move sampled while training and tau > 0 (MCTS.py:237-245)
+        out[m] = tau;
+        if (D.training && tau > 0.0) tau = decayed_tau(D, tau, m);
+    }
+}
+
 }  // namespace ckr
 
 using namespace ckr;
+
+// stream used by the interactive commands: the last one a step / rollout was launched on OUTSIDE a graph capture
+static void note_stream(hipStream_t* last, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs == hipStreamCaptureStatusNone) *last = st;
+}
 
 struct ckr_engine {
     ckr_config cfg;
@@ -1111,7 +1169,7 @@ int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t n) {
 int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) {
     if (!e || sims <= 0) return fail(CKR_ERR_INVALID, "ckr_engine_rollout: bad argument");
     if (e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_rollout needs an engine created with neural_net = 0");
-    e->last_stream = (hipStream_t)stream;
+    note_stream(&e->last_stream, (hipStream_t)stream);
     hipLaunchKernelGGL(k_rollout, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
     CKR_HIP(hipGetLastError());
     e->steps++;
@@ -1122,7 +1180,7 @@ int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x
     if (!e || !d_x) return fail(CKR_ERR_INVALID, "ckr_engine_step: null engine or feature buffer");
     if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_step drives the NEURAL_NET search; use ckr_engine_rollout");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
-    e->last_stream = (hipStream_t)stream;
+    note_stream(&e->last_stream, (hipStream_t)stream);
     hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net);
     CKR_HIP(hipGetLastError());
     e->steps++;
@@ -1138,7 +1196,7 @@ int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_ne
         if (int rc = dalloc(e, &e->d_tmp_v, (size_t)S, false)) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
-    e->last_stream = st;
+    note_stream(&e->last_stream, st);
     hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, st, (const Dev*)e->d_dev, e->d_row_tmp, d_range);
     hipLaunchKernelGGL(k_rows_move, dim3((S + 3) / 4), dim3(256), 0, st, (const Dev*)e->d_dev, (const int32_t*)e->d_row_tmp,
                        (const float*)d_p, (const float*)d_v, e->d_tmp_p, e->d_tmp_v, d_net);
@@ -1151,7 +1209,7 @@ int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_ne
 
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_stats: null argument");
-    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipDeviceSynchronize());
     unsigned long long shards[CNT_SHARDS * CNT_STRIDE], c[CNT_N] = {0};
     CKR_HIP(hipMemcpy(shards, e->dev.counters, sizeof(shards), hipMemcpyDeviceToHost));
     for (int s = 0; s < CNT_SHARDS; ++s)
@@ -1167,7 +1225,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
 }
 
 static int fetch_results(ckr_engine* e, std::vector<ckr_game_result>& all) {
-    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipDeviceSynchronize());
     all.resize((size_t)e->n_games_total);
     CKR_HIP(hipMemcpy(all.data(), e->dev.results, all.size() * sizeof(ckr_game_result), hipMemcpyDeviceToHost));
     return CKR_OK;
@@ -1256,7 +1314,7 @@ int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, in
     if (!e->dev.manual) return fail(CKR_ERR_STATE, "ckr_engine_command needs an engine created with manual_play = 1");
     const size_t S = (size_t)e->cfg.n_slots;
     if (!e->d_cmd) CKR_HIP(hipMalloc((void**)&e->d_cmd, 3 * S * sizeof(int32_t)));
-    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipDeviceSynchronize());
     CKR_HIP(hipMemcpy(e->d_cmd, cmd, S * sizeof(int32_t), hipMemcpyHostToDevice));
     CKR_HIP(hipMemcpy(e->d_cmd + S, arg, S * sizeof(int32_t), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_command, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, (const Dev*)e->d_dev,
@@ -1270,7 +1328,7 @@ int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, in
 int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* status, int32_t* move_count, int32_t* searching) {
     if (!e || slot < 0 || slot >= e->cfg.n_slots || !board || !status || !move_count || !searching)
         return fail(CKR_ERR_INVALID, "ckr_engine_game: bad argument");
-    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipDeviceSynchronize());
     int32_t ph = 0;
     CKR_HIP(hipMemcpy(board, e->dev.g_board + slot, sizeof(ckr_board), hipMemcpyDeviceToHost));
     CKR_HIP(hipMemcpy(status, e->dev.g_status + slot, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1293,7 +1351,7 @@ static int read_node(ckr_engine* e, size_t idx, ckr_node_info* out) {
 int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* root, ckr_node_info* children, int32_t* n_children) {
     if (!e || slot < 0 || slot >= e->cfg.n_slots || tree < 0 || tree > 1 || !root || !children || !n_children)
         return fail(CKR_ERR_INVALID, "ckr_engine_root: bad argument");
-    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipDeviceSynchronize());
     const int ti = slot * 2 + tree;
     int32_t cursor = -1, half = 0;
     CKR_HIP(hipMemcpy(&cursor, e->dev.t_cursor + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1314,9 +1372,66 @@ int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* ro
 
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out) {
     if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_leaves: null argument");
-    CKR_HIP(hipStreamSynchronize(e->last_stream));
+    CKR_HIP(hipDeviceSynchronize());
     CKR_HIP(hipMemcpy(out, e->dev.leaves, (size_t)e->cfg.n_slots * sizeof(ckr_board), hipMemcpyDeviceToHost));
     return CKR_OK;
+}
+
+// ---- probes (tests only; see include/ckr.h)
+static int probe_dev(Dev& D, Dev** d_dev, uint64_t seed, double alpha) {
+    memset(&D, 0, sizeof(D));
+    D.seed_lo = (uint32_t)seed; D.seed_hi = (uint32_t)(seed >> 32); D.alpha = alpha; D.training = 1;
+    CKR_HIP(hipMalloc((void**)d_dev, sizeof(Dev)));
+    return CKR_OK;
+}
+
+int ckr_probe_dirichlet(double alpha, int32_t n, int32_t samples, uint64_t seed, double* out) {
+    if (!(alpha > 0.0) || n < 1 || n > 64 || samples < 1 || !out) return fail(CKR_ERR_INVALID, "ckr_probe_dirichlet: bad argument");
+    if (int rc = require_device()) return rc;
+    Dev D; Dev* d_dev = nullptr; double* d_out = nullptr;
+    if (int rc = probe_dev(D, &d_dev, seed, alpha)) return rc;
+    const size_t bytes = (size_t)samples * n * sizeof(double);
+    hipError_t e = hipMalloc((void**)&d_out, bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_dirichlet, dim3((samples + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)d_dev, (int)n, (int)samples, d_out);
+        e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_out); (void)hipFree(d_dev);
+    return e == hipSuccess ? CKR_OK : fail(CKR_ERR_HIP, "ckr_probe_dirichlet: %s", hipGetErrorString(e));
+}
+
+int ckr_probe_temperature(const int32_t* visits, int32_t n, double tau, int32_t samples, uint64_t seed, int32_t* picks) {
+    if (!visits || n < 1 || n > 64 || !(tau > 0.0) || samples < 1 || !picks) return fail(CKR_ERR_INVALID, "ckr_probe_temperature: bad argument");
+    if (int rc = require_device()) return rc;
+    Dev D; Dev* d_dev = nullptr; int32_t* d_buf = nullptr;
+    if (int rc = probe_dev(D, &d_dev, seed, 1.0)) return rc;
+    hipError_t e = hipMalloc((void**)&d_buf, ((size_t)samples + 64) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_buf, visits, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_temperature, dim3((samples + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)d_dev,
+                           (const int32_t*)d_buf, (int)n, tau, (int)samples, d_buf + 64);
+        e = hipMemcpy(picks, d_buf + 64, (size_t)samples * sizeof(int32_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_buf); (void)hipFree(d_dev);
+    return e == hipSuccess ? CKR_OK : fail(CKR_ERR_HIP, "ckr_probe_temperature: %s", hipGetErrorString(e));
+}
+
+int ckr_probe_tau_schedule(double tau0, double tau_decay, int32_t tau_decay_delay, int32_t moves, double* out) {
+    if (moves < 1 || !out) return fail(CKR_ERR_INVALID, "ckr_probe_tau_schedule: bad argument");
+    if (int rc = require_device()) return rc;
+    Dev D; Dev* d_dev = nullptr; double* d_out = nullptr;
+    if (int rc = probe_dev(D, &d_dev, 0, 1.0)) return rc;
+    D.tau0 = tau0; D.tau_decay = tau_decay; D.tau_decay_delay = tau_decay_delay;
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)moves * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_tau, dim3(1), dim3(64), 0, (hipStream_t)0, (const Dev*)d_dev, (int)moves, d_out);
+        e = hipMemcpy(out, d_out, (size_t)moves * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_out); (void)hipFree(d_dev);
+    return e == hipSuccess ? CKR_OK : fail(CKR_ERR_HIP, "ckr_probe_tau_schedule: %s", hipGetErrorString(e));
 }
 
 }  // extern "C"

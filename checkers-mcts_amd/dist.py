@@ -19,12 +19,19 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def local_device(local_rank):
+    """cuda device of this rank.  More ranks than GPUs (the 2-rank gloo test on a 1-GPU box) share devices."""
+    return torch.device("cuda", int(local_rank) % max(1, torch.cuda.device_count()))
+
+
 def init_from_env(backend=None):
-    """Initialise the default process group when launched under torchrun."""
+    """Initialise the default process group when launched under torchrun.  Backend: the argument,
+    else $CKR_DIST_BACKEND, else RCCL ("nccl") when a GPU is present, gloo otherwise.  With gloo the
+    gather payloads are staged through host memory (gather_rows)."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CKR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -48,6 +55,9 @@ def gather_rows(local, dst=0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
+    home = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:        # gloo moves host memory: stage the rows
+        local = local.cpu()
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = torch.zeros(world, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(sizes, n)
@@ -59,7 +69,7 @@ def gather_rows(local, dst=0):
     dist.gather(padded, bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0).to(home)
 
 
 def barrier():
@@ -67,10 +77,14 @@ def barrier():
         dist.barrier()
 
 
+def _reduce_device(device):
+    return "cpu" if dist.get_backend() == "gloo" else device
+
+
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -78,6 +92,6 @@ def max_over_ranks(value, device):
 def sum_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

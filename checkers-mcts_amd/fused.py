@@ -55,8 +55,10 @@ XS, WS = 8.0, 1024.0         # power-of-two operand scales of the split-fp16 pat
 
 
 def pack_split_weights(w, first):
-    """Ring-slot image of ckr_conv_stack_f16x3: fp16 [n_slots][128 out][16 hi | 16 lo | 8 pad]
-    of w * WS; slot = tap (first layer: 14 planes in one 16-channel slice) or tap*8 + slice."""
+    """Ring-slot image of ckr_conv_stack_f16x3: fp16 [n_slots][128 out][4 chunks of 8] of w * WS; slot = tap
+    (first layer: 14 planes in one 16-channel slice) or tap*8 + slice.  A row's logical 16-byte chunks are
+    [hi k 0-7 | hi k 8-15 | lo k 0-7 | lo k 8-15]; chunk c of row r is stored at position c ^ ((r >> 2) & 3)
+    (the kernel's bank-conflict-free LDS layout: the image is DMA'd into the ring verbatim, no padding)."""
     cout, cin = w.shape[0], w.shape[1]
     assert cout == 128 and w.shape[2:] == (3, 3) and cin <= (16 if first else 128)
     q = 1 if first else 8
@@ -66,10 +68,13 @@ def pack_split_weights(w, first):
         raise OverflowError("conv weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
     hi = t.to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
-    img = torch.zeros((9, q, cout, 40), dtype=torch.float16, device=w.device)
-    img[..., 0:16] = hi.reshape(9, cout, q, 16).permute(0, 2, 1, 3)
-    img[..., 16:32] = lo.reshape(9, cout, q, 16).permute(0, 2, 1, 3)
-    return img.reshape(9 * q, cout, 40).contiguous()
+    rows = torch.stack([hi.reshape(9, cout, q, 2, 8), lo.reshape(9, cout, q, 2, 8)], dim=3)      # [tap][out][slice][hi|lo][k-half][8]
+    rows = rows.permute(0, 2, 1, 3, 4, 5).reshape(9 * q, cout, 4, 8)                            # [slot][out][logical chunk][8]
+    r = torch.arange(cout, device=w.device)
+    phys = torch.arange(4, device=w.device)[None, :] ^ ((r[:, None] >> 2) & 3)                   # logical chunk stored at `phys`
+    img = torch.empty_like(rows)
+    img[:, r[:, None], phys] = rows
+    return img.reshape(9 * q, cout, 32).contiguous()
 
 
 def pack_dense_weights(w):

@@ -75,11 +75,27 @@ def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None):
 
 
 def _is_128_wide(*specs):
-    """The fused kernels are built for NUM_KERNELS = 128 (training_pipeline.py:61)."""
+    """The fused kernels are built for NUM_KERNELS = 128 (training_pipeline.py:61).  Modules and
+    checkpoint files are inspected (the width is the first body conv's output-channel count)."""
     for sp in specs:
-        if isinstance(sp, torch.nn.Module) and sp.body[0]["conv"].weight.shape[0] != 128:
-            return False
+        if isinstance(sp, torch.nn.Module):
+            if sp.body[0]["conv"].weight.shape[0] != 128:
+                return False
+        elif isinstance(sp, str) and not sp.startswith("random:") and os.path.isfile(sp):
+            if network_width(sp) != 128:
+                return False
     return True
+
+
+def network_width(path):
+    """NUM_KERNELS of a saved network (torch state_dict or Keras .h5 weights)."""
+    if path.endswith((".h5", ".hdf5", ".keras")):
+        from . import keras_h5
+        return keras_h5.num_kernels(path)
+    sd = torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return int(sd["body.0.conv.weight"].shape[0])
 
 
 class StepRunner:
@@ -135,7 +151,7 @@ class StepRunner:
             else:
                 self._eager_step()
 
-    def run_to_completion(self, check_every=50, compact_tail=True):
+    def run_to_completion(self, check_every=50, compact_tail=True, trace=None):
         """Steps until every game is over.  Tail handling: once fewer slots are active than the
         batch has rows (by more than ~3 %), the active slots are moved to the front of the batch
         (Engine.compact_rows) and the conv kernel stops at the last active row, so the last
@@ -148,6 +164,8 @@ class StepRunner:
         while True:
             self.step(check_every)
             active = self.eng.stats()["active_slots"]
+            if trace is not None:
+                trace.append((self.steps, active))
             if hasattr(self.evaluator, "check_range"):
                 self.evaluator.check_range()
             if active == 0:
@@ -211,7 +229,7 @@ class generate_Checkers_data:
         self-play -> training without the pickle round trip."""
         rank, local_rank, world = ckdist.init_from_env()
         first, count = ckdist.shard_range(self.num_cpus, rank, world)
-        dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+        dev = ckdist.local_device(local_rank) if world > 1 else torch.device("cuda", torch.cuda.current_device())
         raw_dev = torch.zeros((0, ckengine.TUPLE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         if count > 0:
             cfg = ckengine.config_from_kwargs(
@@ -279,7 +297,7 @@ class tournament_Checkers:
         """Returns [[game_num, p1_fn, p2_fn, outcome, move_count], ...] (:552) on rank 0."""
         rank, local_rank, world = ckdist.init_from_env()
         first, count = ckdist.shard_range(self.num_cpus, rank, world)
-        dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+        dev = ckdist.local_device(local_rank) if world > 1 else torch.device("cuda", torch.cuda.current_device())
         rows = torch.zeros((0, 8), dtype=torch.int32, device=dev)
         if count > 0:
             cfg = ckengine.config_from_kwargs(

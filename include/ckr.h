@@ -192,7 +192,9 @@ typedef struct {
     int32_t  games_per_slot;     /* NUM_SELFPLAY_GAMES / TOURNEY_GAMES per worker */
     int32_t  first_worker_id;    /* global id of slot 0 (RNG stream + reporting; sharding) */
     int32_t  budget;             /* BUDGET with CONSTRAINT == 'rollout' */
-    int32_t  terminate_cnt;      /* TERMINATE_CNT; <= 0: play to a natural end */
+    int32_t  terminate_cnt;      /* TERMINATE_CNT: self-play needs > 0 (it sizes the tuple region: TERMINATE_CNT + 1 per game,
+                                    training_pipeline.py:387-405); tournament / manual_play engines ignore it and play
+                                    to the natural end */
     int32_t  training;           /* TRAINING */
     int32_t  tournament;         /* 1: tournament_Checkers loop (two nets, no tuples) */
     int32_t  tau_decay_delay;    /* TEMP_DECAY_DELAY */
@@ -338,6 +340,21 @@ int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* sta
  * tree order; *n_children = -1 when the tree has no node for the live state. */
 int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* root,
                     ckr_node_info* children, int32_t* n_children);
+
+/* ---- probes of the stochastic paths (parity tests only) ------------------ *
+ * The reference draws from NumPy's MT19937 (np.random.dirichlet, MCTS.py:107-108; np.random.choice,
+ * MCTS.py:246), which cannot be reproduced bit for bit; the engine uses Philox4x32-10.  These entry
+ * points run the SAME device functions the search calls (dirichlet_lane / temperature_pick /
+ * decayed_tau in csrc/ckr_engine.hip) on explicit inputs so that tests can compare their output
+ * distributions with NumPy's.  HOST buffers, synchronous. */
+/* `samples` draws of Dirichlet(alpha * 1_n): out[samples][n] (select_child's noise, MCTS.py:107-108). */
+int ckr_probe_dirichlet(double alpha, int32_t n, int32_t samples, uint64_t seed, double* out);
+/* `samples` move choices of best_child with TRAINING and tau > 0 (MCTS.py:240-246) for the child visit
+ * counts visits[n]: picks[samples] = child index, P(i) = visits[i]^(1/tau) / sum. */
+int ckr_probe_temperature(const int32_t* visits, int32_t n, double tau, int32_t samples, uint64_t seed, int32_t* picks);
+/* tau in force at move 0 .. moves-1 of a worker whose every move is sampled (MCTS.py:243-245: decay after
+ * TEMP_DECAY_DELAY moves, snap to 0 at np.isclose): out[moves]. */
+int ckr_probe_tau_schedule(double tau0, double tau_decay, int32_t tau_decay_delay, int32_t moves, double* out);
 
 #ifdef __cplusplus
 }

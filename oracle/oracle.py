@@ -237,27 +237,50 @@ OUTCOME_NAMES = {0: None, 1: "player1_wins", 2: "player2_wins", 3: "draw"}
 
 
 class WorkerBatch:
-    """n independent workers advanced together (CPU baseline: one network batch per step)."""
+    """n independent workers advanced together (CPU baseline: one network batch per step).
+    threads > 1: the workers are split into contiguous chunks, one per host thread (ctypes
+    releases the GIL; a worker's state is private, the library has no globals)."""
 
-    def __init__(self, cfgs):
+    def __init__(self, cfgs, threads=1):
         self._L = lib()
-        self._L.ckro_workers_advance.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        self._L.ckro_workers_advance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         self._L.ckro_workers_advance.restype = C.c_int
-        self._L.ckro_workers_submit.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_float),
-                                                C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        self._L.ckro_workers_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         self.workers = [Worker(c) for c in cfgs]
         self.n = len(self.workers)
         self._arr = (C.c_void_p * self.n)(*[w._h for w in self.workers])
         self.x = np.zeros((self.n, 8, 8, 14), np.float32)
         self.active = np.zeros(self.n, np.int32)
+        self.threads = max(1, min(int(threads), self.n))
+        bounds = np.linspace(0, self.n, self.threads + 1).astype(int)
+        self._chunks = [(int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+        self._pool = None
+        if len(self._chunks) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(len(self._chunks))
+
+    def _advance_chunk(self, ab):
+        a, b = ab
+        return self._L.ckro_workers_advance(C.addressof(self._arr) + a * C.sizeof(C.c_void_p), b - a,
+                                            self.x.ctypes.data + a * 896 * 4, self.active.ctypes.data + a * 4)
 
     def advance(self):
-        return self._L.ckro_workers_advance(self._arr, self.n, _f32(self.x), self.active.ctypes.data_as(C.POINTER(C.c_int)))
+        if self._pool is None:
+            return self._advance_chunk((0, self.n))
+        return sum(self._pool.map(self._advance_chunk, self._chunks))
 
     def submit(self, p, v):
         p = np.ascontiguousarray(p, np.float32)
-        v = np.ascontiguousarray(v, np.float32)
-        self._L.ckro_workers_submit(self._arr, self.n, _f32(p), _f32(v), self.active.ctypes.data_as(C.POINTER(C.c_int)))
+        v = np.ascontiguousarray(v, np.float32).reshape(-1)
+
+        def sub(ab):
+            a, b = ab
+            self._L.ckro_workers_submit(C.addressof(self._arr) + a * C.sizeof(C.c_void_p), b - a,
+                                        p.ctypes.data + a * 512 * 4, v.ctypes.data + a * 4, self.active.ctypes.data + a * 4)
+        if self._pool is None:
+            sub((0, self.n))
+        else:
+            list(self._pool.map(sub, self._chunks))
 
     def stats(self):
         out = {}

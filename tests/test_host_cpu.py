@@ -122,3 +122,12 @@ def test_net_shapes_and_flops_cpu():
     assert p.shape == (2, 512) and v.shape == (2,)
     macs = 64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128 + 64 * 128 * 8 + 512 * 512 + 64 * 128 + 64 * 64 + 64
     assert abs(2 * macs - FLOPS_PER_EVAL) / FLOPS_PER_EVAL < 1e-3
+
+
+def test_bench_refuses_world_mismatch():
+    """bench.py --gpus N must not silently run on fewer ranks."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
