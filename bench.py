@@ -84,6 +84,8 @@ def parse():
                     help="fused: conv stack in the hand-written MFMA kernels (fp32 = split-fp16 operands, or bf16); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager, HIP-event instrumented steps for the roofline")
+    ap.add_argument("--max-sims-per-step", type=int, default=0,
+                    help="cap on network-free simulations (terminal visits) a slot runs back to back in one step (0 = engine default)")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool per tree and semispace (0 = engine default)")
     ap.add_argument("--extra-steps", type=int, default=300,
                     help="timed steps of the extra legs (bf16 throughput mode, arena, random rollouts; N = 1 only, 0 = skip)")
@@ -255,7 +257,8 @@ def make_leg(a, dev, mode, first_worker, games_per_slot):
     kw = dict(MCTS_KWARGS, BUDGET=a.budget)
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
                                       first_worker_id=first_worker, feature_dtype=dtype, seed=20260929, device=dev.index,
-                                      nodes_per_tree=a.nodes_per_tree or None)
+                                      nodes_per_tree=a.nodes_per_tree or None,
+                                      **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
     eng = ckengine.Engine(cfg, feature_dtype=dtype)
     which = a.evaluator or ("fused" if mode in ("bf16", "fp32") else "torch")
     if which == "fused":

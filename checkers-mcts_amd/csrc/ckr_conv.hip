@@ -264,7 +264,9 @@ __global__ __launch_bounds__(NT, 1) void k_conv_stack(const Args A) {
     for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, wave, lane);
     for (int i = tid; i < ACT_BYTES / 16; i += NT) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (tid < rows_valid) {                                       // 14 bf16 = 28 B per position: k-slots 0 and 1
+    const long long brd = board0 + (tid >> 6);                    // boards outside the launch's range keep all-zero planes
+    const bool in_range = !A.range || (brd >= A.range[0] && brd < A.range[1]);
+    if (tid < rows_valid && in_range) {                           // 14 bf16 = 28 B per position: k-slots 0 and 1
         const uint32_t* src = reinterpret_cast<const uint32_t*>(A.x + (board0 * 64 + tid) * 14);
         const uint32_t v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
         *reinterpret_cast<uint4*>(act + act_addr(tid, 0)) = make_uint4(v0, v1, v2, v3);

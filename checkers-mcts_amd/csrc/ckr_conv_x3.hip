@@ -302,7 +302,11 @@ __global__ __launch_bounds__(NT, 1) void k_conv_stack_x3(const Args A) {
     for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, wave, lane);
     for (int i = tid; i < ACT_BYTES / 16; i += NT) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (tid < rows_valid) {                                       // 14 float32 planes per position -> hi / lo, k-slots 0 and 1
+    // boards of the tile that lie outside the launch's board range (arena shares, tail of a run) keep all-zero
+    // planes: their rows may hold stale data, which must neither cost range checks nor raise the overflow flag
+    const long long brd = board0 + (tid >> 6);
+    const bool in_range = !A.range || (brd >= A.range[0] && brd < A.range[1]);
+    if (tid < rows_valid && in_range) {                           // 14 float32 planes per position -> hi / lo, k-slots 0 and 1
         const float2* src = reinterpret_cast<const float2*>(A.x + (board0 * 64 + tid) * 14);
         _Float16 h[16], lo[16];
         float amax = 0.0f;

@@ -1066,7 +1066,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.n_slots = c->n_slots; D.games_per_slot = c->games_per_slot; D.first_worker = c->first_worker_id;
     D.budget = c->budget; D.terminate_cnt = c->terminate_cnt; D.training = c->training; D.tournament = c->tournament;
     D.tau_decay_delay = c->tau_decay_delay; D.reset_tau = c->reset_tau_each_game; D.C = c->nodes_per_tree;
-    D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 64;
+    D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 4;
     D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
     D.total_games = c->n_slots * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;

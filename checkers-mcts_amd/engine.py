@@ -22,10 +22,18 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
-                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=64, device=0,
+                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=4, device=0,
                        manual_play=False, dynamic_queue=False, rollout_first=False):
     """Build a ckr_config from the reference's kwargs dicts, with the
-    reference's own error behaviour for unsupported settings."""
+    reference's own error behaviour for unsupported settings.
+
+    max_sims_per_step: how many network-free simulations (descents that end on a terminal child,
+    MCTS.py:93-94) a slot may run back to back inside one step before it hands out a leaf.  It
+    only moves simulations between steps -- every slot's sequence of simulations, hence every
+    result, is the same for any value.  A step lasts as long as its longest slot, and won / lost
+    endgames produce long runs of terminal visits: measured on cfg3 in steady state the tree
+    kernel takes 0.035 / 0.07 / 0.10 / 0.28 ms at caps 1 / 4 / 8 / 64 while a cap of 1 leaves
+    8.7 % of the network batch empty; 4 is the throughput optimum (profiles/README.md, round 2)."""
     k = mcts_kwargs
     for key in MCTS_KEYS:
         if key not in k:

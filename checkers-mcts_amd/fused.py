@@ -153,8 +153,10 @@ class FusedEvaluator:
             out = y_body if i == len(blocks) - 2 else (y_pol if i == len(blocks) - 1 else None)
             layers[i] = ConvLayer(w.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                   out.data_ptr() if out is not None else None, cin_pad)
-        pol_feat = torch.empty((S, 512), dtype=torch.float32, device=dev)
-        val_feat = torch.empty((S, 64), dtype=torch.float32, device=dev)
+        # zero-filled, not empty: rows outside a launch's board range are never written by the conv kernel but are
+        # read by the tail kernels (whose range check must not trip over uninitialised memory)
+        pol_feat = torch.zeros((S, 512), dtype=torch.float32, device=dev)
+        val_feat = torch.zeros((S, 64), dtype=torch.float32, device=dev)
         t = dict(pol_w=_f32(net.pol2["conv"].weight).reshape(8, 128).contiguous(), pol_b=_f32(net.pol2["conv"].bias),
                  val_w=_f32(net.val1["conv"].weight).reshape(128).contiguous(), val_b=_f32(net.val1["conv"].bias))
         t["pol_scale"], t["pol_shift"] = bn_affine(net.pol2["bn"])
@@ -169,8 +171,8 @@ class FusedEvaluator:
                     w2=_f32(net.val_fc2.weight).reshape(64).contiguous(), b2=float(net.val_fc2.bias.detach().float().item()))
         return dict(layers=layers, n=len(blocks), heads=heads, keep=keep + list(t.values()), y_body=y_body, y_pol=y_pol,
                     pol_feat=pol_feat, val_feat=val_feat, tail=tail,
-                    p=torch.empty((S, 512), dtype=torch.float32, device=dev),
-                    v=torch.empty((S,), dtype=torch.float32, device=dev))
+                    p=torch.zeros((S, 512), dtype=torch.float32, device=dev),
+                    v=torch.zeros((S,), dtype=torch.float32, device=dev))
 
     def _overflow_ptr(self, device):
         if self.overflow is None:
@@ -213,9 +215,9 @@ class FusedEvaluator:
         if not hasattr(self, "_dest"):
             self._dest = torch.zeros(S, dtype=torch.int32, device=dev)
             self._ranges = torch.zeros(4, dtype=torch.int32, device=dev)      # {0, n_new, n_new, n_new + n_old}
-            self._xg = torch.empty_like(x)
-            self._p = torch.empty((S, 512), dtype=torch.float32, device=dev)
-            self._v = torch.empty((S,), dtype=torch.float32, device=dev)
+            self._xg = torch.zeros_like(x)
+            self._p = torch.zeros((S, 512), dtype=torch.float32, device=dev)
+            self._v = torch.zeros((S,), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(self._L.ckr_arena_partition(engine.net_id.data_ptr(), S, x.data_ptr(), x[0].numel() * x.element_size(),
                                                self._dest.data_ptr(), self._ranges.data_ptr(), self._xg.data_ptr(), stream))

@@ -11,9 +11,10 @@ processes of a torchrun job with a single gather of the finished tuples.
 Differences a user can observe (all documented in DESIGN.md):
   * NUM_CPUS is not clamped to the host's core count (it sizes the GPU batch).
   * One pickle per job (written by rank 0) instead of one per worker process.
-  * NN_FN / NEW_NN_FN / OLD_NN_FN name a torch checkpoint (state_dict), a
-    torch.nn.Module, or "random:<seed>" for a freshly initialised network;
-    Keras .h5 files cannot be read here (no h5py / TensorFlow).
+  * NN_FN / NEW_NN_FN / OLD_NN_FN name a Keras .h5 model file as the reference
+    writes them (read by keras_h5.py: no h5py / TensorFlow needed), a torch
+    checkpoint (state_dict), a torch.nn.Module, or "random:<seed>" for a freshly
+    initialised network.
   * MCTS.new_root_node's "All child nodes should be visited!" ValueError is
     replaced by the alternative its own message suggests (a fresh root) and is
     counted in the run statistics.
@@ -38,14 +39,17 @@ def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128):
         spec = "random:0"
     if isinstance(spec, str) and spec.startswith("random:"):
         return make_net(num_kernels, seed=int(spec.split(":", 1)[1]), device=device, dtype=dtype)
-    if isinstance(spec, str) and spec.endswith((".h5", ".hdf5", ".keras")):
-        raise ValueError("Keras model files cannot be loaded in this build (no h5py/TensorFlow); "
-                         "export the weights to a torch state_dict: %s" % spec)
+    if isinstance(spec, str) and spec.endswith((".h5", ".hdf5")):          # the reference's own model files (training_pipeline.py:185-191)
+        from . import keras_h5
+        net = keras_h5.load_keras_weights(spec).to(device=device, dtype=dtype)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        return net.to(memory_format=torch.channels_last) if device != "cpu" else net
     if isinstance(spec, str):
         sd = torch.load(spec, map_location="cpu")
         if isinstance(sd, dict) and "state_dict" in sd:
             sd = sd["state_dict"]
-        k = sd["body.1.conv.weight"].shape[0]
+        k = sd["body.0.conv.weight"].shape[0]
         net = PolicyValueNet(k)
         net.load_state_dict(sd)
         net = net.eval().to(device=device, dtype=dtype)

@@ -204,7 +204,8 @@ typedef struct {
     int32_t  reset_tau_each_game;/* 0 = reference behaviour: tau is per worker, never reset (Q18) */
     int32_t  nodes_per_tree;     /* semispace capacity of one search tree */
     int32_t  feature_dtype;      /* 0 float32, 1 float16, 2 bfloat16 */
-    int32_t  max_sims_per_step;  /* cap on NN-free simulations run back-to-back in one step */
+    int32_t  max_sims_per_step;  /* cap on NN-free simulations (terminal visits) a slot runs back to back in one step before it
+                                    hands out a leaf; results do not depend on it (<= 0: 4, the measured throughput optimum) */
     int32_t  record_root_stats;  /* 1: keep per-ply child W / P next to the tuples (tests) */
     int32_t  manual_play;        /* 1: interactive search API (MCTS / MCTS_Node facade): slots park after
                                     BUDGET simulations and moves are applied by ckr_engine_command */

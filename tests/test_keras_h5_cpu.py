@@ -1,0 +1,121 @@
+"""CPU: import of the reference's Keras model files (training_pipeline.py:185-191,
+345,515-516) without h5py / TensorFlow.
+
+The fixture tests/golden/keras_model_k8.h5 was written by a REAL HDF5 library (h5py 3.3 / HDF5 1.10.6,
+tests/golden/make_keras_h5.py) in exactly the group / dataset / attribute structure tf.keras
+`model.save()` produces for create_nn's model; the product's pure-Python reader must return every
+array bit for bit, and the imported network must compute what Keras semantics prescribe for those
+weights (checked against an independent float64 evaluation written directly on the Keras layouts:
+HWIO kernels, NHWC activations, (H, W, C) Flatten, Dense kernels (in, out))."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+H5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_model_k8.h5")
+EXPECTED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_model_k8_expected.json")
+
+
+def test_reader_returns_every_array_bit_for_bit():
+    from checkers_mcts_amd import keras_h5
+    exp = json.load(open(EXPECTED))
+    f = keras_h5.H5File(H5)
+    assert set(f.root.links) == {"model_weights", "optimizer_weights"}
+    assert f.root.attrs["keras_version"] == "2.4.0" and f.root.attrs["backend"] == "tensorflow"
+    assert json.loads(f.root.attrs["model_config"])["class_name"] == "Functional"
+    mw = f.get("model_weights")
+    assert list(mw.attrs["layer_names"]) == exp["layer_order"]                    # fixed-length string array attribute
+    assert list(f.get("optimizer_weights").attrs["weight_names"]) == ["Adam/iter:0"]   # variable-length string array
+    ds = f.datasets(mw)
+    assert len(ds) == len(exp["arrays"]) == 70
+    for wname, e in exp["arrays"].items():
+        lname = wname.split("/")[0]
+        assert wname in list(f.get("model_weights/" + lname).attrs["weight_names"])
+        a = f.read(ds[lname + "/" + wname])
+        assert a.dtype == np.float32 and list(a.shape) == e["shape"]
+        assert zlib.crc32(np.ascontiguousarray(a).tobytes()) == e["crc32"]
+        assert float(a.astype(np.float64).sum()) == e["sum"] and float(a.reshape(-1)[0]) == e["first"]
+    assert int(f.read(f.get("optimizer_weights/Adam/iter:0"))) == 1234             # scalar int64 dataset
+    with pytest.raises(KeyError):
+        f.get("model_weights/no_such_layer")
+
+
+def keras_forward(layers, order, x):
+    """float64 evaluation of create_nn's graph (training_pipeline.py:59-114) on Keras-layout weights."""
+    def rank(stem):
+        import re
+        found = sorted((int(m.group(1) or 0), n) for n in order for m in [re.match(r"^%s(?:_(\d+))?$" % stem, n)] if m)
+        return [n for _, n in found]
+    convs, bns, dense = rank("conv2d"), rank("batch_normalization"), rank("dense")
+
+    def conv(x, name):
+        k, b = layers[name]["kernel"].astype(np.float64), layers[name]["bias"].astype(np.float64)
+        kh = k.shape[0]
+        pad = kh // 2
+        xp = np.pad(x, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+        out = np.zeros(x.shape[:3] + (k.shape[3],))
+        for i in range(kh):
+            for j in range(kh):
+                out += np.einsum("byxc,co->byxo", xp[:, i:i + 8, j:j + 8], k[i, j])
+        return np.maximum(out + b, 0.0)                                        # activation='relu'
+
+    def bn(x, name):
+        w = {k: v.astype(np.float64) for k, v in layers[name].items()}
+        return w["gamma"] * (x - w["moving_mean"]) / np.sqrt(w["moving_variance"] + 1e-3) + w["beta"]
+
+    def fc(x, name):
+        return x @ layers[name]["kernel"].astype(np.float64) + layers[name]["bias"].astype(np.float64)
+
+    h = x.astype(np.float64)
+    for i in range(7):
+        h = bn(conv(h, convs[i]), bns[i])
+    p = bn(conv(bn(conv(h, convs[7]), bns[7]), convs[8]), bns[8]).reshape(len(x), -1)      # Flatten: (H, W, C)
+    logits = fc(p, "policy_head")
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    v = bn(conv(h, convs[9]), bns[9]).reshape(len(x), -1)
+    v = bn(np.maximum(fc(v, dense[0]), 0.0), bns[10])
+    return e / e.sum(1, keepdims=True), np.tanh(fc(v, "value_head")).reshape(-1)
+
+
+def test_imported_network_computes_keras_semantics():
+    from checkers_mcts_amd import keras_h5
+    from checkers_mcts_amd.pipeline import load_network, network_width
+    layers = keras_h5.read_keras_layers(H5)
+    order = json.load(open(EXPECTED))["layer_order"]
+    rng = np.random.RandomState(5)
+    x = (rng.rand(6, 8, 8, 14) < 0.25).astype(np.float32)
+    x[..., 5] = rng.randint(0, 80, size=(6, 1, 1)) / 80.0                           # the draw-counter plane
+    p_ref, v_ref = keras_forward(layers, order, x)
+    net = load_network(H5, device="cpu")
+    assert net.num_kernels == 8 and network_width(H5) == 8 and keras_h5.num_kernels(H5) == 8
+    with torch.no_grad():
+        p, v = net(torch.from_numpy(x).permute(0, 3, 1, 2))
+    assert np.abs(p.numpy() - p_ref).max() < 1e-5 and np.abs(v.numpy() - v_ref).max() < 1e-5
+    assert np.abs(p_ref - 1.0 / 512).max() > 1e-3                                    # the test is not vacuous: outputs vary
+    # layer-name counters: the same weights under first-model names (conv2d, conv2d_1, ...) map identically
+    ren = {}
+    for n, w in layers.items():
+        stem, _, num = n.rpartition("_")
+        if stem in ("conv2d", "batch_normalization") and num.isdigit():
+            k = int(num) - (10 if stem == "conv2d" else 11)
+            ren[stem + ("" if k == 0 else "_%d" % k)] = w
+        elif n == "dense_1":
+            ren["dense"] = w
+        else:
+            ren[n] = w
+    sd0, _ = keras_h5.keras_state_dict(layers)
+    sd1, _ = keras_h5.keras_state_dict(ren)
+    assert all((sd0[k] == sd1[k]).all() for k in sd0)
+    with pytest.raises(ValueError, match="not a Checkers-MCTS create_nn model"):
+        keras_h5.keras_state_dict({k: v for k, v in layers.items() if k != "policy_head"})
+
+
+def test_not_hdf5_raises(tmp_path):
+    from checkers_mcts_amd import keras_h5
+    bad = tmp_path / "x.h5"
+    bad.write_bytes(b"not an hdf5 file" * 10)
+    with pytest.raises(keras_h5.H5Error):
+        keras_h5.H5File(str(bad))
