@@ -15,17 +15,20 @@
 // subnormal range; they are folded into bias / BatchNorm constants on the host
 // (fused.pack_split_weights), the kernel never multiplies by them.
 //
-// Layout (cf. ckr_conv.hip): a workgroup keeps FOUR boards (256 positions) resident in LDS
-// through all layers as unpadded rows of [128 hi | 128 lo] fp16 (512 B) whose 16-byte k-slots are
-// XOR-swizzled with the row number (conflict-free ds_read_b128, one v_xor per read): 128 KB, and
-// 4 096 boards make exactly four rounds of 256 workgroups.  Weights stream through a 3-slot LDS
-// ring of 16-input-channel slices (128 output rows x [16 hi | 16 lo] = 8 KB, 64-B rows without
-// padding: the four 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3, which keeps
-// the 16 lanes one ds_read_b128 cycle serves on 16 distinct bank groups; the swizzle is applied
-// by the host packer, so the HBM image is the LDS image) filled by buffer_load ... lds two
-// slots ahead, exactly one 1-KB piece per wave and slot.  8 waves (two per SIMD): wave (wc, wp) owns channels
-// [64wc,+64) x positions [64wp,+64) = 2 x 2 MFMA tiles; per 16-deep k-chunk 8 fragment reads
-// feed 12 MFMAs.
+// Layout: a workgroup of FOUR waves keeps TWO boards (128 positions) resident in LDS through all
+// layers as unpadded rows of [128 hi | 128 lo] fp16 (512 B) whose 16-byte k-slots are XOR-swizzled
+// with the row number (conflict-free ds_read_b128, one v_xor per read): 64 KB, so two workgroups
+// share a CU and one wave of each shares a SIMD.  Wave wc owns output channels [32 wc, +32) of
+// all 128 positions: 1 x 4 MFMA tiles, 12 MFMAs per 16-deep k-chunk fed by 8 ds_read_b128
+// (activation fragments) and 2 buffer_load_dwordx4 (weight fragments).  The weights do NOT pass
+// through LDS: the host packs them in MFMA fragment order ([slot][wave][hi | lo][lane] x 16 B, one
+// contiguous stream for the whole network) and every wave loads its own A fragments from L2 / L1
+// straight into a 4-deep register ring, three k-chunks ahead.  Nothing inside a layer is shared
+// between waves any more -- no weight ring, no per-chunk barrier -- so the waves free-run and the
+// two workgroups of a CU drift apart: one's epilogue (VALU + LDS stores, no MFMA) runs under the
+// other's MFMAs.  (Predecessor, round 1: 8 waves x 4 boards with a 3-slot LDS weight ring filled by
+// buffer_load ... lds and one s_barrier per k-chunk; the barrier + DMA issue cost 9 % of the
+// kernel, its epilogues another 7 % with the matrix pipe idle.)
 #include "ckr_host.h"
 #include <hip/hip_runtime.h>
 
@@ -34,34 +37,33 @@ namespace ckrx {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int MAX_LAYERS = 9;
-constexpr int NT = 512;                                          // 8 waves
-constexpr int TILE = 4;                                          // boards per workgroup
+constexpr int NT = 256;                                          // 4 waves
+constexpr int TILE = 2;                                          // boards per workgroup
 constexpr int XP = 64 * TILE;                                    // positions per workgroup
+constexpr int PT = XP / 32;                                      // position tiles per wave
 constexpr int AROW = 512;                                        // [128 hi | 128 lo] fp16, swizzled, no padding
 constexpr int LO = 256;                                          // byte offset of the lo half of a row
 constexpr int ZBASE = XP * AROW;                                 // 512-B zero region for out-of-board taps
 constexpr int ACT_BYTES = ZBASE + 512;
-constexpr int WPITCH = 64;                                       // [16 hi | 16 lo] fp16 per weight row, chunks swizzled, no padding
-constexpr int WLO = 32;                                          // logical chunk 2: xor into the swizzled chunk address
-constexpr int SLOT_BYTES = 128 * WPITCH;                         // 16 input channels of one tap
-constexpr int SLOT_U4 = SLOT_BYTES / 16;
-constexpr int PIECES = SLOT_BYTES / 1024;                        // 8 DMA pieces of 1 KB: one per wave
-static_assert(PIECES == 8, "one DMA piece per wave and slot");
-constexpr int NRING = 3;
-constexpr int PRM_BYTES = 3 * 128 * 4;
-constexpr int LDS_BYTES = ACT_BYTES + NRING * SLOT_BYTES + PRM_BYTES;   // 157 696 B
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int PRM_BYTES = 2 * 128 * 4;                           // BatchNorm scale | shift of the running layer (wave-private quarters)
+constexpr int STAGE_BYTES = 8 * 131 * 4 + 32;                    // staging of the 1x1 heads' weights
+constexpr int LDS_BYTES = ACT_BYTES + PRM_BYTES + STAGE_BYTES;   // 71 296 B: two workgroups per CU
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+constexpr int SLOT_BYTES = 4 * 2 * 64 * 16;                      // one 16-input-channel slice of a tap: [wave][hi | lo][lane] x 16 B
+constexpr int RING = 4;                                          // register ring of A fragments: RING - 1 slots ahead of the MFMAs
 
 struct LayerDev {
-    const uint4* w;            // [n_slots][128 rows][64 B, swizzled]: first layer 9 slots (one per tap), else 72 (tap*8 + slice)
     const float* bias; const float* scale; const float* shift;   // pre-scaled on the host
     float* out;                // optional [B,8,8,128] float32 (activation * XS)
 };
 struct Args {
     const float* x;            // [B,8,8,14] float32 NHWC
+    const uint4* w;            // the whole network's weight stream: layer 0 = 9 slots (one per tap, 14 planes in one
+                               // 16-channel slice), then 72 per layer (tap * 8 + slice), + RING - 1 slots of padding
+    long long w_bytes;
     long long n_boards;
     int n_layers;
     int has_heads;
@@ -75,70 +77,59 @@ struct Args {
 // byte address of the hi half's 16-byte k-slot `ks` (8 channels) of activation row `r` (lo: + LO)
 __device__ __forceinline__ int act_addr(int r, int ks) { return r * AROW + ((ks ^ (r & 15)) << 4); }
 
-// one ring slot = 8 wave-instructions of 64 lanes x 16 B: wave w moves bytes [1024 w, +1024)
-__device__ __forceinline__ void issue_slot(const uint4* __restrict__ src, char* dst, int wave, int lane) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, SLOT_BYTES, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+struct AF { f16x8 h, l; };                                       // this lane's A fragment (32 channels x 16 k): hi, lo
+struct BF { f16x8 h[PT], l[PT]; };                               // B fragments of the wave's four position tiles
+
+// A fragments of global slot g: two fully coalesced 1-KB loads per wave (buffer addressing: the slot offset
+// lives in an SGPR, hi / lo are immediate offsets)
+__device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rsrc, int voff, int g, AF& a) {
+    const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, g * SLOT_BYTES, 0);
+    const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024, g * SLOT_BYTES, 0);
+    a.h = *reinterpret_cast<const f16x8*>(&h);
+    a.l = *reinterpret_cast<const f16x8*>(&l);
 }
 
-struct Frags { f16x8 ah[2], al[2], bh[2], bl[2]; };
-
-// the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half);
-// wa = byte offset of this lane's hi weight chunk (k-half `half`) of row wrow0 inside a slot, swizzled
-__device__ __forceinline__ void load_frags(const char* __restrict__ act, const char* __restrict__ wbuf, int c8, int wa,
-                                           const int (&rowaddr)[2], Frags& f) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        f.ah[ct] = *reinterpret_cast<const f16x8*>(wbuf + (wa + 32 * ct * WPITCH));
-        f.al[ct] = *reinterpret_cast<const f16x8*>(wbuf + ((wa + 32 * ct * WPITCH) ^ WLO));
-    }
+// the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half)
+__device__ __forceinline__ void load_b(const char* __restrict__ act, int c8, const int (&rowaddr)[PT], BF& f) {
     const int kc = (2 * c8) << 4;
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        f.bh[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc));
-        f.bl[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc) + LO);
+    for (int pt = 0; pt < PT; ++pt) {
+        f.h[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc));
+        f.l[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc) + LO);
     }
 }
 
-__device__ __forceinline__ void mfma_block(const Frags& f, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void mfma_block(const AF& a, const BF& b, f32x16 (&acc)[PT]) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[ct], f.bl[pt], acc[ct][pt], 0, 0, 0);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[ct], f.bh[pt], acc[ct][pt], 0, 0, 0);
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
 }
 
-// 8 ds_read_b128 of the next slot between the first MFMAs of the current one; the ring refill (one
-// buffer_load ... lds per wave) is pinned behind the first MFMA: issued straight after the barrier release
-// it would hold back both waves of a SIMD while the matrix pipe has nothing queued
-__device__ __forceinline__ void interleave_reads_with_mfma() {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
-    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // the DMA piece (VMEM read), when the step has one
+// one k-chunk: 12 MFMAs with the next chunk's 8 ds_read_b128 and the two weight loads of the chunk RING - 1 ahead
+// spread between them
+__device__ __forceinline__ void interleave() {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 0; i < 2 * PT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // 1 VMEM read
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * PT - 2 * PT - 2, 0);
 }
 
-// Row addresses (k-slot `half`) of the two B-tile rows this lane reads for tap (dy, dx); out-of-board
-// taps read the zero region with the swizzle of the row they replace (conflict-free).
-__device__ __forceinline__ void tap_rows(int prow0, int tap, int half, int (&rowaddr)[2]) {
+// Row addresses (k-slot `half`) of the B-tile rows this lane reads for tap (dy, dx); out-of-board taps read the
+// zero region with the swizzle of the row they replace (conflict-free).
+__device__ __forceinline__ void tap_rows(int prow0, int tap, int half, int (&rowaddr)[PT]) {
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
         const int p = prow0 + 32 * pt, y = (p >> 3) & 7, x = p & 7, r = p + 8 * dy + dx;
         const bool ok = (unsigned)(y + dy) < 8u && (unsigned)(x + dx) < 8u;
         rowaddr[pt] = (ok ? r * AROW : ZBASE) + (((r & 15) ^ half) << 4);
@@ -154,33 +145,35 @@ __device__ __forceinline__ void split1(float y, _Float16& h, _Float16& l, float&
 }
 
 // ReLU + BatchNorm affine (bias already in the accumulators, constants pre-scaled), split, store in place
-__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, int prow0, const f32x16 (&acc)[2][2],
-                                         int32_t* overflow) {
+__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, const f32x16 (&acc)[PT], int32_t* overflow) {
 #pragma clang fp contract(fast)
-    asm volatile("" : "+v"(prow0), "+v"(lane));    // compute the store addresses here, not at kernel entry
+    asm volatile("" : "+v"(lane));                 // compute the store addresses here, not at kernel entry
+    const int prow0 = lane & 31;
     float amax = 0.0f;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * wc + 8 * g + 4 * (lane >> 5);
+        const float4 sc = *reinterpret_cast<const float4*>(prm + c0);
+        const float4 sh = *reinterpret_cast<const float4*>(prm + 128 + c0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 64 * wc + 32 * ct + 8 * g + 4 * (lane >> 5);
-            const float4 sc = *reinterpret_cast<const float4*>(prm + c0);
-            const float4 sh = *reinterpret_cast<const float4*>(prm + 128 + c0);
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                f16x4 h, l;
-                _Float16 hh, ll;
-                split1(sc.x * fmaxf(acc[ct][pt][4 * g + 0], 0.0f) + sh.x, hh, ll, amax); h[0] = hh; l[0] = ll;
-                split1(sc.y * fmaxf(acc[ct][pt][4 * g + 1], 0.0f) + sh.y, hh, ll, amax); h[1] = hh; l[1] = ll;
-                split1(sc.z * fmaxf(acc[ct][pt][4 * g + 2], 0.0f) + sh.z, hh, ll, amax); h[2] = hh; l[2] = ll;
-                split1(sc.w * fmaxf(acc[ct][pt][4 * g + 3], 0.0f) + sh.w, hh, ll, amax); h[3] = hh; l[3] = ll;
-                char* dst = act + act_addr(prow0 + 32 * pt, c0 >> 3) + ((c0 & 7) << 1);
-                *reinterpret_cast<f16x4*>(dst) = h;
-                *reinterpret_cast<f16x4*>(dst + LO) = l;
-            }
+        for (int pt = 0; pt < PT; ++pt) {
+            f16x4 h, l;
+            _Float16 hh, ll;
+            split1(sc.x * fmaxf(acc[pt][4 * g + 0], 0.0f) + sh.x, hh, ll, amax); h[0] = hh; l[0] = ll;
+            split1(sc.y * fmaxf(acc[pt][4 * g + 1], 0.0f) + sh.y, hh, ll, amax); h[1] = hh; l[1] = ll;
+            split1(sc.z * fmaxf(acc[pt][4 * g + 2], 0.0f) + sh.z, hh, ll, amax); h[2] = hh; l[2] = ll;
+            split1(sc.w * fmaxf(acc[pt][4 * g + 3], 0.0f) + sh.w, hh, ll, amax); h[3] = hh; l[3] = ll;
+            char* dst = act + act_addr(prow0 + 32 * pt, c0 >> 3) + ((c0 & 7) << 1);
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + LO) = l;
         }
+    }
     if (overflow && amax > 60000.0f) *overflow = 1;               // results are saturated: the caller must not trust them
 }
+
+// all LDS traffic of this wave done, then the workgroup's four waves meet (a bare s_barrier: __syncthreads()
+// would also drain vmcnt, i.e. the weight fragments in flight for the next layer)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // 1x1 convolution head on the LDS-resident activations: thread = position, float32 arithmetic
 template <int NOUT>
@@ -220,88 +213,81 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
     __syncthreads();
 }
 
-// One layer.  `ring` = ring index of the layer's slot 0; slots s, s+1, s+2 are landed / in flight when step s
-// starts.  CPT = ring slots (16-channel slices) per tap: 1 (first layer: 14 planes in one slice) or 8.
-// Each step: boundary (slot s+1 landed for every wave; the buffer of slot s -- whose fragments are
-// already in registers -- is re-filled with slot s+3), fragment loads of slot s+1, MFMAs of slot s.
-template <int CPT>
-__device__ __forceinline__ void run_layer(const Args& A, int l, char* act, char* wring, float* prm, int tid, int wave,
-                                          int lane, int wc, int prow0, int wrow0, int& ring) {
+// One layer.  g0 = global index of the layer's slot 0 in the weight stream; R0 = its position in the register ring
+// (the ring holds slots s .. s + RING - 2 when step s starts, also across layers).  CPT = slots (16-channel slices)
+// per tap: 1 (first layer: 14 planes in one slice) or 8.  Per step: weight fragments of slot s + RING - 1 requested,
+// activation fragments of slot s + 1 read, 12 MFMAs of slot s.
+template <int CPT, int R0>
+__device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float* prm, __amdgpu_buffer_rsrc_t rsrc, int voff,
+                                          int g0, AF (&ring)[RING], int wc, int lane) {
     constexpr int NSLOTS = 9 * CPT;
     const LayerDev& L = A.L[l];
-    asm volatile("" : "+v"(prow0), "+v"(wrow0), "+v"(lane));     // per-layer address arithmetic stays inside the layer
-    const int half = lane >> 5;
-    const int wa = wrow0 * WPITCH + ((half ^ ((lane >> 2) & 3)) << 4);    // (row >> 2) & 3 == (lane >> 2) & 3: wrow0 = 64 wc + (lane & 31)
-    f32x16 acc[2][2];
+    asm volatile("" : "+v"(lane));                 // per-layer address arithmetic stays inside the layer
+    const int half = lane >> 5, prow0 = lane & 31;
+    f32x16 acc[PT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int q = 0; q < 4; ++q) {
+        const float4 bi = *reinterpret_cast<const float4*>(L.bias + 32 * wc + 8 * q + 4 * half);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bi = *reinterpret_cast<const float4*>(L.bias + 64 * wc + 32 * ct + 8 * q + 4 * half);
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                acc[ct][pt][4 * q + 0] = bi.x; acc[ct][pt][4 * q + 1] = bi.y;
-                acc[ct][pt][4 * q + 2] = bi.z; acc[ct][pt][4 * q + 3] = bi.w;
-            }
+        for (int pt = 0; pt < PT; ++pt) {
+            acc[pt][4 * q + 0] = bi.x; acc[pt][4 * q + 1] = bi.y;
+            acc[pt][4 * q + 2] = bi.z; acc[pt][4 * q + 3] = bi.w;
         }
-    if (tid < 128) { prm[tid] = L.scale[tid]; prm[128 + tid] = L.shift[tid]; }
-    Frags f0, f1;
-    int rowaddr[2];
+    }
+    // the wave's own 32 channels of the BatchNorm constants: written and read by this wave only (no barrier)
+    if (lane < 32) { prm[32 * wc + lane] = L.scale[32 * wc + lane]; prm[128 + 32 * wc + lane] = L.shift[32 * wc + lane]; }
+    BF b0, b1;
+    int rowaddr[PT];
     tap_rows(prow0, 0, half, rowaddr);
-    load_frags(act, wring + ring * SLOT_BYTES, 0, wa, rowaddr, f0);
+    load_b(act, 0, rowaddr, b0);
     __builtin_amdgcn_sched_barrier(0);
-    // one step: slot s (fragments in fc) is multiplied while the fragments of slot s+1 load into fn
-    auto step = [&](int s, int tap, int c8, Frags& fc, Frags& fn) {
-        char* cur = wring + ring * SLOT_BYTES;
-        const int nring = ring == NRING - 1 ? 0 : ring + 1;
-        // (a bare s_barrier: __syncthreads() would also wait vmcnt(0) and drain the look-ahead; every wave has
-        // one piece of slot s+1 and one of slot s+2 outstanding)
-        asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
-        if (s + 3 < NSLOTS) issue_slot(L.w + (size_t)(s + 3) * SLOT_U4, cur, wave, lane);
-        else if (l + 1 < A.n_layers) issue_slot(A.L[l + 1].w + (size_t)(s + 3 - NSLOTS) * SLOT_U4, cur, wave, lane);
+    auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BF& bc, BF& bn) {
+        load_a(rsrc, voff, g0 + s + RING - 1, apf);               // beyond the layer: the next layer's first slots / the padding
         if (s + 1 < NSLOTS) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
-            load_frags(act, wring + nring * SLOT_BYTES, c8 == CPT - 1 ? 0 : c8 + 1, wa, rowaddr, fn);
-            mfma_block(fc, acc);
-            interleave_reads_with_mfma();
-        } else {
-            mfma_block(fc, acc);
+            load_b(act, c8 == CPT - 1 ? 0 : c8 + 1, rowaddr, bn);
         }
-        ring = nring;
+        mfma_block(ac, bc, acc);
+        interleave();
     };
     if constexpr (CPT == 1) {
 #pragma unroll
         for (int s = 0; s < NSLOTS; ++s) {
-            if (s & 1) step(s, s, 0, f1, f0);
-            else step(s, s, 0, f0, f1);
+            if (s & 1) step(s, s, 0, ring[(R0 + s) % RING], ring[(R0 + s + RING - 1) % RING], b1, b0);
+            else step(s, s, 0, ring[(R0 + s) % RING], ring[(R0 + s + RING - 1) % RING], b0, b1);
         }
     } else {
+        static_assert(CPT % RING == 0 || CPT == 1, "ring positions must repeat per tap");
         for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
             for (int c8 = 0; c8 < CPT; c8 += 2) {
-                step(tap * CPT + c8, tap, c8, f0, f1);
-                step(tap * CPT + c8 + 1, tap, c8 + 1, f1, f0);
+                step(tap * CPT + c8, tap, c8, ring[(R0 + c8) % RING], ring[(R0 + c8 + RING - 1) % RING], b0, b1);
+                step(tap * CPT + c8 + 1, tap, c8 + 1, ring[(R0 + c8 + 1) % RING], ring[(R0 + c8 + RING) % RING], b1, b0);
             }
         }
     }
-    epilogue(act, prm, wc, lane, prow0, acc, A.overflow);
-    __syncthreads();
+    lds_barrier();                                 // every wave has read its last activation fragments
+    epilogue(act, prm, wc, lane, acc, A.overflow);
+    lds_barrier();                                 // the layer's output is complete
 }
 
-__global__ __launch_bounds__(NT, 1) void k_conv_stack_x3(const Args A) {
+__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* act = smem;
-    char* wring = smem + ACT_BYTES;
-    float* prm = reinterpret_cast<float*>(smem + ACT_BYTES + NRING * SLOT_BYTES);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wc = wave >> 2, wp = wave & 3;
+    float* prm = reinterpret_cast<float*>(smem + ACT_BYTES);
+    float* stage = reinterpret_cast<float*>(smem + ACT_BYTES + PRM_BYTES);
+    const int tid = threadIdx.x, wc = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const long long board0 = (long long)blockIdx.x * TILE;
     const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
     if (A.range && (board0 >= A.range[1] || board0 + TILE <= A.range[0])) return;   // arena / tail: not this launch's share
 
-    for (int i = 0; i < NRING; ++i) issue_slot(A.L[0].w + (size_t)i * SLOT_U4, wring + i * SLOT_BYTES, wave, lane);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, (int)A.w_bytes, 0x00020000);
+    const int voff = wc * 2048 + lane * 16;
+    AF ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) load_a(rsrc, voff, i, ring[i]);
     for (int i = tid; i < ACT_BYTES / 16; i += NT) reinterpret_cast<uint4*>(act)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    lds_barrier();
     // boards of the tile that lie outside the launch's board range (arena shares, tail of a run) keep all-zero
     // planes: their rows may hold stale data, which must neither cost range checks nor raise the overflow flag
     const long long brd = board0 + (tid >> 6);
@@ -326,14 +312,10 @@ __global__ __launch_bounds__(NT, 1) void k_conv_stack_x3(const Args A) {
         *reinterpret_cast<f16x8*>(act + act_addr(tid, 1) + LO) = w1;
         if (A.overflow && amax > 60000.0f) *A.overflow = 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int prow0 = 64 * wp + (lane & 31);
-    const int wrow0 = 64 * wc + (lane & 31);
-    int ring = 0;
+    lds_barrier();
     for (int l = 0; l < A.n_layers; ++l) {
-        if (l == 0) run_layer<1>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
-        else run_layer<8>(A, l, act, wring, prm, tid, wave, lane, wc, prow0, wrow0, ring);
+        if (l == 0) run_layer<1, 0>(A, l, act, prm, rsrc, voff, 0, ring, wc, lane);
+        else run_layer<8, 9 % RING>(A, l, act, prm, rsrc, voff, 9 + 72 * (l - 1), ring, wc, lane);
         float* out = A.L[l].out;
         if (out) {                                                // (tests) activation * XS as float32
             float* dst = out + board0 * 64 * 128;
@@ -345,9 +327,9 @@ __global__ __launch_bounds__(NT, 1) void k_conv_stack_x3(const Args A) {
         }
         if (A.has_heads) {
             if (l == A.n_layers - 2 && A.H.val_out)
-                head_1x1<1>(act, prm, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid, A.inv_xs);
+                head_1x1<1>(act, stage, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid, A.inv_xs);
             if (l == A.n_layers - 1 && A.H.pol_out)
-                head_1x1<8>(act, reinterpret_cast<float*>(wring), A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift,
+                head_1x1<8>(act, stage, A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift,
                             A.H.pol_out, board0, rows_valid, tid, A.inv_xs);
         }
     }
@@ -380,13 +362,22 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     } else {
         A.H = ckr_conv_heads{};
     }
+    // the weight images of the layers form ONE stream (fused.pack_split_stream): layer i + 1 starts where layer i
+    // ends, and RING - 1 slots of padding follow the last one (the fragment prefetch runs that far ahead)
+    const char* expect = (const char*)layers[0].weights;
     for (int i = 0; i < n_layers; ++i) {
         const ckr_conv_layer& s = layers[i];
         if (!s.weights || !s.bias || !s.scale || !s.shift) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null layer pointer");
         if ((i == 0 && s.cin_pad != 32) || (i > 0 && s.cin_pad != 128))
             return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: layer 0 must have cin_pad 32, later layers 128");
-        A.L[i] = LayerDev{(const uint4*)s.weights, s.bias, s.scale, s.shift, (float*)s.out};
+        if ((const char*)s.weights != expect)
+            return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: layer %d's weights do not continue the stream of layer %d "
+                                              "(pack all layers with fused.pack_split_stream)", i, i - 1);
+        expect += (size_t)(i == 0 ? 9 : 72) * SLOT_BYTES;
+        A.L[i] = LayerDev{s.bias, s.scale, s.shift, (float*)s.out};
     }
+    A.w = (const uint4*)layers[0].weights;
+    A.w_bytes = (long long)(expect - (const char*)layers[0].weights) + (long long)(RING - 1) * SLOT_BYTES;
     const int grid = (int)((n_boards + TILE - 1) / TILE);
     hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());

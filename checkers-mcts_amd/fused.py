@@ -55,10 +55,10 @@ XS, WS = 8.0, 1024.0         # power-of-two operand scales of the split-fp16 pat
 
 
 def pack_split_weights(w, first):
-    """Ring-slot image of ckr_conv_stack_f16x3: fp16 [n_slots][128 out][4 chunks of 8] of w * WS; slot = tap
-    (first layer: 14 planes in one 16-channel slice) or tap*8 + slice.  A row's logical 16-byte chunks are
-    [hi k 0-7 | hi k 8-15 | lo k 0-7 | lo k 8-15]; chunk c of row r is stored at position c ^ ((r >> 2) & 3)
-    (the kernel's bank-conflict-free LDS layout: the image is DMA'd into the ring verbatim, no padding)."""
+    """One layer of ckr_conv_stack_f16x3's weight stream: fp16 [n_slots][4 waves][hi | lo][64 lanes][8] of w * WS in
+    MFMA A-fragment order -- slot = tap (first layer: 14 planes in one 16-channel slice) or tap*8 + slice; wave wc
+    owns output channels [32 wc, +32); lane l holds channel 32 wc + (l & 31), input channels 16 slice + 8 (l >> 5) + 0..7.
+    Every (slot, wave, hi | lo) block is one contiguous 1-KB buffer_load_dwordx4 of the wave that consumes it."""
     cout, cin = w.shape[0], w.shape[1]
     assert cout == 128 and w.shape[2:] == (3, 3) and cin <= (16 if first else 128)
     q = 1 if first else 8
@@ -68,13 +68,24 @@ def pack_split_weights(w, first):
         raise OverflowError("conv weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
     hi = t.to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
-    rows = torch.stack([hi.reshape(9, cout, q, 2, 8), lo.reshape(9, cout, q, 2, 8)], dim=3)      # [tap][out][slice][hi|lo][k-half][8]
-    rows = rows.permute(0, 2, 1, 3, 4, 5).reshape(9 * q, cout, 4, 8)                            # [slot][out][logical chunk][8]
-    r = torch.arange(cout, device=w.device)
-    phys = torch.arange(4, device=w.device)[None, :] ^ ((r[:, None] >> 2) & 3)                   # logical chunk stored at `phys`
-    img = torch.empty_like(rows)
-    img[:, r[:, None], phys] = rows
-    return img.reshape(9 * q, cout, 32).contiguous()
+    both = torch.stack([hi, lo], dim=0).reshape(2, 9, 4, 32, q, 2, 8)          # [hl][tap][wc][row][slice][k-half][8]
+    img = both.permute(1, 4, 2, 0, 5, 3, 6)                                      # [tap][slice][wc][hl][k-half][row][8]
+    return img.reshape(9 * q, 4, 2, 64, 8).contiguous()                          # lane = 32 * k-half + row
+
+
+STREAM_PAD_SLOTS = 3         # the kernel's register ring requests weight fragments three slots ahead, also past the last layer
+
+
+def pack_split_stream(weights):
+    """[layer 0 conv weight, layer 1, ...] -> (one contiguous fp16 stream, element offset of every layer): the layers'
+    images back to back + STREAM_PAD_SLOTS slots of zero padding."""
+    imgs = [pack_split_weights(w, i == 0).reshape(-1) for i, w in enumerate(weights)]
+    offs, n = [], 0
+    for im in imgs:
+        offs.append(n)
+        n += im.numel()
+    pad = torch.zeros(STREAM_PAD_SLOTS * 4 * 2 * 64 * 8, dtype=torch.float16, device=imgs[0].device)
+    return torch.cat(imgs + [pad]).contiguous(), offs
 
 
 def pack_dense_weights(w):
@@ -140,21 +151,25 @@ class FusedEvaluator:
         odt = torch.float32 if split else torch.bfloat16
         y_body = torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if self.debug else None
         y_pol = torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if self.debug else None
+        stream = offs = None
+        if split:                                                          # all layers' weights in one fragment-ordered stream
+            stream, offs = pack_split_stream([_f32(blk["conv"].weight) for blk in blocks])
+            keep.append(stream)
         for i, blk in enumerate(blocks):
             cin_pad = 32 if i == 0 else 128
             b = _f32(blk["conv"].bias)
             sc, sh = bn_affine(blk["bn"])
             if split:                                                      # power-of-two scalings: exact
-                w = pack_split_weights(_f32(blk["conv"].weight), i == 0)
+                wptr = stream.data_ptr() + 2 * offs[i]
                 b, sc, sh = (b * (XS * WS)).contiguous(), (sc / WS).contiguous(), (sh * XS).contiguous()
             else:
                 w = pack_conv_weights(_f32(blk["conv"].weight), i == 0)
-            keep += [w, b, sc, sh]
+                keep.append(w)
+                wptr = w.data_ptr()
+            keep += [b, sc, sh]
             out = y_body if i == len(blocks) - 2 else (y_pol if i == len(blocks) - 1 else None)
-            layers[i] = ConvLayer(w.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+            layers[i] = ConvLayer(wptr, b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                   out.data_ptr() if out is not None else None, cin_pad)
-        # zero-filled, not empty: rows outside a launch's board range are never written by the conv kernel but are
-        # read by the tail kernels (whose range check must not trip over uninitialised memory)
         pol_feat = torch.zeros((S, 512), dtype=torch.float32, device=dev)
         val_feat = torch.zeros((S, 64), dtype=torch.float32, device=dev)
         t = dict(pol_w=_f32(net.pol2["conv"].weight).reshape(8, 128).contiguous(), pol_b=_f32(net.pol2["conv"].bias),

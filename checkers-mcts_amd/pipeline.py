@@ -30,8 +30,28 @@ from . import codec, dist as ckdist, engine as ckengine
 from .net import NetEvaluator, PolicyValueNet, make_net
 
 
-def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128):
-    """NN_FN -> network on the device (see module docstring)."""
+class HashNet(torch.nn.Module):
+    """The deterministic integer test network of the parity suite (rules.hashnet, the same arithmetic as the
+    reference-side hash net the golden fixtures were generated with) behind the module interface; spec "hash:<salt>"."""
+
+    def __init__(self, salt):
+        super().__init__()
+        self.salt, self.num_kernels = int(salt), 0
+
+    def forward(self, x_nchw):
+        from . import rules
+        return rules.hashnet(x_nchw.permute(0, 2, 3, 1).contiguous().float(), self.salt)
+
+
+def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128, networks=None):
+    """NN_FN -> network on the device (see module docstring).  `networks` (the optional NETWORKS key of the
+    kwargs dicts) maps file names to replacement specifications or modules: pre-loaded networks by name."""
+    if networks and isinstance(spec, str) and spec in networks:
+        spec = networks[spec]
+    if isinstance(spec, HashNet):
+        return spec
+    if isinstance(spec, str) and spec.startswith("hash:"):
+        return HashNet(int(spec.split(":", 1)[1]))
     if isinstance(spec, torch.nn.Module):
         net = spec.eval().to(device=device, dtype=dtype)
         return net.to(memory_format=torch.channels_last) if device != "cpu" else net
@@ -59,13 +79,16 @@ def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128):
     raise ValueError("unsupported network specification: %r" % (spec,))
 
 
-def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None):
+def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None, networks=None):
     """Evaluator for the engine.  The hand-written MFMA conv stack (fused.FusedEvaluator,
     weights taken from the float32 network) serves bfloat16 (throughput mode, bf16 operands)
     and float32 (split-fp16 operands with float32 accumulation: float32-grade results, the
     parity mode); float16, or kind="torch", runs the PyTorch module instead."""
     if kind not in (None, "fused", "torch"):
         raise ValueError("evaluator kind must be 'fused' or 'torch'")
+    if networks:
+        spec = networks.get(spec, spec) if isinstance(spec, str) else spec
+        spec_old = networks.get(spec_old, spec_old) if isinstance(spec_old, str) else spec_old
     if kind != "torch" and dtype in (torch.bfloat16, torch.float32) and _is_128_wide(spec, spec_old):
         from .fused import FusedEvaluator
         new = load_network(spec, device=device, dtype=torch.float32)
@@ -82,6 +105,8 @@ def _is_128_wide(*specs):
     """The fused kernels are built for NUM_KERNELS = 128 (training_pipeline.py:61).  Modules and
     checkpoint files are inspected (the width is the first body conv's output-channel count)."""
     for sp in specs:
+        if isinstance(sp, HashNet) or (isinstance(sp, str) and sp.startswith("hash:")):
+            return False
         if isinstance(sp, torch.nn.Module):
             if sp.body[0]["conv"].weight.shape[0] != 128:
                 return False
@@ -224,6 +249,7 @@ class generate_Checkers_data:
         # False (default) = the reference's fixed NUM_SELFPLAY_GAMES per worker; True = a finished slot pulls the
         # next unplayed game of the job (same total, no idle tail; ~1.4x games/hour on a 16 384-game run)
         self.dynamic_queue = selfplay_kwargs.get("DYNAMIC_QUEUE", False)
+        self.networks = selfplay_kwargs.get("NETWORKS")                  # {file name: replacement spec / module}
         self.stats = None
         self.results = None
 
@@ -242,7 +268,7 @@ class generate_Checkers_data:
                 feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
             if self.mcts_kwargs["NEURAL_NET"]:
-                runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count), use_graph=self.use_graph)
+                runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count, networks=self.networks), use_graph=self.use_graph)
                 runner.run_to_completion()
             else:                                  # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
                 eng.set_ln_table()
@@ -287,6 +313,7 @@ class tournament_Checkers:
         self.seed = tourney_kwargs.get("SEED", int.from_bytes(os.urandom(4), "little"))
         self.nodes_per_tree = tourney_kwargs.get("NODES_PER_TREE")
         self.use_graph = tourney_kwargs.get("USE_GRAPH", True)
+        self.networks = tourney_kwargs.get("NETWORKS")                   # {file name: replacement spec / module}
         self.stats = None
 
     def start_tournament(self):
@@ -309,8 +336,8 @@ class tournament_Checkers:
                 first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
                 seed=self.seed, device=dev.index)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
-            runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn),
-                                use_graph=self.use_graph)
+            runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn,
+                                                    networks=self.networks), use_graph=self.use_graph)
             runner.run_to_completion()
             self.stats = eng.stats()
             res = eng.results()
@@ -411,7 +438,15 @@ class final_evaluation:
 
     def start_evaluation(self, num_cpus=None):
         M = len(self.model_fn_list)
-        pairs = [(new, old) for new in range(M - 1, 0, -1) for old in range(new)]      # the reference's pop() order
+        if num_cpus is not None:
+            self.num_cpus = num_cpus
+        pairs = []                     # the reference's order: newest model first (pop()), its opponents in chunks of num_cpus
+        for new in range(M - 1, 0, -1):                                   # taken from the END of the remaining list (:646-654)
+            olds = list(range(new))
+            while olds:
+                n = max(1, int(self.num_cpus))
+                chunk, olds = (olds[:], []) if len(olds) <= n else (olds[-n:], olds[:-n])
+                pairs += [(new, old) for old in chunk]
         tk = self.tourney_kwargs
         dtype = tk.get("NN_DTYPE", torch.float32)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -420,7 +455,7 @@ class final_evaluation:
             nodes_per_tree=tk.get("NODES_PER_TREE"), seed=tk.get("SEED", int.from_bytes(os.urandom(4), "little")),
             device=dev.index)
         eng = ckengine.Engine(cfg, feature_dtype=dtype)
-        nets = [load_network(self._spec(fn), device=dev, dtype=dtype) for fn in self.model_fn_list]
+        nets = [load_network(self._spec(fn), device=dev, dtype=dtype, networks=tk.get("NETWORKS")) for fn in self.model_fn_list]
         model_of = torch.tensor(pairs, dtype=torch.long, device=dev)
         StepRunner(eng, RoundRobinEvaluator(nets, model_of), use_graph=tk.get("USE_GRAPH", True)).run_to_completion()
         self.stats = eng.stats()

@@ -144,8 +144,12 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
  * float32, Checkers.py:433; BASELINE's parity bar for pi / v is 1e-5): every operand is
  * split into two fp16 terms and wh*xh + wh*xl + wl*xh is accumulated in the float32
  * accumulators of the 16-bit MFMA (csrc/ckr_conv_x3.hip).
- * d_x: float32 NHWC [n_boards][8][8][14].  layers[i].weights: the split image
- * [n_slots][128][16 hi | 16 lo | 8 pad] fp16 of (w * WS), n_slots = 9 (first layer) or 72; bias / scale / shift pre-scaled
+ * d_x: float32 NHWC [n_boards][8][8][14].  layers[i].weights: the layer's part of ONE weight stream
+ * in MFMA fragment order, fp16 [n_slots][4 waves][hi | lo][64 lanes][8] of (w * WS), n_slots = 9 (first
+ * layer: one 16-channel slice per tap) or 72 (tap * 8 + slice); lane l of wave wc holds output channel
+ * 32 wc + (l & 31), input channels 16 slice + 8 (l >> 5) + 0..7.  The layers' images must follow one
+ * another in memory with 3 slots (24 KB) of readable padding behind the last (the kernel requests
+ * fragments three slots ahead; checked); bias / scale / shift pre-scaled
  * by the host (bias*XS*WS, scale/WS, shift*XS) so that the stored activation is
  * y * XS = hi + lo; x_scale = XS (a power of two).  layers[i].out (tests): float32
  * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32.

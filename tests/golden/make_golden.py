@@ -12,6 +12,8 @@ Fixture families:
   selfplay_v1.npz    generate_Checkers_data._generate_data output (state, pi, q, z)
   tournament_v1.npz  tournament_Checkers._start_tournament outcomes
   rollout_v1.npz     NEURAL_NET=False (random-rollout MCTS) self-play tuples with np.random.randint pinned to 0
+  text_v1.json       the text files the pipeline classes write: tournament_Checkers.start_tournament's two tables,
+                     record_params' dumps, final_evaluation's score table (and the score matrix behind it)
 The fixtures are data (inputs + the reference's outputs); no reference source
 is stored.
 """
@@ -335,8 +337,70 @@ def gen_training():
     print("training: %d tuples" % len(mem))
 
 
+# --------------------------------------------------------------------------- text outputs (N3 / N4)
+def gen_text():
+    """The files the reference writes besides the tuple pickles, produced by its own code under the shim:
+    start_tournament() -> Tournament_<ts>.txt (training_pipeline.py:488-503,561-594), record_params() for
+    every phase (:225-244), final_evaluation.start_evaluation() -> Checkers_Final_Evaluation_<ts>.txt
+    (:632-711).  Networks are hash nets (file name '...salt<k>...' -> salt k, ref_shim.salt_of)."""
+    import json
+    import re
+    out = {}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    for d in ("tournament_results", "training_data", "model", "final_eval"):
+        os.makedirs(os.path.join(tmp, "data", d))
+    os.chdir(tmp)
+    real_stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+    try:
+        # 1. tournament tables
+        budget, games, salt_new, salt_old = 24, 2, 3, 5                                  # tournament_v1 case 1
+        mk = mcts_kwargs(budget, training=False)
+        mk["TEMPERATURE_DECAY"] = 0; mk["TEMP_DECAY_DELAY"] = 0
+        tk = dict(NEW_NN_FN="data/model/new_salt%d.h5" % salt_new, OLD_NN_FN="data/model/old_salt%d.h5" % salt_old,
+                  TOURNEY_GAMES=games, NUM_CPUS=1)
+        fn = tp.tournament_Checkers(tk, mk).start_tournament()
+        out["tournament"] = dict(cfg=[budget, games, salt_new, salt_old], filename_pattern=re.sub(r"_\d.*\.txt$", "_<ts>.txt", fn),
+                                 text=open(fn, encoding="utf-8").read())
+        # 2. record_params
+        params = dict(NUM_SELFPLAY_GAMES=25, TERMINATE_CNT=160, NUM_CPUS=4, UCT_C=4, DIRICHLET_ALPHA=1.0,
+                      NN_FN="data/model/Checkers_Model3_29-Jan-2021(16:46:13).h5", LR=[5e-5, 0.01], FLAG=True, NOTE=None)
+        out["record_params"] = {}
+        for phase, folder in (("selfplay", "training_data"), ("training", "model"), ("evaluation", "tournament_results"),
+                              ("final", "final_eval")):
+            before = set(os.listdir(os.path.join("data", folder)))
+            tp.record_params(phase, **params)
+            (new,) = set(os.listdir(os.path.join("data", folder))) - before
+            out["record_params"][phase] = dict(filename_pattern="data/%s/%s" % (folder, re.sub(r"_\d\d-.*\.txt$", "_<ts>.txt", new)),
+                                               text=open(os.path.join("data", folder, new)).read())
+        try:
+            tp.record_params("bogus", A=1)
+            out["record_params"]["bogus_raises"] = None
+        except ValueError as e:
+            out["record_params"]["bogus_raises"] = str(e)
+        out["record_params"]["kwargs_items"] = [[k, v] for k, v in params.items()]       # a list: the order of the keys is part of the text
+        # 3. final evaluation: three "models" = hash nets with salts 1, 4, 6; every pair plays two games
+        iters, salts, fe_budget = [0, 2, 5], [1, 4, 6], 40
+        for it, sa in zip(iters, salts):
+            open("data/model/Checkers_Model%d_salt%d.h5" % (it, sa), "w").close()
+        mk = mcts_kwargs(fe_budget, training=False)
+        mk["TEMPERATURE_DECAY"] = 0; mk["TEMP_DECAY_DELAY"] = 0
+        fe = tp.final_evaluation(list(iters), dict(NUM_CPUS=1), mk)
+        fe.start_evaluation(1)
+        (txt,) = [f for f in os.listdir("data/final_eval") if f.startswith("Checkers_Final_Evaluation_") and f.endswith(".txt")
+                  and "Params" not in f]
+        out["final_evaluation"] = dict(iters=iters, salts=salts, budget=fe_budget, table=fe.table.tolist(),
+                                       game_outcomes=fe.game_outcomes, text=open(os.path.join("data/final_eval", txt), encoding="utf-8").read())
+    finally:
+        sys.stdout = real_stdout
+        os.chdir(cwd)
+    with open(os.path.join(HERE, "text_v1.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False, sort_keys=True)
+    print("text: tournament %d chars, final evaluation table %s" % (len(out["tournament"]["text"]), out["final_evaluation"]["table"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout", "training"]
+    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout", "training", "text"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:

@@ -10,7 +10,8 @@ from checkers_mcts_amd.fused import FusedEvaluator
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = N.PolicyValueNet(128).keras_init(0).eval().cuda()
 fe = FusedEvaluator(m, S, mode=os.environ.get("CONV_MODE", "bf16"))
-x = (torch.rand(S, 8, 8, 14, device="cuda") < 0.2).to(torch.float32 if os.environ.get("CONV_MODE") == "f16x3" else torch.bfloat16).contiguous()
+density = float(os.environ.get("CONV_DENSITY", "0.2"))       # 0 = all-zero planes: the same instruction stream on zero operands (power / DVFS probe)
+x = (torch.rand(S, 8, 8, 14, device="cuda") < density).to(torch.float32 if os.environ.get("CONV_MODE") == "f16x3" else torch.bfloat16).contiguous()
 n = fe.nets[0]
 import ctypes as C
 from checkers_mcts_amd import _lib
