@@ -80,6 +80,8 @@ def parse():
                     help="games every slot plays back to back in the run (reference semantics: NUM_SELFPLAY_GAMES per worker)")
     ap.add_argument("--no-complete", action="store_true", help="skip leg 3 (play the run to its end; M2)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-split", action="store_true",
+                    help="one engine / one stream per GPU instead of two half-batches on two HIP streams (pipeline.SplitRunner)")
     ap.add_argument("--evaluator", choices=["fused", "torch"], default=None,
                     help="fused: conv stack in the hand-written MFMA kernels (fp32 = split-fp16 operands, or bf16); torch: MIOpen via PyTorch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -248,57 +250,108 @@ def conv_roofline(mode, conv_flops, slots, t_conv):
     return out
 
 
-def make_leg(a, dev, mode, first_worker, games_per_slot):
-    """Engine + evaluator + step runner of one precision mode."""
-    from checkers_mcts_amd import engine as ckengine
-    from checkers_mcts_amd.net import NetEvaluator, make_net
-    from checkers_mcts_amd.pipeline import StepRunner
-    dtype = DTYPES[mode]
-    kw = dict(MCTS_KWARGS, BUDGET=a.budget)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
-                                      first_worker_id=first_worker, feature_dtype=dtype, seed=20260929, device=dev.index,
-                                      nodes_per_tree=a.nodes_per_tree or None,
-                                      **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
-    eng = ckengine.Engine(cfg, feature_dtype=dtype)
-    which = a.evaluator or ("fused" if mode in ("bf16", "fp32") else "torch")
-    if which == "fused":
-        if mode not in ("bf16", "fp32"):
+class Leg:
+    """The engine(s) + evaluator(s) + step runner of one precision mode on this rank: one engine on one stream, or
+    (split) two half-batch engines on two streams (pipeline.SplitRunner)."""
+
+    def __init__(self, a, dev, mode, first_worker, games_per_slot, split):
+        from checkers_mcts_amd import engine as ckengine
+        from checkers_mcts_amd.net import NetEvaluator, make_net
+        from checkers_mcts_amd.pipeline import SplitRunner, StepRunner
+        dtype = DTYPES[mode]
+        kw = dict(MCTS_KWARGS, BUDGET=a.budget)
+        self.which = a.evaluator or ("fused" if mode in ("bf16", "fp32") else "torch")
+        if self.which == "fused" and mode not in ("bf16", "fp32"):
             raise SystemExit("--evaluator fused needs --nn-dtype bf16 or fp32")
-        from checkers_mcts_amd.fused import FusedEvaluator
-        evaluator = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
-                                   mode="bf16" if mode == "bf16" else "f16x3")
-    else:
-        evaluator = NetEvaluator(make_net(128, seed=0, device=dev, dtype=dtype))
-    return eng, evaluator, StepRunner(eng, evaluator, use_graph=not a.no_graph), which
+
+        def make_engine(offset, n):
+            cfg = ckengine.config_from_kwargs(kw, n_slots=n, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
+                                              first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
+                                              device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
+                                              **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
+            return ckengine.Engine(cfg, feature_dtype=dtype)
+
+        def make_evaluator(n):
+            if self.which == "fused":
+                from checkers_mcts_amd.fused import FusedEvaluator
+                return FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), n,
+                                      mode="bf16" if mode == "bf16" else "f16x3")
+            return NetEvaluator(make_net(128, seed=0, device=dev, dtype=dtype))
+
+        self.dev, self.split = dev, bool(split)
+        if split:
+            self.runner = SplitRunner(make_engine, make_evaluator, a.slots, use_graph=not a.no_graph)
+            self.engines = self.runner.engines
+            self.evaluators = [r.evaluator for _, r, _ in self.runner.parts]
+        else:
+            eng = make_engine(0, a.slots)
+            self.runner = StepRunner(eng, make_evaluator(a.slots), use_graph=not a.no_graph)
+            self.engines, self.evaluators = [eng], [self.runner.evaluator]
+        self.boards_per_launch = self.engines[0].cfg.n_slots
+
+    def warmup(self, n=3):
+        self.runner.warmup(n)
+
+    def step(self, n):
+        self.runner.step(n)
+
+    @property
+    def steps(self):
+        return self.runner.steps
+
+    def stats(self):
+        out = {}
+        for e in self.engines:
+            for k, v in e.stats().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
+    def check_range(self):
+        for ev in self.evaluators:
+            if hasattr(ev, "check_range"):
+                ev.check_range()
+
+    def run_to_completion(self, trace):
+        if self.split:
+            self.runner.run_to_completion(check_every=100, trace=trace)
+        else:
+            self.runner.run_to_completion(check_every=100, trace=trace)
+
+    def pack_tuples_device(self):
+        return torch.cat([e.pack_tuples_device() for e in self.engines], dim=0)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
 
 
-def timed_window(runner, eng, dev, steps, barrier=lambda: None):
+def timed_window(leg, dev, steps, barrier=lambda: None):
     torch.cuda.synchronize(dev)
-    s0 = eng.stats()
+    s0 = leg.stats()
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    runner.step(steps)
+    leg.step(steps)
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
-    s1 = eng.stats()
+    s1 = leg.stats()
     return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games")}
 
 
 def throughput_leg(a, dev, mode):
     """extra: the same workload in the other precision mode (steady state after a pre-roll)."""
-    eng, evaluator, runner, which = make_leg(a, dev, mode, 0, 64)
-    runner.warmup(3)
-    runner.step(preroll_steps(a))
-    dt, d = timed_window(runner, eng, dev, a.extra_steps)
-    t_conv = time_conv(evaluator, eng.x, dev) if which == "fused" else 0.0
-    eng.close()
+    leg = Leg(a, dev, mode, 0, 64, not a.no_split)
+    leg.warmup(3)
+    leg.step(preroll_steps(a))
+    dt, d = timed_window(leg, dev, a.extra_steps)
+    t_conv = time_conv(leg.evaluators[0], leg.engines[0].x, dev) if leg.which == "fused" else 0.0
     out = {"value": d["expansions"] / dt, "unit": "node-expansions/s", "steps": a.extra_steps,
            "ms_per_step": dt / a.extra_steps * 1e3, "dtype": DTYPE_LABEL[mode], "plies": d["plies"],
            "terminal_visits": d["terminal_visits"], "preroll_steps": preroll_steps(a)}
-    if which == "fused":
-        out["roofline"] = conv_roofline(mode, evaluator.CONV_FLOPS_PER_BOARD, a.slots, t_conv)
+    if leg.which == "fused":
+        out["roofline"] = conv_roofline(mode, leg.evaluators[0].CONV_FLOPS_PER_BOARD, leg.boards_per_launch, t_conv)
+    leg.close()
     if mode == "bf16":
         out["note"] = ("throughput mode, NOT a parity mode: bf16 operands (pi within 5e-3, v within 5e-2 of the float32 network); "
                        "the creditable figure is the float32-grade headline")
@@ -321,7 +374,11 @@ def arena_leg(a, dev):
     runner = StepRunner(eng, ev, use_graph=not a.no_graph)
     runner.warmup(3)
     runner.step(30)
-    dt, d = timed_window(runner, eng, dev, a.extra_steps)
+
+    class _One:                                           # single engine, single stream
+        step = staticmethod(runner.step)
+        stats = staticmethod(eng.stats)
+    dt, d = timed_window(_One, dev, a.extra_steps)
     eng.close()
     return {"sims_per_s": (d["expansions"] + d["terminal_visits"]) / dt, "ms_per_step": dt / a.extra_steps * 1e3,
             "steps": a.extra_steps, "budget": 800, "dtype": DTYPE_LABEL["fp32"],
@@ -377,47 +434,50 @@ def main():
     pre = preroll_steps(a)
     # enough games per slot that no slot runs dry before the timed window is over when leg 3 is skipped
     games_per_slot = a.games_per_slot if not a.no_complete else max(2, (pre + a.steps + a.warmup) // (a.budget * 30) + 2)
-    eng, evaluator, runner, which = make_leg(a, dev, mode, first, games_per_slot)
+    leg = Leg(a, dev, mode, first, games_per_slot, not a.no_split)
+    which = leg.which
 
     # ---- 1. pre-roll (untimed for `value`, timed for the whole run)
     ckdist.barrier()
     torch.cuda.synchronize(dev)
     t_run0 = time.perf_counter()
-    runner.warmup(3)
-    if pre > runner.steps:
-        runner.step(pre - runner.steps)
-    if hasattr(evaluator, "check_range"):
-        evaluator.check_range()
+    leg.warmup(3)
+    if pre > leg.steps:
+        leg.step(pre - leg.steps)
+    leg.check_range()
     # ---- 2. warm-up + the timed window
-    runner.step(a.warmup)
-    dt_local, d = timed_window(runner, eng, dev, a.steps, ckdist.barrier)
+    leg.step(a.warmup)
+    dt_local, d = timed_window(leg, dev, a.steps, ckdist.barrier)
     dt = ckdist.max_over_ranks(dt_local, dev)
     exp_total = ckdist.sum_over_ranks(d["expansions"], dev)
     term_total = ckdist.sum_over_ranks(d["terminal_visits"], dev)
     plies_total = ckdist.sum_over_ranks(d["plies"], dev)
     games_window = ckdist.sum_over_ranks(d["games"], dev)
-    active_after_window = eng.stats()["active_slots"]
+    active_after_window = leg.stats()["active_slots"]
 
-    # ---- instrumented eager pass (its wall time is taken out of the whole-run figure): HIP events on the launch stream
+    # ---- instrumented eager pass on the first engine (its wall time is taken out of the whole-run figure): HIP events on
+    # the launch stream around the tree kernel and the network launches of single steps
     t_probe0 = time.perf_counter()
     t_tree = t_nn = t_conv = 0.0
     if a.profile_steps > 0:
+        eng0, ev0 = leg.engines[0], leg.evaluators[0]
+        r0 = leg.runner.parts[0][1] if leg.split else leg.runner
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.profile_steps)]
         with torch.no_grad():
             for e0, e1, e2 in ev:
                 e0.record()
-                eng.step(runner.p, runner.v)
+                eng0.step(r0.p, r0.v)
                 e1.record()
-                p, v = evaluator(eng)
-                if not getattr(evaluator, "static_outputs", False):
-                    runner.p.copy_(p); runner.v.copy_(v)
+                p, v = ev0(eng0)
+                if not getattr(ev0, "static_outputs", False):
+                    r0.p.copy_(p); r0.v.copy_(v)
                 e2.record()
         torch.cuda.synchronize(dev)
         t_tree = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in ev])) / 1e3
         t_nn = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in ev])) / 1e3
-        # the dominant kernel on its own: one launch per step, against the engine's current leaf features
+        # the dominant kernel on its own: one launch per step (and half-batch), against the engine's current leaf features
         if which == "fused":
-            t_conv = time_conv(evaluator, eng.x, dev, groups=max(3, a.profile_steps // 4))
+            t_conv = time_conv(ev0, eng0.x, dev, groups=max(3, a.profile_steps // 4))
     torch.cuda.synchronize(dev)
     t_probe = time.perf_counter() - t_probe0
 
@@ -425,12 +485,12 @@ def main():
     whole = None
     if not a.no_complete:
         trace = []
-        runner.run_to_completion(check_every=100, trace=trace)
+        leg.run_to_completion(trace)
         torch.cuda.synchronize(dev)
         ckdist.barrier()
         t_play = ckdist.max_over_ranks(time.perf_counter() - t_run0 - t_probe, dev)
-        st = eng.stats()
-        payload = eng.pack_tuples_device()
+        st = leg.stats()
+        payload = leg.pack_tuples_device()
         torch.cuda.synchronize(dev)
         ckdist.barrier()
         g0 = time.perf_counter()
@@ -441,7 +501,7 @@ def main():
         if rank == 0:
             n_rows = int(gathered.shape[0])
             whole = {"games": int(tot["games"]), "games_per_slot": games_per_slot, "seconds": t_play + t_gather,
-                     "play_seconds": t_play, "steps": runner.steps,
+                     "play_seconds": t_play, "steps": leg.steps,
                      "expansions": tot["expansions"], "expansions_per_s": tot["expansions"] / (t_play + t_gather),
                      "plies": tot["plies"], "mean_plies_per_game": tot["plies"] / max(1.0, tot["games"]),
                      "terminal_visit_fraction": tot["terminal_visits"] / max(1.0, tot["expansions"] + tot["terminal_visits"]),
@@ -456,16 +516,17 @@ def main():
     out = None
     if rank == 0:
         peak = MFMA_PEAK_TFLOPS[mode]
-        nn_tflops = FLOPS_PER_EVAL * a.slots / t_nn / 1e12 if t_nn else None
-        tree = {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "bound": "latency", "algorithmic_bytes_per_sim": 536,
-                "achieved_GBps": 536.0 * a.slots / t_tree / 1e9 if t_tree else None}
+        nb = leg.boards_per_launch
+        nn_tflops = FLOPS_PER_EVAL * nb / t_nn / 1e12 if t_nn else None
+        tree = {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "slots_per_launch": nb, "bound": "latency",
+                "algorithmic_bytes_per_sim": 536, "achieved_GBps": 536.0 * nb / t_tree / 1e9 if t_tree else None}
         if which == "fused":
-            roofline = conv_roofline(mode, evaluator.CONV_FLOPS_PER_BOARD, a.slots, t_conv)
+            roofline = conv_roofline(mode, leg.evaluators[0].CONV_FLOPS_PER_BOARD, nb, t_conv)
         else:
             roofline = {"bound": "mfma", "kernel": "network forward via PyTorch/MIOpen (conv3x3 x8 + heads), launch group per step",
                         "achieved": nn_tflops, "peak": peak, "unit": "TFLOP/s",
                         "frac": (nn_tflops / peak) if nn_tflops else None, "traffic": None,
-                        "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": a.slots}
+                        "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": nb}
         roofline.update({"network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
                          "tree_kernel": tree})
         value = exp_total / dt
@@ -489,6 +550,7 @@ def main():
                                       % (a.budget, a.slots),
                           "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": mode, "preroll_steps": pre,
                           "hip_graph": not a.no_graph, "evaluator": which,
+                          "streams": "2 half-batches of %d slots on 2 HIP streams" % nb if leg.split else "1",
                           "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
                "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py); rules, search, tuples "
                          "bit-exact vs the reference golden vectors (under NumPy >= 2 promotion rules)" if mode == "fp32" else
@@ -499,7 +561,7 @@ def main():
                "games_per_hour": whole["games"] / whole["seconds"] * 3600.0 if whole else None,
                "games_per_hour_steady_state_est": (plies_total / dt) * 3600.0 / whole["mean_plies_per_game"] if whole and plies_total else None,
                "whole_run": whole, "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
-    eng.close()
+    leg.close()
     ckdist.barrier()
     if rank == 0:
         print(json.dumps(out))

@@ -210,7 +210,8 @@ __device__ void fresh_root(Wave& w, int t) {
 
 // Semispace copy of the subtree under the cursor (breadth first, children stay
 // contiguous).  64 nodes per pass: lane = node, wave scan assigns child blocks.
-__device__ void compact(Wave& w, int t) {
+// Returns the new index of node `track` (a node of the subtree; -1: none asked for).
+__device__ int compact(Wave& w, int t, int track = -1) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const int half = D.t_half[ti];
@@ -222,6 +223,7 @@ __device__ void compact(Wave& w, int t) {
         D.n_status[dst] = D.n_status[src + root];
     }
     wave_mem_fence();
+    int moved = track == root ? 0 : -1;
     int q = 0, free_ = 1;
     while (q < free_) {
         const int cnt = min(64, free_ - q), idx = q + w.lane;
@@ -240,6 +242,7 @@ __device__ void compact(Wave& w, int t) {
             const size_t s = src + ob + c, d = dst + nb + c;
             D.n_board[d] = D.n_board[s]; D.n_parent[d] = idx; D.n_kids[d] = D.n_kids[s];
             D.n_N[d] = D.n_N[s]; D.n_W[d] = D.n_W[s]; D.n_P[d] = D.n_P[s]; D.n_status[d] = D.n_status[s];
+            if (ob + c == track) moved = nb + c;
         }
         for (int c = nk; c < reserve; ++c) { D.n_kids[dst + nb + c] = 0u; D.n_status[dst + nb + c] = 0u; }
         free_ += total; q += cnt;
@@ -248,6 +251,7 @@ __device__ void compact(Wave& w, int t) {
     if (w.lane == 0) { D.t_half[ti] = half ^ 1; D.t_used[ti] = free_; D.t_cursor[ti] = 0; }
     w.count(CNT_COMPACT);
     wave_mem_fence();
+    return wave_max_i32(moved);
 }
 
 // Start of a ply's search for the side to move: (re)root its tree
@@ -785,9 +789,18 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
     asm volatile("" :: "v"(pre.half), "v"(pre.used), "v"(pre.plen), "v"(pre.entry));   // keep the loads up here
     if (pending >= 0 && phase0 == PH_PLAYING) {
         const int t = t0;
-        if (expand(w, t, pending, p + (size_t)row * 512, v[row], pre)) {
+        bool ok = expand(w, t, pending, p + (size_t)row * 512, v[row], pre);
+        if (!ok) {
+            // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
+            // to 48 children): drop the garbage now and retry; the recorded path is stale after the move, so the
+            // backup walks the parent links (plen > 64)
+            const int moved = compact(w, t, pending);
+            ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
+            ok = moved >= 0 && expand(w, t, moved, p + (size_t)row * 512, v[row], again);
+        }
+        if (ok) {
             if (w.lane == 0) D.g_sims[slot] += 1;
-        } else {
+        } else {                                                          // the live subtree itself does not fit: give up on this game
             w.count(CNT_OVERFLOW);
             end_game(w, 0u, 0, 1);
         }
@@ -840,7 +853,9 @@ __global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, 
             continue;
         }
         const int t = (int)(D.g_board[slot].w & 1u);
-        if (rollout_sim(w, t)) { if (w.lane == 0) D.g_sims[slot] += 1; }
+        bool ok = rollout_sim(w, t);
+        if (!ok) { compact(w, t); ok = rollout_sim(w, t); }               // pool full: a failed simulation has changed nothing yet
+        if (ok) { if (w.lane == 0) D.g_sims[slot] += 1; }
         else { w.count(CNT_OVERFLOW); end_game(w, 0u, 0, 1); }
         wave_mem_fence();
         ++it;

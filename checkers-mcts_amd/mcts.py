@@ -89,18 +89,31 @@ class Checkers:
                 return self.state, self.outcome, self.done
         raise ValueError("Illegal next state (invalid move)!")
 
+    @staticmethod
+    def _board_of_history(history):
+        """Board record of history[-1] with the draw bookkeeping the reference derives from the list itself
+        (Checkers.py:332-343): r = number of immediately preceding states with the same piece count and the same
+        men planes (the scan's first difference is at cnt = r + 1), hist = len(history)."""
+        state = np.asarray(history[-1])
+        pieces, r = np.sum(state[0:4]), 0
+        for prev in reversed(history[-80:-1]):
+            prev = np.asarray(prev)
+            if np.sum(prev[0:4]) != pieces or not ((prev[0] == state[0]).all() and (prev[2] == state[2]).all()):
+                break
+            r += 1
+        return codec.planes_to_boards(state, r=r, hist=len(history))[0]
+
     def get_legal_next_states(self, history):
         if history is self.history or (len(history) == len(self.history) and history[-1] is self.state):
             return [] if codec.status_outcome(self._status) else list(self.legal_next_states)
-        board = codec.planes_to_boards(history[-1], hist=len(history))[0]
-        _, status, succ = self._analyse(board)
+        _, status, succ = self._analyse(self._board_of_history(history))
         return [] if codec.status_outcome(status) else self._successor_planes(succ)
 
     def determine_outcome(self, history, legal_moves=[]):
         if history is self.history:
             status = self._status
         else:
-            _, status, _ = self._analyse(codec.planes_to_boards(history[-1], hist=len(history))[0])
+            _, status, _ = self._analyse(self._board_of_history(history))
         out = int(codec.status_outcome(status))
         return out != 0, codec.OUTCOME_NAMES[out]
 
@@ -109,7 +122,9 @@ class Checkers:
 
     def predict(self, state):
         """Masked, renormalised priors (8,8,8) and value of one state (Checkers.py:425-438)."""
-        board = codec.planes_to_boards(state)[0]
+        # the draw-counter input plane is whatever determine_outcome last wrote into state[5] (k / 80, Checkers.py:338-343,431)
+        k = int(round(float(np.asarray(state)[5, 0, 0]) * 80))
+        board = codec.planes_to_boards(state, r=max(0, k - 1), hist=80 if k > 0 else 1)[0]
         b = rules.boards_to_device(board[None])
         x = rules.features(b)
         p, v = _evaluate_features(self.neural_net, x)

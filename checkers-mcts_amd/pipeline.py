@@ -203,6 +203,106 @@ class StepRunner:
                 rows = self.eng.compact_rows(self.p, self.v)
 
 
+SPLIT_MIN_SLOTS = 1024          # a half-batch below 1 024 leaves (2 per CU-resident conv workgroup) no longer fills 256 CUs
+
+
+class SplitRunner:
+    """Two half-batches on two HIP streams: the slots of a job are divided between two engines (contiguous worker-id
+    blocks -- results do not depend on the division, see dist.py) that step independently, each with its own HIP
+    graph on its own stream.  While one half's leaves are in the conv stack (matrix pipe), the other half's tree
+    kernel and head kernels (latency-bound, a few % of the chip) run beside it instead of in front of it: the step's
+    serial chain tree -> network -> tree is hidden behind the other half's network time.
+
+    make_engine(first_worker_offset, n_slots) -> Engine; make_evaluator(n_slots) -> evaluator."""
+
+    def __init__(self, make_engine, make_evaluator, n_slots, use_graph=True, device=None):
+        h0 = (n_slots + 1) // 2
+        self.parts = []
+        for first, cnt in ((0, h0), (h0, n_slots - h0)):
+            if cnt <= 0:
+                continue
+            eng = make_engine(first, cnt)
+            stream = torch.cuda.Stream(device=eng.device)
+            with torch.cuda.stream(stream):
+                runner = StepRunner(eng, make_evaluator(cnt), use_graph=use_graph)
+            self.parts.append((eng, runner, stream))
+        self.device = self.parts[0][0].device
+
+    @property
+    def engines(self):
+        return [e for e, _, _ in self.parts]
+
+    @property
+    def steps(self):
+        return max(r.steps for _, r, _ in self.parts)
+
+    def warmup(self, n=3):
+        for eng, runner, stream in self.parts:
+            with torch.cuda.stream(stream):
+                runner.warmup(n)
+        torch.cuda.synchronize(self.device)
+
+    def step(self, n=1):
+        for _ in range(n):                                   # alternate the two graphs: both queues always hold work
+            for eng, runner, stream in self.parts:
+                with torch.cuda.stream(stream):
+                    runner.step(1)
+
+    def stats(self):
+        out = {}
+        for eng in self.engines:
+            for k, v in eng.stats().items():
+                out[k] = out.get(k, 0) + v
+        out["steps"] = max(e.stats()["steps"] for e in self.engines)
+        return out
+
+    def run_to_completion(self, check_every=50, trace=None):
+        if self.steps == 0:
+            self.warmup()
+        live = list(self.parts)
+        rows = {id(e): e.cfg.n_slots for e, _, _ in live}
+        while live:
+            for _ in range(check_every):
+                for eng, runner, stream in live:
+                    with torch.cuda.stream(stream):
+                        runner.step(1)
+            total = 0
+            for part in list(live):
+                eng, runner, stream = part
+                with torch.cuda.stream(stream):
+                    active = eng.stats()["active_slots"]
+                    if hasattr(runner.evaluator, "check_range"):
+                        runner.evaluator.check_range()
+                    S = eng.cfg.n_slots
+                    if active == 0:
+                        live.remove(part)
+                    elif getattr(runner.evaluator, "supports_row_range", False) and active <= rows[id(eng)] - max(6, S // 32):
+                        rows[id(eng)] = eng.compact_rows(runner.p, runner.v)
+                total += active
+            if trace is not None:
+                trace.append((self.steps, total))
+        return self.steps
+
+    def results(self):
+        return [r for e in self.engines for r in e.results()]
+
+    def pack_tuples_device(self):
+        return torch.cat([e.pack_tuples_device() for e in self.engines], dim=0)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+
+def _warn_pool_overflows(stats, what):
+    """Games abandoned because a search tree outgrew its node pool even after compaction are dropped from the
+    output (their tuples / results would be incomplete): never silently."""
+    if stats and stats.get("pool_overflows", 0) > 0:
+        import warnings
+        warnings.warn("%s: %d game(s) were abandoned because a search tree outgrew the node pool (NODES_PER_TREE); they are "
+                      "missing from the output -- raise NODES_PER_TREE" % (what, stats["pool_overflows"]), RuntimeWarning)
+
+
 def _timestamp():
     return datetime.now(tz=None).strftime("%d-%b-%Y(%H:%M:%S)")          # training_pipeline.py:465-469
 
@@ -250,6 +350,8 @@ class generate_Checkers_data:
         # next unplayed game of the job (same total, no idle tail; ~1.4x games/hour on a 16 384-game run)
         self.dynamic_queue = selfplay_kwargs.get("DYNAMIC_QUEUE", False)
         self.networks = selfplay_kwargs.get("NETWORKS")                  # {file name: replacement spec / module}
+        # two half-batches on two HIP streams (SplitRunner) once each half still fills the chip; results are identical
+        self.split_streams = selfplay_kwargs.get("SPLIT_STREAMS", True)
         self.stats = None
         self.results = None
 
@@ -262,22 +364,57 @@ class generate_Checkers_data:
         dev = ckdist.local_device(local_rank) if world > 1 else torch.device("cuda", torch.cuda.current_device())
         raw_dev = torch.zeros((0, ckengine.TUPLE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         if count > 0:
-            cfg = ckengine.config_from_kwargs(
-                self.mcts_kwargs, n_slots=count, games_per_slot=self.NUM_SELFPLAY_GAMES,
-                terminate_cnt=self.TERMINATE_CNT, first_worker_id=first, nodes_per_tree=self.nodes_per_tree,
-                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue)
-            eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
-            if self.mcts_kwargs["NEURAL_NET"]:
-                runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count, networks=self.networks), use_graph=self.use_graph)
-                runner.run_to_completion()
-            else:                                  # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
-                eng.set_ln_table()
-                eng.run_rollouts()
-            self.stats = eng.stats()
-            self.results = eng.results()
-            raw_dev = eng.pack_tuples_device()
-            eng.close()
+            try:
+                raw_dev = self._play(dev, first, count, None)
+            except OverflowError as e:                 # an activation left the range of the split-fp16 kernels: the steps
+                import warnings                        # since the last check are tainted, so the job is replayed (same seed,
+                warnings.warn("%s -- replaying the job with the PyTorch float32 evaluator" % e, RuntimeWarning)   # same games)
+                raw_dev = self._play(dev, first, count, "torch")
         return ckdist.gather_rows(raw_dev, dst=0)           # the ONE collective of the job
+
+    def _play(self, dev, first, count, kind):
+        """This rank's share of the job on its GPU: `count` workers from global id `first`; returns the packed tuples."""
+        def make_engine(offset, n):
+            cfg = ckengine.config_from_kwargs(
+                self.mcts_kwargs, n_slots=n, games_per_slot=self.NUM_SELFPLAY_GAMES,
+                terminate_cnt=self.TERMINATE_CNT, first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree,
+                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue)
+            return ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
+
+        if not self.mcts_kwargs["NEURAL_NET"]:     # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
+            eng = make_engine(0, count)
+            eng.set_ln_table()
+            eng.run_rollouts()
+            engines = [eng]
+        elif self.split_streams and count >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue:
+            runner = SplitRunner(make_engine, lambda n: make_evaluator(self.nn_fn, dev, self.nn_dtype, n, kind=kind, networks=self.networks),
+                                 count, use_graph=self.use_graph)
+            try:
+                runner.run_to_completion()
+            except OverflowError:
+                runner.close()
+                raise
+            engines = runner.engines
+        else:
+            eng = make_engine(0, count)
+            runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count, kind=kind, networks=self.networks),
+                                use_graph=self.use_graph)
+            try:
+                runner.run_to_completion()
+            except OverflowError:
+                eng.close()
+                raise
+            engines = [eng]
+        self.stats = {}
+        for e in engines:
+            for k, v in e.stats().items():
+                self.stats[k] = self.stats.get(k, 0) + v
+        self.results = [r for e in engines for r in e.results()]
+        _warn_pool_overflows(self.stats, "self-play")
+        raw_dev = torch.cat([e.pack_tuples_device() for e in engines], dim=0)
+        for e in engines:
+            e.close()
+        return raw_dev
 
     def generate_data(self):
         """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
@@ -340,6 +477,7 @@ class tournament_Checkers:
                                                     networks=self.networks), use_graph=self.use_graph)
             runner.run_to_completion()
             self.stats = eng.stats()
+            _warn_pool_overflows(self.stats, "tournament")
             res = eng.results()
             eng.close()
             rows = torch.tensor([[r[k] for k in ("worker", "game", "outcome", "move_count", "adjudicated",
@@ -351,9 +489,11 @@ class tournament_Checkers:
         res = sorted(gathered.cpu().tolist())
         fn1, fn2 = str(self.nn1_fn).replace("data/model/", ""), str(self.nn2_fn).replace("data/model/", "")
         out = []
-        for i, (worker, game, outcome, moves, _adj, p1_net, _nt, _failed) in enumerate(res):
+        for worker, game, outcome, moves, _adj, p1_net, _nt, failed in res:
+            if failed:                                           # abandoned (node pool exhausted): no result to tabulate
+                continue
             p1_fn, p2_fn = (fn1, fn2) if p1_net == 0 else (fn2, fn1)
-            out.append([i + 1, p1_fn, p2_fn, codec.OUTCOME_NAMES[outcome], moves])
+            out.append([len(out) + 1, p1_fn, p2_fn, codec.OUTCOME_NAMES[outcome], moves])
         return out
 
     def _save_tourney_results(self, game_outcomes):

@@ -114,3 +114,53 @@ def test_cfg5_arena_800_sims_natural_end(E):
     old = sum((r["outcome"] == 1 and r["p1_net"] == 1) or (r["outcome"] == 2 and r["p1_net"] == 0) for r in res)
     draws = sum(r["outcome"] == 3 for r in res)
     assert new + old + draws == 512
+
+
+def test_cfg3_with_the_real_network_float32_grade(E):
+    """cfg3 with the random-init policy/value network in the float32-grade kernels (the bench's configuration), all
+    4 096 games to the end through the drop-in runner: accounting identities and well-formed tuples."""
+    import torch
+    from checkers_mcts_amd.pipeline import SplitRunner, make_evaluator
+    kw = mk(100, eps=0.25, tau=1.0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def make_engine(offset, n):
+        return E.Engine(E.config_from_kwargs(kw, n_slots=n, first_worker_id=offset, games_per_slot=1, terminate_cnt=200,
+                                             seed=20260929))
+    runner = SplitRunner(make_engine, lambda n: make_evaluator("random:0", dev, torch.float32, n), 4096)
+    runner.run_to_completion()
+    st, res = runner.stats(), runner.results()
+    raw = np.frombuffer(runner.pack_tuples_device().cpu().numpy().tobytes(), dtype=E.TUPLE_DTYPE)
+    runner.close()
+    assert len(res) == 4096 and st["games"] == 4096 and st["pool_overflows"] == 0 and all(r["failed"] == 0 for r in res)
+    plies = sum(r["move_count"] for r in res)
+    assert st["plies"] == plies and st["expansions"] + st["terminal_visits"] == 100 * plies
+    assert len(raw) == plies + 4096 - sum(r["adjudicated"] for r in res)
+    assert sorted(set(int(w) for w in raw["worker"])) == list(range(4096))
+    check_tuples(E, raw, 100)
+    lens = np.array([r["move_count"] for r in res])
+    assert 40 < lens.mean() < 160 and lens.max() <= 200                       # games of a random-init net: SURVEY 88 plies
+
+
+def test_fused_evaluator_full_batch_rows_vs_float64(oracle):
+    """Both precision modes of the fused evaluator on the bench's batch (4 096 rows of real leaf-like features): rows
+    sampled from every part of the batch (first / last workgroup tiles, both boards of a tile) against the float64
+    restatement -- float32-grade mode within 1e-5 (pi, v), bf16 mode within its throughput-mode tolerance."""
+    import torch
+    import net_ref
+    from checkers_mcts_amd import net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from test_rules_gpu import random_boards
+    S = 4096
+    m = N.PolicyValueNet(128).keras_init(3).perturb_bn(7).eval().cuda()
+    x = rules.features(rules.boards_to_device(random_boards(S, 4242))).contiguous()
+    rows = np.unique(np.concatenate([np.arange(0, 8), np.arange(S - 8, S), np.random.RandomState(1).randint(0, S, 48)]))
+    sd = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
+    rp, rv = net_ref.forward(sd, x[torch.from_numpy(rows).cuda()].cpu().numpy())
+    p, v = FusedEvaluator(m, S, mode="f16x3").forward_features(x)
+    torch.cuda.synchronize()
+    assert np.abs(p[rows].cpu().numpy() - rp).max() < 1e-5 and np.abs(v[rows].cpu().numpy() - rv).max() < 1e-5
+    assert torch.allclose(p.sum(1), torch.ones(S, device="cuda"), atol=1e-5)
+    pb, vb = FusedEvaluator(m, S, mode="bf16").forward_features(x.to(torch.bfloat16).contiguous())
+    torch.cuda.synchronize()
+    assert np.abs(pb[rows].cpu().numpy() - rp).max() < 5e-3 and np.abs(vb[rows].cpu().numpy() - rv).max() < 5e-2

@@ -115,6 +115,44 @@ def test_environment_protocol(oracle):
         env.step(np.ones((15, 8, 8)))
 
 
+def test_non_live_histories_keep_the_draw_rule():
+    """get_legal_next_states / determine_outcome on a history that is NOT the environment's live list (the MCTS
+    facade's per-node histories, a GUI replaying a game) derive the 80-state draw bookkeeping from the list itself
+    (Checkers.py:332-360); predict feeds the draw-counter plane the state carries (Checkers.py:431)."""
+    from checkers_mcts_amd import rules
+    from checkers_mcts_amd.mcts import Checkers
+    import checkers_mcts_amd.codec as codec
+
+    def check(env, other):
+        hist = [h.copy() for h in env.history]
+        assert other.determine_outcome(hist) == (env.done, env.outcome)
+        nxt = other.get_legal_next_states(hist)
+        assert len(nxt) == (0 if env.done else len(env.legal_next_states))
+        assert all((a == b).all() for a, b in zip(nxt, env.legal_next_states))
+
+    other = Checkers(lambda eng: rules.hashnet(eng.x, 2))
+    for seed in range(6):                                            # ordinary games: wins, losses, captures, kingings
+        env = Checkers()
+        rng = np.random.RandomState(100 + seed)
+        while not env.done and env.move_count < 400:
+            env.step(env.legal_next_states[rng.randint(len(env.legal_next_states))])
+            if env.move_count % 5 == 0 or env.done:
+                check(env, other)
+    # two lone kings shuffling in opposite corners: nothing but king moves -> the 80-state draw (Checkers.py:357-360)
+    env = Checkers()
+    env._set(np.array([1 << 0, 1 << 31, (1 << 0) | (1 << 31), codec.make_meta(0, 1, 0, 0, 0, 1)], np.uint32))
+    env.history, env._records = [env.state], [env._board]
+    while not env.done and env.move_count < 120:
+        back = [st for st in env.legal_next_states
+                if len(env.history) >= 3 and (st[0:4] == env.history[-3][0:4]).all()]       # undo this side's previous move
+        env.step(back[0] if back else env.legal_next_states[0])
+        check(env, other)
+    assert env.outcome == "draw" and 79 <= env.move_count <= 81 and env.state[5, 0, 0] == 1.0
+    planes, v = other.predict(env.history[-2])                       # the state before the draw carries k / 80 = 79 / 80 into the net
+    assert env.history[-2][5, 0, 0] == 79 / 80
+    assert planes.shape == (8, 8, 8) and abs(float(planes.sum()) - 1.0) < 1e-5 and abs(float(v)) < 1
+
+
 def test_human_move_then_search(golden_dir):
     """play_Checkers.py pattern: a move the engine did not choose is stepped on
     the environment; the next search re-roots (or rebuilds) from the live state."""

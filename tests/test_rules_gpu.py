@@ -72,9 +72,31 @@ def test_random_boards_vs_oracle(R, oracle):
         assert cnt[i] == len(ok) and (kids[i, :cnt[i]] == ok).all()
 
 
+def playout_positions(oracle, n, seed):
+    """Every position of seeded uniform-random playouts from the initial position, until n are
+    collected; the oracle supplies rules and successors (it is the checker: pinned to the reference on 10^6 positions)."""
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        b = oracle.initial_board()
+        while True:
+            out.append(b)
+            _, status = oracle.movegen(b[None])
+            if status[0] & 3:
+                break
+            kids = oracle.children(b)
+            b = kids[rng.randint(len(kids))]
+    return np.array(out[:n], np.uint32)
+
+
 def test_cfg2_65536_boards(R, oracle):
-    """BASELINE config 2: 65 536 boards, bit-exact masks + status."""
-    boards = random_boards(65536, 20260929)
+    """BASELINE config 2 with SURVEY 8(d)'s composition: 49 152 positions from uniform-random playouts + 16 384
+    synthetic boards (0-12 pieces per side, random king fraction, random side / draw counters), seed 20260929;
+    legal-move masks + status bit-exact."""
+    play = playout_positions(oracle, 49152, 20260929)
+    assert len(play) == 49152 and (play[0] == oracle.initial_board()).all()
+    boards = np.concatenate([play, random_boards(16384, 20260929)])
+    assert boards.shape == (65536, 4)
     mask, status = R.movegen(R.boards_to_device(boards))
     omask, ostatus = oracle.movegen(boards)
     assert (_np(mask) == omask).all() and (_np(status) == ostatus).all()

@@ -57,6 +57,19 @@ def test_selfplay_train_arena_loop_without_pickles(tmp_path, monkeypatch):
     h = hist.history
     assert h["policy_head_loss"][-1] < h["policy_head_loss"][0]           # the policy head learns the visit distributions
     assert os.path.exists(fn)
+    # the TRAINED network (non-trivial weights, biases and BatchNorm moving statistics) through the float32-grade
+    # kernels on real self-play positions: pi / v within 1e-5 of the float64 restatement
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import net_ref
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import load_network
+    trained = load_network(fn, device="cuda")
+    xs, _, _ = T.TrainingData(tuples=tuples).batch(torch.arange(0, 192, device="cuda") * 7)
+    pf, vf = FusedEvaluator(trained, xs.shape[0], mode="f16x3").forward_features(xs.contiguous())
+    rp, rv = net_ref.forward({k: t.detach().cpu().numpy() for k, t in trained.state_dict().items()}, xs.cpu().numpy())
+    assert np.abs(pf.cpu().numpy() - rp).max() < 1e-5 and np.abs(vf.cpu().numpy() - rv).max() < 1e-5
+    assert float(np.abs(rv).max()) > 1e-3                                   # the value head has moved away from its initial zero
     mk_ = dict(kw, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0, BUDGET=12)
     t = tournament_Checkers(dict(NEW_NN_FN=fn, OLD_NN_FN="random:0", TOURNEY_GAMES=2, NUM_CPUS=4, SEED=3), mk_)
     out = t._start_tournament()
