@@ -769,8 +769,10 @@ __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
 }
 
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
+// end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
+// searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
 __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
-                                              const float* __restrict__ v, void* x, int32_t* net_out) {
+                                              const float* __restrict__ v, void* x, int32_t* net_out, int end_ply) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
@@ -812,7 +814,10 @@ __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, con
     ckr_board lb{0u, 0u, 0u, 0u};
     while (D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
-        if (D.g_sims[slot] >= D.budget) {                                // MCTS.computational_budget, :189-201
+        const int sims_done = D.g_sims[slot];
+        const bool out_of_time = end_ply != 0 && sims_done >= 2;         // a root with visited children exists
+        end_ply = out_of_time ? 0 : end_ply;                             // one ply per time window
+        if (sims_done >= D.budget || out_of_time) {                      // MCTS.computational_budget, :189-201
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
             finish_ply(w); continue;
         }
@@ -1068,7 +1073,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (!c || !out) return fail(CKR_ERR_INVALID, "ckr_engine_create: null argument");
     if (int rc = require_device()) return rc;
     if (c->n_slots <= 0 || c->games_per_slot <= 0) return fail(CKR_ERR_INVALID, "n_slots and games_per_slot must be positive");
-    if (c->budget <= 0) return fail(CKR_ERR_INVALID, "BUDGET must be a positive rollout count (CONSTRAINT == 'rollout')");
+    if (c->budget <= 0) return fail(CKR_ERR_INVALID, "BUDGET must be a positive rollout count (CONSTRAINT == 'rollout'); for CONSTRAINT == "
+                                                    "'time' pass INT32_MAX and end the plies with ckr_engine_step_end_ply");
     if (!c->tournament && !c->manual_play && c->terminate_cnt <= 0) return fail(CKR_ERR_INVALID, "self-play needs TERMINATE_CNT > 0");
     if (c->nodes_per_tree < 256 || c->nodes_per_tree >= (1 << 24)) return fail(CKR_ERR_INVALID, "nodes_per_tree must be in [256, 2^24)");
     if (c->feature_dtype < 0 || c->feature_dtype > 2) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1 or 2");
@@ -1086,7 +1092,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.total_games = c->n_slots * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
     D.tuples_per_game = (c->tournament || c->manual_play) ? 0 : c->terminate_cnt + 1;
-    D.margin = c->budget * 16 + 64; if (D.margin > D.C / 2) D.margin = D.C / 2;
+    D.margin = c->budget > (1 << 20) ? D.C / 2 : c->budget * 16 + 64;    // unbounded (time-limited) searches: compact early
+    if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
     D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32);
     e->n_games_total = (int64_t)c->n_slots * c->games_per_slot;
@@ -1191,12 +1198,22 @@ int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) {
     return CKR_OK;
 }
 
+static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream, int end_ply);
+
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
+    return engine_step(e, d_p, d_v, d_x, d_net, stream, 0);
+}
+
+int ckr_engine_step_end_ply(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
+    return engine_step(e, d_p, d_v, d_x, d_net, stream, 1);
+}
+
+static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream, int end_ply) {
     if (!e || !d_x) return fail(CKR_ERR_INVALID, "ckr_engine_step: null engine or feature buffer");
     if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_step drives the NEURAL_NET search; use ckr_engine_rollout");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
     note_stream(&e->last_stream, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net);
+    hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
     CKR_HIP(hipGetLastError());
     e->steps++;
     return CKR_OK;

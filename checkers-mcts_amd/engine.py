@@ -38,11 +38,18 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     for key in MCTS_KEYS:
         if key not in k:
             raise KeyError(key)                       # MCTS.__init__ indexes kwargs directly
-    if k["CONSTRAINT"] != "rollout":
-        if k["CONSTRAINT"] == "time":
-            raise ValueError("CONSTRAINT='time' is not supported by the batched engine (lock-step rollouts)")
+    if k["CONSTRAINT"] not in ("rollout", "time"):
         raise ValueError("Invalid MCTS computational constraint!")        # MCTS.py:200
-    budget = int(k["BUDGET"])
+    if k["CONSTRAINT"] == "time":
+        # BUDGET is seconds of wall-clock search per ply (MCTS.py:196-198): no rollout limit in the engine; the runner
+        # owns the clock and ends the plies with Engine.step(..., end_ply=True)  (time_budget_of(kwargs))
+        if not manual_play and not k["NEURAL_NET"]:
+            raise ValueError("CONSTRAINT='time' with NEURAL_NET=False is only available through the MCTS facade")
+        budget = 2 ** 31 - 1
+        if nodes_per_tree is None:
+            nodes_per_tree = 1 << 18
+    else:
+        budget = int(k["BUDGET"])
     if nodes_per_tree is None:
         nodes_per_tree = max(4096, 48 * budget)
     return _lib.Config(n_slots=int(n_slots), games_per_slot=int(games_per_slot), first_worker_id=int(first_worker_id),
@@ -55,6 +62,11 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
                        device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
                        dynamic_queue=int(bool(dynamic_queue)), seed=int(seed))
+
+
+def time_budget_of(mcts_kwargs):
+    """Seconds of search per ply when CONSTRAINT == 'time' (MCTS.py:196-198), else None."""
+    return float(mcts_kwargs["BUDGET"]) if mcts_kwargs["CONSTRAINT"] == "time" else None
 
 
 class Engine:
@@ -94,9 +106,10 @@ class Engine:
         """Zero-copy [S,14,8,8] view with channels-last strides."""
         return self.x.permute(0, 3, 1, 2)
 
-    def step(self, p=None, v=None):
+    def step(self, p=None, v=None, end_ply=False):
         """One lock-step simulation.  p [S,512] float32 softmax output and
-        v [S] float32 for the leaves of the previous step (None on the first)."""
+        v [S] float32 for the leaves of the previous step (None on the first).
+        end_ply (CONSTRAINT == 'time'): the wall-clock budget is used up -- every searching slot ends its ply in this step."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if p is not None:
             if not (p.dtype == torch.float32 and p.is_contiguous() and v.dtype == torch.float32 and v.is_contiguous()):
@@ -104,7 +117,8 @@ class Engine:
             pp, vp = p.data_ptr(), v.data_ptr()
         else:
             pp = vp = None
-        _lib.check(self._L.ckr_engine_step(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
+        fn = self._L.ckr_engine_step_end_ply if end_ply else self._L.ckr_engine_step
+        _lib.check(fn(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
 
     def compact_rows(self, p, v):

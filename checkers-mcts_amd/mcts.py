@@ -18,6 +18,8 @@ only what the reference keeps in Python objects: the move choice rule
 (best_child, MCTS.py:227-248), the state planes handed to callers, and the
 history list.
 """
+import time
+
 import numpy as np
 import torch
 
@@ -147,7 +149,8 @@ def _evaluate_features(net, x):
         raise ValueError("the game environment has no neural_net")
     if isinstance(net, torch.nn.Module):
         with torch.no_grad():
-            p, v = net(x.permute(0, 3, 1, 2).to(next(net.parameters()).dtype))
+            dtype = next((q.dtype for q in net.parameters()), torch.float32)     # parameter-free modules (pipeline.HashNet)
+            p, v = net(x.permute(0, 3, 1, 2).to(dtype))
         return p.float().contiguous(), v.float().contiguous()
     if hasattr(net, "predict"):                                                # Keras-style host object (Checkers.py:433)
         xs = x.float().cpu().numpy()
@@ -220,15 +223,18 @@ class MCTS:
     @classmethod
     def begin_tree_search(cls, root_node):
         """BUDGET simulations from the live position (MCTS.py:211-224)."""
-        if cls.constraint != "rollout":
+        if cls.constraint not in ("rollout", "time"):
             raise ValueError("Invalid MCTS computational constraint!")
         cls._sync()
         if cls._engine.command(CMD_SEARCH)[0]:
             raise ValueError("begin_tree_search on a finished game")
+        timed = cls.constraint == "time"                     # BUDGET seconds of wall clock instead of BUDGET rollouts (:196-198)
+        cls.start_time = time.time()
+        out_of_time = (lambda: time.time() - cls.start_time >= cls.budget) if timed else (lambda: False)
         if not cls.neural_net:                               # random playouts (MCTS.py:78-89,132-143), all in-kernel
             while True:
-                cls._engine.rollout(cls.budget)
-                if not cls._engine.game(0)[3]:
+                cls._engine.rollout(8 if timed else cls.budget)
+                if not cls._engine.game(0)[3] or out_of_time():
                     break
         else:
             ev = cls._evaluator()
@@ -236,11 +242,12 @@ class MCTS:
             p, v = torch.zeros((1, 512), device=dev), torch.zeros((1,), device=dev)
             while True:
                 cls._engine.step(p, v)
-                if not cls._engine.game(0)[3]:
+                if not cls._engine.game(0)[3] or out_of_time():
                     break
                 p, v = ev(cls._engine)
-        cls.rollout_count = cls.budget
+        n_before = int(getattr(root_node, "_number_of_visits", 0) or 0)
         root_node._load()
+        cls.rollout_count = max(0, int(root_node.n) - n_before) if timed else cls.budget
         if cls.verbose:
             print("Stopped  search after {} rollouts!".format(cls.rollout_count))
 

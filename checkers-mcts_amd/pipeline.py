@@ -132,8 +132,10 @@ class StepRunner:
     network kernels, output copies) is captured once into a HIP graph and
     replayed, so the host only issues one graph launch per simulation step."""
 
-    def __init__(self, eng, evaluator, use_graph=True):
-        self.eng, self.evaluator, self.use_graph = eng, evaluator, use_graph
+    def __init__(self, eng, evaluator, use_graph=True, time_budget=None):
+        """time_budget (seconds; CONSTRAINT == 'time', MCTS.py:196-198): run_to_completion searches every ply for that
+        long and then ends the plies of all slots in one step (Engine.step(end_ply=True))."""
+        self.eng, self.evaluator, self.use_graph, self.time_budget = eng, evaluator, use_graph, time_budget
         S = eng.cfg.n_slots
         self.p = torch.zeros((S, 512), dtype=torch.float32, device=eng.device)
         self.v = torch.zeros((S,), dtype=torch.float32, device=eng.device)
@@ -191,7 +193,19 @@ class StepRunner:
         rows = S
         can_compact = compact_tail and getattr(self.evaluator, "supports_row_range", False)
         while True:
-            self.step(check_every)
+            if self.time_budget is None:
+                self.step(check_every)
+            else:                                            # one ply of every running game: search for the budget, then move
+                import time
+                t0 = time.perf_counter()
+                while True:
+                    self.step(8)
+                    torch.cuda.synchronize(self.eng.device)
+                    if time.perf_counter() - t0 >= self.time_budget:
+                        break
+                self.eng.step(self.p, self.v, end_ply=True)
+                self._eval_into_buffers()
+                self.steps += 1
             active = self.eng.stats()["active_slots"]
             if trace is not None:
                 trace.append((self.steps, active))
@@ -386,7 +400,8 @@ class generate_Checkers_data:
             eng.set_ln_table()
             eng.run_rollouts()
             engines = [eng]
-        elif self.split_streams and count >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue:
+        elif (self.split_streams and count >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue
+              and ckengine.time_budget_of(self.mcts_kwargs) is None):
             runner = SplitRunner(make_engine, lambda n: make_evaluator(self.nn_fn, dev, self.nn_dtype, n, kind=kind, networks=self.networks),
                                  count, use_graph=self.use_graph)
             try:
@@ -398,7 +413,7 @@ class generate_Checkers_data:
         else:
             eng = make_engine(0, count)
             runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count, kind=kind, networks=self.networks),
-                                use_graph=self.use_graph)
+                                use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             try:
                 runner.run_to_completion()
             except OverflowError:
@@ -474,7 +489,8 @@ class tournament_Checkers:
                 seed=self.seed, device=dev.index)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
             runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn,
-                                                    networks=self.networks), use_graph=self.use_graph)
+                                                    networks=self.networks), use_graph=self.use_graph,
+                                time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             runner.run_to_completion()
             self.stats = eng.stats()
             _warn_pool_overflows(self.stats, "tournament")

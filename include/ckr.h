@@ -275,6 +275,14 @@ int ckr_engine_destroy(ckr_engine* e);
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x,
                     int32_t* d_net, void* stream);
 
+/* CONSTRAINT == 'time' (MCTS.computational_budget, MCTS.py:196-198: a search lasts BUDGET seconds of wall-clock time
+ * instead of BUDGET rollouts): create the engine with budget = INT32_MAX, drive ckr_engine_step for the wall-clock
+ * budget, then call this variant once -- the same step, in which every searching slot completes its simulation in
+ * flight and then ends its ply (move choice, tuple, re-root, next search) exactly as if its rollout budget had been
+ * reached.  The host owns the clock, so all games of an engine move once per time window. */
+int ckr_engine_step_end_ply(ckr_engine* e, const float* d_p, const float* d_v, void* d_x,
+                            int32_t* d_net, void* stream);
+
 /* Random-rollout mode (neural_net = 0): up to `sims` complete simulations per slot -- UCT descent
  * (MCTS.py:112-116), one-child expansion (:78-81), uniform random playout (:132-143), backup -- plus
  * the end-of-ply work, all inside one kernel launch.  No network is involved. */

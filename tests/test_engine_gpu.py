@@ -365,3 +365,29 @@ def test_rollout_mode_vs_oracle_and_random_playouts(E, oracle, golden_dir):
             # a retained root carries the playout of its own creation: sum(child N) = N or N - 1
             assert nv.sum() in (e["root_n"], e["root_n"] - 1) and (nv >= 1).all() and abs(e["root_w"]) <= e["root_n"]
     eng.close()
+
+
+def test_time_constrained_search(E):
+    """CONSTRAINT == 'time' (MCTS.computational_budget, MCTS.py:196-198): every ply is searched for BUDGET seconds of wall
+    clock, then all running games move.  Results depend on the machine's speed (as in the reference), so the checks are
+    structural: one ply per time window, searches of more than one simulation, well-formed tuples, games that end."""
+    import time
+    import torch
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(mk(1, eps=0.25, tau=1.0), CONSTRAINT="time", BUDGET=0.02)
+    cfg = E.config_from_kwargs(kw, n_slots=64, games_per_slot=1, terminate_cnt=12, seed=3)
+    eng = E.Engine(cfg)
+    runner = StepRunner(eng, E.hashnet_evaluator(4), use_graph=False, time_budget=E.time_budget_of(kw))
+    t0 = time.perf_counter()
+    runner.run_to_completion()
+    dt = time.perf_counter() - t0
+    st, res, raw = eng.stats(), eng.results(), eng.tuples_raw()
+    eng.close()
+    assert st["games"] == 64 and st["active_slots"] == 0 and all(r["failed"] == 0 for r in res)
+    assert all(r["move_count"] <= 12 for r in res) and st["plies"] == sum(r["move_count"] for r in res)
+    assert dt >= 0.02 * max(r["move_count"] for r in res)                  # every ply got its time
+    live = raw[raw["n_children"] > 0]
+    assert (live["root_n"] >= 2).all() and live["root_n"].max() > 10         # searches are bounded by the clock, not by a count
+    visits = (live["pi"] & 0x7FFFFF).astype(np.int64)
+    used = np.arange(live["pi"].shape[1])[None, :] < live["n_children"][:, None]
+    assert ((visits * used).sum(1) == live["root_n"] - 1).all()

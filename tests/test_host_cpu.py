@@ -71,8 +71,11 @@ def test_config_from_kwargs_maps_reference_keys():
     assert c.training == 1 and c.tournament == 0 and c.first_worker_id == 32 and c.nodes_per_tree >= 4096
     with pytest.raises(ValueError, match="Invalid MCTS computational constraint"):
         E.config_from_kwargs(dict(kw, CONSTRAINT="x"), n_slots=1, games_per_slot=1)
-    with pytest.raises(ValueError):
-        E.config_from_kwargs(dict(kw, CONSTRAINT="time"), n_slots=1, games_per_slot=1)
+    c = E.config_from_kwargs(dict(kw, CONSTRAINT="time", BUDGET=0.25), n_slots=1, games_per_slot=1)     # MCTS.py:196-198
+    assert c.budget == 2 ** 31 - 1 and E.time_budget_of(dict(kw, CONSTRAINT="time", BUDGET=0.25)) == 0.25
+    assert E.time_budget_of(kw) is None
+    with pytest.raises(ValueError):                          # the batched random-rollout kernel has no clock
+        E.config_from_kwargs(dict(kw, CONSTRAINT="time", NEURAL_NET=False), n_slots=1, games_per_slot=1)
     c = E.config_from_kwargs(dict(kw, NEURAL_NET=False), n_slots=1, games_per_slot=1)
     assert c.neural_net == 0 and c.rollout_first == 0
 

@@ -130,7 +130,8 @@ def test_non_live_histories_keep_the_draw_rule():
         assert len(nxt) == (0 if env.done else len(env.legal_next_states))
         assert all((a == b).all() for a, b in zip(nxt, env.legal_next_states))
 
-    other = Checkers(lambda eng: rules.hashnet(eng.x, 2))
+    from checkers_mcts_amd.pipeline import HashNet
+    other = Checkers(HashNet(2))
     for seed in range(6):                                            # ordinary games: wins, losses, captures, kingings
         env = Checkers()
         rng = np.random.RandomState(100 + seed)
@@ -143,8 +144,9 @@ def test_non_live_histories_keep_the_draw_rule():
     env._set(np.array([1 << 0, 1 << 31, (1 << 0) | (1 << 31), codec.make_meta(0, 1, 0, 0, 0, 1)], np.uint32))
     env.history, env._records = [env.state], [env._board]
     while not env.done and env.move_count < 120:
+        own = slice(0, 2) if env.current_player(env.state) == "player1" else slice(2, 4)
         back = [st for st in env.legal_next_states
-                if len(env.history) >= 3 and (st[0:4] == env.history[-3][0:4]).all()]       # undo this side's previous move
+                if len(env.history) >= 3 and (st[own] == env.history[-3][own]).all()]       # undo this side's previous move
         env.step(back[0] if back else env.legal_next_states[0])
         check(env, other)
     assert env.outcome == "draw" and 79 <= env.move_count <= 81 and env.state[5, 0, 0] == 1.0
@@ -190,3 +192,22 @@ def test_facade_random_rollout_mode_matches_reference(golden_dir):
         assert all(float(w).is_integer() for w in e["w"])
     from checkers_mcts_amd.mcts import MCTS
     assert MCTS.reroot_misses == 0
+
+
+def test_facade_time_constraint():
+    """MCTS(CONSTRAINT='time', BUDGET=seconds) through the search API (play_Checkers.py:93 uses it for the GUI opponent)."""
+    import time
+    from checkers_mcts_amd import rules
+    from checkers_mcts_amd.mcts import MCTS, MCTS_Node, Checkers
+    env = Checkers(lambda eng: rules.hashnet(eng.x, 1))
+    MCTS(**dict(kwargs(0.15, env), CONSTRAINT="time"))
+    root = MCTS_Node(env.state, parent=None)
+    t0 = time.time()
+    MCTS.begin_tree_search(root)
+    assert 0.15 <= time.time() - t0 < 2.0
+    assert root.n > 5 and sum(c.n for c in root.children) == root.n - 1 and MCTS.rollout_count == root.n
+    best = MCTS.best_child(root)
+    env.step(best.state)
+    with pytest.raises(ValueError, match="Invalid MCTS computational constraint"):
+        MCTS(**dict(kwargs(5, env), CONSTRAINT="nodes"))
+        MCTS.begin_tree_search(MCTS_Node(env.state, parent=None))

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Workload for rocprofv3 --pmc passes over the conv-stack kernels: 6 launches each of the bf16 kernel(s)
-and of the split-fp16 kernel on 4096 boards."""
+"""Workload for rocprofv3 --pmc passes over the conv-stack kernels: 6 launches each of the bf16 kernel
+and of the split-fp16 kernel on 4096 boards (CONV_MODES selects; CONV_BOARDS overrides the batch)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from checkers_mcts_amd import net as N
 from checkers_mcts_amd.fused import FusedEvaluator
-S = 4096
+S = int(os.environ.get("CONV_BOARDS", "4096"))
 m = N.PolicyValueNet(128).keras_init(0).eval().cuda()
 xb = (torch.rand(S, 8, 8, 14, device="cuda") < 0.2).to(torch.bfloat16).contiguous()
 for mode in os.environ.get("CONV_MODES", "bf16,f16x3").split(","):
