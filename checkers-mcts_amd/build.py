@@ -16,8 +16,14 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["ckr_rules.hip", "ckr_engine.hip", "ckr_conv.hip", "ckr_conv_x3.hip"]
 LIB = os.path.join(HERE, "libckr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -fno-slp-vectorize: hipcc (ROCm 7.2) SLP-packs adjacent scalar float32 multiply-adds into v_pk_fma_f32 / v_pk_mul_f32
+# with op_sel swizzles.  In the 1x1 policy head of ckr_conv_x3.hip that code returned wrong sums in lanes 48-63 of one
+# accumulator for ~13 % of the boards -- only when two workgroups shared a CU (4 096-board batches; never at <= 1 023
+# boards), bit-reproducible offsets, gone with this flag (tests/test_fullsize_gpu.py::
+# test_fused_evaluator_full_batch_rows_vs_float64 is the regression test).  Packed f32 VALU is no gain beside MFMAs
+# anyway (MI355X_MICROARCH.md, "price of one filler").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def sources():
