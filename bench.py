@@ -56,12 +56,22 @@ DTYPES = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 DTYPE_LABEL = {"fp32": "fp32-grade (fp16x3 split operands, fp32 accumulate)", "bf16": "bf16", "fp16": "fp16"}
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}      # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-# HBM-side bytes per launch of 4 096 boards from the committed rocprofv3 --pmc passes (separate passes for
-# FETCH_SIZE and WRITE_SIZE; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950): see profiles/README.md
+# L2 <-> fabric bytes per launch from the committed rocprofv3 --pmc passes (separate passes for FETCH_SIZE and WRITE_SIZE,
+# per-dispatch means; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), keyed by boards per launch: see
+# profiles/README.md.  Not re-measured by this script; launches of another size are scaled from the nearest entry.
 PMC_TRAFFIC = {
-    "fp32": dict(bytes=(2 * 89742.0 + 9216.0) * 1024.0, source="profiles/r01_pmc_conv_kernels.csv (2 x FETCH_SIZE + WRITE_SIZE)"),
-    "bf16": dict(bytes=(2 * 14918.2 + 9216.0) * 1024.0, source="profiles/r01_pmc_conv_kernels.csv (2 x FETCH_SIZE + WRITE_SIZE)"),
+    "fp32": {4096: (2 * 86088.9 + 9216.0) * 1024.0, 2048: (2 * 36175.1 + 4608.0) * 1024.0,
+             "source": "profiles/r02_pmc_conv_4096_boards.csv / r02_pmc_conv_2048_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
+    "bf16": {4096: (2 * 15114.1 + 9216.0) * 1024.0,
+             "source": "profiles/r02_pmc_conv_4096_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
 }
+
+
+def pmc_traffic(mode, boards):
+    t = PMC_TRAFFIC[mode]
+    sizes = [k for k in t if isinstance(k, int)]
+    near = min(sizes, key=lambda k: abs(k - boards))
+    return t[near] * boards / near, t["source"]
 
 
 def parse():
@@ -233,14 +243,17 @@ def conv_roofline(mode, conv_flops, slots, t_conv):
     (one multiply-add per weight and position, as for any float32 convolution); the kernel EXECUTES
     three fp16 MFMAs per multiply-add, reported as executed_*."""
     tf = conv_flops * slots / t_conv / 1e12 if t_conv else None
-    tr = PMC_TRAFFIC[mode]
+    traffic, source = pmc_traffic(mode, slots)
     out = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s",
            "frac": tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
-           "traffic": tr["bytes"] * slots / 4096.0, "traffic_source": tr["source"],
+           "traffic": traffic, "traffic_source": source,
            "ms_per_launch": t_conv * 1e3, "flops_per_unit": conv_flops, "units_per_launch": slots}
     if mode == "fp32":
         out["kernel"] = ("k_conv_stack_x3 (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, activations LDS-resident; "
-                         "split-fp16 operands: float32-grade results, 3 fp16 MFMAs per multiply-add; one launch per step)")
+                         "split-fp16 operands: float32-grade results, 3 fp16 MFMAs per multiply-add; one launch per step and "
+                         "half-batch)")
+        out["bound_note"] = ("the matrix pipe at the clock the chip grants: on self-play operands sclk drops to ~1.85 GHz (2.38 GHz "
+                             "on all-zero planes, same binary: 0.80-0.83 executed) -- profiles/r02_power_probe.jsonl")
         out.update({"executed_tflops": 3.0 * tf if tf else None,
                     "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"] if tf else None,
                     "vs_fp32_matrix_peak": tf / MFMA_PEAK_TFLOPS["fp32"] if tf else None})

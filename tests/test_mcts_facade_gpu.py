@@ -150,8 +150,19 @@ def test_non_live_histories_keep_the_draw_rule():
         env.step(back[0] if back else env.legal_next_states[0])
         check(env, other)
     assert env.outcome == "draw" and 79 <= env.move_count <= 81 and env.state[5, 0, 0] == 1.0
-    planes, v = other.predict(env.history[-2])                       # the state before the draw carries k / 80 = 79 / 80 into the net
-    assert env.history[-2][5, 0, 0] == 79 / 80
+    assert env.history[-2][5, 0, 0] == 0.0                           # 79 states: the scan needs 80 (Checkers.py:332)
+
+    class Recorder:                                                  # Keras-style net object (Checkers.py:433): keeps its input
+        def predict(self, x):
+            self.x = np.array(x)
+            return np.full((1, 512), 1.0 / 512, np.float32), np.zeros((1, 1), np.float32)
+    rec = Recorder()
+    probe = Checkers(rec)
+    state = env.history[-2].copy()
+    state[5] = 37 / 80                                               # what determine_outcome writes into a long game's states (:338-343)
+    planes, v = probe.predict(state)
+    assert rec.x.shape == (1, 8, 8, 14) and (rec.x[0, :, :, 5] == np.float32(37 / 80)).all()
+    assert (rec.x[0, :, :, :5] == np.moveaxis(state[:5], 0, -1)).all()
     assert planes.shape == (8, 8, 8) and abs(float(planes.sum()) - 1.0) < 1e-5 and abs(float(v)) < 1
 
 
