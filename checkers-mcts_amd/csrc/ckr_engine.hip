@@ -76,17 +76,35 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+// double-precision pow() is ~100 registers of OCML code: kept out of line so that its pressure (and the spills around it)
+// stays on the rare paths that need it -- gamma variates with alpha != 1, one temperature pick per ply -- instead of
+// shaping the register allocation of every descent
+__device__ __attribute__((noinline)) double pow_cold(double x, double y) { return pow(x, y); }
+
 // ---- gamma / Dirichlet noise (MCTS.py:107-108); distribution-level parity only
-__device__ double gamma_sample(const Dev& D, double a, uint32_t c0, uint32_t c1, uint32_t c2) {
+__device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint32_t seed_hi, double a, uint32_t c0, uint32_t c1, uint32_t c2);
+
+__device__ __forceinline__ double gamma_sample(const Dev& D, double a, uint32_t c0, uint32_t c1, uint32_t c2) {
+    if (a == 1.0) {                                        // exponential variate; float32 log (noise, not parity arithmetic)
+        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0u);
+        const float uf = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+        return (double)(-logf(uf));
+    }
+    return gamma_general(D.seed_lo, D.seed_hi, a, c0, c1, c2);
+}
+
+// alpha != 1: Marsaglia-Tsang (alpha < 1 through the alpha + 1 variate and a uniform power)
+__device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint32_t seed_hi, double a, uint32_t c0, uint32_t c1, uint32_t c2) {
+    struct { uint32_t seed_lo, seed_hi; } D{seed_lo, seed_hi};
     uint32_t it = 0;
     double boost = 1.0;
     if (a < 1.0) {
         const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0x80000000u);
         boost = pow(u01(r.x, r.y), 1.0 / a); a += 1.0;
     }
-    if (a == 1.0) {                                        // exponential variate; float32 log (noise, not parity arithmetic)
+    if (a == 1.0) {
         const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0u);
-        const float uf = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
+        const float uf = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;
         return (double)(-logf(uf)) * boost;
     }
     const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
@@ -112,7 +130,7 @@ __device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_
 // as an inverse-CDF pick over the children in tree order; `ev` = 64 doubles of LDS.  All lanes return the pick.
 __device__ __forceinline__ int temperature_pick(const Dev& D, double* ev, int cn, bool act, int n, double tau,
                                                 uint32_t worker, uint32_t ctr, int lane) {
-    ev[lane] = act ? pow((double)cn, 1.0 / tau) : 0.0;
+    ev[lane] = act ? pow_cold((double)cn, 1.0 / tau) : 0.0;
     __builtin_amdgcn_wave_barrier();
     double cum = 0.0;
     for (int j = 0; j <= lane && j < n; ++j) cum += ev[j];
@@ -472,7 +490,7 @@ __device__ uint32_t playout(Wave& w, ckr_board b) {
     }
 }
 
-// one simulation of the non-NN tree policy
+// one simulation of the non-NN tree policy; false when the node pool is full (nothing has been changed then)
 __device__ bool rollout_sim(Wave& w, int t) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
@@ -771,7 +789,7 @@ __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
-__global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
+__global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
                                               const float* __restrict__ v, void* x, int32_t* net_out, int end_ply) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];

@@ -6,9 +6,14 @@
 namespace ckr {
 
 __device__ __forceinline__ uint32_t sel8(const uint32_t m[8], int d) {
+    // a chain of selects, kept as such: left alone, LLVM turns it into an indexed load from a scratch copy of m[]
+    // (2 KB of private-memory stores per wave and call site -- most of k_step's HBM write traffic in round 1)
     uint32_t v = m[0];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) v = (d == i) ? m[i] : v;
+    for (int i = 1; i < 8; ++i) {
+        v = (d == i) ? m[i] : v;
+        asm volatile("" : "+v"(v));
+    }
     return v;
 }
 

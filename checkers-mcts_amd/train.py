@@ -481,9 +481,13 @@ def plot_history(history, nn, TRAINING_ITERATION):
 def load_model(filename, **kwargs):
     """Network saved by train_nn / save_nn_to_disk, ready for further training (tensorflow.keras
     load_model in train_Checkers.py:163)."""
-    sd = torch.load(filename, map_location="cpu")
-    net = PolicyValueNet(sd["body.1.conv.weight"].shape[0])
-    net.load_state_dict(sd)
+    if str(filename).endswith((".h5", ".hdf5")):                        # a model saved by the reference (Keras)
+        from . import keras_h5
+        net = keras_h5.load_keras_weights(filename).train()
+    else:
+        sd = torch.load(filename, map_location="cpu")
+        net = PolicyValueNet(sd["body.0.conv.weight"].shape[0])
+        net.load_state_dict(sd)
     for name in ("CONV_REG", "DENSE_REG", "POLICY_LOSS_WEIGHT", "VALUE_LOSS_WEIGHT"):
         if name in kwargs:
             setattr(net, name.lower(), float(kwargs[name]))

@@ -25,7 +25,7 @@ def main():
     from checkers_mcts_amd.net import NetEvaluator, make_net
     from checkers_mcts_amd.pipeline import StepRunner
     rank, local_rank, world = ckdist.init_from_env()
-    dev = torch.device("cuda", local_rank)
+    dev = ckdist.local_device(local_rank)
     torch.cuda.set_device(dev)
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[a.nn_dtype]
     kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=a.budget, MULTIPROC=False, NEURAL_NET=True,
@@ -58,12 +58,13 @@ def main():
     t_all = ckdist.max_over_ranks(time.perf_counter() - t0, dev)
     exp = ckdist.sum_over_ranks(st["expansions"], dev)
     games = ckdist.sum_over_ranks(st["games"], dev)
+    terms = ckdist.sum_over_ranks(st["terminal_visits"], dev)           # collectives on every rank, not inside the rank-0 branch
     if rank == 0:
         moves = np.array([r["move_count"] for r in res] or [0])
         out = dict(n_gpus=world, slots_per_gpu=a.slots, games_per_slot=a.games_per_slot, dynamic_queue=a.dynamic, budget=a.budget, nn_dtype=a.nn_dtype, steps=steps,
                    seconds=t_all, play_seconds=t_play, gather_seconds=t_gather, games=games,
                    games_per_hour=games / t_all * 3600, expansions=exp, expansions_per_s=exp / t_all,
-                   sims_per_s=(exp + ckdist.sum_over_ranks(st["terminal_visits"], dev)) / t_all, ms_per_step=t_play / max(1, steps) * 1e3,
+                   sims_per_s=(exp + terms) / t_all, ms_per_step=t_play / max(1, steps) * 1e3,
                    tuples_gathered=int(gathered.shape[0]), rank0_stats=st,
                    rank0_game_length=dict(mean=float(moves.mean()), min=int(moves.min()), max=int(moves.max())),
                    rank0_outcomes={str(k): int((np.array([r["outcome"] for r in res]) == k).sum()) for k in (1, 2, 3)},
