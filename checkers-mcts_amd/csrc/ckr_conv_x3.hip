@@ -410,13 +410,23 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+// Value-head tail folded into the same launch (training_pipeline.py:106-112: Dense(64)+ReLU -> BatchNorm -> Dense(1) ->
+// tanh on the 64 value features of a position): after the softmax, wave w evaluates positions 2w and 2w + 1 of the
+// workgroup's 16 (lane = hidden unit) -- the arithmetic of k_value_mlp (ckr_conv.hip), one launch less per step.
+struct ValueTail {
+    const float* in;           // [n][64] value features (NULL: policy head only)
+    const float* w1t; const float* b1; const float* sc; const float* sh; const float* w2;
+    float b2;
+    float* v;                  // [n]
+};
+
 // 8 waves: wave w = outputs [64w, +64) = 4 MFMA tiles x MT row tiles of 16 positions; B / A fragments
 // run two k-steps ahead of the MFMAs in a 3-deep register ring (the loads are L2 hits with ~1 us
 // latency and nothing else hides them).  Every workgroup reads the whole 1 MB weight image from L2.
 template <int MT>
 __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ feat, long long n, const uint4* __restrict__ wp,
                                                      const float* __restrict__ bias, float x_scale, float inv_scale,
-                                                     float* __restrict__ p, int32_t* __restrict__ overflow) {
+                                                     float* __restrict__ p, int32_t* __restrict__ overflow, const ValueTail V) {
     __shared__ float red[2][8][16 * MT];
     __shared__ uint4 a_hi[16][4][16 * MT], a_lo[16][4][16 * MT];      // A fragments [k-step][k-group][position]: 16 B each
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, grp = lane >> 4;
@@ -544,6 +554,25 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
                 for (int nt = 0; nt < 4; ++nt) dst[16 * nt] = acc[mt][nt][r] / tot;
             }
         }
+    if (V.in) {
+#pragma clang fp contract(fast)
+        float wcol[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) wcol[i] = V.w1t[i * 64 + lane];
+        const float bb = V.b1[lane], s1 = V.sc[lane], s2 = V.sh[lane], ww = V.w2[lane];
+        for (int rr = 0; rr < 2 * MT; ++rr) {
+            const long long r = row0 + (long long)(2 * MT * wave + rr);
+            if (r >= n) break;
+            const float xi = V.in[r * 64 + lane];
+            float h = bb;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) h += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xi), i)) * wcol[i];
+            float y = (s1 * fmaxf(h, 0.0f) + s2) * ww;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) y += __shfl_xor(y, d);
+            if (lane == 0) V.v[r] = tanhf(y + V.b2);
+        }
+    }
 }
 
 }  // namespace ckrp
@@ -557,7 +586,23 @@ extern "C" int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_p
     // MT = 1: 16 positions per workgroup (measured 22 us per 4 096 positions; MT = 2: 31 us, MT = 4: 53 us -- fewer CUs busy)
     hipLaunchKernelGGL(ckrp::k_policy_head<1>, dim3((unsigned)((n + 15) / 16)), dim3(512), 0,
                        (hipStream_t)stream, d_feat, (long long)n, (const uint4*)d_w_packed, d_bias, x_scale,
-                       1.0f / (x_scale * w_scale), d_p, d_overflow);
+                       1.0f / (x_scale * w_scale), d_p, d_overflow, ckrp::ValueTail{});
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+extern "C" int ckr_heads_tail(const float* d_pol_feat, const float* d_val_feat, int64_t n, const void* d_w_packed,
+                              const float* d_bias, float x_scale, float w_scale, const float* w1t, const float* b1,
+                              const float* scale, const float* shift, const float* w2, float b2, float* d_p, float* d_v,
+                              int32_t* d_overflow, void* stream) {
+    if (n < 0 || !(x_scale > 0.0f) || !(w_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_heads_tail: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    if (!d_pol_feat || !d_val_feat || !d_w_packed || !d_bias || !w1t || !b1 || !scale || !shift || !w2 || !d_p || !d_v)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_heads_tail: null pointer");
+    hipLaunchKernelGGL(ckrp::k_policy_head<1>, dim3((unsigned)((n + 15) / 16)), dim3(512), 0,
+                       (hipStream_t)stream, d_pol_feat, (long long)n, (const uint4*)d_w_packed, d_bias, x_scale,
+                       1.0f / (x_scale * w_scale), d_p, d_overflow, ckrp::ValueTail{d_val_feat, w1t, b1, scale, shift, w2, b2, d_v});
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -8,9 +8,9 @@ operands, the parity mode and the default for NN_DTYPE float32) or
 from the input planes to the head features, conv bias + ReLU + inference
 BatchNorm fused into the epilogue, and the heads' two 1x1 convolutions
 (training_pipeline.py:93-96,102-105) applied before anything leaves the chip.
-What reaches HBM per position is 512 + 64 floats.  The tail is two launches:
-`ckr_policy_head` (Dense(512) + softmax, float32-grade split-fp16 MFMA) and
-`ckr_value_mlp` (Dense(64)+ReLU -> BN -> Dense(1) -> tanh).  PyTorch holds the memory,
+What reaches HBM per position is 512 + 64 floats.  The tail is one launch,
+`ckr_heads_tail`: Dense(512) + softmax (float32-grade split-fp16 MFMA) and the
+value MLP (Dense(64)+ReLU -> BN -> Dense(1) -> tanh).  PyTorch holds the memory,
 the streams and the HIP graph; no torch operator runs in the inference step.
 Weights come from a float32 `net.PolicyValueNet`.
 """
@@ -133,6 +133,7 @@ class FusedEvaluator:
         self.overflow = None
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
+        self._L.ckr_heads_tail.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
         self.nets = [self._prepare(net)]
@@ -206,11 +207,11 @@ class FusedEvaluator:
         stream = torch.cuda.current_stream(x.device).cuda_stream
         self._conv(n, x, stream, board_range)
         t = n["tail"]
-        _lib.check(self._L.ckr_policy_head(n["pol_feat"].data_ptr(), self.S, t["fc_packed"].data_ptr(), t["fc_b"].data_ptr(),
-                                           XS, WS, n["p"].data_ptr(), self._overflow_ptr(x.device), stream))   # Dense(512) + softmax
-        _lib.check(self._L.ckr_value_mlp(n["val_feat"].data_ptr(), self.S, t["w1t"].data_ptr(), t["b1"].data_ptr(),
-                                         t["sc"].data_ptr(), t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"],
-                                         n["v"].data_ptr(), stream))
+        # Dense(512) + softmax and the value MLP: one launch
+        _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), self.S, t["fc_packed"].data_ptr(),
+                                          t["fc_b"].data_ptr(), XS, WS, t["w1t"].data_ptr(), t["b1"].data_ptr(), t["sc"].data_ptr(),
+                                          t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"], n["p"].data_ptr(), n["v"].data_ptr(),
+                                          self._overflow_ptr(x.device), stream))
         return n["p"], n["v"]
 
     @torch.no_grad()

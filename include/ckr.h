@@ -186,6 +186,12 @@ int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_packed, cons
 int ckr_value_mlp(const float* d_in, int64_t n, const float* w1t, const float* b1,
                   const float* scale, const float* shift, const float* w2, float b2,
                   float* d_v, void* stream);
+/* Both head tails in ONE launch: ckr_policy_head on d_pol_feat[n][512] and the arithmetic of ckr_value_mlp on
+ * d_val_feat[n][64] (the evaluator's step: conv stack + this = two launches). */
+int ckr_heads_tail(const float* d_pol_feat, const float* d_val_feat, int64_t n, const void* d_w_packed,
+                   const float* d_bias, float x_scale, float w_scale, const float* w1t, const float* b1,
+                   const float* scale, const float* shift, const float* w2, float b2, float* d_p, float* d_v,
+                   int32_t* d_overflow, void* stream);
 
 /* ---- batched self-play / arena engine ----------------------------------- */
 
