@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["ckr_rules.hip", "ckr_engine.hip", "ckr_conv.hip", "ckr_conv_x3.hip"]
+SOURCES = ["ckr_rules.hip", "ckr_engine.hip", "ckr_conv.hip", "ckr_conv_x3.hip", "ckr_train.hip"]
 LIB = os.path.join(HERE, "libckr.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc (ROCm 7.2) SLP-packs adjacent scalar float32 multiply-adds into v_pk_fma_f32 / v_pk_mul_f32

@@ -280,8 +280,22 @@ def train_nn(training_data, neural_network, **kwargs):
 
     use_graph = dev.type == "cuda" and kwargs.get("USE_GRAPH", True)
     captured = {}                            # "train": (graph, static x / pi / tv, static sums); lr lives in a device tensor
+    # TRAIN_BACKEND "hip" (default on a GPU for the reference's 128-kernel network in float32): forward, backward and Adam
+    # of full batches run in the hand-written kernels of csrc/ckr_train.hip (train_hip.HipTrainStep); "torch": autograd +
+    # torch.optim.Adam (also used for the last, ragged batch of an epoch and for mixed-precision training)
+    backend = kwargs.get("TRAIN_BACKEND", "hip" if (dev.type == "cuda" and amp == torch.float32 and net.num_kernels == 128
+                                                     and BATCH_SIZE % 2 == 0) else "torch")
+    hip = None
+    if backend == "hip":
+        from .train_hip import HipTrainStep
+        hip = HipTrainStep(net, BATCH_SIZE, net.conv_reg, net.dense_reg, net.policy_loss_weight, net.value_loss_weight)
+    elif backend != "torch":
+        raise ValueError("TRAIN_BACKEND must be 'hip' or 'torch'")
 
     def train_batch(x, pi, tv, acc, n_rows):
+        if hip is not None and int(x.shape[0]) == BATCH_SIZE:
+            hip.step(x, pi, tv, lr_t, acc, n_rows)
+            return
         opt.zero_grad(set_to_none=False)
         loss, ce, mse = losses(net, x, pi, tv, amp, with_penalty=False)
         loss.backward()
@@ -316,8 +330,13 @@ def train_nn(training_data, neural_network, **kwargs):
         else:
             acc = torch.zeros(3, dtype=torch.float64, device=dev)
         pen_eval = None if train else l2_penalty_value(net)
+        rows_seen = 0
         for b in batches:
             sel = idx[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
+            if train and hip is not None and int(sel.shape[0]) < BATCH_SIZE <= int(idx.shape[0]):
+                # the HIP step works on full batches: the epoch's last, ragged batch is filled up with its first samples
+                sel = torch.cat([sel, idx[:BATCH_SIZE - int(sel.shape[0])]])
+            rows_seen += int(sel.shape[0])
             if train:
                 lr_t.fill_(float(lr))
                 if dev.type != "cuda":
@@ -341,13 +360,15 @@ def train_nn(training_data, neural_network, **kwargs):
                 with torch.no_grad():
                     loss, ce, mse = losses(net, x, pi, tv, amp, with_penalty=False)
                 acc += torch.stack([loss.detach() + pen_eval, ce.detach(), mse.detach()]).double() * float(sel.shape[0])
-        tot, ce_s, mse_s = (acc / float(idx.shape[0])).tolist()
+        tot, ce_s, mse_s = (acc / float(rows_seen)).tolist()
         return tot, ce_s, mse_s
 
     for epoch in range(EPOCHS):
         net.train()
         tl, tce, tmse = run(train_idx, True)
         history.add(loss=tl, policy_head_loss=tce, value_head_loss=tmse)
+        if hip is not None:
+            hip.store_to_module()             # validation, checkpoints and the returned network read the module
         if n_val:
             net.eval()
             vl, vce, vmse = run(val_idx, False)

@@ -1,0 +1,246 @@
+"""The training step of the reference's network in hand-written HIP kernels (csrc/ckr_train.hip).
+
+`HipTrainStep` replaces the PyTorch autograd / MIOpen / fused-Adam step of train.train_nn: one call =
+forward in training mode (BatchNormalization on batch statistics, moving statistics updated), the
+Keras losses of training_pipeline.py:49-114 (categorical cross-entropy on the clipped, renormalised
+softmax + MSE, l2 penalties on every conv / dense kernel and bias), backward, Adam (Keras epsilon 1e-7).
+All arithmetic is float32 like Keras': the 3x3 convolutions run as im2col GEMMs on the float32 matrix
+pipe (`ckr_gemm_nt`), everything else is elementwise / reduction kernels.  torch supplies the memory
+and the stream; no torch operator runs inside a step, so the step captures into a HIP graph.
+
+The parameters live in ONE flat float32 buffer in the kernels' layouts (conv kernels as
+[out][tap * Cin + c]); `load_from_module` / `store_to_module` convert from / to net.PolicyValueNet.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+KPAD0 = 128                      # 9 taps x 14 planes = 126 columns of the first layer's im2col matrix, padded to the GEMM's K granule
+
+
+class HipTrainStep:
+    def __init__(self, net, batch_size, conv_reg, dense_reg, policy_loss_weight=1.0, value_loss_weight=1.0,
+                 betas=(0.9, 0.999), eps=1e-7, bn_eps=1e-3, bn_momentum=0.01):
+        if net.num_kernels != 128:
+            raise ValueError("the hand-written training step is built for NUM_KERNELS = 128")
+        if batch_size % 2:
+            raise ValueError("BATCH_SIZE must be even (GEMM tiles of 128 positions)")
+        self._L = L = _lib.load()
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        L.ckr_gemm_nt.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.ckr_gemm_small.argtypes = [vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp]
+        L.ckr_im2col.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        L.ckr_col2im.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.ckr_transpose.argtypes = [vp, i32, i32, vp, vp]
+        L.ckr_bn_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
+        L.ckr_bn_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.ckr_add.argtypes = [vp, vp, i64, vp, vp]
+        L.ckr_policy_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
+        L.ckr_value_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
+        L.ckr_loss_sums.argtypes = [vp, vp, i32, f32, f32, vp, C.c_double, vp, vp]
+        L.ckr_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp]
+        L.ckr_sum_rows.argtypes = [vp, i32, i32, vp, vp]
+        self.net = net
+        self.wgrad_slices = max(s for s in (1, 2, 4, 8, 16, 32) if (64 * int(batch_size)) % (32 * s) == 0)   # split-K of the weight-gradient GEMMs
+        self.dev = dev = next(net.parameters()).device
+        self.B, self.P = int(batch_size), 64 * int(batch_size)
+        self.wp, self.wv = float(policy_loss_weight), float(value_loss_weight)
+        self.betas, self.eps, self.bn_eps, self.bn_mom = betas, float(eps), float(bn_eps), float(bn_momentum)
+        # ---- flat parameter layout
+        self.slices = {}
+        off = 0
+
+        def add(name, n, reg):
+            nonlocal off
+            self.slices[name] = (off, n, reg)
+            off += (n + 3) // 4 * 4                       # 16-byte aligned segments
+        self.kpad = [KPAD0] + [1152] * 7
+        for l in range(8):
+            add("c%d.w" % l, 128 * self.kpad[l], conv_reg); add("c%d.b" % l, 128, conv_reg)
+            add("c%d.g" % l, 128, 0.0); add("c%d.beta" % l, 128, 0.0)
+        add("p2.w", 8 * 128, conv_reg); add("p2.b", 8, conv_reg); add("p2.g", 8, 0.0); add("p2.beta", 8, 0.0)
+        add("v1.w", 128, conv_reg); add("v1.b", 1, conv_reg); add("v1.g", 1, 0.0); add("v1.beta", 1, 0.0)
+        add("fc.w", 512 * 512, dense_reg); add("fc.b", 512, dense_reg)
+        add("f1.w", 64 * 64, dense_reg); add("f1.b", 64, dense_reg); add("vbn.g", 64, 0.0); add("vbn.beta", 64, 0.0)
+        add("f2.w", 64, dense_reg); add("f2.b", 1, dense_reg)
+        self.n = off
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        self.W, self.G, self.M, self.V, self.reg = z(off), z(off), z(off), z(off), z(off)
+        for name, (o, n, reg) in self.slices.items():
+            self.reg[o:o + n] = reg
+        self.step_t = z(1)
+        self.penalty = z(1)
+        # ---- BatchNorm moving statistics (not optimised): conv blocks, p2, v1, vbn
+        self.run = {k: (z(c), torch.ones(c, dtype=torch.float32, device=dev)) for k, c in
+                    [("c%d" % l, 128) for l in range(8)] + [("p2", 8), ("v1", 1), ("vbn", 64)]}
+        # ---- activations kept for the backward pass, workspaces
+        P, B = self.P, self.B
+        self.col = [z(P, k) for k in self.kpad]
+        self.colT = [z(k, P) for k in self.kpad]
+        self.a = [z(P, 128) for _ in range(8)]            # post-ReLU pre-BatchNorm (the GEMM output, rewritten in place)
+        self.out = [z(P, 128) for _ in range(8)]
+        self.stats = {k: z(2, c) for k, (c) in [("c%d" % l, 128) for l in range(8)] + [("p2", 8), ("v1", 1), ("vbn", 64)]}
+        self.a_p2, self.out_p2 = z(P, 8), z(P, 8)
+        self.a_v1, self.out_v1 = z(P, 1), z(P, 1)
+        self.a_f1, self.out_f1 = z(B, 64), z(B, 64)
+        self.logits, self.dlogits, self.z_f2, self.dz_f2 = z(B, 512), z(B, 512), z(B), z(B)
+        self.ce, self.se = z(B), z(B)
+        self.part = z(2 * 128 * (P // 64 + 1))
+        self.sums = z(2, 128)
+        self.gws = z(32 * 128 * 1152)                     # split-K partial products
+        self.d_act, self.d_act2, self.d_col = z(P, 128), z(P, 128), z(P, 1152)
+        self.dzT, self.wT = z(128, P), z(1152, 128)
+        self.d_p2, self.d_f, self.d_v1, self.d_f1 = z(P, 8), z(B, 512), z(P, 1), z(B, 64)
+        self.load_from_module()
+
+    # ---- parameter views --------------------------------------------------------------------------------
+    def w(self, name, buf=None):
+        o, n, _ = self.slices[name]
+        return (self.W if buf is None else buf)[o:o + n]
+
+    def g(self, name):
+        return self.w(name, self.G)
+
+    def _blocks(self):
+        net = self.net
+        return list(net.body) + [net.pol1]
+
+    @torch.no_grad()
+    def load_from_module(self):
+        net = self.net
+        for l, blk in enumerate(self._blocks()):
+            cw = blk["conv"].weight.detach().float()                       # [out][in][ky][kx]
+            cin = cw.shape[1]
+            m = torch.zeros((128, self.kpad[l]), dtype=torch.float32, device=self.dev)
+            m[:, :9 * cin] = cw.permute(0, 2, 3, 1).reshape(128, 9 * cin)   # k = tap * Cin + c
+            self.w("c%d.w" % l).copy_(m.reshape(-1))
+            self.w("c%d.b" % l).copy_(blk["conv"].bias.detach().float())
+            self.w("c%d.g" % l).copy_(blk["bn"].weight.detach().float()); self.w("c%d.beta" % l).copy_(blk["bn"].bias.detach().float())
+            self.run["c%d" % l][0].copy_(blk["bn"].running_mean); self.run["c%d" % l][1].copy_(blk["bn"].running_var)
+        for key, blk in (("p2", net.pol2), ("v1", net.val1)):
+            self.w(key + ".w").copy_(blk["conv"].weight.detach().float().reshape(-1))
+            self.w(key + ".b").copy_(blk["conv"].bias.detach().float())
+            self.w(key + ".g").copy_(blk["bn"].weight.detach().float()); self.w(key + ".beta").copy_(blk["bn"].bias.detach().float())
+            self.run[key][0].copy_(blk["bn"].running_mean); self.run[key][1].copy_(blk["bn"].running_var)
+        self.w("fc.w").copy_(net.pol_fc.weight.detach().float().reshape(-1)); self.w("fc.b").copy_(net.pol_fc.bias.detach().float())
+        self.w("f1.w").copy_(net.val_fc1.weight.detach().float().reshape(-1)); self.w("f1.b").copy_(net.val_fc1.bias.detach().float())
+        self.w("vbn.g").copy_(net.val_bn.weight.detach().float()); self.w("vbn.beta").copy_(net.val_bn.bias.detach().float())
+        self.run["vbn"][0].copy_(net.val_bn.running_mean); self.run["vbn"][1].copy_(net.val_bn.running_var)
+        self.w("f2.w").copy_(net.val_fc2.weight.detach().float().reshape(-1)); self.w("f2.b").copy_(net.val_fc2.bias.detach().float())
+
+    @torch.no_grad()
+    def store_to_module(self):
+        net = self.net
+        for l, blk in enumerate(self._blocks()):
+            cin = blk["conv"].weight.shape[1]
+            m = self.w("c%d.w" % l).reshape(128, self.kpad[l])[:, :9 * cin].reshape(128, 3, 3, cin).permute(0, 3, 1, 2)
+            blk["conv"].weight.copy_(m); blk["conv"].bias.copy_(self.w("c%d.b" % l))
+            blk["bn"].weight.copy_(self.w("c%d.g" % l)); blk["bn"].bias.copy_(self.w("c%d.beta" % l))
+            blk["bn"].running_mean.copy_(self.run["c%d" % l][0]); blk["bn"].running_var.copy_(self.run["c%d" % l][1])
+        for key, blk in (("p2", net.pol2), ("v1", net.val1)):
+            blk["conv"].weight.copy_(self.w(key + ".w").reshape(blk["conv"].weight.shape)); blk["conv"].bias.copy_(self.w(key + ".b"))
+            blk["bn"].weight.copy_(self.w(key + ".g")); blk["bn"].bias.copy_(self.w(key + ".beta"))
+            blk["bn"].running_mean.copy_(self.run[key][0]); blk["bn"].running_var.copy_(self.run[key][1])
+        net.pol_fc.weight.copy_(self.w("fc.w").reshape(512, 512)); net.pol_fc.bias.copy_(self.w("fc.b"))
+        net.val_fc1.weight.copy_(self.w("f1.w").reshape(64, 64)); net.val_fc1.bias.copy_(self.w("f1.b"))
+        net.val_bn.weight.copy_(self.w("vbn.g")); net.val_bn.bias.copy_(self.w("vbn.beta"))
+        net.val_bn.running_mean.copy_(self.run["vbn"][0]); net.val_bn.running_var.copy_(self.run["vbn"][1])
+        net.val_fc2.weight.copy_(self.w("f2.w").reshape(1, 64)); net.val_fc2.bias.copy_(self.w("f2.b"))
+
+    # ---- launch helpers ---------------------------------------------------------------------------------
+    def _s(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _gemm(self, A, Bt, Cm, M, N, K, slices=1):
+        _lib.check(self._L.ckr_gemm_nt(A.data_ptr(), K, Bt.data_ptr(), K, Cm.data_ptr(), N, M, N, K, slices,
+                                       self.gws.data_ptr() if slices > 1 else None, None, self._s()))
+
+    def _small(self, A, am, ak, Bm, bk, bn, Cm, ldc, M, N, K, acc=0):
+        _lib.check(self._L.ckr_gemm_small(A.data_ptr(), am, ak, Bm.data_ptr(), bk, bn, Cm.data_ptr(), ldc, M, N, K, acc, self._s()))
+
+    def _bn_fwd(self, z, bias, P, Cc, relu, key, gname, bname, out):
+        rm, rv = self.run[key]
+        _lib.check(self._L.ckr_bn_forward(z.data_ptr(), bias.data_ptr() if bias is not None else None, P, Cc, relu,
+                                          self.w(gname).data_ptr(), self.w(bname).data_ptr(), self.bn_eps, self.bn_mom,
+                                          rm.data_ptr(), rv.data_ptr(), self.stats[key].data_ptr(), out.data_ptr(),
+                                          self.part.data_ptr(), self._s()))
+
+    def _bn_bwd(self, dout, a, P, Cc, relu, key, gname, bname, biasname):
+        _lib.check(self._L.ckr_bn_backward(dout.data_ptr(), a.data_ptr(), self.stats[key].data_ptr(), self.w(gname).data_ptr(), P, Cc, relu,
+                                           self.g(gname).data_ptr(), self.g(bname).data_ptr(),
+                                           self.g(biasname).data_ptr() if biasname else None,
+                                           self.part.data_ptr(), self.sums.data_ptr(), self._s()))
+
+    # ---- one optimisation step ------------------------------------------------------------------------------
+    def step(self, x, pi, tv, lr_t, acc=None, n_rows=None):
+        """x [B,8,8,14], pi [B,512], tv [B] float32 on the device; lr_t: float32 device scalar.  acc (float64 [3]) +=
+        n_rows * (total loss incl. penalty, policy CE, value MSE) of this batch, evaluated before the update."""
+        L, s, P, B = self._L, self._s(), self.P, self.B
+        if tuple(x.shape) != (B, 8, 8, 14) or not x.is_contiguous() or x.dtype != torch.float32:
+            raise ValueError("x must be a contiguous float32 [%d, 8, 8, 14] tensor" % B)
+        # ---------------- forward
+        inp = x
+        for l in range(8):
+            cin = 14 if l == 0 else 128
+            _lib.check(L.ckr_im2col(inp.data_ptr(), P, cin, self.kpad[l], self.col[l].data_ptr(), self.colT[l].data_ptr(), s))
+            self._gemm(self.col[l], self.w("c%d.w" % l), self.a[l], P, 128, self.kpad[l], slices=4)
+            self._bn_fwd(self.a[l], self.w("c%d.b" % l), P, 128, 1, "c%d" % l, "c%d.g" % l, "c%d.beta" % l, self.out[l])
+            inp = self.out[6] if l == 6 else self.out[l]          # pol1 (l = 7) reads the body's output
+        body, pol1 = self.out[6], self.out[7]
+        # policy head: 1x1 conv (8) + ReLU + BN -> flatten (H, W, C) -> Dense(512)
+        self._small(pol1, 128, 1, self.w("p2.w"), 1, 128, self.a_p2, 8, P, 8, 128)
+        self._bn_fwd(self.a_p2, self.w("p2.b"), P, 8, 1, "p2", "p2.g", "p2.beta", self.out_p2)
+        self._small(self.out_p2, 512, 1, self.w("fc.w"), 1, 512, self.logits, 512, B, 512, 512)           # logits[b][o] = sum_i f[b][i] W[o][i]
+        _lib.check(L.ckr_policy_loss(self.logits.data_ptr(), self.w("fc.b").data_ptr(), pi.data_ptr(), B, self.wp,
+                                     self.dlogits.data_ptr(), self.ce.data_ptr(), s))
+        # value head: 1x1 conv (1) + ReLU + BN -> flatten -> Dense(64) + ReLU + BN -> Dense(1) -> tanh
+        self._small(body, 128, 1, self.w("v1.w"), 1, 128, self.a_v1, 1, P, 1, 128)
+        self._bn_fwd(self.a_v1, self.w("v1.b"), P, 1, 1, "v1", "v1.g", "v1.beta", self.out_v1)
+        self._small(self.out_v1, 64, 1, self.w("f1.w"), 1, 64, self.a_f1, 64, B, 64, 64)
+        self._bn_fwd(self.a_f1, self.w("f1.b"), B, 64, 1, "vbn", "vbn.g", "vbn.beta", self.out_f1)
+        self._small(self.out_f1, 64, 1, self.w("f2.w"), 1, 64, self.z_f2, 1, B, 1, 64)
+        _lib.check(L.ckr_value_loss(self.z_f2.data_ptr(), self.w("f2.b").data_ptr(), tv.data_ptr(), B, self.wv,
+                                    self.dz_f2.data_ptr(), self.se.data_ptr(), s))
+        # ---------------- backward: value head
+        self._small(self.dz_f2, 0, 1, self.out_f1, 64, 1, self.g("f2.w"), 64, 1, 64, B)                  # dW2[j] = sum_b dz[b] h[b][j]
+        _lib.check(L.ckr_sum_rows(self.dz_f2.data_ptr(), B, 1, self.g("f2.b").data_ptr(), s))
+        self._small(self.dz_f2, 1, 1, self.w("f2.w"), 64, 1, self.d_f1, 64, B, 64, 1)                     # dh[b][j] = dz[b] W2[j]
+        self._bn_bwd(self.d_f1, self.a_f1, B, 64, 1, "vbn", "vbn.g", "vbn.beta", "f1.b")
+        self._small(self.d_f1, 1, 64, self.out_v1, 64, 1, self.g("f1.w"), 64, 64, 64, B)                  # dW1[j][i] = sum_b dz[b][j] f[b][i]
+        self._small(self.d_f1, 64, 1, self.w("f1.w"), 64, 1, self.d_v1, 64, B, 64, 64)                    # df[b][i] = sum_j dz[b][j] W1[j][i]
+        self._bn_bwd(self.d_v1, self.a_v1, P, 1, 1, "v1", "v1.g", "v1.beta", "v1.b")
+        self._small(self.d_v1, 0, 1, body, 128, 1, self.g("v1.w"), 128, 1, 128, P)                        # dw[c] = sum_p dz[p] body[p][c]
+        self._small(self.d_v1, 1, 1, self.w("v1.w"), 128, 1, self.d_act2, 128, P, 128, 1)                 # dbody(value)[p][c] = dz[p] w[c]
+        # ---------------- backward: policy head
+        _lib.check(L.ckr_sum_rows(self.dlogits.data_ptr(), B, 512, self.g("fc.b").data_ptr(), s))
+        self._small(self.dlogits, 1, 512, self.out_p2, 512, 1, self.g("fc.w"), 512, 512, 512, B)          # dW[o][i] = sum_b dl[b][o] f[b][i]
+        self._small(self.dlogits, 512, 1, self.w("fc.w"), 512, 1, self.d_f, 512, B, 512, 512)             # df[b][i] = sum_o dl[b][o] W[o][i]
+        self._bn_bwd(self.d_f, self.a_p2, P, 8, 1, "p2", "p2.g", "p2.beta", "p2.b")                      # d_f viewed [P][8]
+        self._small(self.d_f, 1, 8, pol1, 128, 1, self.g("p2.w"), 128, 8, 128, P)                         # dW[o][c] = sum_p dz[p][o] pol1[p][c]
+        self._small(self.d_f, 8, 1, self.w("p2.w"), 128, 1, self.d_act, 128, P, 128, 8)                   # dpol1[p][c] = sum_o dz[p][o] W[o][c]
+        # ---------------- backward: conv blocks 7 (policy conv) .. 0
+        d = self.d_act
+        for l in range(7, -1, -1):
+            key = "c%d" % l
+            self._bn_bwd(d, self.a[l], P, 128, 1, key, key + ".g", key + ".beta", key + ".b")            # d := dz (in place)
+            _lib.check(L.ckr_transpose(d.data_ptr(), P, 128, self.dzT.data_ptr(), s))
+            self._gemm(self.dzT, self.colT[l], self.g(key + ".w"), 128, self.kpad[l], P, slices=self.wgrad_slices)   # dW = dz^T . col
+            if l == 0:
+                break
+            _lib.check(L.ckr_transpose(self.w(key + ".w").data_ptr(), 128, 1152, self.wT.data_ptr(), s))
+            self._gemm(d, self.wT, self.d_col, P, 1152, 128, slices=1)                                    # dcol = dz . W
+            _lib.check(L.ckr_col2im(self.d_col.data_ptr(), P, 128, 1152, d.data_ptr(), s))                # gradient w.r.t. the block's input
+            if l == 7:                                                                                    # the body's output feeds both heads
+                _lib.check(L.ckr_add(d.data_ptr(), self.d_act2.data_ptr(), P * 128, d.data_ptr(), s))
+        # ---------------- losses of the batch (before the update), Adam with the l2 terms
+        if acc is not None:
+            _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
+                                       lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(),
+                                       self.penalty.data_ptr(), s))
+            _lib.check(L.ckr_loss_sums(self.ce.data_ptr(), self.se.data_ptr(), B, self.wp, self.wv, self.penalty.data_ptr(),
+                                       float(n_rows if n_rows is not None else B), acc.data_ptr(), s))
+        else:
+            _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
+                                       lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(), None, s))

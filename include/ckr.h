@@ -360,6 +360,46 @@ int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* sta
 int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* root,
                     ckr_node_info* children, int32_t* n_children);
 
+/* ---- training step: the device side of train_nn (training_pipeline.py:123-179) ------------------- *
+ * One optimisation step of create_nn's model (:59-114) on a batch of B boards is a sequence of these calls, issued by
+ * train_hip.HipTrainStep (which owns the buffers); all arrays are DEVICE float32, activations [P = 64 B positions][C]
+ * channels last, arithmetic float32 throughout (what Keras computes in).  csrc/ckr_train.hip. */
+/* C[M][N] = sum_k A[m][k] Bt[n][k] (+ add[M][N]) on the float32 matrix pipe (v_mfma_f32_32x32x2_f32): the conv
+ * layers' forward (A = im2col matrix, Bt = kernels [out][tap * Cin + c]), data-gradient and weight-gradient GEMMs.
+ * M, N multiples of 128; K a multiple of 32 * slices; slices > 1: split-K through workspace[slices][M][N], ldc == N. */
+int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N,
+                int32_t K, int32_t slices, float* workspace, const float* add, void* stream);
+/* C[m][n] (+)= sum_k A[m am + k ak] B[k bk + n bn]: the small products of the two heads and their gradients. */
+int ckr_gemm_small(const float* A, int64_t am, int64_t ak, const float* B, int64_t bk, int64_t bn, float* C, int64_t ldc,
+                   int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
+/* col[p][tap * cin + c] = x[p + off(tap)][c] ('same' zero padding per 8x8 board; columns >= 9 cin zero), colT = its
+ * transpose (may be NULL); dx[p][c] = sum of dcol over the taps that read x[p][c]. */
+int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col, float* colT, void* stream);
+int ckr_col2im(const float* dcol, int32_t P, int32_t cin, int32_t kpad, float* dx, void* stream);
+int ckr_transpose(const float* in, int32_t rows, int32_t cols, float* out, void* stream);
+/* Keras block "activation -> BatchNormalization" in training mode: z := act(z + bias) in place (relu != 0: ReLU),
+ * stats[2][C] = batch mean and 1 / sqrt(biased variance + eps), moving statistics updated (torch convention: momentum,
+ * unbiased variance), out = gamma * (z - mean) * inv_std + beta.  part: >= 2 C ceil(P / 64) floats of workspace. */
+int ckr_bn_forward(float* z, const float* bias, int32_t P, int32_t C, int32_t relu, const float* gamma, const float* beta,
+                   float eps, float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part, void* stream);
+/* dout (gradient w.r.t. out) -> gradient w.r.t. the pre-activation, in place; dgamma, dbeta, dbias (may be NULL). */
+int ckr_bn_backward(float* dout, const float* a, const float* stats, const float* gamma, int32_t P, int32_t C, int32_t relu,
+                    float* dgamma, float* dbeta, float* dbias, float* part, float* sums, void* stream);
+int ckr_add(const float* a, const float* b, int64_t n, float* y, void* stream);
+int ckr_sum_rows(const float* in, int32_t rows, int32_t cols, float* out, void* stream);
+int ckr_relu_backward(const float* a, int64_t n, float* d, void* stream);
+/* Keras categorical cross-entropy of softmax(logits + bias) (clipped to [1e-7, 1 - 1e-7] after renormalisation) against
+ * pi: ce[B]; dlogits = weight / B * d(sum ce)/dlogits.  Value head: v = tanh(z + *bias), se[B] = (v - target)^2,
+ * dz = weight / B * d(sum se)/dz. */
+int ckr_policy_loss(const float* logits, const float* bias, const float* pi, int32_t B, float weight, float* dlogits, float* ce, void* stream);
+int ckr_value_loss(const float* z, const float* bias, const float* target, int32_t B, float weight, float* dz, float* se, void* stream);
+/* acc[0..2] (float64) += n_rows * {wp mean(ce) + wv mean(se) + *penalty, mean(ce), mean(se)} */
+int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float wv, const float* penalty, double n_rows, double* acc, void* stream);
+/* Adam (torch.optim.Adam arithmetic, Keras epsilon) on the flat parameter vector with the l2 terms folded in:
+ * g = grad + 2 reg[i] w[i]; *d_step += 1 first; lr read from the device; d_penalty (may be NULL) = sum reg w^2 before the update. */
+int ckr_adam_step(float* w, const float* grad, float* m, float* v, const float* reg, int64_t n, const float* d_lr, float beta1,
+                  float beta2, float eps, float* d_step, float* d_penalty, void* stream);
+
 /* ---- probes of the stochastic paths (parity tests only) ------------------ *
  * The reference draws from NumPy's MT19937 (np.random.dirichlet, MCTS.py:107-108; np.random.choice,
  * MCTS.py:246), which cannot be reproduced bit for bit; the engine uses Philox4x32-10.  These entry
