@@ -1,7 +1,8 @@
 """GPU: the hand-written training step (csrc/ckr_train.hip, train_hip.HipTrainStep; SURVEY 8(f) N2, reference:
 train_nn / create_nn, training_pipeline.py:59-179) against PyTorch autograd + torch.optim.Adam on identical weights
 and batches: the GEMM kernel, every gradient tensor of one step, and the parameter / moving-statistics trajectory of
-several steps.  Both sides compute in float32; tolerances are those of float32 sums taken in different orders."""
+several steps.  The yardstick is a float64 graph of the same network that takes its ReLU decisions from the step under
+test (see float64_loss).  The GEMM kernel, every gradient tensor of one step and the Adam trajectory are compared."""
 import ctypes as C
 
 import numpy as np
@@ -29,6 +30,7 @@ def make_batch(B, seed):
 
 
 def close(a, b, rel, what):
+    a, b = a.double(), b.double()
     scale = float(b.abs().max())
     err = float((a - b).abs().max())
     assert err <= rel * scale + 1e-7, "%s: max error %.3e against scale %.3e" % (what, err, scale)
@@ -54,15 +56,51 @@ def test_gemm_nt_matches_float64():
         _lib.check(L.ckr_gemm_nt(A.data_ptr(), 64, Bt.data_ptr(), 64, Cm.data_ptr(), 100, 100, 256, 64, 1, None, None, None))
 
 
-def torch_grads(net, x, pi, tv):
+def relu_decisions(hs):
+    """The ReLU decisions the HIP step took (its kept post-ReLU activations > 0), in the float64 graph's shapes."""
+    B = hs.B
+    m = {"c%d" % l: (hs.a[l] > 0).reshape(B, 8, 8, 128).permute(0, 3, 1, 2) for l in range(8)}
+    m["p2"] = (hs.a_p2 > 0).reshape(B, 8, 8, 8).permute(0, 3, 1, 2)
+    m["v1"] = (hs.a_v1 > 0).reshape(B, 8, 8, 1).permute(0, 3, 1, 2)
+    m["f1"] = hs.a_f1 > 0
+    return m
+
+
+def float64_loss(net, x, pi, tv, decisions):
+    """The graph of PolicyValueNet.forward + train.losses in FLOAT64 (the module's own forward casts to float32).
+
+    Float32 autograd is no yardstick here: a ReLU whose argument lies within float32 rounding of 0 is decided
+    differently by different float32 evaluations (about one unit per 10^6; a batch of 32 has 2.4 * 10^6), and ONE such
+    unit moves the kernel gradient of its layer by ~1/sqrt(positions) of its scale (measured: torch float32 against
+    float64 3e-3 .. 5e-2, profiles/r02_train_step.txt).  Both derivatives are valid subgradients, so the float64 graph
+    takes the ReLU decisions from the step under test and asserts they differ from its own only where |z| is ~0."""
+    import torch.nn.functional as F
     from checkers_mcts_amd import train as T
-    net.train()
-    for p in net.parameters():
-        p.requires_grad_(True)
-        p.grad = None
-    loss, ce, mse = T.losses(net, x, pi, tv, None, with_penalty=True)
-    loss.backward()
-    return float(loss), float(ce), float(mse)
+    flips = []
+
+    def relu(z, key):
+        d = decisions[key]
+        other = (z > 0) != d
+        if bool(other.any()):
+            flips.append(float(z[other].abs().max() / z.abs().max()))
+        return z * d
+
+    def block(blk, h, key):
+        return blk["bn"](relu(blk["conv"](h), key))
+    B = x.shape[0]
+    h = x.double().permute(0, 3, 1, 2)
+    for l, blk in enumerate(net.body):
+        h = block(blk, h, "c%d" % l)
+    p = block(net.pol2, block(net.pol1, h, "c7"), "p2").permute(0, 2, 3, 1).reshape(B, 512)
+    p = F.softmax(net.pol_fc(p), dim=1)
+    v = block(net.val1, h, "v1").permute(0, 2, 3, 1).reshape(B, 64)
+    v = torch.tanh(net.val_fc2(net.val_bn(relu(net.val_fc1(v), "f1")))).reshape(-1)
+    p = p / p.sum(dim=1, keepdim=True)
+    ce = -(pi.double() * torch.log(p.clamp(1e-7, 1 - 1e-7))).sum(dim=1).mean()
+    mse = F.mse_loss(v, tv.double())
+    loss = net.policy_loss_weight * ce + net.value_loss_weight * mse + T.l2_penalty(net)
+    assert all(f < 1e-5 for f in flips), flips           # only arguments within rounding of 0 may be decided differently
+    return loss, ce, mse
 
 
 @pytest.mark.parametrize("B", [32, 128])
@@ -72,14 +110,16 @@ def test_one_step_gradients_match_autograd(B):
     net = make_net(3)
     net.conv_reg, net.dense_reg, net.policy_loss_weight, net.value_loss_weight = 1e-3, 2e-3, 1.0, 0.7
     x, pi, tv = make_batch(B, 11 + B)
-    ref = copy.deepcopy(net)
+    ref = copy.deepcopy(net).double().train()
     ref.conv_reg, ref.dense_reg, ref.policy_loss_weight, ref.value_loss_weight = 1e-3, 2e-3, 1.0, 0.7
-    loss, ce, mse = torch_grads(ref, x, pi, tv)
     hs = HipTrainStep(net, B, 1e-3, 2e-3, 1.0, 0.7)
     acc = torch.zeros(3, dtype=torch.float64, device="cuda")
     lr = torch.tensor(0.0, device="cuda")                          # lr 0: gradients and statistics only
     hs.step(x, pi, tv, lr, acc, B)
     torch.cuda.synchronize()
+    loss, ce, mse = float64_loss(ref, x, pi, tv, relu_decisions(hs))
+    loss.backward()
+    loss, ce, mse = float(loss), float(ce), float(mse)
     got = (acc / B).tolist()
     assert abs(got[1] - ce) < 2e-5 * max(1.0, abs(ce)) and abs(got[2] - mse) < 2e-5 and abs(got[0] - loss) < 5e-5 * max(1.0, abs(loss))
     two_reg = {"conv": 2e-3, "dense": 4e-3}                        # HipTrainStep folds d(penalty)/dw = 2 reg w into Adam, not into G
@@ -87,10 +127,10 @@ def test_one_step_gradients_match_autograd(B):
     for l, blk in enumerate(blocks):
         cin = blk["conv"].weight.shape[1]
         gw = hs.g("c%d.w" % l).reshape(128, hs.kpad[l])[:, :9 * cin].reshape(128, 3, 3, cin).permute(0, 3, 1, 2)
-        close(gw + two_reg["conv"] * blk["conv"].weight.detach(), blk["conv"].weight.grad, 2e-3, "conv %d kernel" % l)
-        close(hs.g("c%d.b" % l) + two_reg["conv"] * blk["conv"].bias.detach(), blk["conv"].bias.grad, 2e-3, "conv %d bias" % l)
-        close(hs.g("c%d.g" % l), blk["bn"].weight.grad, 2e-3, "bn %d gamma" % l)
-        close(hs.g("c%d.beta" % l), blk["bn"].bias.grad, 2e-3, "bn %d beta" % l)
+        close(gw + two_reg["conv"] * blk["conv"].weight.detach(), blk["conv"].weight.grad, 5e-5, "conv %d kernel" % l)
+        close(hs.g("c%d.b" % l) + two_reg["conv"] * blk["conv"].bias.detach(), blk["conv"].bias.grad, 5e-5, "conv %d bias" % l)
+        close(hs.g("c%d.g" % l), blk["bn"].weight.grad, 5e-5, "bn %d gamma" % l)
+        close(hs.g("c%d.beta" % l), blk["bn"].bias.grad, 5e-5, "bn %d beta" % l)
         close(hs.run["c%d" % l][0], blk["bn"].running_mean, 1e-4, "bn %d moving mean" % l)
         close(hs.run["c%d" % l][1], blk["bn"].running_var, 1e-4, "bn %d moving variance" % l)
     for key, blk in (("p2", ref.pol2), ("v1", ref.val1)):
@@ -98,23 +138,22 @@ def test_one_step_gradients_match_autograd(B):
         close(hs.g(key + ".b") + two_reg["conv"] * blk["conv"].bias.detach(), blk["conv"].bias.grad, 2e-3, key + " bias")
         close(hs.g(key + ".g"), blk["bn"].weight.grad, 2e-3, key + " gamma")
         close(hs.g(key + ".beta"), blk["bn"].bias.grad, 2e-3, key + " beta")
-    close(hs.g("fc.w").reshape(512, 512) + two_reg["dense"] * ref.pol_fc.weight.detach(), ref.pol_fc.weight.grad, 2e-3, "policy dense kernel")
-    close(hs.g("fc.b") + two_reg["dense"] * ref.pol_fc.bias.detach(), ref.pol_fc.bias.grad, 2e-3, "policy dense bias")
-    close(hs.g("f1.w").reshape(64, 64) + two_reg["dense"] * ref.val_fc1.weight.detach(), ref.val_fc1.weight.grad, 2e-3, "value dense 1 kernel")
-    close(hs.g("f1.b") + two_reg["dense"] * ref.val_fc1.bias.detach(), ref.val_fc1.bias.grad, 2e-3, "value dense 1 bias")
-    close(hs.g("vbn.g"), ref.val_bn.weight.grad, 2e-3, "value bn gamma")
-    close(hs.g("vbn.beta"), ref.val_bn.bias.grad, 2e-3, "value bn beta")
-    close(hs.g("f2.w").reshape(1, 64) + two_reg["dense"] * ref.val_fc2.weight.detach(), ref.val_fc2.weight.grad, 2e-3, "value dense 2 kernel")
-    close(hs.g("f2.b") + two_reg["dense"] * ref.val_fc2.bias.detach(), ref.val_fc2.bias.grad, 2e-3, "value dense 2 bias")
+    close(hs.g("fc.w").reshape(512, 512) + two_reg["dense"] * ref.pol_fc.weight.detach(), ref.pol_fc.weight.grad, 5e-4, "policy dense kernel")
+    close(hs.g("fc.b") + two_reg["dense"] * ref.pol_fc.bias.detach(), ref.pol_fc.bias.grad, 5e-4, "policy dense bias")
+    close(hs.g("f1.w").reshape(64, 64) + two_reg["dense"] * ref.val_fc1.weight.detach(), ref.val_fc1.weight.grad, 5e-4, "value dense 1 kernel")
+    close(hs.g("f1.b") + two_reg["dense"] * ref.val_fc1.bias.detach(), ref.val_fc1.bias.grad, 5e-4, "value dense 1 bias")
+    close(hs.g("vbn.g"), ref.val_bn.weight.grad, 5e-4, "value bn gamma")
+    close(hs.g("vbn.beta"), ref.val_bn.bias.grad, 5e-4, "value bn beta")
+    close(hs.g("f2.w").reshape(1, 64) + two_reg["dense"] * ref.val_fc2.weight.detach(), ref.val_fc2.weight.grad, 5e-4, "value dense 2 kernel")
+    close(hs.g("f2.b") + two_reg["dense"] * ref.val_fc2.bias.detach(), ref.val_fc2.bias.grad, 5e-4, "value dense 2 bias")
 
 
-def test_adam_trajectory_matches_torch():
+def test_adam_trajectory_matches_float64():
     import copy
-    from checkers_mcts_amd import train as T
     from checkers_mcts_amd.train_hip import HipTrainStep
     B, steps = 64, 6
     net = make_net(9)
-    ref = copy.deepcopy(net)
+    ref = copy.deepcopy(net).double().train()
     for m in (net, ref):
         m.conv_reg, m.dense_reg, m.policy_loss_weight, m.value_loss_weight = 1e-3, 1e-3, 1.0, 1.0
     hs = HipTrainStep(net, B, 1e-3, 1e-3)
@@ -124,24 +163,25 @@ def test_adam_trajectory_matches_torch():
     ref_losses = []
     for i in range(steps):
         x, pi, tv = make_batch(B, 100 + i)
-        ref.train()
+        hs.step(x, pi, tv, lr, acc, B)
+        torch.cuda.synchronize()
         opt.zero_grad()
-        loss, ce, mse = T.losses(ref, x, pi, tv, None, with_penalty=True)
+        loss, ce, mse = float64_loss(ref, x, pi, tv, relu_decisions(hs))
         loss.backward()
         opt.step()
         ref_losses.append(float(loss))
-        hs.step(x, pi, tv, lr, acc, B)
-    torch.cuda.synchronize()
-    assert abs(float(acc[0]) / B - sum(ref_losses)) < 2e-3 * sum(ref_losses)
+    assert abs(float(acc[0]) / B - sum(ref_losses)) < 1e-4 * sum(ref_losses)
     hs.store_to_module()
     sd, rd = net.state_dict(), ref.state_dict()
     for k in rd:
         if k.endswith("num_batches_tracked"):
             continue
-        close(sd[k].float(), rd[k].float(), 2e-2 if "weight" in k or "bias" in k else 1e-3, k)
-    # the trained module evaluates like the reference one
+        close(sd[k], rd[k], 1e-3, k)
+    # the trained module evaluates like the float64 one
     net.eval(); ref.eval()
     x, _, _ = make_batch(16, 7)
     with torch.no_grad():
-        p1, v1 = net(x.permute(0, 3, 1, 2)); p2, v2 = ref(x.permute(0, 3, 1, 2))
-    assert float((p1 - p2).abs().max()) < 2e-3 and float((v1 - v2).abs().max()) < 2e-2
+        p1, v1 = net(x.permute(0, 3, 1, 2))
+        r32 = copy.deepcopy(ref).float()
+        p2, v2 = r32(x.permute(0, 3, 1, 2))
+    assert float((p1 - p2).abs().max()) < 1e-4 and float((v1 - v2).abs().max()) < 1e-3
