@@ -8,7 +8,7 @@
 namespace ckr {
 
 char* last_error_buf();                 // thread-local, 512 bytes (ckr_rules.hip)
-int   fail(int code, const char* fmt, ...);
+int   fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
 #define CKR_HIP(expr)                                                                     \
     do {                                                                                  \

@@ -6,14 +6,18 @@
 // channels last): forward in training mode (BatchNormalization on batch statistics), backward, Adam.
 // The host side (train_hip.py) owns the buffers and the order of the launches.
 //
-//   * the 3x3 convolutions are GEMMs on an explicit im2col matrix (k = tap * Cin + c): forward
-//     Z = COL . W^T, data gradient dCOL = dZ . W, weight gradient dW = dZ^T . COL -- all three through ONE
-//     "NT" GEMM kernel (C = A . Bt^T, both operands K-contiguous) on the float32 matrix pipe
-//     (v_mfma_f32_32x32x2_f32: exact float32 products, float32 accumulation, the arithmetic Keras uses);
-//     128 x 128 tiles, K chunks of 32 staged through LDS, optional split-K with a deterministic reduction;
-//   * everything else (bias + ReLU + BatchNorm statistics / apply / backward, 1x1 convolutions and the
-//     dense layers of the two heads, losses, Adam with the l2 terms) is bandwidth- or latency-bound
-//     elementwise / reduction work in plain float32.
+//   * the 3x3 convolutions are IMPLICIT GEMMs (k = tap * 128 + c) on the float32 matrix pipe
+//     (v_mfma_f32_32x32x2_f32: exact float32 products, float32 accumulation, the arithmetic Keras uses),
+//     128 x 128 tiles, K chunks of 32 staged through LDS, split-K with a deterministic reduction:
+//       forward        Z[p][o]   = sum_{tap,c} X[p + off(tap)][c] W[o][tap,c]        k_gemm_nt<+1>, rows gathered
+//       data gradient  dX[p][c]  = sum_{tap,o} dZ[p - off(tap)][o] Wt[c][tap,o]      k_gemm_nt<-1>, Wt from k_wflip
+//       weight grad.   dW[o][tap,c] = sum_p dZ[p][o] X[p + off(tap)][c]              k_wgrad_tn, K = positions
+//     no im2col matrix exists for the 128 -> 128 layers; the 14-plane first layer (K = 126) uses a small one;
+//   * the split-K reductions carry the next elementwise step (bias + ReLU + BatchNorm partial sums forward,
+//     the BatchNorm-backward partial sums on the way back), and the BatchNorm apply kernels finish the
+//     per-channel sums in their prologue, so a conv block is 3 launches forward and 6 backward;
+//   * everything else (1x1 convolutions and the dense layers of the two heads, losses, Adam with the l2 terms)
+//     is bandwidth- or latency-bound elementwise / reduction work in plain float32.
 #include "ckr_host.h"
 #include <hip/hip_runtime.h>
 
@@ -28,6 +32,10 @@ constexpr int PITCH = BK + 4;                                     // floats per 
 // C[M][N] (ldc) = sum_k A[m][k] * Bt[n][k]; M % 128 == 0, N % 128 == 0, K % (32 * slices) == 0.
 // gridDim = (N / 128, M / 128, slices); slice z covers k in [z * K / slices, (z + 1) * K / slices) and writes
 // C + z * M * ldc (the caller reduces the slices).
+// GATHER = 0: A is a plain [M][lda] matrix.  GATHER = +1 / -1: A is an activation [M = positions][128] and
+// column k = tap * 128 + c of the virtual matrix is A[p + GATHER * off(tap)][c], 0 outside the 8x8 board
+// (off(tap) = 8 dy + dx, tap = 3 (dy + 1) + (dx + 1)); a chunk of 32 columns never straddles a tap.
+template <int GATHER>
 __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt(const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb,
                                                 float* __restrict__ C, int ldc, int M, int K) {
     __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
@@ -43,26 +51,41 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-    float4 ra[4], rb[4];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + GT * i, row = idx >> 3, c4 = idx & 7;
-            ra[i] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 4 * c4);
-            rb[i] = *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + row) * ldb + k0 + 4 * c4);
-        }
+    // staging registers of the next chunk: named scalars, not arrays (an indexed float4 array captured by a lambda is
+    // moved to LDS by the compiler's alloca promotion here, which puts a vmcnt(0) wait behind every load)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const int frow = tid >> 3, fc4 = tid & 7;                     // this thread stages rows frow + 32 i, columns 4 fc4 .. 4 fc4 + 3
+    unsigned on_board = 0xf;                                      // GATHER: bit i = the tap of staged row i lies on the board
+    auto load_a = [&](int k0, int i) -> float4 {
+        const int row = frow + 32 * i;
+        if (GATHER == 0) return *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 4 * fc4);
+        const int tap = k0 >> 7, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int p = m0 + row, y = ((p >> 3) & 7) + GATHER * dy, x = (p & 7) + GATHER * dx;
+        const bool in = (unsigned)y < 8u && (unsigned)x < 8u;     // branch-free: an off-board tap reads its own row, zeroed when staged
+        on_board = (on_board & ~(1u << i)) | ((unsigned)in << i);
+        return *reinterpret_cast<const float4*>(A + (size_t)(p + (in ? GATHER * (8 * dy + dx) : 0)) * 128 + (k0 & 127) + 4 * fc4);
     };
-    fetch(kbeg);
+    auto load_b = [&](int k0, int i) -> float4 {
+        return *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + frow + 32 * i) * ldb + k0 + 4 * fc4);
+    };
+#define CKR_NT_FETCH(k0)                                                                              \
+    ra0 = load_a(k0, 0); ra1 = load_a(k0, 1); ra2 = load_a(k0, 2); ra3 = load_a(k0, 3);               \
+    rb0 = load_b(k0, 0); rb1 = load_b(k0, 1); rb2 = load_b(k0, 2); rb3 = load_b(k0, 3);
+#define CKR_NT_STAGE(buf, r, i) *reinterpret_cast<float4*>(buf + (frow + 32 * i) * PITCH + 4 * fc4) = r;
+#define CKR_NT_STAGE_A(r, i)                                                                          \
+    { const bool in = GATHER == 0 || ((on_board >> i) & 1u);                                          \
+      *reinterpret_cast<float4*>(As + (frow + 32 * i) * PITCH + 4 * fc4) = make_float4(in ? r.x : 0.f, in ? r.y : 0.f, in ? r.z : 0.f, in ? r.w : 0.f); }
+    CKR_NT_FETCH(kbeg)
     for (int k0 = kbeg; k0 < kbeg + kper; k0 += BK) {
         __syncthreads();                                          // the previous chunk's fragments have been read
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + GT * i, row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<float4*>(As + row * PITCH + 4 * c4) = ra[i];
-            *reinterpret_cast<float4*>(Bs + row * PITCH + 4 * c4) = rb[i];
-        }
+        CKR_NT_STAGE_A(ra0, 0) CKR_NT_STAGE_A(ra1, 1) CKR_NT_STAGE_A(ra2, 2) CKR_NT_STAGE_A(ra3, 3)
+        CKR_NT_STAGE(Bs, rb0, 0) CKR_NT_STAGE(Bs, rb1, 1) CKR_NT_STAGE(Bs, rb2, 2) CKR_NT_STAGE(Bs, rb3, 3)
         __syncthreads();
-        if (k0 + BK < kbeg + kper) fetch(k0 + BK);                // next chunk in flight under the MFMAs
+        {
+            const int kn = min(k0 + BK, kbeg + kper - BK);        // next chunk in flight under the MFMAs (the last one re-reads itself:
+            CKR_NT_FETCH(kn)                                      // no branch, and the loads stay ahead of the MFMAs)
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k8 = 0; k8 < BK; k8 += 8) {                      // lanes 0-31 own k8 + 0..3, lanes 32-63 k8 + 4..7
             float4 fa[2], fb[2];
@@ -94,15 +117,132 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const int row = m0 + 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
                     Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
                 }
+#undef CKR_NT_FETCH
+#undef CKR_NT_STAGE
+#undef CKR_NT_STAGE_A
 }
 
-// out[i] = sum_z part[z][i] (+ add[i]); float4 granularity
-__global__ void k_sum_slices(const float4* __restrict__ part, int slices, long long n4, const float4* __restrict__ add, float4* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    float4 s = add ? add[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < slices; ++z) { const float4 v = part[(size_t)z * n4 + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-    out[i] = s;
+// Weight gradient of a 3x3 convolution with 128 kernels: C[z][o][n0 + c] = sum_{p in slice z} dZ[p][o] * X[p + off(tap)][c]
+// (0 outside the board); gridDim = (taps, 1, slices), n0 = 128 * blockIdx.x, tap = tap0 + blockIdx.x (tap0 = 4 and one
+// block column: a plain dZ^T . X).  Both operands arrive as rows of 128 floats (one position); a thread loads the same
+// four columns of four consecutive positions, transposes the 4 x 4 block in registers and stores, per column m, the four
+// positions as one 16-byte slot: LDS tile [8 position groups][128 columns][4 positions], slot index of column m
+// swizzled (m ^ ((m >> 4) & 3)) so that the 16 lanes of a b128 store pass hit 16 different slots.  The MFMA operand of
+// lane (m, half) for position group 2 j + half is then ONE ds_read_b128 (four k steps), as in k_gemm_nt.
+__device__ __forceinline__ int tn_slot(int kg, int m) { return kg * 128 + (m ^ ((m >> 4) & 3)); }
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_tn(const float* __restrict__ dZ, const float* __restrict__ X, int P, int tap0,
+                                                float* __restrict__ C, int ldc) {
+    __shared__ float4 As[8 * 128];
+    __shared__ float4 Bs[8 * 128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int tap = tap0 + blockIdx.x, dy = tap / 3 - 1, dx = tap % 3 - 1, off = 8 * dy + dx, n0 = 128 * blockIdx.x;
+    const int nchunk = P / BK;                                    // slice z: chunks [z n / Z, (z + 1) n / Z) of 32 positions
+    const int pbeg = (int)((long long)blockIdx.z * nchunk / gridDim.z) * BK, pend = (int)((long long)(blockIdx.z + 1) * nchunk / gridDim.z) * BK;
+    const int c4 = tid & 31, rg = tid >> 5;                       // this thread: columns 4 c4 .. 4 c4 + 3 of positions 4 rg .. 4 rg + 3
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;                // named scalars: see k_gemm_nt
+    unsigned on_board = 0;                                        // bit i = the tap of position 4 rg + i lies on the board
+    auto load_x = [&](int p0, int i) -> float4 {                  // branch-free: an off-board tap reads its own row, zeroed when staged
+        const int p = p0 + 4 * rg + i, y = ((p >> 3) & 7) + dy, x = (p & 7) + dx;
+        const bool in = (unsigned)y < 8u && (unsigned)x < 8u;
+        on_board = (on_board & ~(1u << i)) | ((unsigned)in << i);
+        return *reinterpret_cast<const float4*>(X + (size_t)(p + (in ? off : 0)) * 128 + 4 * c4);
+    };
+#define CKR_TN_FETCH(p0)                                                                               \
+    ra0 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 0) * 128 + 4 * c4);             \
+    ra1 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 1) * 128 + 4 * c4);             \
+    ra2 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 2) * 128 + 4 * c4);             \
+    ra3 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 3) * 128 + 4 * c4);             \
+    rb0 = load_x(p0, 0); rb1 = load_x(p0, 1); rb2 = load_x(p0, 2); rb3 = load_x(p0, 3);
+    CKR_TN_FETCH(pbeg)
+    for (int p0 = pbeg; p0 < pend; p0 += BK) {
+        __syncthreads();
+        As[tn_slot(rg, 4 * c4 + 0)] = make_float4(ra0.x, ra1.x, ra2.x, ra3.x);
+        As[tn_slot(rg, 4 * c4 + 1)] = make_float4(ra0.y, ra1.y, ra2.y, ra3.y);
+        As[tn_slot(rg, 4 * c4 + 2)] = make_float4(ra0.z, ra1.z, ra2.z, ra3.z);
+        As[tn_slot(rg, 4 * c4 + 3)] = make_float4(ra0.w, ra1.w, ra2.w, ra3.w);
+        {
+            const bool i0 = on_board & 1u, i1 = on_board & 2u, i2 = on_board & 4u, i3 = on_board & 8u;
+            Bs[tn_slot(rg, 4 * c4 + 0)] = make_float4(i0 ? rb0.x : 0.f, i1 ? rb1.x : 0.f, i2 ? rb2.x : 0.f, i3 ? rb3.x : 0.f);
+            Bs[tn_slot(rg, 4 * c4 + 1)] = make_float4(i0 ? rb0.y : 0.f, i1 ? rb1.y : 0.f, i2 ? rb2.y : 0.f, i3 ? rb3.y : 0.f);
+            Bs[tn_slot(rg, 4 * c4 + 2)] = make_float4(i0 ? rb0.z : 0.f, i1 ? rb1.z : 0.f, i2 ? rb2.z : 0.f, i3 ? rb3.z : 0.f);
+            Bs[tn_slot(rg, 4 * c4 + 3)] = make_float4(i0 ? rb0.w : 0.f, i1 ? rb1.w : 0.f, i2 ? rb2.w : 0.f, i3 ? rb3.w : 0.f);
+        }
+        __syncthreads();
+        {
+            const int pn = min(p0 + BK, pend - BK);
+            CKR_TN_FETCH(pn)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                             // lanes 0-31 own position group 2 j, lanes 32-63 group 2 j + 1
+            float4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = As[tn_slot(2 * j + half, 64 * wm + 32 * t + l31)];
+                fb[t] = Bs[tn_slot(2 * j + half, 64 * wn + 32 * t + l31)];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.z * (size_t)128 * ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
+                    Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
+                }
+}
+
+#undef CKR_TN_FETCH
+// Wt[l][c][tap * 128 + o] = W[l][o][tap * 128 + c] for the seven 128 -> 128 layers (operand of the data-gradient GEMM);
+// W[l] at w + offs[l] floats.  gridDim = (9 * 128 * 128 / 256, layers).
+struct LayerOffsets { long long off[8]; };
+__global__ void k_wflip(const float* __restrict__ w, LayerOffsets offs, float* __restrict__ wt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // t = (c * 9 + tap) * 128 + o
+    const int o = t & 127, tap = (t >> 7) % 9, c = t / 1152;
+    wt[(size_t)blockIdx.y * 147456 + t] = w[offs.off[blockIdx.y] + (size_t)o * 1152 + tap * 128 + c];
+}
+
+// out[i] = sum_z part[z][i] (+ add[i]); float4 granularity.  Block = 64 columns x 4 slice groups (group g adds slices
+// g, g + 4, ... in order; the four group sums are then added in order): deterministic, 4 x the loads in flight.
+__global__ __launch_bounds__(256) void k_sum_slices(const float4* __restrict__ part, int slices, long long n4, const float4* __restrict__ add, float4* __restrict__ out) {
+    __shared__ float4 red[3][64];
+    const int g = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        if (g == 0 && add) s = add[i];
+#pragma unroll 4
+        for (int z = g; z < slices; z += 4) { const float4 v = part[(size_t)z * n4 + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    }
+    if (g) red[g - 1][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const float4 v = red[j][threadIdx.x]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        out[i] = s;
+    }
 }
 
 // Small matrices (1x1 convolutions with 8 / 1 kernels, the heads' dense layers, their gradients):
@@ -113,16 +253,25 @@ __global__ void k_gemm_small(const float* __restrict__ A, long long am, long lon
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)M * N) return;
     const int m = (int)(t / N), n = (int)(t % N);
+    const float* a = A + m * am;
+    const float* b = B + n * bn;
     float s = 0.0f;
-    for (int k = 0; k < K; ++k) s = fmaf(A[m * am + k * ak], B[k * bk + n * bn], s);
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {                                  // 16 loads in flight, FMAs in k order
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { av[j] = a[(k + j) * ak]; bv[j] = b[(k + j) * bk]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(av[j], bv[j], s);
+    }
+    for (; k < K; ++k) s = fmaf(a[k * ak], b[k * bk], s);
     float* c = C + m * ldc + n;
     *c = accumulate ? *c + s : s;
 }
 
-// ------------------------------------------------------------------------------------------------ im2col / col2im
-// col[p][tap * cin + c] = x[p + off(tap)][c] (0 outside the 8x8 board), columns [9 cin, kpad) zero;
-// colT[k][p] the same transposed (operand of the weight-gradient GEMM).  One thread per (p, k).
-__global__ void k_im2col(const float* __restrict__ x, int P, int cin, int kpad, float* __restrict__ col, float* __restrict__ colT) {
+// ------------------------------------------------------------------------------------------------ im2col (first layer)
+// col[p][tap * cin + c] = x[p + off(tap)][c] (0 outside the 8x8 board), columns [9 cin, kpad) zero.  One thread per (p, k).
+__global__ void k_im2col(const float* __restrict__ x, int P, int cin, int kpad, float* __restrict__ col) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)P * kpad) return;
     const int p = (int)(t / kpad), k = (int)(t % kpad);
@@ -133,31 +282,35 @@ __global__ void k_im2col(const float* __restrict__ x, int P, int cin, int kpad, 
         if ((unsigned)(y + dy) < 8u && (unsigned)(xx + dx) < 8u) v = x[(size_t)(p + 8 * dy + dx) * cin + c];
     }
     col[t] = v;
-    if (colT) colT[(size_t)k * P + p] = v;
 }
 
-// dx[p][c] = sum_tap dcol[p - off(tap)][tap * cin + c] over the positions whose tap lands on p
-__global__ void k_col2im(const float* __restrict__ dcol, int P, int cin, int kpad, float* __restrict__ dx) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)P * cin) return;
-    const int p = (int)(t / cin), c = (int)(t % cin), y = (p >> 3) & 7, xx = p & 7;
-    float s = 0.0f;
+// Tall products of the heads: part[blk][m][n] = sum_{p in block} A[p][m] * B[p][n] (M <= 8, N <= 256, N | 256);
+// the caller sums the blocks (k_sum_rows).  Thread = (row lane, n); 64-row blocks.
+constexpr int TALL_ROWS = 64;
+template <int M>
+__global__ void k_tall_tn(const float* __restrict__ A, const float* __restrict__ B, int P, int N, float* __restrict__ part) {
+    __shared__ float red[256];
+    const int n = threadIdx.x % N, rl = threadIdx.x / N, nrl = blockDim.x / N;
+    const int r0 = blockIdx.x * TALL_ROWS, r1 = min(P, r0 + TALL_ROWS);
+    float acc[M];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dxx = tap % 3 - 1, qy = y - dy, qx = xx - dxx;       // q + off(tap) = p
-        if ((unsigned)qy < 8u && (unsigned)qx < 8u) s += dcol[(size_t)(p - 8 * dy - dxx) * kpad + tap * cin + c];
+    for (int m = 0; m < M; ++m) acc[m] = 0.0f;
+    for (int r = r0 + rl; r < r1; r += nrl) {
+        const float b = B[(size_t)r * N + n];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = fmaf(A[(size_t)r * M + m], b, acc[m]);
     }
-    dx[t] = s;
-}
-
-__global__ void k_transpose(const float* __restrict__ in, int R, int Cc, float* __restrict__ out) {
-    __shared__ float tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8)
-        if (r0 + j < R && c0 + tx < Cc) tile[j][tx] = in[(size_t)(r0 + j) * Cc + c0 + tx];
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8)
-        if (c0 + j < Cc && r0 + tx < R) out[(size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        __syncthreads();
+        red[threadIdx.x] = acc[m];
+        __syncthreads();
+        if (rl == 0) {
+            float sum = acc[m];
+            for (int j = 1; j < nrl; ++j) sum += red[j * N + n];
+            part[((size_t)blockIdx.x * M + m) * N + n] = sum;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ conv block glue
@@ -186,16 +339,35 @@ __global__ void k_bias_relu_stats(float* __restrict__ z, const float* __restrict
     }
 }
 
-// Pass 2 (one block, C threads): mean, biased variance, 1 / sqrt(var + eps); moving statistics with torch's
-// convention (momentum, unbiased variance).  stats[0][C] = mean, stats[1][C] = inv_std.
-__global__ void k_bn_finalize(const float* __restrict__ part, int nblk, int P, int Cc, float eps, float momentum,
+// Sums of the per-block partials part[b][V] (V <= 256 values) by one block: blockDim / V groups of threads take
+// every (blockDim / V)-th block, then the groups are added in order (double; deterministic).  Result in red[0 .. V).
+__device__ inline void sum_partials(const float* __restrict__ part, int nblk, int V, double* red) {
+    const int G = blockDim.x / V, v = threadIdx.x % V, g = threadIdx.x / V;
+    double s = 0.0;
+    if (g < G) {
+#pragma unroll 8
+        for (int b = g; b < nblk; b += G) s += (double)part[(size_t)b * V + v];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < V) {
+        for (int j = 1; j < G; ++j) s += red[j * V + v];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < V) red[v] = s;
+    __syncthreads();
+}
+
+// Pass 2 (one block): mean, biased variance, 1 / sqrt(var + eps); moving statistics with torch's
+// convention (momentum, unbiased variance).  stats[0][C] = mean, stats[1][C] = inv_std.  C <= 128.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int nblk, int P, int Cc, float eps, float momentum,
                               float* __restrict__ stats, float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ double red[256];
+    sum_partials(part, nblk, 2 * Cc, red);
     const int c = threadIdx.x;
     if (c >= Cc) return;
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2 + 0) * Cc + c]; s2 += part[((size_t)b * 2 + 1) * Cc + c]; }
-    const double mean = s / P;
-    double var = s2 / P - mean * mean;
+    const double mean = red[c] / P;
+    double var = red[Cc + c] / P - mean * mean;
     if (var < 0.0) var = 0.0;
     stats[c] = (float)mean;
     stats[Cc + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -236,14 +408,14 @@ __global__ void k_bn_bwd_stats(const float* __restrict__ dout, const float* __re
 }
 
 // Backward pass 2 (one block): dbeta = sum dout, dgamma = sum dout * ahat -> sums[0][C], sums[1][C] and the gradients
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, int Cc, float* __restrict__ sums,
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ part, int nblk, int Cc, float* __restrict__ sums,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[256];
+    sum_partials(part, nblk, 2 * Cc, red);
     const int c = threadIdx.x;
     if (c >= Cc) return;
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2 + 0) * Cc + c]; s2 += part[((size_t)b * 2 + 1) * Cc + c]; }
-    sums[c] = (float)s; sums[Cc + c] = (float)s2;
-    dbeta[c] = (float)s; dgamma[c] = (float)s2;
+    sums[c] = (float)red[c]; sums[Cc + c] = (float)red[Cc + c];
+    dbeta[c] = (float)red[c]; dgamma[c] = (float)red[Cc + c];
 }
 
 // Backward pass 3: da = gamma * inv_std * (dout - dbeta / P - ahat * dgamma / P); dz = da * [a > 0] (ReLU, if any),
@@ -272,25 +444,164 @@ __global__ void k_bn_bwd_apply(float* __restrict__ dout, const float* __restrict
     }
 }
 
-// out[c] = sum_b part[b][c] (double accumulation); one thread per column
-__global__ void k_sum_rows(const float* __restrict__ part, int nblk, int Cc, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cc) return;
+// out[c] = sum_b part[b][c] (double accumulation); blocks of 64 columns x 4 row groups, groups added in order
+__global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ part, int nblk, int Cc, float* __restrict__ out) {
+    __shared__ double red[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * Cc + c];
-    out[c] = (float)s;
+    if (c < Cc) {
+#pragma unroll 8
+        for (int b = g; b < nblk; b += 4) s += (double)part[(size_t)b * Cc + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && c < Cc) out[c] = (float)(((s + red[64 + threadIdx.x]) + red[128 + threadIdx.x]) + red[192 + threadIdx.x]);
 }
 
-// y = a + b (elementwise): the body's output gradient is the sum of the policy and the value branch
-__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ y) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) y[t] = a[t] + b[t];
+// ------------------------------------------------------------------------------------------------ 128-channel conv blocks
+// The same three passes for the [P][128] activations of the conv blocks, float4 per thread (32 threads per row, 32 rows
+// at a time), fused with the split-K reduction of the producing GEMM; the apply kernels finish the per-channel sums
+// of the previous pass in their prologue (every block repeats the small sum; block 0 stores the results).
+//
+// Forward pass 1: a = ReLU(sum_z ws[z] + bias) and the partial sums of a, a^2: part[blk][2][128]
+__global__ __launch_bounds__(1024) void k_fwd_reduce128(const float* __restrict__ ws, int slices, const float* __restrict__ bias, int P, int rpb,
+                                                       float* __restrict__ a, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float red[2][32][128];
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * rpb, r1 = min(P, r0 + rpb);
+    const size_t n = (size_t)P * 128;
+    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const size_t i = (size_t)r * 128 + 4 * c4;
+        float4 v = b;
+#pragma unroll 4
+        for (int z = 0; z < slices; ++z) { const float4 w = *reinterpret_cast<const float4*>(ws + z * n + i); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<float4*>(a + i) = v;
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+    *reinterpret_cast<float4*>(&red[0][rl][4 * c4]) = s;
+    *reinterpret_cast<float4*>(&red[1][rl][4 * c4]) = s2;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int st = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float t = red[st][0][c];
+        for (int j = 1; j < 32; ++j) t += red[st][j][c];
+        part[((size_t)blockIdx.x * 2 + st) * 128 + c] = t;
+    }
 }
 
-// dz = dy * [a > 0]  /  y = max(x + bias, 0) for the dense layer of the value head (no BatchNorm statistics needed here)
-__global__ void k_relu_bwd(const float* __restrict__ a, long long n, float* __restrict__ d) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n && !(a[t] > 0.0f)) d[t] = 0.0f;
+// Forward pass 2 + 3: statistics from the partials, out = gamma * (a - mean) * inv_std + beta
+__global__ __launch_bounds__(1024) void k_bn_apply128(const float* __restrict__ a, const float* __restrict__ part, int npart, int P, int rpb,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                     float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ stats,
+                                                     float* __restrict__ out) {
+    __shared__ double red[1024];
+    __shared__ __attribute__((aligned(16))) float sc[128], sh[128];          // out = a * sc + sh
+    sum_partials(part, npart, 256, red);
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        const double mean = red[c] / P;
+        double var = red[128 + c] / P - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean, inv = (float)(1.0 / sqrt(var + (double)eps));
+        sc[c] = inv; sh[c] = mf;
+        if (blockIdx.x == 0) {
+            stats[c] = mf; stats[128 + c] = inv;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mf;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(var * (double)P / (double)(P > 1 ? P - 1 : 1));
+        }
+    }
+    __syncthreads();
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const float4 inv = *reinterpret_cast<const float4*>(sc + 4 * c4), mean = *reinterpret_cast<const float4*>(sh + 4 * c4);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * c4), bt = *reinterpret_cast<const float4*>(beta + 4 * c4);
+    const int r0 = blockIdx.x * rpb, r1 = min(P, r0 + rpb);
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const size_t i = (size_t)r * 128 + 4 * c4;
+        const float4 v = *reinterpret_cast<const float4*>(a + i);
+        float4 o;
+        o.x = g.x * ((v.x - mean.x) * inv.x) + bt.x; o.y = g.y * ((v.y - mean.y) * inv.y) + bt.y;
+        o.z = g.z * ((v.z - mean.z) * inv.z) + bt.z; o.w = g.w * ((v.w - mean.w) * inv.w) + bt.w;
+        *reinterpret_cast<float4*>(out + i) = o;
+    }
+}
+
+// Backward pass 1: dout = sum_z ws[z] (+ add) (the data gradient of the layer above, reduced over its K slices) and the
+// partial sums of dout, dout * ahat of THIS block's BatchNorm: part[blk][2][128]
+__global__ __launch_bounds__(1024) void k_bwd_reduce128(const float* __restrict__ ws, int slices, const float* __restrict__ add, const float* __restrict__ a,
+                                                       const float* __restrict__ stats, int P, int rpb, float* __restrict__ dout, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float red[2][32][128];
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * rpb, r1 = min(P, r0 + rpb);
+    const size_t n = (size_t)P * 128;
+    const float4 mean = *reinterpret_cast<const float4*>(stats + 4 * c4), inv = *reinterpret_cast<const float4*>(stats + 128 + 4 * c4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const size_t i = (size_t)r * 128 + 4 * c4;
+        float4 v = add ? *reinterpret_cast<const float4*>(add + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int z = 0; z < slices; ++z) { const float4 w = *reinterpret_cast<const float4*>(ws + z * n + i); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        if (slices > 0 || add) *reinterpret_cast<float4*>(dout + i) = v; else v = *reinterpret_cast<const float4*>(dout + i);
+        const float4 av = *reinterpret_cast<const float4*>(a + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        s2.x += v.x * ((av.x - mean.x) * inv.x); s2.y += v.y * ((av.y - mean.y) * inv.y);
+        s2.z += v.z * ((av.z - mean.z) * inv.z); s2.w += v.w * ((av.w - mean.w) * inv.w);
+    }
+    *reinterpret_cast<float4*>(&red[0][rl][4 * c4]) = s;
+    *reinterpret_cast<float4*>(&red[1][rl][4 * c4]) = s2;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int st = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float t = red[st][0][c];
+        for (int j = 1; j < 32; ++j) t += red[st][j][c];
+        part[((size_t)blockIdx.x * 2 + st) * 128 + c] = t;
+    }
+}
+
+// Backward pass 2 + 3: dbeta, dgamma from the partials; dz = gamma * inv_std * (dout - dbeta / P - ahat * dgamma / P) * [a > 0]
+// written over dout; partial sums of dz per channel (the conv bias gradient): part2[blk][128]
+__global__ __launch_bounds__(1024) void k_bn_bwd_apply128(float* __restrict__ dout, const float* __restrict__ a, const float* __restrict__ stats,
+                                                         const float* __restrict__ part, int npart, const float* __restrict__ gamma, int P, int rpb,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part2) {
+    __shared__ double red[1024];
+    __shared__ __attribute__((aligned(16))) float sdb[128], sdg[128];
+    __shared__ __attribute__((aligned(16))) float r2[32][128];
+    sum_partials(part, npart, 256, red);
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        const float db = (float)red[c], dg = (float)red[128 + c];
+        sdb[c] = db / (float)P; sdg[c] = dg / (float)P;
+        if (blockIdx.x == 0) { dbeta[c] = db; dgamma[c] = dg; }
+    }
+    __syncthreads();
+    const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const float4 mean = *reinterpret_cast<const float4*>(stats + 4 * c4), inv = *reinterpret_cast<const float4*>(stats + 128 + 4 * c4);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+    const float4 db = *reinterpret_cast<const float4*>(sdb + 4 * c4), dg = *reinterpret_cast<const float4*>(sdg + 4 * c4);
+    const float4 g = make_float4(gm.x * inv.x, gm.y * inv.y, gm.z * inv.z, gm.w * inv.w);
+    const int r0 = blockIdx.x * rpb, r1 = min(P, r0 + rpb);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const size_t i = (size_t)r * 128 + 4 * c4;
+        const float4 av = *reinterpret_cast<const float4*>(a + i), d = *reinterpret_cast<const float4*>(dout + i);
+        float4 o;
+        o.x = av.x > 0.f ? g.x * (d.x - db.x - ((av.x - mean.x) * inv.x) * dg.x) : 0.f;
+        o.y = av.y > 0.f ? g.y * (d.y - db.y - ((av.y - mean.y) * inv.y) * dg.y) : 0.f;
+        o.z = av.z > 0.f ? g.z * (d.z - db.z - ((av.z - mean.z) * inv.z) * dg.z) : 0.f;
+        o.w = av.w > 0.f ? g.w * (d.w - db.w - ((av.w - mean.w) * inv.w) * dg.w) : 0.f;
+        *reinterpret_cast<float4*>(dout + i) = o;
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(&r2[rl][4 * c4]) = s;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float t = r2[0][threadIdx.x];
+        for (int j = 1; j < 32; ++j) t += r2[j][threadIdx.x];
+        part2[(size_t)blockIdx.x * 128 + threadIdx.x] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ losses
@@ -343,14 +654,24 @@ __global__ void k_value_loss(const float* __restrict__ z, const float* __restric
     dz[b] = weight * 2.0f * e / (float)B * (1.0f - v * v);
 }
 
-// acc[0..2] += n_rows * {w_p * mean ce + w_v * mean se + penalty, mean ce, mean se} (float64 running sums of an epoch)
-__global__ void k_loss_sums(const float* __restrict__ ce, const float* __restrict__ se, int B, float wp, float wv,
-                            const float* __restrict__ penalty, double n_rows, double* __restrict__ acc) {
-    if (threadIdx.x || blockIdx.x) return;
-    double c = 0.0, s = 0.0;
-    for (int b = 0; b < B; ++b) { c += ce[b]; s += se[b]; }
-    c /= B; s /= B;
-    acc[0] += n_rows * ((double)wp * c + (double)wv * s + (penalty ? (double)*penalty : 0.0));
+// acc[0..2] += n_rows * {w_p * mean ce + w_v * mean se + penalty, mean ce, mean se} (float64 running sums of an epoch);
+// penalty = the sum of k_adam's ADAM_BLOCKS partials.  One block of 256 threads, sums in a fixed order.
+constexpr int ADAM_BLOCKS = 512;
+__global__ __launch_bounds__(256) void k_loss_sums(const float* __restrict__ ce, const float* __restrict__ se, int B, float wp, float wv,
+                                                   const double* __restrict__ penalty_parts, double n_rows, double* __restrict__ acc) {
+    __shared__ double red[3][256];
+    double c = 0.0, s = 0.0, pen = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) { c += ce[b]; s += se[b]; }
+    if (penalty_parts) for (int b = threadIdx.x; b < ADAM_BLOCKS; b += 256) pen += penalty_parts[b];
+    red[0][threadIdx.x] = c; red[1][threadIdx.x] = s; red[2][threadIdx.x] = pen;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) for (int j = 0; j < 3; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x) return;
+    c = red[0][0] / B; s = red[1][0] / B;
+    acc[0] += n_rows * ((double)wp * c + (double)wv * s + red[2][0]);
     acc[1] += n_rows * c;
     acc[2] += n_rows * s;
 }
@@ -359,33 +680,34 @@ __global__ void k_loss_sums(const float* __restrict__ ce, const float* __restric
 // One flat parameter vector; reg[i] = the l2 coefficient of element i (CONV_REG / DENSE_REG on kernels and biases,
 // 0 on BatchNorm parameters).  g = grad + 2 reg w;  torch.optim.Adam arithmetic (bias-corrected step size,
 // eps outside the square root), lr and the step counter read from device memory (captured in a HIP graph).
-__global__ void k_adam(float* __restrict__ w, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+// ADAM_BLOCKS blocks stride over the vector; block b also leaves its share of the penalty sum_i reg[i] w[i]^2 of the
+// weights BEFORE the update (Keras adds it to the loss it prints) in penalty_parts[b].
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ w, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                        const float* __restrict__ reg, long long n, const float* __restrict__ lr, float beta1, float beta2, float eps,
-                       const float* __restrict__ step) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float t = *step;
-    const float g = grad[i] + 2.0f * reg[i] * w[i];
-    const float mi = beta1 * m[i] + (1.0f - beta1) * g;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
-    m[i] = mi; v[i] = vi;
+                       const float* __restrict__ step, double* __restrict__ penalty_parts) {
+    __shared__ double red[256];
+    const float t = *step + 1.0f;                                 // k_step_inc runs after this kernel
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    w[i] -= (*lr / bc1) * (mi / denom);
+    const float rate = *lr / bc1, rs = sqrtf(bc2);
+    double pen = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float wi = w[i], r = reg[i];
+        pen += (double)r * (double)wi * (double)wi;
+        const float g = grad[i] + 2.0f * r * wi;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * g;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / rs + eps;
+        w[i] = wi - rate * (mi / denom);
+    }
+    if (!penalty_parts) return;
+    red[threadIdx.x] = pen;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    if (!threadIdx.x) penalty_parts[blockIdx.x] = red[0];
 }
 
 __global__ void k_step_inc(float* step) { if (!threadIdx.x && !blockIdx.x) *step += 1.0f; }
-
-// penalty = sum_i reg[i] w[i]^2 (reporting: Keras adds it to the loss it prints); one block, deterministic
-__global__ __launch_bounds__(1024) void k_penalty(const float* __restrict__ w, const float* __restrict__ reg, long long n, float* __restrict__ out) {
-    __shared__ double red[1024];
-    double s = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 1024) s += (double)reg[i] * (double)w[i] * (double)w[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 512; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
-    if (!threadIdx.x) *out = (float)red[0];
-}
 
 }  // namespace ckrt
 
@@ -395,6 +717,8 @@ using namespace ckrt;
 
 extern "C" {
 
+static int rows_per_block(int P) { return P <= 16384 ? 128 : 128 * ((P + 16383) / 16384); }   // <= 128 partials per reduction
+
 int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                 int32_t slices, float* workspace, const float* add, void* stream) {
     if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0 || M % BM || N % BN || slices < 1 || K % (BK * slices) || (ldc % 4) || (lda % 4) || (ldb % 4))
@@ -402,15 +726,89 @@ int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float
     if (slices > 1 && (!workspace || ldc != N)) return ckr::fail(CKR_ERR_INVALID, "ckr_gemm_nt: split-K needs a workspace and ldc == N");
     if (int rc = ckr::require_device()) return rc;
     float* dst = slices > 1 ? workspace : C;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(N / BN, M / BM, slices), dim3(GT), 0, (hipStream_t)stream, A, (int)lda, Bt, (int)ldb, dst, (int)ldc, (int)M, (int)K);
+    hipLaunchKernelGGL(k_gemm_nt<0>, dim3(N / BN, M / BM, slices), dim3(GT), 0, (hipStream_t)stream, A, (int)lda, Bt, (int)ldb, dst, (int)ldc, (int)M, (int)K);
     if (slices > 1 || add) {
         const long long n4 = (long long)M * N / 4;
         if (slices == 1) {                                        // C = C + add
-            LAUNCH1D(k_sum_slices, n4, stream, (const float4*)C, 1, n4, (const float4*)add, (float4*)C);
+            hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float4*)C, 1, n4, (const float4*)add, (float4*)C);
         } else {
-            LAUNCH1D(k_sum_slices, n4, stream, (const float4*)workspace, (int)slices, n4, (const float4*)add, (float4*)C);
+            hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, (int)slices, n4, (const float4*)add, (float4*)C);
         }
     }
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// The GEMM of a 3x3 convolution with 128 input and 128 output planes on activations act[P][128] (P = 64 * boards):
+// direction +1: workspace[z][p][o] = sum_{k in slice z} act[p + off(tap)][c] * w[o][tap * 128 + c]      (forward; w = the kernel)
+// direction -1: workspace[z][p][c] = sum_{k in slice z} act[p - off(tap)][o] * w[c][tap * 128 + o]      (data gradient; w = ckr_conv_wflip's)
+// The caller's next kernel (ckr_conv_bias_relu_bn / ckr_conv_bn_relu_backward) adds the `slices` partial products.
+int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction, int32_t slices, float* workspace, void* stream) {
+    if (!act || !w || !workspace || P <= 0 || P % 128 || (direction != 1 && direction != -1) || slices < 1 || 1152 % (BK * slices))
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_gemm: P must be a multiple of 128, direction +1 or -1, slices a divisor of 36");
+    if (int rc = ckr::require_device()) return rc;
+    if (direction > 0) hipLaunchKernelGGL(k_gemm_nt<1>, dim3(1, P / BM, slices), dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+    else hipLaunchKernelGGL(k_gemm_nt<-1>, dim3(1, P / BM, slices), dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// Weight gradient: dw[o][tap * 128 + c] (taps = 9, ld = 1152) = sum_p dz[p][o] * x[p + off(tap)][c], or with taps = 1 the plain
+// product dw[o][c] = sum_p dz[p][o] * x[p][c] (ld = 128; the first layer on its im2col matrix).  Split over `slices` ranges of
+// positions (P % (32 * slices) == 0), reduced deterministically through workspace[slices][128][ld].
+int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, float* workspace, float* dw, void* stream) {
+    if (!dz || !x || !dw || !workspace || P <= 0 || (taps != 9 && taps != 1) || slices < 1 || P % BK || slices > P / BK)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_wgrad: taps 9 or 1, P a multiple of 32, 1 <= slices <= P / 32");
+    if (int rc = ckr::require_device()) return rc;
+    const int ld = 128 * taps;
+    hipLaunchKernelGGL(k_wgrad_tn, dim3(taps, 1, slices), dim3(GT), 0, (hipStream_t)stream, dz, x, (int)P, taps == 9 ? 0 : 4, workspace, ld);
+    const long long n4 = 128LL * ld / 4;
+    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, (int)slices, n4, (const float4*)nullptr, (float4*)dw);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// wt[l][c][tap * 128 + o] = w[offsets[l] + o * 1152 + tap * 128 + c], l < layers <= 8 (offsets in floats, host array)
+int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float* wt, void* stream) {
+    if (!w || !offsets || !wt || layers < 1 || layers > 8) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_wflip: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    LayerOffsets lo;
+    for (int l = 0; l < 8; ++l) lo.off[l] = l < layers ? offsets[l] : 0;
+    hipLaunchKernelGGL(k_wflip, dim3(147456 / 256, layers), dim3(256), 0, (hipStream_t)stream, w, lo, wt);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// Forward half of a conv block after its GEMM: a = ReLU(sum of the workspace slices + bias) (kept for the backward pass),
+// batch statistics -> stats[2][128] (mean, 1 / sqrt(var + eps)), moving statistics updated, out = BatchNorm(a).
+// part: workspace of 256 * ceil(P / 128) floats.  The slices may alias a (slices == 1, workspace == a).
+int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* bias, int32_t P, const float* gamma, const float* beta, float eps,
+                          float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part, void* stream) {
+    if (!workspace || slices < 1 || !bias || !gamma || !beta || !run_mean || !run_var || !stats || !a || !out || !part || P <= 0)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bias_relu_bn: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    const int rpb = rows_per_block(P), nblk = (P + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_fwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, bias, (int)P, rpb, a, part);
+    hipLaunchKernelGGL(k_bn_apply128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, (const float*)a, (const float*)part, nblk, (int)P, rpb, gamma, beta,
+                       eps, momentum, run_mean, run_var, stats, out);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// Backward half of a conv block before its GEMMs.  dout = sum of the workspace slices (the data-gradient GEMM of the block
+// above; slices == 0: dout is given) + add (optional: a second consumer's gradient); then dz = d loss / d (conv output) written
+// over dout, dgamma, dbeta, dbias.  a, stats: the block's kept activation and statistics.  part: 384 * ceil(P / 128) floats.
+int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const float* add, float* dout, const float* a, const float* stats,
+                              const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* stream) {
+    if ((slices > 0 && !workspace) || slices < 0 || !dout || !a || !stats || !gamma || !dgamma || !dbeta || !dbias || !part || P <= 0)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bn_relu_backward: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    const int rpb = rows_per_block(P), nblk = (P + rpb - 1) / rpb;
+    float* part2 = part + (size_t)256 * nblk;
+    hipLaunchKernelGGL(k_bwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, add, a, stats, (int)P, rpb, dout, part);
+    hipLaunchKernelGGL(k_bn_bwd_apply128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, dout, a, stats, (const float*)part, nblk, gamma, (int)P, rpb,
+                       dgamma, dbeta, part2);
+    hipLaunchKernelGGL(k_sum_rows, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)part2, nblk, 128, dbias);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
@@ -424,34 +822,31 @@ int ckr_gemm_small(const float* A, int64_t am, int64_t ak, const float* B, int64
     return CKR_OK;
 }
 
-int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col, float* colT, void* stream) {
+// C[m][n] = sum_p A[p][m] * B[p][n]: the weight gradients of the heads' 1x1 convolutions (M = 8 or 1 kernels, N = 128 planes,
+// P positions).  part: workspace of M * N * ceil(P / 64) floats.
+int ckr_gemm_tall(const float* A, const float* B, int32_t P, int32_t M, int32_t N, float* C, float* part, void* stream) {
+    if (!A || !B || !C || !part || P <= 0 || (M != 1 && M != 8) || N < 1 || N > 256 || 256 % N) return ckr::fail(CKR_ERR_INVALID, "ckr_gemm_tall: M 1 or 8, N | 256");
+    if (int rc = ckr::require_device()) return rc;
+    const int nblk = (P + TALL_ROWS - 1) / TALL_ROWS;
+    if (M == 1) hipLaunchKernelGGL(k_tall_tn<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, A, B, (int)P, (int)N, part);
+    else hipLaunchKernelGGL(k_tall_tn<8>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, A, B, (int)P, (int)N, part);
+    hipLaunchKernelGGL(k_sum_rows, dim3((M * N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, (int)(M * N), C);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col, void* stream) {
     if (!x || !col || P <= 0 || P % 64 || cin <= 0 || kpad < 9 * cin) return ckr::fail(CKR_ERR_INVALID, "ckr_im2col: bad argument");
     if (int rc = ckr::require_device()) return rc;
-    LAUNCH1D(k_im2col, (long long)P * kpad, stream, x, (int)P, (int)cin, (int)kpad, col, colT);
+    LAUNCH1D(k_im2col, (long long)P * kpad, stream, x, (int)P, (int)cin, (int)kpad, col);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
 
-int ckr_col2im(const float* dcol, int32_t P, int32_t cin, int32_t kpad, float* dx, void* stream) {
-    if (!dcol || !dx || P <= 0 || P % 64 || cin <= 0 || kpad < 9 * cin) return ckr::fail(CKR_ERR_INVALID, "ckr_col2im: bad argument");
-    if (int rc = ckr::require_device()) return rc;
-    LAUNCH1D(k_col2im, (long long)P * cin, stream, dcol, (int)P, (int)cin, (int)kpad, dx);
-    CKR_HIP(hipGetLastError());
-    return CKR_OK;
-}
-
-int ckr_transpose(const float* in, int32_t R, int32_t Cc, float* out, void* stream) {
-    if (!in || !out || R <= 0 || Cc <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_transpose: bad argument");
-    if (int rc = ckr::require_device()) return rc;
-    hipLaunchKernelGGL(k_transpose, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, (int)R, (int)Cc, out);
-    CKR_HIP(hipGetLastError());
-    return CKR_OK;
-}
-
-static bool chan_ok(int Cc) { return Cc >= 1 && Cc <= 256 && (256 % Cc) == 0; }
+static bool chan_ok(int Cc) { return Cc >= 1 && Cc <= 128 && (128 % Cc) == 0; }
 
 // a = act(z + bias) in place, batch statistics -> stats[2][C], moving statistics updated, out = BatchNorm(a).
-// part: workspace of 2 * C * ceil(P / 64) floats.
+// part: workspace of 2 * C * ceil(P / 64) floats.  (The heads' small layers; the conv blocks use ckr_conv_bias_relu_bn.)
 int ckr_bn_forward(float* z, const float* bias, int32_t P, int32_t Cc, int32_t relu, const float* gamma, const float* beta, float eps,
                    float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part, void* stream) {
     if (!z || !gamma || !beta || !stats || !out || !part || P <= 0 || !chan_ok(Cc)) return ckr::fail(CKR_ERR_INVALID, "ckr_bn_forward: bad argument");
@@ -474,15 +869,7 @@ int ckr_bn_backward(float* dout, const float* a, const float* stats, const float
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)dout, a, stats, (int)P, (int)Cc, part);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, (int)Cc, sums, dgamma, dbeta);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dout, a, stats, (const float*)sums, gamma, (int)P, (int)Cc, (int)relu, part);
-    if (dbias) hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, (int)Cc, dbias);
-    CKR_HIP(hipGetLastError());
-    return CKR_OK;
-}
-
-int ckr_add(const float* a, const float* b, int64_t n, float* y, void* stream) {
-    if (!a || !b || !y || n <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_add: bad argument");
-    if (int rc = ckr::require_device()) return rc;
-    LAUNCH1D(k_add, (long long)n, stream, a, b, (long long)n, y);
+    if (dbias) hipLaunchKernelGGL(k_sum_rows, dim3((Cc + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, (int)Cc, dbias);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
@@ -503,21 +890,23 @@ int ckr_value_loss(const float* z, const float* bias, const float* target, int32
     return CKR_OK;
 }
 
-int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float wv, const float* penalty, double n_rows, double* acc, void* stream) {
+// penalty_parts: the 512 partial sums ckr_adam_step left (or null)
+int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float wv, const double* penalty_parts, double n_rows, double* acc, void* stream) {
     if (!ce || !se || !acc || B <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_loss_sums: bad argument");
     if (int rc = ckr::require_device()) return rc;
-    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, ce, se, (int)B, wp, wv, penalty, n_rows, acc);
+    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, (hipStream_t)stream, ce, se, (int)B, wp, wv, penalty_parts, n_rows, acc);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
 
+// d_penalty_parts: 512 doubles (or null): the l2 penalty of the weights before this update, in 512 partial sums
 int ckr_adam_step(float* w, const float* grad, float* m, float* v, const float* reg, int64_t n, const float* d_lr, float beta1, float beta2,
-                  float eps, float* d_step, float* d_penalty, void* stream) {
+                  float eps, float* d_step, double* d_penalty_parts, void* stream) {
     if (!w || !grad || !m || !v || !reg || !d_lr || !d_step || n <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_adam_step: bad argument");
     if (int rc = ckr::require_device()) return rc;
-    if (d_penalty) hipLaunchKernelGGL(k_penalty, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)w, reg, (long long)n, d_penalty);
+    hipLaunchKernelGGL(k_adam, dim3(ADAM_BLOCKS), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, reg, (long long)n, d_lr, beta1, beta2, eps,
+                       (const float*)d_step, d_penalty_parts);
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(64), 0, (hipStream_t)stream, d_step);
-    LAUNCH1D(k_adam, (long long)n, stream, w, grad, m, v, reg, (long long)n, d_lr, beta1, beta2, eps, (const float*)d_step);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
@@ -525,15 +914,7 @@ int ckr_adam_step(float* w, const float* grad, float* m, float* v, const float* 
 int ckr_sum_rows(const float* in, int32_t rows, int32_t cols, float* out, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_sum_rows: bad argument");
     if (int rc = ckr::require_device()) return rc;
-    LAUNCH1D(k_sum_rows, cols, stream, in, (int)rows, (int)cols, out);
-    CKR_HIP(hipGetLastError());
-    return CKR_OK;
-}
-
-int ckr_relu_backward(const float* a, int64_t n, float* d, void* stream) {
-    if (!a || !d || n <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_relu_backward: bad argument");
-    if (int rc = ckr::require_device()) return rc;
-    LAUNCH1D(k_relu_bwd, (long long)n, stream, a, (long long)n, d);
+    hipLaunchKernelGGL(k_sum_rows, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, (int)rows, (int)cols, out);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

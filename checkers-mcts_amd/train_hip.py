@@ -4,14 +4,15 @@
 forward in training mode (BatchNormalization on batch statistics, moving statistics updated), the
 Keras losses of training_pipeline.py:49-114 (categorical cross-entropy on the clipped, renormalised
 softmax + MSE, l2 penalties on every conv / dense kernel and bias), backward, Adam (Keras epsilon 1e-7).
-All arithmetic is float32 like Keras': the 3x3 convolutions run as im2col GEMMs on the float32 matrix
-pipe (`ckr_gemm_nt`), everything else is elementwise / reduction kernels.  torch supplies the memory
+All arithmetic is float32 like Keras': the 3x3 convolutions run as implicit GEMMs on the float32 matrix
+pipe (`ckr_conv_gemm` forward / data gradient, `ckr_conv_wgrad`), everything else is elementwise / reduction kernels.  torch supplies the memory
 and the stream; no torch operator runs inside a step, so the step captures into a HIP graph.
 
 The parameters live in ONE flat float32 buffer in the kernels' layouts (conv kernels as
 [out][tap * Cin + c]); `load_from_module` / `store_to_module` convert from / to net.PolicyValueNet.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -30,31 +31,38 @@ class HipTrainStep:
         self._L = L = _lib.load()
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         L.ckr_gemm_nt.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
+        L.ckr_conv_bias_relu_bn.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]
+        L.ckr_conv_bn_relu_backward.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ckr_gemm_small.argtypes = [vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp]
-        L.ckr_im2col.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-        L.ckr_col2im.argtypes = [vp, i32, i32, i32, vp, vp]
-        L.ckr_transpose.argtypes = [vp, i32, i32, vp, vp]
+        L.ckr_gemm_tall.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.ckr_im2col.argtypes = [vp, i32, i32, i32, vp, vp]
         L.ckr_bn_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
         L.ckr_bn_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
-        L.ckr_add.argtypes = [vp, vp, i64, vp, vp]
         L.ckr_policy_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
         L.ckr_value_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
         L.ckr_loss_sums.argtypes = [vp, vp, i32, f32, f32, vp, C.c_double, vp, vp]
         L.ckr_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp]
         L.ckr_sum_rows.argtypes = [vp, i32, i32, vp, vp]
         self.net = net
-        self.wgrad_slices = max(s for s in (1, 2, 4, 8, 16, 32) if (64 * int(batch_size)) % (32 * s) == 0)   # split-K of the weight-gradient GEMMs
+        P = 64 * int(batch_size)
+        # split-K until ~256 workgroups exist (one per CU): forward / data gradient over the 36 chunks of K = 1152,
+        # the weight gradient (9 tap tiles) over the positions, never fewer than 4 chunks of 32 per slice on average
+        self.slices = int(os.environ.get("CKR_TRAIN_SLICES", 0)) or next((s for s in (1, 2, 3, 4, 6, 9) if (P // 128) * s >= 256), 9)
+        self.wgrad_slices = int(os.environ.get("CKR_TRAIN_WGRAD_SLICES", 0)) or max(1, min(28, P // 128))   # 9 x 28 = 252 workgroups
         self.dev = dev = next(net.parameters()).device
         self.B, self.P = int(batch_size), 64 * int(batch_size)
         self.wp, self.wv = float(policy_loss_weight), float(value_loss_weight)
         self.betas, self.eps, self.bn_eps, self.bn_mom = betas, float(eps), float(bn_eps), float(bn_momentum)
         # ---- flat parameter layout
-        self.slices = {}
+        self.slices_map = {}
         off = 0
 
         def add(name, n, reg):
             nonlocal off
-            self.slices[name] = (off, n, reg)
+            self.slices_map[name] = (off, n, reg)
             off += (n + 3) // 4 * 4                       # 16-byte aligned segments
         self.kpad = [KPAD0] + [1152] * 7
         for l in range(8):
@@ -68,18 +76,18 @@ class HipTrainStep:
         self.n = off
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         self.W, self.G, self.M, self.V, self.reg = z(off), z(off), z(off), z(off), z(off)
-        for name, (o, n, reg) in self.slices.items():
+        for name, (o, n, reg) in self.slices_map.items():
             self.reg[o:o + n] = reg
         self.step_t = z(1)
-        self.penalty = z(1)
+        self.penalty = torch.zeros(512, dtype=torch.float64, device=dev)
+        self.w_offsets = (C.c_int64 * 7)(*[self.slices_map["c%d.w" % l][0] for l in range(1, 8)])
         # ---- BatchNorm moving statistics (not optimised): conv blocks, p2, v1, vbn
         self.run = {k: (z(c), torch.ones(c, dtype=torch.float32, device=dev)) for k, c in
                     [("c%d" % l, 128) for l in range(8)] + [("p2", 8), ("v1", 1), ("vbn", 64)]}
         # ---- activations kept for the backward pass, workspaces
         P, B = self.P, self.B
-        self.col = [z(P, k) for k in self.kpad]
-        self.colT = [z(k, P) for k in self.kpad]
-        self.a = [z(P, 128) for _ in range(8)]            # post-ReLU pre-BatchNorm (the GEMM output, rewritten in place)
+        self.col0 = z(P, KPAD0)                           # the first layer's im2col matrix
+        self.a = [z(P, 128) for _ in range(8)]            # post-ReLU pre-BatchNorm
         self.out = [z(P, 128) for _ in range(8)]
         self.stats = {k: z(2, c) for k, (c) in [("c%d" % l, 128) for l in range(8)] + [("p2", 8), ("v1", 1), ("vbn", 64)]}
         self.a_p2, self.out_p2 = z(P, 8), z(P, 8)
@@ -87,17 +95,17 @@ class HipTrainStep:
         self.a_f1, self.out_f1 = z(B, 64), z(B, 64)
         self.logits, self.dlogits, self.z_f2, self.dz_f2 = z(B, 512), z(B, 512), z(B), z(B)
         self.ce, self.se = z(B), z(B)
-        self.part = z(2 * 128 * (P // 64 + 1))
+        self.part = z(4 * 128 * (P // 64 + 1) + 8 * 128 * (P // 64 + 1))
         self.sums = z(2, 128)
-        self.gws = z(32 * 128 * 1152)                     # split-K partial products
-        self.d_act, self.d_act2, self.d_col = z(P, 128), z(P, 128), z(P, 1152)
-        self.dzT, self.wT = z(128, P), z(1152, 128)
+        self.ws = z(max(self.slices * P * 128, self.wgrad_slices * 128 * 1152))      # split-K partial products
+        self.wt = z(7, 128, 1152)                          # flipped kernels of layers 1..7 for the data-gradient GEMMs
+        self.d_act, self.d_act2 = z(P, 128), z(P, 128)
         self.d_p2, self.d_f, self.d_v1, self.d_f1 = z(P, 8), z(B, 512), z(P, 1), z(B, 64)
         self.load_from_module()
 
     # ---- parameter views --------------------------------------------------------------------------------
     def w(self, name, buf=None):
-        o, n, _ = self.slices[name]
+        o, n, _ = self.slices_map[name]
         return (self.W if buf is None else buf)[o:o + n]
 
     def g(self, name):
@@ -153,10 +161,6 @@ class HipTrainStep:
     def _s(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
-    def _gemm(self, A, Bt, Cm, M, N, K, slices=1):
-        _lib.check(self._L.ckr_gemm_nt(A.data_ptr(), K, Bt.data_ptr(), K, Cm.data_ptr(), N, M, N, K, slices,
-                                       self.gws.data_ptr() if slices > 1 else None, None, self._s()))
-
     def _small(self, A, am, ak, Bm, bk, bn, Cm, ldc, M, N, K, acc=0):
         _lib.check(self._L.ckr_gemm_small(A.data_ptr(), am, ak, Bm.data_ptr(), bk, bn, Cm.data_ptr(), ldc, M, N, K, acc, self._s()))
 
@@ -173,6 +177,13 @@ class HipTrainStep:
                                            self.g(biasname).data_ptr() if biasname else None,
                                            self.part.data_ptr(), self.sums.data_ptr(), self._s()))
 
+    def _conv_fwd_tail(self, l, ws, slices):
+        key = "c%d" % l
+        rm, rv = self.run[key]
+        _lib.check(self._L.ckr_conv_bias_relu_bn(ws.data_ptr(), slices, self.w(key + ".b").data_ptr(), self.P, self.w(key + ".g").data_ptr(),
+                                                 self.w(key + ".beta").data_ptr(), self.bn_eps, self.bn_mom, rm.data_ptr(), rv.data_ptr(),
+                                                 self.stats[key].data_ptr(), self.a[l].data_ptr(), self.out[l].data_ptr(), self.part.data_ptr(), self._s()))
+
     # ---- one optimisation step ------------------------------------------------------------------------------
     def step(self, x, pi, tv, lr_t, acc=None, n_rows=None):
         """x [B,8,8,14], pi [B,512], tv [B] float32 on the device; lr_t: float32 device scalar.  acc (float64 [3]) +=
@@ -180,14 +191,14 @@ class HipTrainStep:
         L, s, P, B = self._L, self._s(), self.P, self.B
         if tuple(x.shape) != (B, 8, 8, 14) or not x.is_contiguous() or x.dtype != torch.float32:
             raise ValueError("x must be a contiguous float32 [%d, 8, 8, 14] tensor" % B)
-        # ---------------- forward
-        inp = x
-        for l in range(8):
-            cin = 14 if l == 0 else 128
-            _lib.check(L.ckr_im2col(inp.data_ptr(), P, cin, self.kpad[l], self.col[l].data_ptr(), self.colT[l].data_ptr(), s))
-            self._gemm(self.col[l], self.w("c%d.w" % l), self.a[l], P, 128, self.kpad[l], slices=4)
-            self._bn_fwd(self.a[l], self.w("c%d.b" % l), P, 128, 1, "c%d" % l, "c%d.g" % l, "c%d.beta" % l, self.out[l])
-            inp = self.out[6] if l == 6 else self.out[l]          # pol1 (l = 7) reads the body's output
+        # ---------------- forward: first layer on its im2col matrix, layers 1..7 as implicit GEMMs
+        _lib.check(L.ckr_im2col(x.data_ptr(), P, 14, KPAD0, self.col0.data_ptr(), s))
+        _lib.check(L.ckr_gemm_nt(self.col0.data_ptr(), KPAD0, self.w("c0.w").data_ptr(), KPAD0, self.a[0].data_ptr(), 128, P, 128, KPAD0, 1, None, None, s))
+        self._conv_fwd_tail(0, self.a[0], 1)
+        for l in range(1, 8):
+            inp = self.out[6] if l == 7 else self.out[l - 1]      # pol1 (l = 7) reads the body's output
+            _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.ws.data_ptr(), s))
+            self._conv_fwd_tail(l, self.ws, self.slices)
         body, pol1 = self.out[6], self.out[7]
         # policy head: 1x1 conv (8) + ReLU + BN -> flatten (H, W, C) -> Dense(512)
         self._small(pol1, 128, 1, self.w("p2.w"), 1, 128, self.a_p2, 8, P, 8, 128)
@@ -204,6 +215,7 @@ class HipTrainStep:
         _lib.check(L.ckr_value_loss(self.z_f2.data_ptr(), self.w("f2.b").data_ptr(), tv.data_ptr(), B, self.wv,
                                     self.dz_f2.data_ptr(), self.se.data_ptr(), s))
         # ---------------- backward: value head
+        tall = self.part[4 * 128 * (P // 64 + 1):]
         self._small(self.dz_f2, 0, 1, self.out_f1, 64, 1, self.g("f2.w"), 64, 1, 64, B)                  # dW2[j] = sum_b dz[b] h[b][j]
         _lib.check(L.ckr_sum_rows(self.dz_f2.data_ptr(), B, 1, self.g("f2.b").data_ptr(), s))
         self._small(self.dz_f2, 1, 1, self.w("f2.w"), 64, 1, self.d_f1, 64, B, 64, 1)                     # dh[b][j] = dz[b] W2[j]
@@ -211,36 +223,36 @@ class HipTrainStep:
         self._small(self.d_f1, 1, 64, self.out_v1, 64, 1, self.g("f1.w"), 64, 64, 64, B)                  # dW1[j][i] = sum_b dz[b][j] f[b][i]
         self._small(self.d_f1, 64, 1, self.w("f1.w"), 64, 1, self.d_v1, 64, B, 64, 64)                    # df[b][i] = sum_j dz[b][j] W1[j][i]
         self._bn_bwd(self.d_v1, self.a_v1, P, 1, 1, "v1", "v1.g", "v1.beta", "v1.b")
-        self._small(self.d_v1, 0, 1, body, 128, 1, self.g("v1.w"), 128, 1, 128, P)                        # dw[c] = sum_p dz[p] body[p][c]
+        _lib.check(L.ckr_gemm_tall(self.d_v1.data_ptr(), body.data_ptr(), P, 1, 128, self.g("v1.w").data_ptr(), tall.data_ptr(), s))   # dw[c] = sum_p dz[p] body[p][c]
         self._small(self.d_v1, 1, 1, self.w("v1.w"), 128, 1, self.d_act2, 128, P, 128, 1)                 # dbody(value)[p][c] = dz[p] w[c]
         # ---------------- backward: policy head
         _lib.check(L.ckr_sum_rows(self.dlogits.data_ptr(), B, 512, self.g("fc.b").data_ptr(), s))
         self._small(self.dlogits, 1, 512, self.out_p2, 512, 1, self.g("fc.w"), 512, 512, 512, B)          # dW[o][i] = sum_b dl[b][o] f[b][i]
         self._small(self.dlogits, 512, 1, self.w("fc.w"), 512, 1, self.d_f, 512, B, 512, 512)             # df[b][i] = sum_o dl[b][o] W[o][i]
         self._bn_bwd(self.d_f, self.a_p2, P, 8, 1, "p2", "p2.g", "p2.beta", "p2.b")                      # d_f viewed [P][8]
-        self._small(self.d_f, 1, 8, pol1, 128, 1, self.g("p2.w"), 128, 8, 128, P)                         # dW[o][c] = sum_p dz[p][o] pol1[p][c]
+        _lib.check(L.ckr_gemm_tall(self.d_f.data_ptr(), pol1.data_ptr(), P, 8, 128, self.g("p2.w").data_ptr(), tall.data_ptr(), s))     # dW[o][c] = sum_p dz[p][o] pol1[p][c]
         self._small(self.d_f, 8, 1, self.w("p2.w"), 128, 1, self.d_act, 128, P, 128, 8)                   # dpol1[p][c] = sum_o dz[p][o] W[o][c]
         # ---------------- backward: conv blocks 7 (policy conv) .. 0
-        d = self.d_act
+        _lib.check(L.ckr_conv_wflip(self.W.data_ptr(), self.w_offsets, 7, self.wt.data_ptr(), s))
+        d, nslices = self.d_act, 0                                 # block 7's dout is given; below it is the slices of the GEMM above
         for l in range(7, -1, -1):
             key = "c%d" % l
-            self._bn_bwd(d, self.a[l], P, 128, 1, key, key + ".g", key + ".beta", key + ".b")            # d := dz (in place)
-            _lib.check(L.ckr_transpose(d.data_ptr(), P, 128, self.dzT.data_ptr(), s))
-            self._gemm(self.dzT, self.colT[l], self.g(key + ".w"), 128, self.kpad[l], P, slices=self.wgrad_slices)   # dW = dz^T . col
+            add = self.d_act2 if l == 6 else None                                                         # the body's output feeds both heads
+            _lib.check(L.ckr_conv_bn_relu_backward(self.ws.data_ptr(), nslices, add.data_ptr() if add is not None else None, d.data_ptr(),
+                                                   self.a[l].data_ptr(), self.stats[key].data_ptr(), self.w(key + ".g").data_ptr(), P,
+                                                   self.g(key + ".g").data_ptr(), self.g(key + ".beta").data_ptr(), self.g(key + ".b").data_ptr(),
+                                                   self.part.data_ptr(), s))                              # d := dz
             if l == 0:
+                _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices, self.ws.data_ptr(), self.g("c0.w").data_ptr(), s))
                 break
-            _lib.check(L.ckr_transpose(self.w(key + ".w").data_ptr(), 128, 1152, self.wT.data_ptr(), s))
-            self._gemm(d, self.wT, self.d_col, P, 1152, 128, slices=1)                                    # dcol = dz . W
-            _lib.check(L.ckr_col2im(self.d_col.data_ptr(), P, 128, 1152, d.data_ptr(), s))                # gradient w.r.t. the block's input
-            if l == 7:                                                                                    # the body's output feeds both heads
-                _lib.check(L.ckr_add(d.data_ptr(), self.d_act2.data_ptr(), P * 128, d.data_ptr(), s))
-        # ---------------- losses of the batch (before the update), Adam with the l2 terms
+            inp = self.out[6] if l == 7 else self.out[l - 1]
+            _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.ws.data_ptr(), self.g(key + ".w").data_ptr(), s))
+            _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.ws.data_ptr(), s))   # gradient w.r.t. the block's input
+            nslices = self.slices
+        # ---------------- Adam with the l2 terms; losses of the batch (before the update)
+        _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
+                                   lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(),
+                                   self.penalty.data_ptr() if acc is not None else None, s))
         if acc is not None:
-            _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
-                                       lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(),
-                                       self.penalty.data_ptr(), s))
             _lib.check(L.ckr_loss_sums(self.ce.data_ptr(), self.se.data_ptr(), B, self.wp, self.wv, self.penalty.data_ptr(),
                                        float(n_rows if n_rows is not None else B), acc.data_ptr(), s))
-        else:
-            _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
-                                       lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(), None, s))

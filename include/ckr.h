@@ -364,41 +364,61 @@ int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* ro
  * One optimisation step of create_nn's model (:59-114) on a batch of B boards is a sequence of these calls, issued by
  * train_hip.HipTrainStep (which owns the buffers); all arrays are DEVICE float32, activations [P = 64 B positions][C]
  * channels last, arithmetic float32 throughout (what Keras computes in).  csrc/ckr_train.hip. */
-/* C[M][N] = sum_k A[m][k] Bt[n][k] (+ add[M][N]) on the float32 matrix pipe (v_mfma_f32_32x32x2_f32): the conv
- * layers' forward (A = im2col matrix, Bt = kernels [out][tap * Cin + c]), data-gradient and weight-gradient GEMMs.
- * M, N multiples of 128; K a multiple of 32 * slices; slices > 1: split-K through workspace[slices][M][N], ldc == N. */
+/* C[M][N] = sum_k A[m][k] Bt[n][k] (+ add[M][N]) on the float32 matrix pipe (v_mfma_f32_32x32x2_f32): the first
+ * layer's forward GEMM on its im2col matrix (the 14-plane input: K = 126 -> 128).  M, N multiples of 128; K a multiple of
+ * 32 * slices; slices > 1: split-K through workspace[slices][M][N], ldc == N. */
 int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N,
                 int32_t K, int32_t slices, float* workspace, const float* add, void* stream);
+/* The 3x3 convolutions with 128 input and 128 output planes as IMPLICIT GEMMs on act[P][128] (no im2col matrix):
+ * direction +1 (forward; w = the kernel [o][tap * 128 + c]):      workspace[z][p][o] = sum_k act[p + off(tap)][c] w[o][k]
+ * direction -1 (data gradient; w = ckr_conv_wflip's [c][tap * 128 + o]): workspace[z][p][c] = sum_k act[p - off(tap)][o] w[c][k]
+ * for the k = tap * 128 + . of slice z (36 % slices == 0); positions outside the 8x8 board read 0.  The next call
+ * (ckr_conv_bias_relu_bn / ckr_conv_bn_relu_backward) adds the slices. */
+int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction, int32_t slices, float* workspace, void* stream);
+/* dw[o][tap * 128 + c] = sum_p dz[p][o] x[p + off(tap)][c] (taps = 9), or dw[o][c] = sum_p dz[p][o] x[p][c] (taps = 1: the
+ * first layer on its im2col matrix); the P / 32 chunks of positions split over `slices` <= P / 32, workspace[slices][128][128 taps]. */
+int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, float* workspace, float* dw, void* stream);
+/* wt[l][c][tap * 128 + o] = w[offsets[l] + o * 1152 + tap * 128 + c] for l < layers <= 8; offsets: HOST array, in floats. */
+int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float* wt, void* stream);
+/* Forward of a conv block after its GEMM: a = ReLU(sum of `slices` workspace slices + bias) (kept for the backward pass),
+ * stats[2][128] = batch mean, 1 / sqrt(biased variance + eps), moving statistics updated (torch convention: momentum,
+ * unbiased variance), out = gamma * (a - mean) * inv_std + beta.  part: >= 256 ceil(P / 128) floats of workspace. */
+int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* bias, int32_t P, const float* gamma, const float* beta,
+                          float eps, float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part,
+                          void* stream);
+/* Backward of a conv block before its GEMMs: dout = sum of the workspace slices (slices == 0: dout as given) + add (may be
+ * NULL); dz = gradient w.r.t. the convolution's output written over dout; dgamma, dbeta, dbias.  part: >= 384 ceil(P / 128). */
+int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const float* add, float* dout, const float* a, const float* stats,
+                              const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* stream);
 /* C[m][n] (+)= sum_k A[m am + k ak] B[k bk + n bn]: the small products of the two heads and their gradients. */
 int ckr_gemm_small(const float* A, int64_t am, int64_t ak, const float* B, int64_t bk, int64_t bn, float* C, int64_t ldc,
                    int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
-/* col[p][tap * cin + c] = x[p + off(tap)][c] ('same' zero padding per 8x8 board; columns >= 9 cin zero), colT = its
- * transpose (may be NULL); dx[p][c] = sum of dcol over the taps that read x[p][c]. */
-int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col, float* colT, void* stream);
-int ckr_col2im(const float* dcol, int32_t P, int32_t cin, int32_t kpad, float* dx, void* stream);
-int ckr_transpose(const float* in, int32_t rows, int32_t cols, float* out, void* stream);
-/* Keras block "activation -> BatchNormalization" in training mode: z := act(z + bias) in place (relu != 0: ReLU),
- * stats[2][C] = batch mean and 1 / sqrt(biased variance + eps), moving statistics updated (torch convention: momentum,
- * unbiased variance), out = gamma * (z - mean) * inv_std + beta.  part: >= 2 C ceil(P / 64) floats of workspace. */
+/* C[m][n] = sum_p A[p][m] B[p][n], M = 1 or 8, N | 256: the weight gradients of the heads' 1x1 convolutions (a reduction
+ * over all positions).  part: >= M N ceil(P / 64) floats. */
+int ckr_gemm_tall(const float* A, const float* B, int32_t P, int32_t M, int32_t N, float* C, float* part, void* stream);
+/* col[p][tap * cin + c] = x[p + off(tap)][c] ('same' zero padding per 8x8 board; columns >= 9 cin zero): the first layer. */
+int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col, void* stream);
+/* Keras block "activation -> BatchNormalization" in training mode for the heads' small layers (C | 128):
+ * z := act(z + bias) in place (relu != 0: ReLU), stats, moving statistics, out as above.  part: >= 2 C ceil(P / 64) floats. */
 int ckr_bn_forward(float* z, const float* bias, int32_t P, int32_t C, int32_t relu, const float* gamma, const float* beta,
                    float eps, float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part, void* stream);
 /* dout (gradient w.r.t. out) -> gradient w.r.t. the pre-activation, in place; dgamma, dbeta, dbias (may be NULL). */
 int ckr_bn_backward(float* dout, const float* a, const float* stats, const float* gamma, int32_t P, int32_t C, int32_t relu,
                     float* dgamma, float* dbeta, float* dbias, float* part, float* sums, void* stream);
-int ckr_add(const float* a, const float* b, int64_t n, float* y, void* stream);
 int ckr_sum_rows(const float* in, int32_t rows, int32_t cols, float* out, void* stream);
-int ckr_relu_backward(const float* a, int64_t n, float* d, void* stream);
 /* Keras categorical cross-entropy of softmax(logits + bias) (clipped to [1e-7, 1 - 1e-7] after renormalisation) against
  * pi: ce[B]; dlogits = weight / B * d(sum ce)/dlogits.  Value head: v = tanh(z + *bias), se[B] = (v - target)^2,
  * dz = weight / B * d(sum se)/dz. */
 int ckr_policy_loss(const float* logits, const float* bias, const float* pi, int32_t B, float weight, float* dlogits, float* ce, void* stream);
 int ckr_value_loss(const float* z, const float* bias, const float* target, int32_t B, float weight, float* dz, float* se, void* stream);
-/* acc[0..2] (float64) += n_rows * {wp mean(ce) + wv mean(se) + *penalty, mean(ce), mean(se)} */
-int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float wv, const float* penalty, double n_rows, double* acc, void* stream);
+/* acc[0..2] (float64) += n_rows * {wp mean(ce) + wv mean(se) + penalty, mean(ce), mean(se)}; penalty = the sum of the 512
+ * partial sums ckr_adam_step left in penalty_parts (NULL: 0). */
+int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float wv, const double* penalty_parts, double n_rows, double* acc, void* stream);
 /* Adam (torch.optim.Adam arithmetic, Keras epsilon) on the flat parameter vector with the l2 terms folded in:
- * g = grad + 2 reg[i] w[i]; *d_step += 1 first; lr read from the device; d_penalty (may be NULL) = sum reg w^2 before the update. */
+ * g = grad + 2 reg[i] w[i]; step number = *d_step + 1, then *d_step += 1; lr read from the device; d_penalty_parts (512 doubles,
+ * may be NULL) = sum reg w^2 before the update, in 512 partial sums. */
 int ckr_adam_step(float* w, const float* grad, float* m, float* v, const float* reg, int64_t n, const float* d_lr, float beta1,
-                  float beta2, float eps, float* d_step, float* d_penalty, void* stream);
+                  float beta2, float eps, float* d_step, double* d_penalty_parts, void* stream);
 
 /* ---- probes of the stochastic paths (parity tests only) ------------------ *
  * The reference draws from NumPy's MT19937 (np.random.dirichlet, MCTS.py:107-108; np.random.choice,

@@ -56,6 +56,51 @@ def test_gemm_nt_matches_float64():
         _lib.check(L.ckr_gemm_nt(A.data_ptr(), 64, Bt.data_ptr(), 64, Cm.data_ptr(), 100, 100, 256, 64, 1, None, None, None))
 
 
+def test_implicit_conv_gemms_match_float64_conv():
+    """ckr_conv_gemm (forward, data gradient through the flipped kernels) and ckr_conv_wgrad against float64 conv2d / autograd."""
+    import torch.nn.functional as F
+    from checkers_mcts_amd import _lib
+    L = _lib.load()
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    P = 64 * B
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(B, 8, 8, 128, generator=g).cuda()                       # channels last, as the step keeps it
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.05).cuda()           # [o][c][ky][kx]
+    dz = torch.randn(B, 8, 8, 128, generator=g).cuda()
+    wk = w.permute(0, 2, 3, 1).reshape(128, 1152).contiguous()             # [o][tap * 128 + c]
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y = F.conv2d(xd, wd, padding=1)
+    y.backward(dz.double().permute(0, 3, 1, 2))
+    for slices in (1, 4, 9):
+        ws = torch.zeros(slices, P, 128, device="cuda")
+        _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, slices, ws.data_ptr(), st))
+        got = ws.double().sum(0).reshape(B, 8, 8, 128).permute(0, 3, 1, 2)
+        assert float((got - y.detach()).abs().max()) < 1e-5 * float(y.abs().max())
+        wt = torch.zeros(128, 1152, device="cuda")
+        _lib.check(L.ckr_conv_wflip(wk.data_ptr(), (i64 * 1)(0), 1, wt.data_ptr(), st))
+        assert torch.equal(wt.reshape(128, 9, 128), wk.reshape(128, 9, 128).permute(2, 1, 0))
+        _lib.check(L.ckr_conv_gemm(dz.data_ptr(), wt.data_ptr(), P, -1, slices, ws.data_ptr(), st))
+        got = ws.double().sum(0).reshape(B, 8, 8, 128).permute(0, 3, 1, 2)
+        assert float((got - xd.grad).abs().max()) < 1e-5 * float(xd.grad.abs().max())
+    for slices in (1, 5, 12):
+        ws = torch.zeros(slices, 128, 1152, device="cuda")
+        dw = torch.zeros(128, 1152, device="cuda")
+        _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, slices, ws.data_ptr(), dw.data_ptr(), st))
+        got = dw.double().reshape(128, 3, 3, 128).permute(0, 3, 1, 2)
+        assert float((got - wd.grad).abs().max()) < 1e-5 * float(wd.grad.abs().max())
+        _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 1, slices, ws.data_ptr(), dw.data_ptr(), st))   # taps = 1: dz^T . x
+        ref = dz.double().reshape(P, 128).t() @ x.double().reshape(P, 128)
+        assert float((dw.reshape(-1)[:128 * 128].reshape(128, 128).double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    with pytest.raises(ValueError):
+        _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, 5, ws.data_ptr(), st))
+
+
 def relu_decisions(hs):
     """The ReLU decisions the HIP step took (its kept post-ReLU activations > 0), in the float64 graph's shapes."""
     B = hs.B
@@ -66,7 +111,7 @@ def relu_decisions(hs):
     return m
 
 
-def float64_loss(net, x, pi, tv, decisions):
+def float64_loss(net, x, pi, tv, decisions, flip_tol=1e-5):
     """The graph of PolicyValueNet.forward + train.losses in FLOAT64 (the module's own forward casts to float32).
 
     Float32 autograd is no yardstick here: a ReLU whose argument lies within float32 rounding of 0 is decided
@@ -99,7 +144,7 @@ def float64_loss(net, x, pi, tv, decisions):
     ce = -(pi.double() * torch.log(p.clamp(1e-7, 1 - 1e-7))).sum(dim=1).mean()
     mse = F.mse_loss(v, tv.double())
     loss = net.policy_loss_weight * ce + net.value_loss_weight * mse + T.l2_penalty(net)
-    assert all(f < 1e-5 for f in flips), flips           # only arguments within rounding of 0 may be decided differently
+    assert all(f < flip_tol for f in flips), flips       # only arguments within rounding of 0 may be decided differently
     return loss, ce, mse
 
 
@@ -166,7 +211,7 @@ def test_adam_trajectory_matches_float64():
         hs.step(x, pi, tv, lr, acc, B)
         torch.cuda.synchronize()
         opt.zero_grad()
-        loss, ce, mse = float64_loss(ref, x, pi, tv, relu_decisions(hs))
+        loss, ce, mse = float64_loss(ref, x, pi, tv, relu_decisions(hs), flip_tol=5e-3)   # the two sets of weights drift apart (Adam on near-zero gradients)
         loss.backward()
         opt.step()
         ref_losses.append(float(loss))
@@ -176,7 +221,11 @@ def test_adam_trajectory_matches_float64():
     for k in rd:
         if k.endswith("num_batches_tracked"):
             continue
-        close(sd[k], rd[k], 1e-3, k)
+        a, b = sd[k].double(), rd[k].double()
+        # Adam's first steps move every weight by ~lr * sign(gradient): the handful of elements whose total gradient is
+        # within rounding of 0 go either way, so the maximum norm is bounded by the distance walked, the l2 norm is tight
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-9, k
+        assert float((a - b).abs().max()) <= 2 * steps * 2e-3, k
     # the trained module evaluates like the float64 one
     net.eval(); ref.eval()
     x, _, _ = make_batch(16, 7)
