@@ -800,7 +800,7 @@ int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* b
 // over dout, dgamma, dbeta, dbias.  a, stats: the block's kept activation and statistics.  part: 384 * ceil(P / 128) floats.
 int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const float* add, float* dout, const float* a, const float* stats,
                               const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* stream) {
-    if ((slices > 0 && !workspace) || slices < 0 || !dout || !a || !stats || !gamma || !dgamma || !dbeta || !dbias || !part || P <= 0)
+    if ((slices > 0 && !workspace) || slices < 0 || !dout || !a || !stats || !gamma || !dgamma || !dbeta || !part || P <= 0)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bn_relu_backward: bad argument");
     if (int rc = ckr::require_device()) return rc;
     const int rpb = rows_per_block(P), nblk = (P + rpb - 1) / rpb;
@@ -808,7 +808,18 @@ int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const floa
     hipLaunchKernelGGL(k_bwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, add, a, stats, (int)P, rpb, dout, part);
     hipLaunchKernelGGL(k_bn_bwd_apply128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, dout, a, stats, (const float*)part, nblk, gamma, (int)P, rpb,
                        dgamma, dbeta, part2);
-    hipLaunchKernelGGL(k_sum_rows, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)part2, nblk, 128, dbias);
+    if (dbias) hipLaunchKernelGGL(k_sum_rows, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)part2, nblk, 128, dbias);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// The conv bias gradient from the partial sums ckr_conv_bn_relu_backward (called with dbias == NULL) left in `part`:
+// a separate call so that it can run on another stream, off the critical path of the backward chain.
+int ckr_conv_bias_grad(const float* part, int32_t P, float* dbias, void* stream) {
+    if (!part || !dbias || P <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bias_grad: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    const int rpb = rows_per_block(P), nblk = (P + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_sum_rows, dim3(2), dim3(256), 0, (hipStream_t)stream, part + (size_t)256 * nblk, nblk, 128, dbias);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

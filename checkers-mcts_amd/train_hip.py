@@ -36,6 +36,7 @@ class HipTrainStep:
         L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
         L.ckr_conv_bias_relu_bn.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]
         L.ckr_conv_bn_relu_backward.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.ckr_conv_bias_grad.argtypes = [vp, i32, vp, vp]
         L.ckr_gemm_small.argtypes = [vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp]
         L.ckr_gemm_tall.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.ckr_im2col.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -95,11 +96,15 @@ class HipTrainStep:
         self.a_f1, self.out_f1 = z(B, 64), z(B, 64)
         self.logits, self.dlogits, self.z_f2, self.dz_f2 = z(B, 512), z(B, 512), z(B), z(B)
         self.ce, self.se = z(B), z(B)
-        self.part = z(4 * 128 * (P // 64 + 1) + 8 * 128 * (P // 64 + 1))
-        self.sums = z(2, 128)
-        self.ws = z(max(self.slices * P * 128, self.wgrad_slices * 128 * 1152))      # split-K partial products
+        part_n, tall_n = 4 * 128 * (P // 64 + 1), 8 * 128 * (P // 64 + 1)
+        self.part, self.tall, self.sums = z(part_n), z(tall_n), z(2, 128)            # main stream's reduction workspaces
+        self.part_b = z(part_n)                                                      # conv blocks alternate part / part_b (the bias gradient reads them on the side stream)
+        self.part_v, self.tall_v, self.sums_v = z(part_n), z(tall_n), z(2, 128)      # the value head's (side stream)
+        self.ws = z(max(self.slices * P * 128, 4 * B * 512))                         # split-K partial products: forward / data gradient
+        self.ws_w = z(self.wgrad_slices * 128 * 1152)                                # ... and weight gradient (side stream)
+        self.side = torch.cuda.Stream(device=dev)
         self.wt = z(7, 128, 1152)                          # flipped kernels of layers 1..7 for the data-gradient GEMMs
-        self.d_act, self.d_act2 = z(P, 128), z(P, 128)
+        self.d_act, self.d_act_b, self.d_act2 = z(P, 128), z(P, 128), z(P, 128)
         self.d_p2, self.d_f, self.d_v1, self.d_f1 = z(P, 8), z(B, 512), z(P, 1), z(B, 64)
         self.load_from_module()
 
@@ -164,18 +169,18 @@ class HipTrainStep:
     def _small(self, A, am, ak, Bm, bk, bn, Cm, ldc, M, N, K, acc=0):
         _lib.check(self._L.ckr_gemm_small(A.data_ptr(), am, ak, Bm.data_ptr(), bk, bn, Cm.data_ptr(), ldc, M, N, K, acc, self._s()))
 
-    def _bn_fwd(self, z, bias, P, Cc, relu, key, gname, bname, out):
+    def _bn_fwd(self, z, bias, P, Cc, relu, key, gname, bname, out, part):
         rm, rv = self.run[key]
         _lib.check(self._L.ckr_bn_forward(z.data_ptr(), bias.data_ptr() if bias is not None else None, P, Cc, relu,
                                           self.w(gname).data_ptr(), self.w(bname).data_ptr(), self.bn_eps, self.bn_mom,
                                           rm.data_ptr(), rv.data_ptr(), self.stats[key].data_ptr(), out.data_ptr(),
-                                          self.part.data_ptr(), self._s()))
+                                          part.data_ptr(), self._s()))
 
-    def _bn_bwd(self, dout, a, P, Cc, relu, key, gname, bname, biasname):
+    def _bn_bwd(self, dout, a, P, Cc, relu, key, gname, bname, biasname, part, sums):
         _lib.check(self._L.ckr_bn_backward(dout.data_ptr(), a.data_ptr(), self.stats[key].data_ptr(), self.w(gname).data_ptr(), P, Cc, relu,
                                            self.g(gname).data_ptr(), self.g(bname).data_ptr(),
                                            self.g(biasname).data_ptr() if biasname else None,
-                                           self.part.data_ptr(), self.sums.data_ptr(), self._s()))
+                                           part.data_ptr(), sums.data_ptr(), self._s()))
 
     def _conv_fwd_tail(self, l, ws, slices):
         key = "c%d" % l
@@ -184,71 +189,116 @@ class HipTrainStep:
                                                  self.w(key + ".beta").data_ptr(), self.bn_eps, self.bn_mom, rm.data_ptr(), rv.data_ptr(),
                                                  self.stats[key].data_ptr(), self.a[l].data_ptr(), self.out[l].data_ptr(), self.part.data_ptr(), self._s()))
 
+    def _fork(self, main):
+        """The side stream continues from this point of the main stream."""
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.side.wait_event(ev)
+
+    def _value_head(self, tv):
+        """Forward, loss and backward of the value head on the CURRENT stream; leaves d loss / d body in d_act2.
+        1x1 conv (1) + ReLU + BN -> flatten -> Dense(64) + ReLU + BN -> Dense(1) -> tanh (training_pipeline.py:102-112)."""
+        L, s, P, B, body = self._L, self._s(), self.P, self.B, self.out[6]
+        part, sums = self.part_v, self.sums_v
+        self._small(body, 128, 1, self.w("v1.w"), 1, 128, self.a_v1, 1, P, 1, 128)
+        self._bn_fwd(self.a_v1, self.w("v1.b"), P, 1, 1, "v1", "v1.g", "v1.beta", self.out_v1, part)
+        self._small(self.out_v1, 64, 1, self.w("f1.w"), 1, 64, self.a_f1, 64, B, 64, 64)
+        self._bn_fwd(self.a_f1, self.w("f1.b"), B, 64, 1, "vbn", "vbn.g", "vbn.beta", self.out_f1, part)
+        self._small(self.out_f1, 64, 1, self.w("f2.w"), 1, 64, self.z_f2, 1, B, 1, 64)
+        _lib.check(L.ckr_value_loss(self.z_f2.data_ptr(), self.w("f2.b").data_ptr(), tv.data_ptr(), B, self.wv,
+                                    self.dz_f2.data_ptr(), self.se.data_ptr(), s))
+        self._small(self.dz_f2, 0, 1, self.out_f1, 64, 1, self.g("f2.w"), 64, 1, 64, B)                  # dW2[j] = sum_b dz[b] h[b][j]
+        _lib.check(L.ckr_sum_rows(self.dz_f2.data_ptr(), B, 1, self.g("f2.b").data_ptr(), s))
+        self._small(self.dz_f2, 1, 1, self.w("f2.w"), 64, 1, self.d_f1, 64, B, 64, 1)                     # dh[b][j] = dz[b] W2[j]
+        self._bn_bwd(self.d_f1, self.a_f1, B, 64, 1, "vbn", "vbn.g", "vbn.beta", "f1.b", part, sums)
+        self._small(self.d_f1, 1, 64, self.out_v1, 64, 1, self.g("f1.w"), 64, 64, 64, B)                  # dW1[j][i] = sum_b dz[b][j] f[b][i]
+        self._small(self.d_f1, 64, 1, self.w("f1.w"), 64, 1, self.d_v1, 64, B, 64, 64)                    # df[b][i] = sum_j dz[b][j] W1[j][i]
+        self._bn_bwd(self.d_v1, self.a_v1, P, 1, 1, "v1", "v1.g", "v1.beta", "v1.b", part, sums)
+        _lib.check(L.ckr_gemm_tall(self.d_v1.data_ptr(), body.data_ptr(), P, 1, 128, self.g("v1.w").data_ptr(), self.tall_v.data_ptr(), s))   # dw[c] = sum_p dz[p] body[p][c]
+        self._small(self.d_v1, 1, 1, self.w("v1.w"), 128, 1, self.d_act2, 128, P, 128, 1)                 # dbody(value)[p][c] = dz[p] w[c]
+
+    def _policy_head(self, pi):
+        """Forward, loss and backward of the policy head behind the policy conv block (layer 7); leaves d loss / d pol1 in d_act.
+        1x1 conv (8) + ReLU + BN -> flatten (H, W, C) -> Dense(512) -> softmax (training_pipeline.py:93-100)."""
+        L, s, P, B, pol1 = self._L, self._s(), self.P, self.B, self.out[7]
+        self._small(pol1, 128, 1, self.w("p2.w"), 1, 128, self.a_p2, 8, P, 8, 128)
+        self._bn_fwd(self.a_p2, self.w("p2.b"), P, 8, 1, "p2", "p2.g", "p2.beta", self.out_p2, self.part)
+        if B % 128 == 0:                                                                                  # logits[b][o] = sum_i f[b][i] W[o][i]
+            _lib.check(L.ckr_gemm_nt(self.out_p2.data_ptr(), 512, self.w("fc.w").data_ptr(), 512, self.logits.data_ptr(), 512, B, 512, 512,
+                                     4, self.ws.data_ptr(), None, s))
+        else:
+            self._small(self.out_p2, 512, 1, self.w("fc.w"), 1, 512, self.logits, 512, B, 512, 512)
+        _lib.check(L.ckr_policy_loss(self.logits.data_ptr(), self.w("fc.b").data_ptr(), pi.data_ptr(), B, self.wp,
+                                     self.dlogits.data_ptr(), self.ce.data_ptr(), s))
+        _lib.check(L.ckr_sum_rows(self.dlogits.data_ptr(), B, 512, self.g("fc.b").data_ptr(), s))
+        self._small(self.dlogits, 1, 512, self.out_p2, 512, 1, self.g("fc.w"), 512, 512, 512, B)          # dW[o][i] = sum_b dl[b][o] f[b][i]
+        self._small(self.dlogits, 512, 1, self.w("fc.w"), 512, 1, self.d_f, 512, B, 512, 512)             # df[b][i] = sum_o dl[b][o] W[o][i]
+        self._bn_bwd(self.d_f, self.a_p2, P, 8, 1, "p2", "p2.g", "p2.beta", "p2.b", self.part, self.sums)   # d_f viewed [P][8]
+        _lib.check(L.ckr_gemm_tall(self.d_f.data_ptr(), pol1.data_ptr(), P, 8, 128, self.g("p2.w").data_ptr(), self.tall.data_ptr(), s))   # dW[o][c] = sum_p dz[p][o] pol1[p][c]
+        self._small(self.d_f, 8, 1, self.w("p2.w"), 128, 1, self.d_act, 128, P, 128, 8)                   # dpol1[p][c] = sum_o dz[p][o] W[o][c]
+
     # ---- one optimisation step ------------------------------------------------------------------------------
     def step(self, x, pi, tv, lr_t, acc=None, n_rows=None):
         """x [B,8,8,14], pi [B,512], tv [B] float32 on the device; lr_t: float32 device scalar.  acc (float64 [3]) +=
-        n_rows * (total loss incl. penalty, policy CE, value MSE) of this batch, evaluated before the update."""
-        L, s, P, B = self._L, self._s(), self.P, self.B
+        n_rows * (total loss incl. penalty, policy CE, value MSE) of this batch, evaluated before the update.
+
+        Two streams: the conv chain runs on the current stream; the value head (which hangs off the body's output, beside
+        the policy conv block) and the weight-gradient GEMMs (which hang off each block's dz, beside the data-gradient GEMM
+        and the next block's BatchNorm backward) run on a side stream, forked and joined with events.  At batch 128 one
+        GEMM fills the chip with ~1 workgroup per CU; the pairs share the CUs.  Captured as one HIP graph by train.py."""
+        L, P, B = self._L, self.P, self.B
         if tuple(x.shape) != (B, 8, 8, 14) or not x.is_contiguous() or x.dtype != torch.float32:
             raise ValueError("x must be a contiguous float32 [%d, 8, 8, 14] tensor" % B)
+        main = torch.cuda.current_stream(self.dev)
+        s = main.cuda_stream
         # ---------------- forward: first layer on its im2col matrix, layers 1..7 as implicit GEMMs
         _lib.check(L.ckr_im2col(x.data_ptr(), P, 14, KPAD0, self.col0.data_ptr(), s))
         _lib.check(L.ckr_gemm_nt(self.col0.data_ptr(), KPAD0, self.w("c0.w").data_ptr(), KPAD0, self.a[0].data_ptr(), 128, P, 128, KPAD0, 1, None, None, s))
         self._conv_fwd_tail(0, self.a[0], 1)
         for l in range(1, 8):
             inp = self.out[6] if l == 7 else self.out[l - 1]      # pol1 (l = 7) reads the body's output
+            if l == 7:                                            # the value head, beside the policy conv block and the policy head
+                self._fork(main)
+                with torch.cuda.stream(self.side):
+                    self._value_head(tv)
+                    value_done = torch.cuda.Event()
+                    value_done.record(self.side)
             _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.ws.data_ptr(), s))
             self._conv_fwd_tail(l, self.ws, self.slices)
-        body, pol1 = self.out[6], self.out[7]
-        # policy head: 1x1 conv (8) + ReLU + BN -> flatten (H, W, C) -> Dense(512)
-        self._small(pol1, 128, 1, self.w("p2.w"), 1, 128, self.a_p2, 8, P, 8, 128)
-        self._bn_fwd(self.a_p2, self.w("p2.b"), P, 8, 1, "p2", "p2.g", "p2.beta", self.out_p2)
-        self._small(self.out_p2, 512, 1, self.w("fc.w"), 1, 512, self.logits, 512, B, 512, 512)           # logits[b][o] = sum_i f[b][i] W[o][i]
-        _lib.check(L.ckr_policy_loss(self.logits.data_ptr(), self.w("fc.b").data_ptr(), pi.data_ptr(), B, self.wp,
-                                     self.dlogits.data_ptr(), self.ce.data_ptr(), s))
-        # value head: 1x1 conv (1) + ReLU + BN -> flatten -> Dense(64) + ReLU + BN -> Dense(1) -> tanh
-        self._small(body, 128, 1, self.w("v1.w"), 1, 128, self.a_v1, 1, P, 1, 128)
-        self._bn_fwd(self.a_v1, self.w("v1.b"), P, 1, 1, "v1", "v1.g", "v1.beta", self.out_v1)
-        self._small(self.out_v1, 64, 1, self.w("f1.w"), 1, 64, self.a_f1, 64, B, 64, 64)
-        self._bn_fwd(self.a_f1, self.w("f1.b"), B, 64, 1, "vbn", "vbn.g", "vbn.beta", self.out_f1)
-        self._small(self.out_f1, 64, 1, self.w("f2.w"), 1, 64, self.z_f2, 1, B, 1, 64)
-        _lib.check(L.ckr_value_loss(self.z_f2.data_ptr(), self.w("f2.b").data_ptr(), tv.data_ptr(), B, self.wv,
-                                    self.dz_f2.data_ptr(), self.se.data_ptr(), s))
-        # ---------------- backward: value head
-        tall = self.part[4 * 128 * (P // 64 + 1):]
-        self._small(self.dz_f2, 0, 1, self.out_f1, 64, 1, self.g("f2.w"), 64, 1, 64, B)                  # dW2[j] = sum_b dz[b] h[b][j]
-        _lib.check(L.ckr_sum_rows(self.dz_f2.data_ptr(), B, 1, self.g("f2.b").data_ptr(), s))
-        self._small(self.dz_f2, 1, 1, self.w("f2.w"), 64, 1, self.d_f1, 64, B, 64, 1)                     # dh[b][j] = dz[b] W2[j]
-        self._bn_bwd(self.d_f1, self.a_f1, B, 64, 1, "vbn", "vbn.g", "vbn.beta", "f1.b")
-        self._small(self.d_f1, 1, 64, self.out_v1, 64, 1, self.g("f1.w"), 64, 64, 64, B)                  # dW1[j][i] = sum_b dz[b][j] f[b][i]
-        self._small(self.d_f1, 64, 1, self.w("f1.w"), 64, 1, self.d_v1, 64, B, 64, 64)                    # df[b][i] = sum_j dz[b][j] W1[j][i]
-        self._bn_bwd(self.d_v1, self.a_v1, P, 1, 1, "v1", "v1.g", "v1.beta", "v1.b")
-        _lib.check(L.ckr_gemm_tall(self.d_v1.data_ptr(), body.data_ptr(), P, 1, 128, self.g("v1.w").data_ptr(), tall.data_ptr(), s))   # dw[c] = sum_p dz[p] body[p][c]
-        self._small(self.d_v1, 1, 1, self.w("v1.w"), 128, 1, self.d_act2, 128, P, 128, 1)                 # dbody(value)[p][c] = dz[p] w[c]
-        # ---------------- backward: policy head
-        _lib.check(L.ckr_sum_rows(self.dlogits.data_ptr(), B, 512, self.g("fc.b").data_ptr(), s))
-        self._small(self.dlogits, 1, 512, self.out_p2, 512, 1, self.g("fc.w"), 512, 512, 512, B)          # dW[o][i] = sum_b dl[b][o] f[b][i]
-        self._small(self.dlogits, 512, 1, self.w("fc.w"), 512, 1, self.d_f, 512, B, 512, 512)             # df[b][i] = sum_o dl[b][o] W[o][i]
-        self._bn_bwd(self.d_f, self.a_p2, P, 8, 1, "p2", "p2.g", "p2.beta", "p2.b")                      # d_f viewed [P][8]
-        _lib.check(L.ckr_gemm_tall(self.d_f.data_ptr(), pol1.data_ptr(), P, 8, 128, self.g("p2.w").data_ptr(), tall.data_ptr(), s))     # dW[o][c] = sum_p dz[p][o] pol1[p][c]
-        self._small(self.d_f, 8, 1, self.w("p2.w"), 128, 1, self.d_act, 128, P, 128, 8)                   # dpol1[p][c] = sum_o dz[p][o] W[o][c]
+        self._policy_head(pi)
         # ---------------- backward: conv blocks 7 (policy conv) .. 0
         _lib.check(L.ckr_conv_wflip(self.W.data_ptr(), self.w_offsets, 7, self.wt.data_ptr(), s))
-        d, nslices = self.d_act, 0                                 # block 7's dout is given; below it is the slices of the GEMM above
+        bufs = (self.d_act, self.d_act_b)                          # dz of block l lives in bufs[(7 - l) % 2] while its weight gradient runs
+        nslices, wgrad_done = 0, {}
         for l in range(7, -1, -1):
-            key = "c%d" % l
-            add = self.d_act2 if l == 6 else None                                                         # the body's output feeds both heads
+            key, d = "c%d" % l, bufs[(7 - l) % 2]
+            if l == 6:
+                main.wait_event(value_done)                       # the body's output feeds both heads
+            if l + 2 in wgrad_done:
+                main.wait_event(wgrad_done[l + 2])                # this buffer was read by the weight gradient two blocks up
+            add = self.d_act2 if l == 6 else None
+            part = (self.part, self.part_b)[(7 - l) % 2]
             _lib.check(L.ckr_conv_bn_relu_backward(self.ws.data_ptr(), nslices, add.data_ptr() if add is not None else None, d.data_ptr(),
                                                    self.a[l].data_ptr(), self.stats[key].data_ptr(), self.w(key + ".g").data_ptr(), P,
-                                                   self.g(key + ".g").data_ptr(), self.g(key + ".beta").data_ptr(), self.g(key + ".b").data_ptr(),
-                                                   self.part.data_ptr(), s))                              # d := dz
+                                                   self.g(key + ".g").data_ptr(), self.g(key + ".beta").data_ptr(), None,
+                                                   part.data_ptr(), s))                                   # d := dz
+            self._fork(main)
+            with torch.cuda.stream(self.side):
+                ss = self.side.cuda_stream
+                _lib.check(L.ckr_conv_bias_grad(part.data_ptr(), P, self.g(key + ".b").data_ptr(), ss))
+                if l == 0:
+                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
+                else:
+                    inp = self.out[6] if l == 7 else self.out[l - 1]
+                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.ws_w.data_ptr(), self.g(key + ".w").data_ptr(), ss))
+                wgrad_done[l] = torch.cuda.Event()
+                wgrad_done[l].record(self.side)
             if l == 0:
-                _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices, self.ws.data_ptr(), self.g("c0.w").data_ptr(), s))
                 break
-            inp = self.out[6] if l == 7 else self.out[l - 1]
-            _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.ws.data_ptr(), self.g(key + ".w").data_ptr(), s))
             _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.ws.data_ptr(), s))   # gradient w.r.t. the block's input
             nslices = self.slices
+        main.wait_event(wgrad_done[1])
+        main.wait_event(wgrad_done[0])
         # ---------------- Adam with the l2 terms; losses of the batch (before the update)
         _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
                                    lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(),

@@ -387,9 +387,13 @@ int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* b
                           float eps, float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part,
                           void* stream);
 /* Backward of a conv block before its GEMMs: dout = sum of the workspace slices (slices == 0: dout as given) + add (may be
- * NULL); dz = gradient w.r.t. the convolution's output written over dout; dgamma, dbeta, dbias.  part: >= 384 ceil(P / 128). */
+ * NULL); dz = gradient w.r.t. the convolution's output written over dout; dgamma, dbeta, dbias (may be NULL, see
+ * ckr_conv_bias_grad).  part: >= 384 ceil(P / 128). */
 int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const float* add, float* dout, const float* a, const float* stats,
                               const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* stream);
+/* dbias from the partial sums a ckr_conv_bn_relu_backward call with dbias == NULL left in `part` (so that it can run on another
+ * stream, off the backward chain's critical path). */
+int ckr_conv_bias_grad(const float* part, int32_t P, float* dbias, void* stream);
 /* C[m][n] (+)= sum_k A[m am + k ak] B[k bk + n bn]: the small products of the two heads and their gradients. */
 int ckr_gemm_small(const float* A, int64_t am, int64_t ak, const float* B, int64_t bk, int64_t bn, float* C, int64_t ldc,
                    int32_t M, int32_t N, int32_t K, int32_t accumulate, void* stream);
