@@ -420,6 +420,54 @@ def rollout_leg(a, dev):
     return {"rollouts_per_s": sims / dt, "plies": s1["plies"] - s0["plies"], "seconds": dt, "budget": 400}
 
 
+def training_leg(dev, batch=128, reps=30):
+    """one optimisation step of the 128-wide network on the reference's BATCH_SIZE (train_Checkers.py:116), the
+    hand-written HIP step (csrc/ckr_train.hip) and the PyTorch autograd / MIOpen / fused-Adam step, each one HIP graph."""
+    from checkers_mcts_amd import net as N, train as T
+    from checkers_mcts_amd.train_hip import HipTrainStep
+    torch.manual_seed(0)
+    x = (torch.rand(batch, 8, 8, 14, device=dev) < 0.2).float().contiguous()
+    pi = torch.softmax(torch.randn(batch, 512, device=dev), 1).contiguous()
+    tv = (torch.rand(batch, device=dev) * 2 - 1).contiguous()
+    lr = torch.tensor(1e-3, device=dev)
+    acc = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    def graph_ms(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g.replay(); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record(); torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    hs = HipTrainStep(N.PolicyValueNet(128).keras_init(0).float().to(dev), batch, 1e-3, 1e-3)
+    hip_ms = graph_ms(lambda: hs.step(x, pi, tv, lr, acc, batch))
+    ref = N.PolicyValueNet(128).keras_init(0).float().to(dev).to(memory_format=torch.channels_last).train()
+    ref.conv_reg = ref.dense_reg = 1e-3; ref.policy_loss_weight = ref.value_loss_weight = 1.0
+    opt = torch.optim.Adam(ref.parameters(), lr=lr, betas=(0.9, 0.999), eps=1e-7, fused=True, capturable=True)
+
+    def torch_step():
+        opt.zero_grad(set_to_none=False)
+        T.losses(ref, x, pi, tv, None, with_penalty=False)[0].backward()
+        T.add_l2_gradients(ref)
+        opt.step()
+    torch_ms = graph_ms(torch_step)
+    flops = 2.0 * 64 * batch * 128 * (3 * 7 * 1152 + 2 * 126)
+    return {"batch": batch, "samples_per_s": batch / hip_ms * 1e3, "ms_per_step": hip_ms, "dtype": "f32",
+            "conv_gemm_tflops_over_whole_step": flops / hip_ms / 1e9, "fp32_matrix_peak_tflops": 157.3,
+            "torch_miopen_ms_per_step": torch_ms, "speedup_vs_torch_miopen": torch_ms / hip_ms}
+
+
 def preroll_steps(a):
     return a.preroll if a.preroll >= 0 else 90 * a.budget
 
@@ -551,6 +599,7 @@ def main():
             extra["bf16_throughput_mode" if other == "bf16" else "fp32_grade_mode"] = throughput_leg(a, dev, other)
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
             extra["random_rollout_mode"] = rollout_leg(a, dev)
+            extra["training_step"] = training_leg(dev)
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(a.budget, a.cpu_seconds)
@@ -566,7 +615,7 @@ def main():
                           "streams": "2 half-batches of %d slots on 2 HIP streams" % nb if leg.split else "1",
                           "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
                "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py); rules, search, tuples "
-                         "bit-exact vs the reference golden vectors (under NumPy >= 2 promotion rules)" if mode == "fp32" else
+                         "bit-exact vs the reference golden vectors (NumPy >= 2 promotion rules; the vectors regenerate bit-identically under NumPy 1.26 legacy rules)" if mode == "fp32" else
                          "throughput mode (not a parity claim)",
                "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total, "games_finished_in_window": games_window,
                "active_slots_after_window": active_after_window,

@@ -30,6 +30,7 @@ import training_pipeline as tp
 from MCTS import MCTS, MCTS_Node
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CKR_GOLDEN_OUT", HERE)      # another directory for a run under a different NumPy (see numpy1/README.md)
 codec = rt.codec
 
 
@@ -77,7 +78,7 @@ def gen_rules(seed=20260929, n_games=120, n_endgames=60, n_synth=6000):
     for fn in (_all_kings_board, _empty_side_board):
         for s in fn():
             add(env, [s], 3)
-    np.savez_compressed(os.path.join(HERE, "rules_v1.npz"), boards=np.array(boards, np.uint32),
+    np.savez_compressed(os.path.join(OUT, "rules_v1.npz"), boards=np.array(boards, np.uint32),
                         masks=np.array(masks, np.uint32), status=np.array(status, np.uint32),
                         child_off=np.array(off, np.int64), children=np.concatenate(kids).astype(np.uint32),
                         kind=np.array(kind, np.uint8))
@@ -139,10 +140,10 @@ def gen_predict(seed=7, n=200):
         salt = int(rng.randint(0, 5))
         p, v = ref_shim.HashNet(salt).predict(x)
         hx.append(x.astype(np.float32).reshape(896)); hp.append(p[0]); hv.append(v[0, 0]); hsalt.append(salt)
-    np.savez_compressed(os.path.join(HERE, "predict_v1.npz"), boards=np.array(boards, np.uint32),
+    np.savez_compressed(os.path.join(OUT, "predict_v1.npz"), boards=np.array(boards, np.uint32),
                         masks=np.array(masks, np.uint32), raw_p=np.array(raw, np.float32),
                         planes=np.array(outp, np.float32))
-    np.savez_compressed(os.path.join(HERE, "hashnet_v1.npz"), x=np.array(hx, np.float32),
+    np.savez_compressed(os.path.join(OUT, "hashnet_v1.npz"), x=np.array(hx, np.float32),
                         p=np.array(hp, np.float32), v=np.array(hv, np.float32), salt=np.array(hsalt, np.uint32))
     print("predict:", len(boards), "vectors")
 
@@ -197,7 +198,7 @@ def gen_search(cases=((30, 0, 24), (100, 1, 10), (12, 2, 400))):
         out["c%d_p" % ci] = np.array(ps, np.float32)
         print("search case", ci, "budget", budget, "plies", len(rows), "outcome", env.outcome)
     out["n_cases"] = np.array(len(cases))
-    np.savez_compressed(os.path.join(HERE, "search_v1.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "search_v1.npz"), **out)
 
 
 # --------------------------------------------------------------------------- self-play tuples
@@ -224,7 +225,7 @@ def gen_selfplay(cases=((30, 40, 2, 0), (20, 1000, 1, 1), (8, 1000, 1, 4), (25, 
     finally:
         os.chdir(cwd)
     out["n_cases"] = np.array(len(cases))
-    np.savez_compressed(os.path.join(HERE, "selfplay_v1.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "selfplay_v1.npz"), **out)
 
 
 # --------------------------------------------------------------------------- random-rollout mode
@@ -257,7 +258,7 @@ def gen_rollout(cases=((60, 20, 1), (100, 10, 1))):
         np.random.randint = real_randint
     out["ln_table"] = np.array([0.0] + [float(np.log(n)) for n in range(1, 4096)], np.float64)
     out["n_cases"] = np.array(len(cases))
-    np.savez_compressed(os.path.join(HERE, "rollout_v1.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "rollout_v1.npz"), **out)
 
 
 # --------------------------------------------------------------------------- tournament
@@ -290,7 +291,7 @@ def gen_tournament(cases=((30, 4, 1, 2), (24, 2, 3, 5), (40, 2, 7, 8))):
     finally:
         os.chdir(cwd)
     out["n_cases"] = np.array(len(cases))
-    np.savez_compressed(os.path.join(HERE, "tournament_v1.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "tournament_v1.npz"), **out)
 
 
 # --------------------------------------------------------------------------- training-side helpers (N2)
@@ -333,7 +334,7 @@ def gen_training():
             c.clr_iterations = float(it)
             seq.append(float(c.clr()))
         out["clr_" + name] = np.array(seq, np.float64)
-    np.savez_compressed(os.path.join(HERE, "training_v1.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "training_v1.npz"), **out)
     print("training: %d tuples" % len(mem))
 
 
@@ -394,7 +395,7 @@ def gen_text():
     finally:
         sys.stdout = real_stdout
         os.chdir(cwd)
-    with open(os.path.join(HERE, "text_v1.json"), "w", encoding="utf-8") as f:
+    with open(os.path.join(OUT, "text_v1.json"), "w", encoding="utf-8") as f:
         json.dump(out, f, indent=1, ensure_ascii=False, sort_keys=True)
     print("text: tournament %d chars, final evaluation table %s" % (len(out["tournament"]["text"]), out["final_evaluation"]["table"]))
 
