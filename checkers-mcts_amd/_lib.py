@@ -22,7 +22,8 @@ class Config(C.Structure):
                 ("reset_tau_each_game", C.c_int32), ("nodes_per_tree", C.c_int32),
                 ("feature_dtype", C.c_int32), ("max_sims_per_step", C.c_int32),
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
-                ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("seed", C.c_uint64)]
+                ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
+                ("reserved", C.c_int32), ("seed", C.c_uint64)]
 
 
 class NodeInfo(C.Structure):

@@ -202,6 +202,32 @@ __device__ __forceinline__ void backup_outcome_path(Wave& w, int t, uint32_t ent
     }
 }
 
+// ---- the game behind the tree.  GAME 0 = Checkers (everything in ckr_device.hip.h); GAME 1 = Tic-Tac-Toe, the
+// reference's second environment (TicTacToe.py:25-142), offered in the random-rollout mode only: the README's validation
+// of the search core (README:100-168).  Same 16-byte record: p1 / p2 = X / O cells (bit 3 x + y, the order np.where walks
+// the empty squares, TicTacToe.py:66-68), meta as for Checkers (side, mover, action = the cell just taken, history length).
+// Functions shared with the network path default to GAME 0, whose code is unchanged.
+__device__ __forceinline__ bool ttt_line(uint32_t p) {
+    return (p & 0007u) == 0007u || (p & 0070u) == 0070u || (p & 0700u) == 0700u ||      // state[x] rows
+           (p & 0111u) == 0111u || (p & 0222u) == 0222u || (p & 0444u) == 0444u ||      // columns
+           (p & 0421u) == 0421u || (p & 0124u) == 0124u;                                // diagonals
+}
+template <int GAME> __device__ __forceinline__ void rules_movegen(const ckr_board b, uint32_t m[8], uint32_t& status) {
+    if (GAME == 0) { movegen(b, m, status); return; }
+    // TicTacToe.determine_outcome (TicTacToe.py:75-104): player 1's lines first, then player 2's, then the full board
+    const uint32_t outcome = ttt_line(b.p1) ? 1u : ttt_line(b.p2) ? 2u : __popc(b.p1 | b.p2) == 9 ? 3u : 0u;
+    const uint32_t legal = outcome ? 0u : (~(b.p1 | b.p2) & 0x1FFu);                    // get_legal_next_states, :56-73
+    m[0] = legal;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m[i] = 0u;
+    status = outcome | ((uint32_t)__popc(legal) << 8);
+}
+template <int GAME> __device__ __forceinline__ uint4 rules_initial_board() {
+    if (GAME == 0) return make_uint4(0x00000FFFu, 0xFFF00000u, 0u, make_meta(0, 1, 0, 0, 0, 1));   // Checkers.py:405-423
+    return make_uint4(0u, 0u, 0u, make_meta(0, 1, 0, 0, 0, 1));                                     // TicTacToe.py:33
+}
+template <int GAME> __device__ __forceinline__ uint32_t rules_initial_status() { return GAME == 0 ? (7u << 8) : (9u << 8); }
+
 // ---- tree bookkeeping
 __device__ void write_node(const Dev& D, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
     st_board(&D.n_board[idx], b);
@@ -211,12 +237,12 @@ __device__ void write_node(const Dev& D, size_t idx, const ckr_board b, int pare
 
 // MCTS_Node(state) for a tree that has no node for the live game state
 // (start of the game, MCTS.py:350-376, or the reply-missing case :289-295).
-__device__ void fresh_root(Wave& w, int t) {
+template <int GAME = 0> __device__ void fresh_root(Wave& w, int t) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const ckr_board b = ld_board(&D.g_board[w.slot]);
     uint32_t m[8], st;
-    movegen(b, m, st);
+    rules_movegen<GAME>(b, m, st);
     if (w.lane == 0) {
         D.t_half[ti] = 0;
         write_node(D, w.tbase(t, 0), b, -1, 0.0f, st | (meta_mover(b.meta) << 4));
@@ -275,13 +301,13 @@ __device__ int compact(Wave& w, int t, int track = -1) {
 // Start of a ply's search for the side to move: (re)root its tree
 // (MCTS.new_root_node, MCTS.py:251-295 -- the cursor already followed every
 // ply played, see advance_cursor) and reset the rollout counter (:216-217).
-__device__ void start_search(Wave& w) {
+template <int GAME = 0> __device__ void start_search(Wave& w) {
     const Dev& D = w.D;
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
     if (D.t_cursor[ti] < 0) {
         if (D.t_searched[ti]) w.count(CNT_MISS);
-        fresh_root(w, t);
+        fresh_root<GAME>(w, t);
     } else if (D.C - D.t_used[ti] < D.margin) {
         compact(w, t);
     }
@@ -289,13 +315,13 @@ __device__ void start_search(Wave& w) {
     wave_mem_fence();
 }
 
-__device__ void new_game(Wave& w) {
+template <int GAME = 0> __device__ void new_game(Wave& w) {
     const Dev& D = w.D;
     if (w.lane == 0) {
         // Checkers.reset / init_board (Checkers.py:405-423); the mover into the
         // initial state is player 2 (MCTS.py:170-173)
-        D.g_board[w.slot] = make_uint4(0x00000FFFu, 0xFFF00000u, 0u, make_meta(0, 1, 0, 0, 0, 1));
-        D.g_status[w.slot] = 7u << 8;
+        D.g_board[w.slot] = rules_initial_board<GAME>();
+        D.g_status[w.slot] = rules_initial_status<GAME>();
         D.g_moves[w.slot] = 0;
         for (int t = 0; t < 2; ++t) {
             D.t_cursor[w.slot * 2 + t] = -1; D.t_used[w.slot * 2 + t] = 0;
@@ -304,7 +330,7 @@ __device__ void new_game(Wave& w) {
         if (D.reset_tau || D.g_game[w.slot] == 0) D.g_tau[w.slot] = D.tau0;
     }
     wave_mem_fence();
-    start_search(w);
+    start_search<GAME>(w);
 }
 
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
@@ -469,14 +495,30 @@ __device__ __forceinline__ void kth_action(const ckr_board b, const uint32_t m[8
     s_out = src & 31;
 }
 
+// successor k of the reference's legal_next_states list
+template <int GAME> __device__ __forceinline__ ckr_board rules_child(const ckr_board b, const uint32_t m[8], int k) {
+    if (GAME == 0) {
+        int d, s;
+        kth_action(b, m, k, d, s);
+        return make_child(b, d, s);
+    }
+    uint32_t left = m[0];                                    // empty cells in np.where order = ascending bit index
+    for (int i = 0; i < k; ++i) left &= left - 1u;
+    const uint32_t cell = (uint32_t)__ffs((int)left) - 1u, side = b.meta & 1u, hist = meta_hist(b.meta);
+    ckr_board c = b;
+    if (side == 0u) c.p1 |= 1u << cell; else c.p2 |= 1u << cell;                                  // TicTacToe.py:69-71
+    c.meta = make_meta(side ^ 1u, side, cell, 1, 0, hist < 8191u ? hist + 1u : hist);
+    return c;
+}
+
 // uniform random playout to the end of the game (MCTS.py:139-143); returns the outcome code
-__device__ uint32_t playout(Wave& w, ckr_board b) {
+template <int GAME> __device__ uint32_t playout(Wave& w, ckr_board b) {
     const Dev& D = w.D;
     const uint32_t ctr = D.g_rng[w.slot];
     if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
     for (uint32_t ply = 0;; ++ply) {
         uint32_t m[8], st;
-        movegen(b, m, st);
+        rules_movegen<GAME>(b, m, st);
         if (st_outcome(st) != 0u) return st_outcome(st);
         const uint32_t n = st_nlegal(st);
         uint32_t k = 0u;
@@ -484,14 +526,12 @@ __device__ uint32_t playout(Wave& w, ckr_board b) {
             const u32x4 r = philox(D.seed_lo, D.seed_hi, (uint32_t)(D.first_worker + w.slot), ctr, ply, 0x52u);
             k = (uint32_t)(((unsigned long long)r.x * n) >> 32);
         }
-        int d, s;
-        kth_action(b, m, (int)k, d, s);
-        b = make_child(b, d, s);
+        b = rules_child<GAME>(b, m, (int)k);
     }
 }
 
 // one simulation of the non-NN tree policy; false when the node pool is full (nothing has been changed then)
-__device__ bool rollout_sim(Wave& w, int t) {
+template <int GAME> __device__ bool rollout_sim(Wave& w, int t) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const size_t tb = w.tb(t);
@@ -515,19 +555,17 @@ __device__ bool rollout_sim(Wave& w, int t) {
             }
             const ckr_board b = ld_board(&D.n_board[tb + node]);
             uint32_t m[8], bst;
-            movegen(b, m, bst);
-            int d, s;
-            kth_action(b, m, nleg - 1 - created, d, s);
-            const ckr_board c = make_child(b, d, s);
+            rules_movegen<GAME>(b, m, bst);
+            const ckr_board c = rules_child<GAME>(b, m, nleg - 1 - created);
             uint32_t cm[8], cst;
-            movegen(c, cm, cst);
+            rules_movegen<GAME>(c, cm, cst);
             const int ci = base + created;
             if (w.lane == 0) {
                 write_node(D, tb + ci, c, node, 0.0f, cst | ((b.meta & 1u) << 4));
                 D.n_kids[tb + node] = (uint32_t)base | ((uint32_t)(created + 1) << 24);
             }
             wave_mem_fence();
-            const uint32_t outcome = playout(w, c);          // MCTS.py:89 child_node.simulation()
+            const uint32_t outcome = playout<GAME>(w, c);          // MCTS.py:89 child_node.simulation()
             backup_outcome(w, t, ci, outcome);
             w.count(CNT_EXP); w.count(CNT_NODES);
             wave_mem_fence();
@@ -572,7 +610,7 @@ __device__ size_t tuple_index(const Wave& w, int ply) {
     return (size_t)w.D.g_gid[w.slot] * (size_t)w.D.tuples_per_game + (size_t)ply;
 }
 
-__device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
+template <int GAME = 0> __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
     const Dev& D = w.D;
     const int game = D.g_game[w.slot], moves = D.g_moves[w.slot];
     int n_tuples = 0;
@@ -581,7 +619,7 @@ __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed)
         if (!adjudicated) {                                // terminal tuple, :406-409
             const ckr_board gb = ld_board(&D.g_board[w.slot]);
             uint32_t m[8], st;
-            movegen(gb, m, st);
+            rules_movegen<GAME>(gb, m, st);
             ckr_tuple* T = &D.tuples[tuple_index(w, moves)];
             if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
             if (w.lane == 0) {
@@ -624,7 +662,7 @@ __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed)
     if (gid >= 0) {
         if (w.lane == 0) D.g_gid[w.slot] = gid;
         wave_mem_fence();
-        new_game(w);
+        new_game<GAME>(w);
     } else {
         if (w.lane == 0) D.g_phase[w.slot] = PH_FINISHED;
         wave_mem_fence();
@@ -634,7 +672,7 @@ __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed)
 // ---- end of a ply: MCTS.best_child (MCTS.py:227-248), Checkers.step
 // (Checkers.py:62-75), tuple emission, TERMINATE_CNT adjudication
 // (training_pipeline.py:387-405), cursor updates for both trees.
-__device__ void finish_ply(Wave& w) {
+template <int GAME = 0> __device__ void finish_ply(Wave& w) {
     const Dev& D = w.D;
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
@@ -665,7 +703,7 @@ __device__ void finish_ply(Wave& w) {
     if (!D.tournament) {
         const ckr_board rb = ld_board(&D.n_board[tb + root]);
         uint32_t m[8], st;
-        movegen(rb, m, st);
+        rules_movegen<GAME>(rb, m, st);
         const size_t tix = tuple_index(w, moves);
         ckr_tuple* T = &D.tuples[tix];
         if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
@@ -720,8 +758,8 @@ __device__ void finish_ply(Wave& w) {
         const int k1 = __popc(cb.p1 & cb.kings), k2 = __popc(cb.p2 & cb.kings);
         outcome = p1 > p2 ? 1u : p1 < p2 ? 2u : k1 > k2 ? 1u : k1 < k2 ? 2u : 3u;
     }
-    if (outcome) end_game(w, outcome, adjudicated, 0);
-    else start_search(w);
+    if (outcome) end_game<GAME>(w, outcome, adjudicated, 0);
+    else start_search<GAME>(w);
 }
 
 __device__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
@@ -767,7 +805,7 @@ __device__ __forceinline__ void flush_counters(Wave& w) {
 // Kernels take the engine descriptor by POINTER to device memory: every field read is a
 // uniform scalar load (a by-value struct whose address is taken is copied to scratch and
 // turned ~0.5 KB/lane of private-memory traffic per launch).
-__global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
+template <int GAME> __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
@@ -781,7 +819,7 @@ __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
         D.g_phase[slot] = gid0 < D.total_games ? PH_PLAYING : PH_FINISHED;
     }
     wave_mem_fence();
-    if (gid0 < D.total_games) new_game(w);
+    if (gid0 < D.total_games) new_game<GAME>(w);
     if (D.manual && w.lane == 0) D.g_phase[slot] = PH_IDLE;
     flush_counters(w);
 }
@@ -861,7 +899,7 @@ __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, con
 
 // Random-rollout mode: up to `sims` complete simulations per slot and launch (select, expand one
 // child, playout, backup all in-kernel), including the end-of-ply work when the budget is reached.
-__global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, int sims) {
+template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, int sims) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
@@ -872,14 +910,14 @@ __global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, 
     for (int it = 0; it < sims && D.g_phase[slot] == PH_PLAYING;) {
         if (D.g_sims[slot] >= D.budget) {
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
-            finish_ply(w);
+            finish_ply<GAME>(w);
             continue;
         }
         const int t = (int)(D.g_board[slot].w & 1u);
-        bool ok = rollout_sim(w, t);
-        if (!ok) { compact(w, t); ok = rollout_sim(w, t); }               // pool full: a failed simulation has changed nothing yet
+        bool ok = rollout_sim<GAME>(w, t);
+        if (!ok) { compact(w, t); ok = rollout_sim<GAME>(w, t); }               // pool full: a failed simulation has changed nothing yet
         if (ok) { if (w.lane == 0) D.g_sims[slot] += 1; }
-        else { w.count(CNT_OVERFLOW); end_game(w, 0u, 0, 1); }
+        else { w.count(CNT_OVERFLOW); end_game<GAME>(w, 0u, 0, 1); }
         wave_mem_fence();
         ++it;
     }
@@ -1097,6 +1135,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (c->nodes_per_tree < 256 || c->nodes_per_tree >= (1 << 24)) return fail(CKR_ERR_INVALID, "nodes_per_tree must be in [256, 2^24)");
     if (c->feature_dtype < 0 || c->feature_dtype > 2) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1 or 2");
     if (c->alpha <= 0.0 && c->epsilon != 0.0) return fail(CKR_ERR_INVALID, "DIRICHLET_ALPHA must be > 0");
+    if (c->game != 0 && c->game != 1) return fail(CKR_ERR_INVALID, "game must be 0 (Checkers) or 1 (Tic-Tac-Toe)");
+    if (c->game == 1 && (c->neural_net || c->manual_play || c->tournament))
+        return fail(CKR_ERR_INVALID, "Tic-Tac-Toe (game = 1) is offered in the random-rollout self-play mode only (neural_net = 0)");
     CKR_HIP(hipSetDevice(c->device));
     ckr_engine* e = new ckr_engine();
     e->cfg = *c;
@@ -1168,7 +1209,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
         }
         e->d_dev = d_dev;
     }
-    hipLaunchKernelGGL(k_init, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
+    if (c->game == 1) hipLaunchKernelGGL(k_init<1>, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
+    else hipLaunchKernelGGL(k_init<0>, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
         ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "engine init kernel failed");
     }
@@ -1210,7 +1252,8 @@ int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) {
     if (!e || sims <= 0) return fail(CKR_ERR_INVALID, "ckr_engine_rollout: bad argument");
     if (e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_rollout needs an engine created with neural_net = 0");
     note_stream(&e->last_stream, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_rollout, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
+    if (e->cfg.game == 1) hipLaunchKernelGGL(k_rollout<1>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
+    else hipLaunchKernelGGL(k_rollout<0>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
     CKR_HIP(hipGetLastError());
     e->steps++;
     return CKR_OK;

@@ -15,6 +15,8 @@ from . import _lib
 
 FEATURE_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
+GAMES = {"checkers": 0, "tictactoe": 1}
+
 # MCTS(**kwargs) keys (MCTS.py:43-55)
 MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOSE", "TRAINING",
              "DIRICHLET_ALPHA", "DIRICHLET_EPSILON", "TEMPERATURE_TAU", "TEMPERATURE_DECAY", "TEMP_DECAY_DELAY")
@@ -23,7 +25,7 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=4, device=0,
-                       manual_play=False, dynamic_queue=False, rollout_first=False):
+                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers"):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -33,7 +35,10 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     result, is the same for any value.  A step lasts as long as its longest slot, and won / lost
     endgames produce long runs of terminal visits: measured on cfg3 in steady state the tree
     kernel takes 0.035 / 0.07 / 0.10 / 0.28 ms at caps 1 / 4 / 8 / 64 while a cap of 1 leaves
-    8.7 % of the network batch empty; 4 is the throughput optimum (profiles/README.md, round 2)."""
+    8.7 % of the network batch empty; 4 is the throughput optimum (profiles/README.md, round 2).
+
+    game: "checkers", or "tictactoe" -- the reference's second environment (GAME_ENV = TicTacToe(), play_TTT.py:47-60),
+    random-rollout self-play only (NEURAL_NET False): the README's known-answer validation of the search core."""
     k = mcts_kwargs
     for key in MCTS_KEYS:
         if key not in k:
@@ -61,7 +66,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        feature_dtype=FEATURE_DTYPES[feature_dtype], max_sims_per_step=int(max_sims_per_step),
                        record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
                        device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
-                       dynamic_queue=int(bool(dynamic_queue)), seed=int(seed))
+                       dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], seed=int(seed))
 
 
 def time_budget_of(mcts_kwargs):

@@ -225,6 +225,10 @@ typedef struct {
     int32_t  rollout_first;      /* test hook: playouts take legal_next_states[0] instead of a random successor */
     int32_t  dynamic_queue;      /* 1: a slot that finishes a game takes the next unplayed one of the engine
                                     (n_slots x games_per_slot in total) instead of a fixed per-worker count */
+    int32_t  game;               /* 0 = Checkers.  1 = Tic-Tac-Toe (TicTacToe.py:25-142), the reference's second environment, for
+                                    the README's validation of the search core (README:100-168): random-rollout self-play only
+                                    (neural_net = 0); ckr_board p1 / p2 = X / O cells (bit 3 x + y), action = the cell taken */
+    int32_t  reserved;
     uint64_t seed;               /* Philox key for Dirichlet noise / temperature sampling */
 } ckr_config;
 

@@ -283,6 +283,67 @@ int ckro_children(const ckro_board* b, ckro_board out[CKRO_MAX_CHILDREN])
 }
 
 /* ------------------------------------------------------------------------ */
+/* Tic-Tac-Toe: the reference's second environment (TicTacToe.py:25-142)      */
+/* ------------------------------------------------------------------------ */
+/* Record: p1 / p2 = X / O cells, bit 3 x + y of state[player][x][y]; meta as for Checkers (side to move, mover,
+ * action = the cell just taken, history length).  Plane-coordinate code, like the rest of this file. */
+static uint32_t ttt_status(const ckro_board* b, int* n_empty)
+{
+    int pl[2][3][3], filled = 0;
+    for (int x = 0; x < 3; ++x)
+        for (int y = 0; y < 3; ++y) {
+            pl[0][x][y] = (int)((b->p1 >> (3 * x + y)) & 1u); pl[1][x][y] = (int)((b->p2 >> (3 * x + y)) & 1u);
+            filled += pl[0][x][y] + pl[1][x][y];
+        }
+    int best[2];
+    for (int p = 0; p < 2; ++p) {                                       /* determine_outcome, TicTacToe.py:75-104 */
+        int m = 0;
+        for (int i = 0; i < 3; ++i) {
+            int col = pl[p][0][i] + pl[p][1][i] + pl[p][2][i], row = pl[p][i][0] + pl[p][i][1] + pl[p][i][2];
+            if (col > m) m = col;
+            if (row > m) m = row;
+        }
+        int d1 = pl[p][0][0] + pl[p][1][1] + pl[p][2][2], d2 = pl[p][0][2] + pl[p][1][1] + pl[p][2][0];
+        if (d1 > m) m = d1;
+        if (d2 > m) m = d2;
+        best[p] = m;
+    }
+    uint32_t outcome = best[0] == 3 ? 1u : best[1] == 3 ? 2u : filled == 9 ? 3u : 0u;
+    *n_empty = outcome ? 0 : 9 - filled;
+    return outcome | ((uint32_t)*n_empty << 8);
+}
+
+static void ttt_generate(const ckro_board* b, gen_t* G, uint32_t* status)
+{
+    memset(G, 0, sizeof(*G));
+    int n_empty;
+    *status = ttt_status(b, &n_empty);
+    if (CKRO_OUTCOME(*status)) return;                                  /* get_legal_next_states, :56-73: [] when done */
+    uint32_t side = CKRO_SIDE(b->meta), hist = (b->meta >> 19) & 0x1FFFu;
+    for (int x = 0; x < 3; ++x)                                         /* np.where(board == 0): x outer, y inner */
+        for (int y = 0; y < 3; ++y) {
+            int cell = 3 * x + y;
+            if (((b->p1 | b->p2) >> cell) & 1u) continue;
+            ckro_board c = *b;
+            if (side == 0) c.p1 |= 1u << cell; else c.p2 |= 1u << cell;
+            c.meta = (side ^ 1u) | (side << 1) | ((uint32_t)cell << 2) | (1u << 11) | ((hist < 8191u ? hist + 1u : hist) << 19);
+            G->mask[0] |= 1u << cell;
+            G->legal[G->n_legal++] = c;
+        }
+}
+
+/* successors (in the reference's list order), legal-mask words and status word of a position of either game */
+static int generate(int game, const ckro_board* b, gen_t* G, uint32_t* status, const ckro_board** succ)
+{
+    if (game == 1) { ttt_generate(b, G, status); *succ = G->legal; return G->n_legal; }
+    check_moves(b, G);
+    int cnt = G->n_jumps ? G->n_jumps : G->n_legal;
+    *status = outcome_status(b, cnt, G->n_jumps > 0);
+    *succ = G->n_jumps ? G->jumps : G->legal;
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------ */
 /* network adapter: Checkers.predict / set_prior_probs                       */
 /* ------------------------------------------------------------------------ */
 
@@ -451,13 +512,12 @@ static onode* node_new(ckro_worker* w, const ckro_board* b, onode* parent)
 {
     onode* n = (onode*)calloc(1, sizeof(onode));
     n->b = *b; n->parent = parent;
-    gen_t G; check_moves(b, &G);
-    int cnt = G.n_jumps ? G.n_jumps : G.n_legal;
+    gen_t G; const ckro_board* succ;
+    int cnt = generate(w->cfg.game, b, &G, &n->status, &succ);
     memcpy(n->mask, G.mask, sizeof(G.mask));
-    n->status = outcome_status(b, cnt, G.n_jumps > 0);
     if (CKRO_OUTCOME(n->status) == 0 && cnt > 0) {
         n->unvisited = (ckro_board*)malloc((size_t)cnt * sizeof(ckro_board));
-        memcpy(n->unvisited, G.n_jumps ? G.jumps : G.legal, (size_t)cnt * sizeof(ckro_board));
+        memcpy(n->unvisited, succ, (size_t)cnt * sizeof(ckro_board));
         n->n_unvisited = cnt; n->n_total = cnt;
     }
     n->terminal = n->n_unvisited ? 0 : 1;
@@ -557,12 +617,11 @@ static int playout(ckro_worker* w, const onode* from)
 {
     ckro_board b = from->b;
     for (;;) {
-        gen_t G; check_moves(&b, &G);
-        int cnt = G.n_jumps ? G.n_jumps : G.n_legal;
-        uint32_t st = outcome_status(&b, cnt, G.n_jumps > 0);
+        gen_t G; const ckro_board* succ; uint32_t st;
+        int cnt = generate(w->cfg.game, &b, &G, &st, &succ);
         if (CKRO_OUTCOME(st)) return (int)CKRO_OUTCOME(st);
         int k = w->cfg.rollout_first ? 0 : (int)(rng_next(&w->rng) % (uint64_t)cnt);   /* np.random.randint(0, len) */
-        b = G.n_jumps ? G.jumps[k] : G.legal[k];
+        b = succ[k];
     }
 }
 
@@ -755,7 +814,8 @@ int ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf)
             if (w->game_idx >= cfg->num_games) { w->phase = PH_FINISHED; return 0; }
             /* game_env fresh / reset, Checkers.py:405-413 */
             w->hist_len = 0;
-            ckro_initial_board(&w->state);
+            if (cfg->game == 1) { w->state.p1 = w->state.p2 = w->state.kings = 0u; w->state.meta = (1u << 1) | (1u << 19); }   /* TicTacToe.py:33 */
+            else ckro_initial_board(&w->state);
             hist_push(w, &w->state);
             w->move_count = 0; w->done = 0; w->outcome = 0;
             node_free(w->tree_top[0]); node_free(w->tree_top[1]);
@@ -847,7 +907,7 @@ int ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf)
             if (!cfg->tournament && !w->terminated_game) {    /* :406-409 */
                 ckro_tuple* t = tuple_push(w);
                 t->board = w->state; t->status = w->state_status;
-                uint32_t st; ckro_movegen(&w->state, t->mask, &st);
+                { gen_t G; const ckro_board* succ; uint32_t st; generate(cfg->game, &w->state, &G, &st, &succ); memcpy(t->mask, G.mask, sizeof(G.mask)); }
                 t->game = w->game_idx; t->ply = w->move_count; t->n_children = 0; t->chosen = -1;
                 t->q = (w->outcome == 3) ? 0.0f : -1.0f; t->q_is_int = 1;
             }

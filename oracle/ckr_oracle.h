@@ -105,6 +105,7 @@ typedef struct {
     int    rollout_first;    /* test hook: playouts take legal_next_states[0] instead of a random index */
     const double* ln_table;  /* optional ln(n) for n < ln_table_n, as the host's np.log computes it */
     int    ln_table_n;
+    int    game;             /* 0 = Checkers; 1 = Tic-Tac-Toe (TicTacToe.py), random-rollout mode only (README:100-168) */
 } ckro_config;
 
 typedef struct {

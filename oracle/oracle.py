@@ -30,7 +30,8 @@ class Config(C.Structure):
                 ("tau", C.c_double), ("tau_decay", C.c_double),
                 ("tau_decay_delay", C.c_int), ("terminate_cnt", C.c_int),
                 ("num_games", C.c_int), ("tournament", C.c_int), ("seed", C.c_uint64),
-                ("neural_net", C.c_int), ("rollout_first", C.c_int), ("ln_table", C.c_void_p), ("ln_table_n", C.c_int)]
+                ("neural_net", C.c_int), ("rollout_first", C.c_int), ("ln_table", C.c_void_p), ("ln_table_n", C.c_int),
+                ("game", C.c_int)]
 
 
 class Tuple(C.Structure):
@@ -143,7 +144,8 @@ def mask_renorm(mask, p512):
     return out
 
 
-def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, seed=0, rollout_first=False, ln_table=None):
+def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, seed=0, rollout_first=False, ln_table=None,
+                game="checkers"):
     """Config from the reference's kwargs dict (MCTS.py:43-55)."""
     k = mcts_kwargs
     return Config(uct_c=float(k["UCT_C"]), budget=int(k["BUDGET"]), training=int(bool(k["TRAINING"])),
@@ -153,7 +155,7 @@ def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, see
                   num_games=int(num_games), tournament=int(bool(tournament)), seed=int(seed),
                   neural_net=int(bool(k.get("NEURAL_NET", True))), rollout_first=int(bool(rollout_first)),
                   ln_table=(ln_table.ctypes.data if ln_table is not None else None),
-                  ln_table_n=(len(ln_table) if ln_table is not None else 0))
+                  ln_table_n=(len(ln_table) if ln_table is not None else 0), game={"checkers": 0, "tictactoe": 1}[game])
 
 
 class Worker:

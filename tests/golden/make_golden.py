@@ -12,6 +12,7 @@ Fixture families:
   selfplay_v1.npz    generate_Checkers_data._generate_data output (state, pi, q, z)
   tournament_v1.npz  tournament_Checkers._start_tournament outcomes
   rollout_v1.npz     NEURAL_NET=False (random-rollout MCTS) self-play tuples with np.random.randint pinned to 0
+  ttt_v1.npz         the README's Tic-Tac-Toe validation: MCTS vs MCTS with random rollouts (randint pinned), root statistics per ply
   text_v1.json       the text files the pipeline classes write: tournament_Checkers.start_tournament's two tables,
                      record_params' dumps, final_evaluation's score table (and the score matrix behind it)
 The fixtures are data (inputs + the reference's outputs); no reference source
@@ -261,6 +262,77 @@ def gen_rollout(cases=((60, 20, 1), (100, 10, 1))):
     np.savez_compressed(os.path.join(OUT, "rollout_v1.npz"), **out)
 
 
+# --------------------------------------------------------------------------- Tic-Tac-Toe (generic environment)
+def ttt_record(state, history_len, mover, action):
+    """16-byte record of a TicTacToe.py state (3,3,3): p1 / p2 = X / O cells, bit 3 x + y (the order np.where walks the
+    empty squares, TicTacToe.py:66-68); meta as for Checkers: side to move, mover, action = the cell just taken."""
+    p1 = sum(1 << (3 * x + y) for x in range(3) for y in range(3) if state[0, x, y])
+    p2 = sum(1 << (3 * x + y) for x in range(3) for y in range(3) if state[1, x, y])
+    side = int(state[2, 0, 0])
+    meta = side | (mover << 1) | ((action & 0x1FF) << 2) | ((1 if action >= 0 else 0) << 11) | (min(history_len, 8191) << 19)
+    return (p1, p2, 0, meta if action >= 0 else (side | (mover << 1) | (min(history_len, 8191) << 19)))
+
+
+def gen_ttt(cases=((50, 1), (200, 1), (1000, 1), (2000, 1))):
+    """The README's validation of the search core (README:100-168): MCTS against MCTS at Tic-Tac-Toe with random rollouts
+    (NEURAL_NET False), driven exactly as play_TTT.py drives it (two trees, new_root_node after every reply).
+    np.random.randint is pinned to 0 (the playout takes the first legal successor) so that the run is reproducible;
+    recorded per ply: the root's children in tree order (cell, N, W), the root's N / W, the chosen cell; per game the outcome."""
+    from TicTacToe import TicTacToe
+    out = {}
+    real_randint = np.random.randint
+    np.random.randint = lambda *a, **k: 0
+    try:
+        for ci, (budget, games) in enumerate(cases):
+            cells, ns, ws, off, root_n, root_w, chosen, side, outcomes, plies = [], [], [], [0], [], [], [], [], [], []
+            for _ in range(games):
+                env = TicTacToe()
+                initial = env.state
+                mk = mcts_kwargs(budget, training=False, env=env)
+                mk["NEURAL_NET"] = False
+                MCTS(**mk)
+                root1 = MCTS_Node(initial, parent=None)
+                best1 = best2 = root2 = None
+                while not env.done:
+                    if env.current_player(env.state) == "player1":
+                        if env.move_count != 0:
+                            root1 = MCTS.new_root_node(best1)
+                        root = root1
+                    else:
+                        root2 = MCTS_Node(env.state, parent=None, initial_state=initial) if env.move_count == 1 else MCTS.new_root_node(best2)
+                        root = root2
+                    MCTS.begin_tree_search(root)
+                    best = MCTS.best_child(root)
+                    if root is root1:
+                        best1 = best
+                    else:
+                        best2 = best
+
+                    def cell_of(child):
+                        d = (child.state[0] + child.state[1]) - (root.state[0] + root.state[1])
+                        x, y = np.argwhere(d == 1)[0]
+                        return int(3 * x + y)
+                    for c in root.children:
+                        cells.append(cell_of(c)); ns.append(c.n); ws.append(np.float32(c.w))
+                    off.append(len(cells))
+                    root_n.append(root.n); root_w.append(np.float32(root.w)); chosen.append(cell_of(best))
+                    side.append(int(root.state[2, 0, 0]))
+                    env.step(best.state)
+                outcomes.append(rt.OUTCOME_CODE[env.outcome]); plies.append(env.move_count)
+            out["c%d_cfg" % ci] = np.array([budget, games], np.int64)
+            out["c%d_cell" % ci] = np.array(cells, np.int64); out["c%d_n" % ci] = np.array(ns, np.int64)
+            out["c%d_w" % ci] = np.array(ws, np.float32); out["c%d_off" % ci] = np.array(off, np.int64)
+            out["c%d_root_n" % ci] = np.array(root_n, np.int64); out["c%d_root_w" % ci] = np.array(root_w, np.float32)
+            out["c%d_chosen" % ci] = np.array(chosen, np.int64); out["c%d_side" % ci] = np.array(side, np.int64)
+            out["c%d_outcome" % ci] = np.array(outcomes, np.int64); out["c%d_plies" % ci] = np.array(plies, np.int64)
+            print("ttt case", ci, "budget", budget, "outcomes", outcomes, "plies", plies)
+    finally:
+        np.random.randint = real_randint
+    out["ln_table"] = np.array([0.0] + [float(np.log(n)) for n in range(1, 4096)], np.float64)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "ttt_v1.npz"), **out)
+
+
 # --------------------------------------------------------------------------- tournament
 def gen_tournament(cases=((30, 4, 1, 2), (24, 2, 3, 5), (40, 2, 7, 8))):
     out = {}
@@ -401,7 +473,7 @@ def gen_text():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout", "training", "text"]
+    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout", "training", "text", "ttt"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:

@@ -149,3 +149,27 @@ def test_rollout_mode_tuples_bit_exact(oracle, golden_dir):
             q = float(int(t["q"])) if t["q_is_int"] else t["q64"]
             assert q == g["c%d_q" % ci][i] and t["q_is_int"] == bool(g["c%d_q_is_int" % ci][i])
             assert t["z"] == g["c%d_z" % ci][i]
+
+
+def test_tictactoe_root_statistics_bit_exact(oracle, golden_dir):
+    """The reference's second environment (TicTacToe.py; README:100-168): MCTS against MCTS with random rollouts, playout index
+    pinned to 0 on both sides; root children (cell, N, W bits), root N / W, chosen cell and outcome of every ply."""
+    g = _load(golden_dir, "ttt_v1.npz")
+    ln = np.ascontiguousarray(g["ln_table"])
+    for ci in range(int(g["n_cases"])):
+        budget, games = (int(v) for v in g["c%d_cfg" % ci])
+        kw = dict(_mk(budget), NEURAL_NET=False, TRAINING=False)
+        w = oracle.Worker(oracle.make_config(kw, terminate_cnt=16, num_games=games, rollout_first=True, ln_table=ln, game="tictactoe"))
+        w.run(lambda x, net: None)
+        tu = [t for t in w.tuples() if t["chosen"] >= 0]
+        off = g["c%d_off" % ci]
+        assert len(tu) == len(off) - 1
+        for i, t in enumerate(tu):
+            sl = slice(off[i], off[i + 1])
+            assert (t["action"] == g["c%d_cell" % ci][sl]).all() and (t["visits"] == g["c%d_n" % ci][sl]).all()
+            assert (t["wsum"].view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert t["root_n"] == g["c%d_root_n" % ci][i] and t["root_w"] == g["c%d_root_w" % ci][i]
+            assert t["chosen"] == g["c%d_chosen" % ci][i] and (int(t["board"][3]) & 1) == g["c%d_side" % ci][i]
+        res = w.results()
+        assert [r["outcome"] for r in res] == list(g["c%d_outcome" % ci])
+        assert [r["move_count"] for r in res] == list(g["c%d_plies" % ci])
