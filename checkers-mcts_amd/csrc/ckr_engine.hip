@@ -1120,6 +1120,7 @@ template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool
 }
 
 static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
+static_assert(sizeof(ckr_config) == 128, "ckr_config layout is mirrored by _lib.Config (ctypes)");
 
 extern "C" {
 
