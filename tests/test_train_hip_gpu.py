@@ -148,7 +148,7 @@ def float64_loss(net, x, pi, tv, decisions, flip_tol=1e-5):
     return loss, ce, mse
 
 
-@pytest.mark.parametrize("B", [32, 128])
+@pytest.mark.parametrize("B", [32, 128, 320])         # 320: 256-row reduction blocks, split-K 2, uneven weight-gradient slices
 def test_one_step_gradients_match_autograd(B):
     import copy
     from checkers_mcts_amd.train_hip import HipTrainStep
