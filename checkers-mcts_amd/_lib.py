@@ -53,7 +53,7 @@ EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_bat
            "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_engine_create", "ckr_engine_compact_rows",
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_end_ply", "ckr_engine_stats", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
-           "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_set_ln_table",
+           "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_rollout_end_ply", "ckr_engine_set_ln_table",
            "ckr_probe_dirichlet", "ckr_probe_temperature", "ckr_probe_tau_schedule",
            "ckr_gemm_nt", "ckr_conv_gemm", "ckr_conv_wgrad", "ckr_conv_wflip", "ckr_conv_bias_relu_bn", "ckr_conv_bn_relu_backward", "ckr_conv_bias_grad",
            "ckr_gemm_small", "ckr_gemm_tall", "ckr_im2col", "ckr_bn_forward", "ckr_bn_backward",
@@ -99,6 +99,7 @@ def load():
         L.ckr_engine_leaves.argtypes = [vp, vp]
         L.ckr_engine_command.argtypes = [vp, vp, vp, vp]
         L.ckr_engine_rollout.argtypes = [vp, C.c_int32, vp]
+        L.ckr_engine_rollout_end_ply.argtypes = [vp, C.c_int32, vp]
         L.ckr_engine_set_ln_table.argtypes = [vp, vp, C.c_int32]
         L.ckr_engine_game.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
         L.ckr_engine_root.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(NodeInfo), C.POINTER(NodeInfo), C.POINTER(C.c_int32)]

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, con
 
 // Random-rollout mode: up to `sims` complete simulations per slot and launch (select, expand one
 // child, playout, backup all in-kernel), including the end-of-ply work when the budget is reached.
-template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, int sims) {
+template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const Dev* __restrict__ Dp, int sims, int end_ply) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
@@ -907,8 +907,12 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
     Wave w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (slot == 0) w.count(CNT_STEPS);
+    // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198): the wall-clock budget of the running searches is used up -- a slot
+    // whose root has visited children ends its ply first, then goes on with the next search
     for (int it = 0; it < sims && D.g_phase[slot] == PH_PLAYING;) {
-        if (D.g_sims[slot] >= D.budget) {
+        const bool out_of_time = end_ply != 0 && D.g_sims[slot] >= 2;
+        end_ply = out_of_time ? 0 : end_ply;
+        if (D.g_sims[slot] >= D.budget || out_of_time) {
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
             finish_ply<GAME>(w);
             continue;
@@ -1249,16 +1253,19 @@ int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t n) {
     return CKR_OK;
 }
 
-int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) {
+static int engine_rollout(ckr_engine* e, int32_t sims, int end_ply, void* stream) {
     if (!e || sims <= 0) return fail(CKR_ERR_INVALID, "ckr_engine_rollout: bad argument");
     if (e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_rollout needs an engine created with neural_net = 0");
     note_stream(&e->last_stream, (hipStream_t)stream);
-    if (e->cfg.game == 1) hipLaunchKernelGGL(k_rollout<1>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
-    else hipLaunchKernelGGL(k_rollout<0>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims);
+    if (e->cfg.game == 1) hipLaunchKernelGGL(k_rollout<1>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims, end_ply);
+    else hipLaunchKernelGGL(k_rollout<0>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, (int)sims, end_ply);
     CKR_HIP(hipGetLastError());
     e->steps++;
     return CKR_OK;
 }
+
+int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) { return engine_rollout(e, sims, 0, stream); }
+int ckr_engine_rollout_end_ply(ckr_engine* e, int32_t sims, void* stream) { return engine_rollout(e, sims, 1, stream); }
 
 static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream, int end_ply);
 

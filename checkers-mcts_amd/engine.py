@@ -48,8 +48,6 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     if k["CONSTRAINT"] == "time":
         # BUDGET is seconds of wall-clock search per ply (MCTS.py:196-198): no rollout limit in the engine; the runner
         # owns the clock and ends the plies with Engine.step(..., end_ply=True)  (time_budget_of(kwargs))
-        if not manual_play and not k["NEURAL_NET"]:
-            raise ValueError("CONSTRAINT='time' with NEURAL_NET=False is only available through the MCTS facade")
         budget = 2 ** 31 - 1
         if nodes_per_tree is None:
             nodes_per_tree = 1 << 18
@@ -135,10 +133,12 @@ class Engine:
                                                    self.row_range.data_ptr(), stream))
         return int(self.row_range[1].item())
 
-    def rollout(self, sims):
-        """Random-rollout mode: up to `sims` complete simulations per slot in one launch."""
+    def rollout(self, sims, end_ply=False):
+        """Random-rollout mode: up to `sims` complete simulations per slot in one launch.
+        end_ply (CONSTRAINT == 'time'): the wall-clock budget is used up -- every searching slot ends its ply first."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self._L.ckr_engine_rollout(self._h, int(sims), stream))
+        fn = self._L.ckr_engine_rollout_end_ply if end_ply else self._L.ckr_engine_rollout
+        _lib.check(fn(self._h, int(sims), stream))
 
     def set_ln_table(self, ln=None, n=4096):
         """ln(n) exactly as this host's np.log computes it for python ints (the reference's UCT term)."""
@@ -147,12 +147,27 @@ class Engine:
         ln = np.ascontiguousarray(ln, np.float64)
         _lib.check(self._L.ckr_engine_set_ln_table(self._h, ln.ctypes.data, len(ln)))
 
-    def run_rollouts(self, sims_per_launch=None, max_launches=1 << 30):
-        """Drive a NEURAL_NET=False engine to completion."""
-        k = sims_per_launch or self.cfg.budget
-        for i in range(max_launches):
-            self.rollout(k)
-            if i % 8 == 7 and self.stats()["active_slots"] == 0:
+    def run_rollouts(self, sims_per_launch=None, max_launches=1 << 30, time_budget=None):
+        """Drive a NEURAL_NET=False engine to completion.  time_budget (seconds; CONSTRAINT == 'time', MCTS.py:196-198):
+        every ply is searched for that long (all games move once per window; the host owns the clock)."""
+        if time_budget is None:
+            k = sims_per_launch or self.cfg.budget
+            for i in range(max_launches):
+                self.rollout(k)
+                if i % 8 == 7 and self.stats()["active_slots"] == 0:
+                    break
+            return self.stats()
+        import time
+        k = sims_per_launch or 64
+        for _ in range(max_launches):
+            t0 = time.perf_counter()
+            while True:
+                self.rollout(k)
+                torch.cuda.current_stream(self.device).synchronize()
+                if time.perf_counter() - t0 >= time_budget:
+                    break
+            self.rollout(k, end_ply=True)
+            if self.stats()["active_slots"] == 0:
                 break
         return self.stats()
 

@@ -398,7 +398,7 @@ class generate_Checkers_data:
         if not self.mcts_kwargs["NEURAL_NET"]:     # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
             eng = make_engine(0, count)
             eng.set_ln_table()
-            eng.run_rollouts()
+            eng.run_rollouts(time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             engines = [eng]
         elif (self.split_streams and count >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue
               and ckengine.time_budget_of(self.mcts_kwargs) is None):

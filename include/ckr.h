@@ -297,6 +297,10 @@ int ckr_engine_step_end_ply(ckr_engine* e, const float* d_p, const float* d_v, v
  * (MCTS.py:112-116), one-child expansion (:78-81), uniform random playout (:132-143), backup -- plus
  * the end-of-ply work, all inside one kernel launch.  No network is involved. */
 int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream);
+/* CONSTRAINT == 'time' (MCTS.py:189-201) in the random-rollout mode: create the engine with budget = INT32_MAX, call
+ * ckr_engine_rollout until BUDGET seconds have passed, then this: every searching slot ends its ply (MCTS.best_child on the
+ * statistics gathered so far) and continues with up to `sims` simulations of the next search. */
+int ckr_engine_rollout_end_ply(ckr_engine* e, int32_t sims, void* stream);
 /* ln(n) for n < count exactly as the caller's np.log computes it (the UCT term uses np.log); without
  * this call the C library's log() is used.  HOST array. */
 int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t count);

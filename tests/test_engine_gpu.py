@@ -391,3 +391,22 @@ def test_time_constrained_search(E):
     visits = (live["pi"] & 0x7FFFFF).astype(np.int64)
     used = np.arange(live["pi"].shape[1])[None, :] < live["n_children"][:, None]
     assert ((visits * used).sum(1) == live["root_n"] - 1).all()
+
+
+def test_time_constrained_rollout_search(E):
+    """CONSTRAINT == 'time' (MCTS.py:189-201) in the random-rollout mode: every ply is searched for BUDGET seconds of wall clock,
+    then all games move; the number of rollouts per search is whatever fitted, the accounting stays exact."""
+    kw = dict(mk(0.02), CONSTRAINT="time", NEURAL_NET=False)
+    for game, terminate in (("checkers", 12), ("tictactoe", 16)):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=32, games_per_slot=1, terminate_cnt=terminate, seed=3, game=game))
+        eng.set_ln_table()
+        st = eng.run_rollouts(time_budget=E.time_budget_of(kw))
+        assert st["games"] == 32 and st["pool_overflows"] == 0 and st["active_slots"] == 0
+        t = sorted_tuples(eng)
+        searched = t[t["chosen"] >= 0]
+        assert len(searched) == st["plies"] and (searched["root_n"] >= 2).all()
+        assert len(set(searched["root_n"].tolist())) > 1              # not a fixed rollout count
+        for e in searched:
+            a, nv = E.tuple_actions_visits(e)
+            assert int(nv.sum()) in (int(e["root_n"]), int(e["root_n"]) - 1) and e["chosen"] in a
+        eng.close()

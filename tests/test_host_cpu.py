@@ -74,8 +74,8 @@ def test_config_from_kwargs_maps_reference_keys():
     c = E.config_from_kwargs(dict(kw, CONSTRAINT="time", BUDGET=0.25), n_slots=1, games_per_slot=1)     # MCTS.py:196-198
     assert c.budget == 2 ** 31 - 1 and E.time_budget_of(dict(kw, CONSTRAINT="time", BUDGET=0.25)) == 0.25
     assert E.time_budget_of(kw) is None
-    with pytest.raises(ValueError):                          # the batched random-rollout kernel has no clock
-        E.config_from_kwargs(dict(kw, CONSTRAINT="time", NEURAL_NET=False), n_slots=1, games_per_slot=1)
+    c = E.config_from_kwargs(dict(kw, CONSTRAINT="time", BUDGET=0.1, NEURAL_NET=False), n_slots=1, games_per_slot=1)   # the host owns the clock
+    assert c.budget == 2 ** 31 - 1 and c.neural_net == 0
     c = E.config_from_kwargs(dict(kw, NEURAL_NET=False), n_slots=1, games_per_slot=1)
     assert c.neural_net == 0 and c.rollout_first == 0
 
