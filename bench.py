@@ -568,7 +568,7 @@ def main():
                      "terminal_visit_fraction": tot["terminal_visits"] / max(1.0, tot["expansions"] + tot["terminal_visits"]),
                      "pool_overflows": int(tot["pool_overflows"]),
                      "gather": {"collective": "all_gather(sizes) + gather(padded rows) to rank 0 (%s)"
-                                              % ("RCCL" if world > 1 else "single rank: no collective issued"),
+                                              % (("RCCL" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend() + ", rows staged through host memory") if world > 1 else "single rank: no collective issued"),
                                 "tuples": n_rows, "bytes": n_rows * 288, "seconds": t_gather},
                      "active_slots_trace": trace[:: max(1, len(trace) // 40)],
                      "semantics": "fixed number of games per worker slot, played back to back (training_pipeline.py:349); "
