@@ -249,6 +249,11 @@ class HipTrainStep:
         L, P, B = self._L, self.P, self.B
         if tuple(x.shape) != (B, 8, 8, 14) or not x.is_contiguous() or x.dtype != torch.float32:
             raise ValueError("x must be a contiguous float32 [%d, 8, 8, 14] tensor" % B)
+        for name, t, shape in (("pi", pi, (B, 512)), ("tv", tv, (B,))):
+            if tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32 or t.device != x.device:
+                raise ValueError("%s must be a contiguous float32 %s tensor on %s" % (name, list(shape), x.device))
+        if acc is not None and (acc.dtype != torch.float64 or acc.numel() < 3):
+            raise ValueError("acc must be a float64 tensor of 3 running sums")
         main = torch.cuda.current_stream(self.dev)
         s = main.cuda_stream
         # ---------------- forward: first layer on its im2col matrix, layers 1..7 as implicit GEMMs
