@@ -13,6 +13,8 @@
 //       data gradient  dX[p][c]  = sum_{tap,o} dZ[p - off(tap)][o] Wt[c][tap,o]      k_gemm_nt<-1>, Wt from k_wflip
 //       weight grad.   dW[o][tap,c] = sum_p dZ[p][o] X[p + off(tap)][c]              k_wgrad_tn, K = positions
 //     no im2col matrix exists for the 128 -> 128 layers; the 14-plane first layer (K = 126) uses a small one;
+//     by default the three run on the bf16 matrix pipe with every float32 operand split into three bfloat16 pieces
+//     (k_gemm_nt6 / k_wgrad_tn6: six products per multiply-add, float32-grade, 2.65 x the float32 matrix rate);
 //   * the split-K reductions carry the next elementwise step (bias + ReLU + BatchNorm partial sums forward,
 //     the BatchNorm-backward partial sums on the way back), and the BatchNorm apply kernels finish the
 //     per-channel sums in their prologue, so a conv block is 3 launches forward and 6 backward;
@@ -122,6 +124,125 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef CKR_NT_STAGE_A
 }
 
+// ------------------------------------------------------------------------------------------------ the same GEMMs on the bf16 pipe
+// float32 operands split into THREE bfloat16 pieces, x = b1 + b2 + b3 (each rounded to nearest even, residuals exact in
+// float32: 3 x 8 significant bits cover the 24 of a float32), and the six products that matter
+//     b1 b1' + b1 b2' + b2 b1' + b2 b2' + b1 b3' + b3 b1'        (dropped: b2 b3', b3 b2', b3 b3' <= 2^-26 of the product)
+// accumulated in the float32 accumulators of v_mfma_f32_32x32x16_bf16 (bf16 products are exact in float32): float32-grade
+// results with float32's exponent range (no scaling) at 1/6 of the 2.5 PFLOP/s bf16 rate = 2.65 x the float32 matrix rate.
+// Pieces are made when a chunk is staged into LDS (v_cvt_pk_bf16_f32); LDS row = [b1 x 32 | b2 x 32 | b3 x 32] + 16 B pad.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+struct Split4 { uint2 p1, p2, p3; };                               // 4 floats -> 3 x (4 bf16)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 t = {a, b};
+    const bf16x2 r = __builtin_convertvector(t, bf16x2);
+    return *reinterpret_cast<const unsigned*>(&r);
+}
+__device__ __forceinline__ Split4 split3(float4 v) {
+    Split4 o;
+    o.p1 = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    v.x -= __uint_as_float(o.p1.x << 16); v.y -= __uint_as_float(o.p1.x & 0xffff0000u);
+    v.z -= __uint_as_float(o.p1.y << 16); v.w -= __uint_as_float(o.p1.y & 0xffff0000u);
+    o.p2 = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    v.x -= __uint_as_float(o.p2.x << 16); v.y -= __uint_as_float(o.p2.x & 0xffff0000u);
+    v.z -= __uint_as_float(o.p2.y << 16); v.w -= __uint_as_float(o.p2.y & 0xffff0000u);
+    o.p3 = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    return o;
+}
+#define CKR_MFMA6(acc, A, B)                                                                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], acc, 0, 0, 0);                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], acc, 0, 0, 0);                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], acc, 0, 0, 0);                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], acc, 0, 0, 0);                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], acc, 0, 0, 0);                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], acc, 0, 0, 0);
+
+constexpr int P6 = 26;                                             // LDS row pitch in 8-byte units: 3 x 64 B + 16 B
+template <int GATHER>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nt6(const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb,
+                                                float* __restrict__ C, int ldc, int M, int K) {
+    __shared__ __attribute__((aligned(16))) uint2 As[BM * P6];
+    __shared__ __attribute__((aligned(16))) uint2 Bs[BN * P6];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kper = K / gridDim.z, kbeg = blockIdx.z * kper;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;                // named scalars: see k_gemm_nt
+    const int frow = tid >> 3, fc4 = tid & 7;
+    unsigned on_board = 0xf;
+    auto load_a = [&](int k0, int i) -> float4 {
+        const int row = frow + 32 * i;
+        if (GATHER == 0) return *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 4 * fc4);
+        const int tap = k0 >> 7, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int p = m0 + row, y = ((p >> 3) & 7) + GATHER * dy, x = (p & 7) + GATHER * dx;
+        const bool in = (unsigned)y < 8u && (unsigned)x < 8u;
+        on_board = (on_board & ~(1u << i)) | ((unsigned)in << i);
+        return *reinterpret_cast<const float4*>(A + (size_t)(p + (in ? GATHER * (8 * dy + dx) : 0)) * 128 + (k0 & 127) + 4 * fc4);
+    };
+    auto load_b = [&](int k0, int i) -> float4 {
+        return *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + frow + 32 * i) * ldb + k0 + 4 * fc4);
+    };
+#define CKR_NT6_FETCH(k0)                                                                             \
+    ra0 = load_a(k0, 0); ra1 = load_a(k0, 1); ra2 = load_a(k0, 2); ra3 = load_a(k0, 3);               \
+    rb0 = load_b(k0, 0); rb1 = load_b(k0, 1); rb2 = load_b(k0, 2); rb3 = load_b(k0, 3);
+#define CKR_NT6_STAGE(buf, r, i, keep)                                                                \
+    { const bool in = keep;                                                                           \
+      const Split4 sp = split3(make_float4(in ? r.x : 0.f, in ? r.y : 0.f, in ? r.z : 0.f, in ? r.w : 0.f)); \
+      uint2* dst = buf + (frow + 32 * i) * P6 + fc4;                                                  \
+      dst[0] = sp.p1; dst[8] = sp.p2; dst[16] = sp.p3; }
+    CKR_NT6_FETCH(kbeg)
+    for (int k0 = kbeg; k0 < kbeg + kper; k0 += BK) {
+        __syncthreads();
+        CKR_NT6_STAGE(As, ra0, 0, GATHER == 0 || (on_board & 1u)) CKR_NT6_STAGE(As, ra1, 1, GATHER == 0 || (on_board & 2u))
+        CKR_NT6_STAGE(As, ra2, 2, GATHER == 0 || (on_board & 4u)) CKR_NT6_STAGE(As, ra3, 3, GATHER == 0 || (on_board & 8u))
+        CKR_NT6_STAGE(Bs, rb0, 0, true) CKR_NT6_STAGE(Bs, rb1, 1, true) CKR_NT6_STAGE(Bs, rb2, 2, true) CKR_NT6_STAGE(Bs, rb3, 3, true)
+        __syncthreads();
+        {
+            const int kn = min(k0 + BK, kbeg + kper - BK);
+            CKR_NT6_FETCH(kn)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                           // lanes 0-31 own k = 16 kk + 0..7, lanes 32-63 16 kk + 8..15
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    fa[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half);
+                    fb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { CKR_MFMA6(acc[a][b], fa[a], fb[b]) }
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.z * (size_t)M * ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
+                    Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
+                }
+#undef CKR_NT6_FETCH
+#undef CKR_NT6_STAGE
+}
+
 // Weight gradient of a 3x3 convolution with 128 kernels: C[z][o][n0 + c] = sum_{p in slice z} dZ[p][o] * X[p + off(tap)][c]
 // (0 outside the board); gridDim = (taps, 1, slices), n0 = 128 * blockIdx.x, tap = tap0 + blockIdx.x (tap0 = 4 and one
 // block column: a plain dZ^T . X).  Both operands arrive as rows of 128 floats (one position); a thread loads the same
@@ -215,6 +336,99 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 #undef CKR_TN_FETCH
+
+// The weight gradient on the bf16 pipe (see k_gemm_nt6): K = positions.  A thread holds 4 columns x 4 consecutive positions;
+// per column and piece the four positions are one 8-byte half of a 16-byte slot of 8 positions (threads rg = 2 j, 2 j + 1
+// fill the two halves): LDS tile [3 pieces][4 position groups of 8][128 columns] slots, column index swizzled as in
+// k_wgrad_tn.  The MFMA operand of lane (m, half) for k step kk is the slot of position group 2 kk + half.
+__device__ __forceinline__ int tn6_slot(int piece, int kg8, int m) { return (piece * 4 + kg8) * 128 + (m ^ ((m >> 4) & 3)); }
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_tn6(const float* __restrict__ dZ, const float* __restrict__ X, int P, int tap0,
+                                                float* __restrict__ C, int ldc) {
+    __shared__ __attribute__((aligned(16))) uint2 As[2 * 3 * 4 * 128];
+    __shared__ __attribute__((aligned(16))) uint2 Bs[2 * 3 * 4 * 128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int tap = tap0 + blockIdx.x, dy = tap / 3 - 1, dx = tap % 3 - 1, off = 8 * dy + dx, n0 = 128 * blockIdx.x;
+    const int nchunk = P / BK;
+    const int pbeg = (int)((long long)blockIdx.z * nchunk / gridDim.z) * BK, pend = (int)((long long)(blockIdx.z + 1) * nchunk / gridDim.z) * BK;
+    const int c4 = tid & 31, rg = tid >> 5;                       // columns 4 c4 .. 4 c4 + 3 of positions 4 rg .. 4 rg + 3
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    unsigned on_board = 0;
+    auto load_x = [&](int p0, int i) -> float4 {
+        const int p = p0 + 4 * rg + i, y = ((p >> 3) & 7) + dy, x = (p & 7) + dx;
+        const bool in = (unsigned)y < 8u && (unsigned)x < 8u;
+        on_board = (on_board & ~(1u << i)) | ((unsigned)in << i);
+        return *reinterpret_cast<const float4*>(X + (size_t)(p + (in ? off : 0)) * 128 + 4 * c4);
+    };
+#define CKR_TN6_FETCH(p0)                                                                              \
+    ra0 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 0) * 128 + 4 * c4);             \
+    ra1 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 1) * 128 + 4 * c4);             \
+    ra2 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 2) * 128 + 4 * c4);             \
+    ra3 = *reinterpret_cast<const float4*>(dZ + (size_t)(p0 + 4 * rg + 3) * 128 + 4 * c4);             \
+    rb0 = load_x(p0, 0); rb1 = load_x(p0, 1); rb2 = load_x(p0, 2); rb3 = load_x(p0, 3);
+    // column j of the thread's 4 x 4 block: positions 4 rg .. 4 rg + 3 -> one half slot per piece
+#define CKR_TN6_STAGE(buf, j, v0, v1, v2, v3)                                                          \
+    { const Split4 sp = split3(make_float4(v0, v1, v2, v3));                                           \
+      const int hs = rg & 1;                                                                           \
+      buf[2 * tn6_slot(0, rg >> 1, 4 * c4 + j) + hs] = sp.p1;                                          \
+      buf[2 * tn6_slot(1, rg >> 1, 4 * c4 + j) + hs] = sp.p2;                                          \
+      buf[2 * tn6_slot(2, rg >> 1, 4 * c4 + j) + hs] = sp.p3; }
+    CKR_TN6_FETCH(pbeg)
+    for (int p0 = pbeg; p0 < pend; p0 += BK) {
+        __syncthreads();
+        CKR_TN6_STAGE(As, 0, ra0.x, ra1.x, ra2.x, ra3.x) CKR_TN6_STAGE(As, 1, ra0.y, ra1.y, ra2.y, ra3.y)
+        CKR_TN6_STAGE(As, 2, ra0.z, ra1.z, ra2.z, ra3.z) CKR_TN6_STAGE(As, 3, ra0.w, ra1.w, ra2.w, ra3.w)
+        {
+            const bool i0 = on_board & 1u, i1 = on_board & 2u, i2 = on_board & 4u, i3 = on_board & 8u;
+            CKR_TN6_STAGE(Bs, 0, i0 ? rb0.x : 0.f, i1 ? rb1.x : 0.f, i2 ? rb2.x : 0.f, i3 ? rb3.x : 0.f)
+            CKR_TN6_STAGE(Bs, 1, i0 ? rb0.y : 0.f, i1 ? rb1.y : 0.f, i2 ? rb2.y : 0.f, i3 ? rb3.y : 0.f)
+            CKR_TN6_STAGE(Bs, 2, i0 ? rb0.z : 0.f, i1 ? rb1.z : 0.f, i2 ? rb2.z : 0.f, i3 ? rb3.z : 0.f)
+            CKR_TN6_STAGE(Bs, 3, i0 ? rb0.w : 0.f, i1 ? rb1.w : 0.f, i2 ? rb2.w : 0.f, i3 ? rb3.w : 0.f)
+        }
+        __syncthreads();
+        {
+            const int pn = min(p0 + BK, pend - BK);
+            CKR_TN6_FETCH(pn)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                           // lanes 0-31: positions 16 kk + 0..7, lanes 32-63: 16 kk + 8..15
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    fa[t][q] = *reinterpret_cast<const bf16x8*>(As + 2 * tn6_slot(q, 2 * kk + half, 64 * wm + 32 * t + l31));
+                    fb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + 2 * tn6_slot(q, 2 * kk + half, 64 * wn + 32 * t + l31));
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { CKR_MFMA6(acc[a][b], fa[a], fb[b]) }
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.z * (size_t)128 * ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
+                    Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
+                }
+#undef CKR_TN6_FETCH
+#undef CKR_TN6_STAGE
+}
 // Wt[l][c][tap * 128 + o] = W[l][o][tap * 128 + c] for the seven 128 -> 128 layers (operand of the data-gradient GEMM);
 // W[l] at w + offs[l] floats.  gridDim = (9 * 128 * 128 / 256, layers).
 struct LayerOffsets { long long off[8]; };
@@ -743,12 +957,19 @@ int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float
 // direction +1: workspace[z][p][o] = sum_{k in slice z} act[p + off(tap)][c] * w[o][tap * 128 + c]      (forward; w = the kernel)
 // direction -1: workspace[z][p][c] = sum_{k in slice z} act[p - off(tap)][o] * w[c][tap * 128 + o]      (data gradient; w = ckr_conv_wflip's)
 // The caller's next kernel (ckr_conv_bias_relu_bn / ckr_conv_bn_relu_backward) adds the `slices` partial products.
-int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction, int32_t slices, float* workspace, void* stream) {
+int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction, int32_t slices, int32_t pipe, float* workspace, void* stream) {
     if (!act || !w || !workspace || P <= 0 || P % 128 || (direction != 1 && direction != -1) || slices < 1 || 1152 % (BK * slices))
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_gemm: P must be a multiple of 128, direction +1 or -1, slices a divisor of 36");
     if (int rc = ckr::require_device()) return rc;
-    if (direction > 0) hipLaunchKernelGGL(k_gemm_nt<1>, dim3(1, P / BM, slices), dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
-    else hipLaunchKernelGGL(k_gemm_nt<-1>, dim3(1, P / BM, slices), dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+    if (pipe != 0 && pipe != 1) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_gemm: pipe must be 0 (float32 MFMA) or 1 (split bfloat16 x 6)");
+    const dim3 grid(1, P / BM, slices);
+    if (pipe == 0) {
+        if (direction > 0) hipLaunchKernelGGL(k_gemm_nt<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+        else hipLaunchKernelGGL(k_gemm_nt<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+    } else {
+        if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+        else hipLaunchKernelGGL(k_gemm_nt6<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+    }
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
@@ -756,12 +977,14 @@ int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction
 // Weight gradient: dw[o][tap * 128 + c] (taps = 9, ld = 1152) = sum_p dz[p][o] * x[p + off(tap)][c], or with taps = 1 the plain
 // product dw[o][c] = sum_p dz[p][o] * x[p][c] (ld = 128; the first layer on its im2col matrix).  Split over `slices` ranges of
 // positions (P % (32 * slices) == 0), reduced deterministically through workspace[slices][128][ld].
-int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, float* workspace, float* dw, void* stream) {
+int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, int32_t pipe, float* workspace, float* dw, void* stream) {
     if (!dz || !x || !dw || !workspace || P <= 0 || (taps != 9 && taps != 1) || slices < 1 || P % BK || slices > P / BK)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_wgrad: taps 9 or 1, P a multiple of 32, 1 <= slices <= P / 32");
     if (int rc = ckr::require_device()) return rc;
     const int ld = 128 * taps;
-    hipLaunchKernelGGL(k_wgrad_tn, dim3(taps, 1, slices), dim3(GT), 0, (hipStream_t)stream, dz, x, (int)P, taps == 9 ? 0 : 4, workspace, ld);
+    if (pipe != 0 && pipe != 1) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_wgrad: pipe must be 0 (float32 MFMA) or 1 (split bfloat16 x 6)");
+    if (pipe == 0) hipLaunchKernelGGL(k_wgrad_tn, dim3(taps, 1, slices), dim3(GT), 0, (hipStream_t)stream, dz, x, (int)P, taps == 9 ? 0 : 4, workspace, ld);
+    else hipLaunchKernelGGL(k_wgrad_tn6, dim3(taps, 1, slices), dim3(GT), 0, (hipStream_t)stream, dz, x, (int)P, taps == 9 ? 0 : 4, workspace, ld);
     const long long n4 = 128LL * ld / 4;
     hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float4*)workspace, (int)slices, n4, (const float4*)nullptr, (float4*)dw);
     CKR_HIP(hipGetLastError());

@@ -23,7 +23,7 @@ KPAD0 = 128                      # 9 taps x 14 planes = 126 columns of the first
 
 class HipTrainStep:
     def __init__(self, net, batch_size, conv_reg, dense_reg, policy_loss_weight=1.0, value_loss_weight=1.0,
-                 betas=(0.9, 0.999), eps=1e-7, bn_eps=1e-3, bn_momentum=0.01):
+                 betas=(0.9, 0.999), eps=1e-7, bn_eps=1e-3, bn_momentum=0.01, pipe=None):
         if net.num_kernels != 128:
             raise ValueError("the hand-written training step is built for NUM_KERNELS = 128")
         if batch_size % 2:
@@ -31,8 +31,8 @@ class HipTrainStep:
         self._L = L = _lib.load()
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         L.ckr_gemm_nt.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
-        L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
-        L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
         L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
         L.ckr_conv_bias_relu_bn.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]
         L.ckr_conv_bn_relu_backward.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
@@ -48,6 +48,9 @@ class HipTrainStep:
         L.ckr_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp]
         L.ckr_sum_rows.argtypes = [vp, i32, i32, vp, vp]
         self.net = net
+        # matrix pipe of the conv GEMMs: "f32" = float32 MFMA, "bf16x6" = float32 operands as three bfloat16 pieces, six products
+        # per multiply-add on the bf16 MFMA (float32-grade results, 2.65 x the rate); see include/ckr.h
+        self.pipe = {"f32": 0, "bf16x6": 1}[pipe or os.environ.get("CKR_TRAIN_PIPE", "bf16x6")]
         P = 64 * int(batch_size)
         # split-K until ~256 workgroups exist (one per CU): forward / data gradient over the 36 chunks of K = 1152,
         # the weight gradient (9 tap tiles) over the positions, never fewer than 4 chunks of 32 per slice on average
@@ -268,7 +271,7 @@ class HipTrainStep:
                     self._value_head(tv)
                     value_done = torch.cuda.Event()
                     value_done.record(self.side)
-            _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.ws.data_ptr(), s))
+            _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.pipe, self.ws.data_ptr(), s))
             self._conv_fwd_tail(l, self.ws, self.slices)
         self._policy_head(pi)
         # ---------------- backward: conv blocks 7 (policy conv) .. 0
@@ -292,15 +295,15 @@ class HipTrainStep:
                 ss = self.side.cuda_stream
                 _lib.check(L.ckr_conv_bias_grad(part.data_ptr(), P, self.g(key + ".b").data_ptr(), ss))
                 if l == 0:
-                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
+                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices, self.pipe, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
                 else:
                     inp = self.out[6] if l == 7 else self.out[l - 1]
-                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.ws_w.data_ptr(), self.g(key + ".w").data_ptr(), ss))
+                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.pipe, self.ws_w.data_ptr(), self.g(key + ".w").data_ptr(), ss))
                 wgrad_done[l] = torch.cuda.Event()
                 wgrad_done[l].record(self.side)
             if l == 0:
                 break
-            _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.ws.data_ptr(), s))   # gradient w.r.t. the block's input
+            _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.pipe, self.ws.data_ptr(), s))   # gradient w.r.t. the block's input
             nslices = self.slices
         main.wait_event(wgrad_done[1])
         main.wait_event(wgrad_done[0])

@@ -382,10 +382,14 @@ int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float
  * direction -1 (data gradient; w = ckr_conv_wflip's [c][tap * 128 + o]): workspace[z][p][c] = sum_k act[p - off(tap)][o] w[c][k]
  * for the k = tap * 128 + . of slice z (36 % slices == 0); positions outside the 8x8 board read 0.  The next call
  * (ckr_conv_bias_relu_bn / ckr_conv_bn_relu_backward) adds the slices. */
-int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction, int32_t slices, float* workspace, void* stream);
+int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction, int32_t slices, int32_t pipe, float* workspace, void* stream);
+/* pipe (ckr_conv_gemm, ckr_conv_wgrad): 0 = the float32 matrix instruction (v_mfma_f32_32x32x2_f32, exact float32 products);
+ * 1 = the bf16 matrix instruction on float32 operands split into three bfloat16 pieces each, six products per multiply-add
+ * accumulated in float32 (v_mfma_f32_32x32x16_bf16): float32-grade results (dropped terms <= 2^-26 of a product), float32
+ * exponent range, 2.65 x the float32 matrix rate. */
 /* dw[o][tap * 128 + c] = sum_p dz[p][o] x[p + off(tap)][c] (taps = 9), or dw[o][c] = sum_p dz[p][o] x[p][c] (taps = 1: the
  * first layer on its im2col matrix); the P / 32 chunks of positions split over `slices` <= P / 32, workspace[slices][128][128 taps]. */
-int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, float* workspace, float* dw, void* stream);
+int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, int32_t pipe, float* workspace, float* dw, void* stream);
 /* wt[l][c][tap * 128 + o] = w[offsets[l] + o * 1152 + tap * 128 + c] for l < layers <= 8; offsets: HOST array, in floats. */
 int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float* wt, void* stream);
 /* Forward of a conv block after its GEMM: a = ReLU(sum of `slices` workspace slices + bias) (kept for the backward pass),

@@ -56,14 +56,15 @@ def test_gemm_nt_matches_float64():
         _lib.check(L.ckr_gemm_nt(A.data_ptr(), 64, Bt.data_ptr(), 64, Cm.data_ptr(), 100, 100, 256, 64, 1, None, None, None))
 
 
-def test_implicit_conv_gemms_match_float64_conv():
+@pytest.mark.parametrize("pipe", [0, 1])
+def test_implicit_conv_gemms_match_float64_conv(pipe):
     """ckr_conv_gemm (forward, data gradient through the flipped kernels) and ckr_conv_wgrad against float64 conv2d / autograd."""
     import torch.nn.functional as F
     from checkers_mcts_amd import _lib
     L = _lib.load()
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
-    L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
-    L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
     g = torch.Generator().manual_seed(5)
     B = 6
@@ -79,26 +80,26 @@ def test_implicit_conv_gemms_match_float64_conv():
     y.backward(dz.double().permute(0, 3, 1, 2))
     for slices in (1, 4, 9):
         ws = torch.zeros(slices, P, 128, device="cuda")
-        _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, slices, ws.data_ptr(), st))
+        _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, slices, pipe, ws.data_ptr(), st))
         got = ws.double().sum(0).reshape(B, 8, 8, 128).permute(0, 3, 1, 2)
         assert float((got - y.detach()).abs().max()) < 1e-5 * float(y.abs().max())
         wt = torch.zeros(128, 1152, device="cuda")
         _lib.check(L.ckr_conv_wflip(wk.data_ptr(), (i64 * 1)(0), 1, wt.data_ptr(), st))
         assert torch.equal(wt.reshape(128, 9, 128), wk.reshape(128, 9, 128).permute(2, 1, 0))
-        _lib.check(L.ckr_conv_gemm(dz.data_ptr(), wt.data_ptr(), P, -1, slices, ws.data_ptr(), st))
+        _lib.check(L.ckr_conv_gemm(dz.data_ptr(), wt.data_ptr(), P, -1, slices, pipe, ws.data_ptr(), st))
         got = ws.double().sum(0).reshape(B, 8, 8, 128).permute(0, 3, 1, 2)
         assert float((got - xd.grad).abs().max()) < 1e-5 * float(xd.grad.abs().max())
     for slices in (1, 5, 12):
         ws = torch.zeros(slices, 128, 1152, device="cuda")
         dw = torch.zeros(128, 1152, device="cuda")
-        _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, slices, ws.data_ptr(), dw.data_ptr(), st))
+        _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, slices, pipe, ws.data_ptr(), dw.data_ptr(), st))
         got = dw.double().reshape(128, 3, 3, 128).permute(0, 3, 1, 2)
         assert float((got - wd.grad).abs().max()) < 1e-5 * float(wd.grad.abs().max())
-        _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 1, slices, ws.data_ptr(), dw.data_ptr(), st))   # taps = 1: dz^T . x
+        _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 1, slices, pipe, ws.data_ptr(), dw.data_ptr(), st))   # taps = 1: dz^T . x
         ref = dz.double().reshape(P, 128).t() @ x.double().reshape(P, 128)
         assert float((dw.reshape(-1)[:128 * 128].reshape(128, 128).double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
     with pytest.raises(ValueError):
-        _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, 5, ws.data_ptr(), st))
+        _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, 5, pipe, ws.data_ptr(), st))
 
 
 def relu_decisions(hs):
@@ -149,7 +150,8 @@ def float64_loss(net, x, pi, tv, decisions, flip_tol=1e-5):
 
 
 @pytest.mark.parametrize("B", [32, 128, 320])         # 320: 256-row reduction blocks, split-K 2, uneven weight-gradient slices
-def test_one_step_gradients_match_autograd(B):
+@pytest.mark.parametrize("pipe", ["f32", "bf16x6"])
+def test_one_step_gradients_match_autograd(B, pipe):
     import copy
     from checkers_mcts_amd.train_hip import HipTrainStep
     net = make_net(3)
@@ -157,7 +159,7 @@ def test_one_step_gradients_match_autograd(B):
     x, pi, tv = make_batch(B, 11 + B)
     ref = copy.deepcopy(net).double().train()
     ref.conv_reg, ref.dense_reg, ref.policy_loss_weight, ref.value_loss_weight = 1e-3, 2e-3, 1.0, 0.7
-    hs = HipTrainStep(net, B, 1e-3, 2e-3, 1.0, 0.7)
+    hs = HipTrainStep(net, B, 1e-3, 2e-3, 1.0, 0.7, pipe=pipe)
     acc = torch.zeros(3, dtype=torch.float64, device="cuda")
     lr = torch.tensor(0.0, device="cuda")                          # lr 0: gradients and statistics only
     hs.step(x, pi, tv, lr, acc, B)
@@ -224,7 +226,7 @@ def test_adam_trajectory_matches_float64():
         a, b = sd[k].double(), rd[k].double()
         # Adam's first steps move every weight by ~lr * sign(gradient): the handful of elements whose total gradient is
         # within rounding of 0 go either way, so the maximum norm is bounded by the distance walked, the l2 norm is tight
-        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-9, k
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-2 * steps * 2e-3 * float(b.numel()) ** 0.5, k   # rms within 1 % of the walk
         assert float((a - b).abs().max()) <= 2 * steps * 2e-3, k
     # the trained module evaluates like the float64 one
     net.eval(); ref.eval()

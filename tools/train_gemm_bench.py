@@ -11,8 +11,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 REPS = 50
 L = _lib.load()
 vp, i32 = C.c_void_p, C.c_int32
-L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, vp, vp]
-L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+PIPE = {"f32": 0, "bf16x6": 1}[os.environ.get("CKR_TRAIN_PIPE", "bf16x6")]
 P = 64 * B
 x = torch.randn(P, 128, device="cuda")
 w = torch.randn(128, 1152, device="cuda") * 0.05
@@ -35,22 +36,22 @@ def timed(fn):
     return e0.elapsed_time(e1) / REPS * 1e3
 
 
-out = {"batch": B, "flops_per_gemm": flops, "forward": {}, "dgrad": {}, "wgrad": {}}
+out = {"pipe": os.environ.get("CKR_TRAIN_PIPE", "bf16x6"), "batch": B, "flops_per_gemm": flops, "forward": {}, "dgrad": {}, "wgrad": {}}
 for s in (1, 2, 3, 4, 6, 9):
-    us = timed(lambda: _lib.check(L.ckr_conv_gemm(x.data_ptr(), w.data_ptr(), P, 1, s, ws.data_ptr(), st)))
+    us = timed(lambda: _lib.check(L.ckr_conv_gemm(x.data_ptr(), w.data_ptr(), P, 1, s, PIPE, ws.data_ptr(), st)))
     out["forward"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
-    us = timed(lambda: _lib.check(L.ckr_conv_gemm(dz.data_ptr(), w.data_ptr(), P, -1, s, ws.data_ptr(), st)))
+    us = timed(lambda: _lib.check(L.ckr_conv_gemm(dz.data_ptr(), w.data_ptr(), P, -1, s, PIPE, ws.data_ptr(), st)))
     out["dgrad"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
 for s in (14, 16, 28, 32, 56, 64):
-    us = timed(lambda: _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, s, ws.data_ptr(), dw.data_ptr(), st)))
+    us = timed(lambda: _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, s, PIPE, ws.data_ptr(), dw.data_ptr(), st)))
     out["wgrad"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
 if os.environ.get("POWER"):                                        # socket power and shader clock under each GEMM, rocm-smi polled from a side thread
     import threading, time, statistics
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from power_probe import sample
     out["power"] = {}
-    for name, fn in (("forward", lambda: L.ckr_conv_gemm(x.data_ptr(), w.data_ptr(), P, 1, 4 if B <= 128 else 1, ws.data_ptr(), st)),
-                     ("wgrad", lambda: L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, 32, ws.data_ptr(), dw.data_ptr(), st))):
+    for name, fn in (("forward", lambda: L.ckr_conv_gemm(x.data_ptr(), w.data_ptr(), P, 1, 4 if B <= 128 else 1, PIPE, ws.data_ptr(), st)),
+                     ("wgrad", lambda: L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, 32, PIPE, ws.data_ptr(), dw.data_ptr(), st))):
         stop, got = threading.Event(), []
 
         def poll():
