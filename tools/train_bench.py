@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training-step throughput: the hand-written HIP step (train_hip.HipTrainStep) and the PyTorch
-autograd / MIOpen / fused-Adam step on the same network and batch, each captured in a HIP graph; + the float32 MFMA
-GEMM of the conv layers on its own.  One JSON line."""
+autograd / MIOpen / fused-Adam step on the same network and batch, each captured in a HIP graph.  CKR_TRAIN_PIPE = bf16x6 (default) | f32
+selects the matrix pipe of the conv GEMMs.  One JSON line."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The three GEMMs of one 128 -> 128 conv block of the training step on their own (ckr_conv_gemm forward / data gradient,
-ckr_conv_wgrad), for a batch of B boards, over the split-K factors: microseconds per launch and TFLOP/s against the
-float32 matrix peak (157.3 TFLOP/s).  HIP events around REPS back-to-back launches."""
+ckr_conv_wgrad), for a batch of B boards, over the split-K factors: microseconds per launch and TFLOP/s (float32 matrix
+peak: 157.3 TFLOP/s; CKR_TRAIN_PIPE = bf16x6 (default) | f32 selects the kernels).  HIP events around REPS back-to-back launches."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
