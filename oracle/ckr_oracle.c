@@ -370,7 +370,12 @@ static uint32_t fmix32(uint32_t h)
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
 }
 
-void ckro_hashnet(const float* x896, uint32_t salt, float* p512, float* v)
+void ckro_hashnet_ex(const float* x896, uint32_t salt, int inexact, float* p512, float* v);
+void ckro_hashnet(const float* x896, uint32_t salt, float* p512, float* v) { ckro_hashnet_ex(x896, salt, 0, p512, v); }
+
+/* inexact != 0: tests/golden/ref_shim.InexactNet -- p * float32(0.7) + float32(1/3), v * float32(0.3), every step
+ * rounded to float32 (NumPy float32 array arithmetic; this file is built with -ffp-contract=off) */
+void ckro_hashnet_ex(const float* x896, uint32_t salt, int inexact, float* p512, float* v)
 {
     uint32_t w[4] = {0, 0, 0, 0};
     for (int x = 0; x < 8; ++x)
@@ -388,6 +393,11 @@ void ckro_hashnet(const float* x896, uint32_t salt, float* p512, float* v)
     for (uint32_t i = 0; i < 512; ++i)
         p512[i] = (float)((fmix32(h + i * 0x9E3779B1u) >> 16) + 1u) * (1.0f / 33554432.0f);
     *v = (float)((int)(fmix32(h ^ 0xDEADBEEFu) & 0xFFFFu) - 32768) * (1.0f / 65536.0f);
+    if (inexact) {
+        const volatile float third = (float)(1.0 / 3.0);
+        for (int i = 0; i < 512; ++i) { volatile float t = p512[i] * 0.7f; p512[i] = t + third; }
+        *v = *v * 0.3f;
+    }
 }
 
 /* numpy's float32 pairwise summation (the reduction np.sum runs on the
@@ -442,7 +452,7 @@ typedef struct onode {
     ckro_board* unvisited;  int n_unvisited;  /* successor list, reference order */
     int terminal;
     int n;        /* _number_of_visits */
-    float w;      /* _total_reward (float32 under NEP 50) */
+    double w;     /* _total_reward: a float32 value under NEP 50 (w_accum 0), float64 under the legacy rules (w_accum 1) */
     float p;      /* _prior_prob */
 } onode;
 
@@ -525,26 +535,41 @@ static onode* node_new(ckro_worker* w, const ckro_board* b, onode* parent)
     return n;
 }
 
-static float node_q(const onode* n) { return n->n ? n->w / (float)n->n : 0.0f; }   /* MCTS.py:389-394 */
+/* MCTS_Node.q, MCTS.py:389-394: w / n.  NEP 50 (NumPy >= 2): np.float32 / int stays float32.  Legacy rules (the
+ * reference's pinned NumPy 1.19, requirements.txt:68): np.float64 / int, float64.  A node that has only ever received
+ * python-int rewards (a terminal node) holds an int: int / int is a float64 division in both regimes, and exact (+-1, 0). */
+static double node_q(const ckro_worker* w, const onode* n)
+{
+    if (!n->n) return 0.0;
+    if (w->cfg.w_accum) return n->w / (double)n->n;
+    return (double)((float)n->w / (float)n->n);
+}
+/* self._total_reward += reward, MCTS.py:424: float32 + float32 under NEP 50 (python ints are cast to float32); under the
+ * legacy rules `python int + np.float32` and `-1 * np.float32` are float64, so W accumulates in float64 */
+static void node_add(const ckro_worker* w, onode* n, float reward)
+{
+    if (w->cfg.w_accum) n->w += (double)reward;
+    else n->w = (double)((float)n->w + reward);
+}
 
 /* MCTS.determine_reward, MCTS.py:149-186.  The credited player is the one
  * who moved into the node (parent.player, or history[-2] for the root). */
-static void backprop_value(onode* node, float v, int sim_player)
+static void backprop_value(const ckro_worker* w, onode* node, float v, int sim_player)
 {   /* MCTS_Node.backpropagation, MCTS.py:419-430 */
     for (onode* n = node; n; n = n->parent) {
         int parent_player = (int)CKRO_MOVER(n->b.meta);
         float reward = (sim_player != parent_player) ? -1.0f * v : v;
-        n->n += 1; n->w += reward;
+        n->n += 1; node_add(w, n, reward);
     }
 }
-static void backprop_outcome(onode* node, int outcome)
+static void backprop_outcome(const ckro_worker* w, onode* node, int outcome)
 {
     for (onode* n = node; n; n = n->parent) {
         int parent_player = (int)CKRO_MOVER(n->b.meta);
         int reward = 0;
         if (outcome == 1) reward = parent_player == 0 ? 1 : -1;
         else if (outcome == 2) reward = parent_player == 1 ? 1 : -1;
-        n->n += 1; n->w += (float)reward;
+        n->n += 1; node_add(w, n, (float)reward);
     }
 }
 
@@ -581,7 +606,7 @@ static onode* select_child(ckro_worker* w, onode* node)
         volatile double t1 = w->cfg.uct_c * psa;
         volatile double t2 = t1 * sqrt_n;
         volatile double t3 = t2 / (double)(1 + c->n);
-        uct[i] = (double)node_q(c) + t3;
+        uct[i] = node_q(w, c) + t3;
     }
     return node->children[argmax_f64(uct, nc)];
 }
@@ -597,13 +622,13 @@ static int sim_step(ckro_worker* w, onode* root)
         if (!node->terminal) {
             onode* child = select_child(w, node);
             if (child->terminal) {                           /* :93-94, default_policy :145-146 */
-                backprop_outcome(child, (int)CKRO_OUTCOME(child->status));
+                backprop_outcome(w, child, (int)CKRO_OUTCOME(child->status));
                 w->stats[1]++;
                 return 0;
             }
             node = child;
         } else {                                             /* :97-99 (root terminal) */
-            backprop_outcome(node, (int)CKRO_OUTCOME(node->status));
+            backprop_outcome(w, node, (int)CKRO_OUTCOME(node->status));
             w->stats[1]++;
             return 0;
         }
@@ -655,20 +680,20 @@ static void sim_step_rollout(ckro_worker* w, onode* root)
             onode* c = node_new(w, &node->unvisited[node->n_unvisited - 1], node);
             node->n_unvisited--;
             node->children[node->n_children++] = c;
-            backprop_outcome(c, playout(w, c));
+            backprop_outcome(w, c, playout(w, c));
             w->stats[0]++;
             return;
         }
         if (!node->terminal) {
             onode* child = select_child_uct(w, node);
             if (child->terminal) {
-                backprop_outcome(child, (int)CKRO_OUTCOME(child->status));
+                backprop_outcome(w, child, (int)CKRO_OUTCOME(child->status));
                 w->stats[1]++;
                 return;
             }
             node = child;
         } else {
-            backprop_outcome(node, (int)CKRO_OUTCOME(node->status));
+            backprop_outcome(w, node, (int)CKRO_OUTCOME(node->status));
             w->stats[1]++;
             return;
         }
@@ -691,7 +716,7 @@ static void expand_pending(ckro_worker* w, const float* p512, float v)
     free(node->unvisited); node->unvisited = NULL;
     for (int i = 0; i < cnt; ++i)
         node->children[i]->p = planes[CKRO_ACTION(node->children[i]->b.meta)];
-    backprop_value(node, v, (int)CKRO_SIDE(node->b.meta));
+    backprop_value(w, node, v, (int)CKRO_SIDE(node->b.meta));
     w->pending = NULL;
     w->stats[0]++;
 }
@@ -887,9 +912,11 @@ int ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf)
                 t->wsum[i] = root->children[i]->w; t->prior[i] = root->children[i]->p;
             }
             t->root_n = root->n; t->root_w = root->w; t->chosen = (int)CKRO_ACTION(bc->b.meta);
-            float q = node_q(root);
+            /* qval = -root.q / root.q (:365-368): np.float32 under NEP 50 (t->q); float64 under the legacy rules and in
+             * the rollout mode, where W is a python int (t->q64) */
+            float q = (float)node_q(w, root);
             t->q = (w->parent_player != (int)CKRO_SIDE(root->b.meta)) ? -q : q;
-            { double q64 = root->n ? (double)root->w / (double)root->n : 0.0;
+            { double q64 = root->n ? root->w / (double)root->n : 0.0;
               t->q64 = (w->parent_player != (int)CKRO_SIDE(root->b.meta)) ? -q64 : q64; }
             w->stats[2]++;
             if (!cfg->tournament && cfg->terminate_cnt > 0 && !w->done && w->move_count >= cfg->terminate_cnt) {
@@ -947,8 +974,8 @@ int ckro_worker_num_results(const ckro_worker* w) { return w->n_results; }
 const ckro_game_result* ckro_worker_results(const ckro_worker* w) { return w->results; }
 void ckro_worker_stats(const ckro_worker* w, uint64_t out[8]) { memcpy(out, w->stats, sizeof(w->stats)); }
 
-int ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n, float* wsum,
-                          float* prior, int32_t* root_n, float* root_w)
+int ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n, double* wsum,
+                          float* prior, int32_t* root_n, double* root_w)
 {
     const onode* root = w->root[w->last_tree];
     if (!root) return 0;

@@ -14,8 +14,12 @@
  * own arithmetic (Keras/TensorFlow, absent from /root/reference) is
  * "parity unpinned"; see DESIGN.md.
  *
- * Numerics follow the reference as it runs under NumPy >= 2 (NEP 50): node W
- * is float32, Q = W/N in float32, PUCT scores in float64.
+ * Numerics follow the reference in either NumPy promotion regime (ckro_config.w_accum):
+ * 0 = as it runs under NumPy >= 2 (NEP 50): node W is float32, Q = W/N in float32;
+ * 1 = as it runs under its pinned NumPy 1.19 (requirements.txt:68, legacy value-based
+ * promotion): W and Q float64.  PUCT scores are float64 in both.  Both regimes are
+ * pinned by fixtures generated under the matching interpreter
+ * (tests/golden/search_inexact_np{1,2}.npz, selfplay_inexact_np{1,2}.npz).
  */
 #ifndef CKR_ORACLE_H
 #define CKR_ORACLE_H
@@ -80,6 +84,9 @@ int ckro_children(const ckro_board* b, ckro_board out[CKRO_MAX_CHILDREN]);
  * `salt` selects one of a family of nets (tournament: two different nets).
  * Output p[512] > 0 (not normalised) and v in [-0.5, 0.5). */
 void ckro_hashnet(const float* x896, uint32_t salt, float* p512, float* v);
+/* inexact != 0: the same followed by p * 0.7f + float32(1/3), v * 0.3f (tests/golden/ref_shim.InexactNet): outputs
+ * whose sums are NOT exact, so that the search's accumulation precision and order become observable. */
+void ckro_hashnet_ex(const float* x896, uint32_t salt, int inexact, float* p512, float* v);
 
 /* Build the NHWC float32 network input (Checkers.py:431-432). */
 void ckro_features(const ckro_board* b, float* x896);
@@ -106,6 +113,8 @@ typedef struct {
     const double* ln_table;  /* optional ln(n) for n < ln_table_n, as the host's np.log computes it */
     int    ln_table_n;
     int    game;             /* 0 = Checkers; 1 = Tic-Tac-Toe (TicTacToe.py), random-rollout mode only (README:100-168) */
+    int    w_accum;          /* MCTS_Node._total_reward / .q arithmetic (MCTS.py:389-394,419-430): 0 = float32 (the reference
+                                under NumPy >= 2), 1 = float64 (under its pinned NumPy 1.19, requirements.txt:68) */
 } ckro_config;
 
 typedef struct {
@@ -117,13 +126,13 @@ typedef struct {
     int        n_children;    /* 0 for the terminal tuple */
     uint16_t   action[CKRO_MAX_CHILDREN];  /* child order = tree order */
     uint32_t   visits[CKRO_MAX_CHILDREN];
-    float      wsum[CKRO_MAX_CHILDREN];    /* child W (float32) */
+    double     wsum[CKRO_MAX_CHILDREN];    /* child W (w_accum 0: a float32 value) */
     float      prior[CKRO_MAX_CHILDREN];   /* child P (float32) */
     int        root_n;        /* root N after the search */
-    float      root_w;
+    double     root_w;
     int        chosen;        /* action code picked by best_child (-1: terminal tuple) */
     float      q;
-    double     q64;           /* rollout mode: q = W/N in float64 (W is a python int there) */
+    double     q64;           /* q = W/N in float64: rollout mode (W is a python int there) and w_accum 1 */
     int        q_is_int;      /* terminal tuple: q is a python int */
     int        z;
 } ckro_tuple;
@@ -157,7 +166,7 @@ void ckro_worker_stats(const ckro_worker* w, uint64_t out[8]);
 /* Root children of the tree that searched last: (action, N, W, P) in tree
  * order; returns count.  For the search fixtures. */
 int  ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n,
-                           float* wsum, float* prior, int32_t* root_n, float* root_w);
+                           double* wsum, float* prior, int32_t* root_n, double* root_w);
 
 /* batch helpers (CPU baseline): advance / submit an array of workers */
 int  ckro_workers_advance(ckro_worker** ws, int n, float* x, int* active);

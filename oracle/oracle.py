@@ -31,15 +31,15 @@ class Config(C.Structure):
                 ("tau_decay_delay", C.c_int), ("terminate_cnt", C.c_int),
                 ("num_games", C.c_int), ("tournament", C.c_int), ("seed", C.c_uint64),
                 ("neural_net", C.c_int), ("rollout_first", C.c_int), ("ln_table", C.c_void_p), ("ln_table_n", C.c_int),
-                ("game", C.c_int)]
+                ("game", C.c_int), ("w_accum", C.c_int)]
 
 
 class Tuple(C.Structure):
     _fields_ = [("board", C.c_uint32 * 4), ("mask", C.c_uint32 * 8), ("status", C.c_uint32),
                 ("game", C.c_int), ("ply", C.c_int), ("n_children", C.c_int),
                 ("action", C.c_uint16 * MAX_CHILDREN), ("visits", C.c_uint32 * MAX_CHILDREN),
-                ("wsum", C.c_float * MAX_CHILDREN), ("prior", C.c_float * MAX_CHILDREN),
-                ("root_n", C.c_int), ("root_w", C.c_float), ("chosen", C.c_int),
+                ("wsum", C.c_double * MAX_CHILDREN), ("prior", C.c_float * MAX_CHILDREN),
+                ("root_n", C.c_int), ("root_w", C.c_double), ("chosen", C.c_int),
                 ("q", C.c_float), ("q64", C.c_double), ("q_is_int", C.c_int), ("z", C.c_int)]
 
 
@@ -62,7 +62,7 @@ def lib():
         L.ckro_movegen.argtypes = [u32p, u32p, u32p]
         L.ckro_children.argtypes = [u32p, u32p]
         L.ckro_children.restype = C.c_int
-        L.ckro_hashnet.argtypes = [f32p, C.c_uint32, f32p, f32p]
+        L.ckro_hashnet_ex.argtypes = [f32p, C.c_uint32, C.c_int, f32p, f32p]
         L.ckro_features.argtypes = [u32p, f32p]
         L.ckro_mask_renorm.argtypes = [u32p, f32p, f32p]
         L.ckro_worker_create.argtypes = [C.POINTER(Config)]
@@ -81,7 +81,7 @@ def lib():
         L.ckro_worker_results.restype = C.POINTER(GameResult)
         L.ckro_worker_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.ckro_worker_last_root.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_int32),
-                                            f32p, f32p, C.POINTER(C.c_int32), f32p]
+                                            C.POINTER(C.c_double), f32p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.ckro_worker_last_root.restype = C.c_int
         _lib = L
     return _lib
@@ -128,11 +128,12 @@ def features(board):
     return x.reshape(8, 8, 14)
 
 
-def hashnet(x, salt=0):
+def hashnet(x, salt=0, inexact=False):
+    """HashNet (inexact: InexactNet) of tests/golden/ref_shim.py on one NHWC input."""
     x = np.ascontiguousarray(x, np.float32).reshape(-1)
     p = np.zeros(512, np.float32)
     v = np.zeros(1, np.float32)
-    lib().ckro_hashnet(_f32(x), C.c_uint32(salt), _f32(p), _f32(v))
+    lib().ckro_hashnet_ex(_f32(x), C.c_uint32(salt), C.c_int(int(bool(inexact))), _f32(p), _f32(v))
     return p, v[0]
 
 
@@ -144,9 +145,13 @@ def mask_renorm(mask, p512):
     return out
 
 
+W_ACCUM = {"float32": 0, "float64": 1, "np2": 0, "np1": 1, 0: 0, 1: 1}
+
+
 def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, seed=0, rollout_first=False, ln_table=None,
-                game="checkers"):
-    """Config from the reference's kwargs dict (MCTS.py:43-55)."""
+                game="checkers", w_accum="float32"):
+    """Config from the reference's kwargs dict (MCTS.py:43-55).  w_accum: 'float32' = the reference under NumPy >= 2,
+    'float64' = under its pinned NumPy 1.19 (legacy promotion)."""
     k = mcts_kwargs
     return Config(uct_c=float(k["UCT_C"]), budget=int(k["BUDGET"]), training=int(bool(k["TRAINING"])),
                   alpha=float(k["DIRICHLET_ALPHA"]), epsilon=float(k["DIRICHLET_EPSILON"]),
@@ -155,7 +160,8 @@ def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, see
                   num_games=int(num_games), tournament=int(bool(tournament)), seed=int(seed),
                   neural_net=int(bool(k.get("NEURAL_NET", True))), rollout_first=int(bool(rollout_first)),
                   ln_table=(ln_table.ctypes.data if ln_table is not None else None),
-                  ln_table_n=(len(ln_table) if ln_table is not None else 0), game={"checkers": 0, "tictactoe": 1}[game])
+                  ln_table_n=(len(ln_table) if ln_table is not None else 0), game={"checkers": 0, "tictactoe": 1}[game],
+                  w_accum=W_ACCUM[w_accum])
 
 
 class Worker:
@@ -206,8 +212,8 @@ class Worker:
             out.append(dict(board=np.array(t.board[:], np.uint32), mask=np.array(t.mask[:], np.uint32),
                             status=int(t.status), game=t.game, ply=t.ply,
                             action=np.array(t.action[:k], np.uint16), visits=np.array(t.visits[:k], np.uint32),
-                            wsum=np.array(t.wsum[:k], np.float32), prior=np.array(t.prior[:k], np.float32),
-                            root_n=t.root_n, root_w=np.float32(t.root_w), chosen=t.chosen,
+                            wsum=np.array(t.wsum[:k], np.float64), prior=np.array(t.prior[:k], np.float32),
+                            root_n=t.root_n, root_w=float(t.root_w), chosen=t.chosen,
                             q=np.float32(t.q), q64=float(t.q64), q_is_int=bool(t.q_is_int), z=int(t.z)))
         return out
 
@@ -226,13 +232,13 @@ class Worker:
     def last_root(self):
         a = (C.c_uint16 * MAX_CHILDREN)()
         n = (C.c_int32 * MAX_CHILDREN)()
-        w = (C.c_float * MAX_CHILDREN)()
+        w = (C.c_double * MAX_CHILDREN)()
         p = (C.c_float * MAX_CHILDREN)()
-        rn, rw = C.c_int32(0), C.c_float(0)
+        rn, rw = C.c_int32(0), C.c_double(0)
         k = self._L.ckro_worker_last_root(self._h, a, n, w, p, C.byref(rn), C.byref(rw))
         return dict(action=np.array(a[:k], np.uint16), n=np.array(n[:k], np.int32),
-                    w=np.array(w[:k], np.float32), p=np.array(p[:k], np.float32),
-                    root_n=rn.value, root_w=np.float32(rw.value))
+                    w=np.array(w[:k], np.float64), p=np.array(p[:k], np.float32),
+                    root_n=rn.value, root_w=float(rw.value))
 
 
 OUTCOME_NAMES = {0: None, 1: "player1_wins", 2: "player2_wins", 3: "draw"}

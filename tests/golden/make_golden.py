@@ -9,6 +9,10 @@ Fixture families:
   hashnet_v1.npz     HashNet.predict vectors (pins the C / HIP re-statements)
   search_v1.npz      deterministic searches via the MCTS API: per-ply root
                      children (action, N, W, P) and the chosen action
+  search_inexact_np{1,2}.npz, selfplay_inexact_np{1,2}.npz
+                     the same with a network whose outputs do not sum exactly, under the legacy NumPy promotion
+                     rules (np1: /opt/conda/bin/python3.9, NumPy 1.26 = the reference's pinned 1.19 behaviour,
+                     MCTS_Node.w float64) and under NEP 50 (np2: this interpreter, w float32)
   selfplay_v1.npz    generate_Checkers_data._generate_data output (state, pi, q, z)
   tournament_v1.npz  tournament_Checkers._start_tournament outcomes
   rollout_v1.npz     NEURAL_NET=False (random-rollout MCTS) self-play tuples with np.random.randint pinned to 0
@@ -150,56 +154,132 @@ def gen_predict(seed=7, n=200):
 
 
 # --------------------------------------------------------------------------- search (MCTS API)
+def _action_of(state):
+    return (int(state[14, 0, 0]) - 6) * 64 + 8 * int(state[14, 0, 1]) + int(state[14, 0, 2])
+
+
+def _drive_searches(net, budget, max_plies):
+    """Drive MCTS / MCTS_Node exactly as training_pipeline.py:353-386 does; per ply: the root's children in tree order
+    (action, N, W, P), the root's (N, W, chosen action, side); W kept as the reference holds it (its type is reported)."""
+    env = rt.new_env()
+    env.neural_net = net
+    MCTS(**mcts_kwargs(budget, training=False, env=env))
+    rows, acts, ns, ws, ps, off, wtypes = [], [], [], [], [], [0], set()
+    initial = env.state
+    root1 = MCTS_Node(initial, parent=None)
+    best1 = best2 = root2 = None
+    while not env.done and env.move_count < max_plies:
+        if env.current_player(env.state) == "player1":
+            if env.move_count != 0:
+                root1 = MCTS.new_root_node(best1)
+            root = root1
+        else:
+            if env.move_count == 1:
+                root2 = MCTS_Node(env.state, parent=None, initial_state=initial)
+            else:
+                root2 = MCTS.new_root_node(best2)
+            root = root2
+        MCTS.begin_tree_search(root)
+        best = MCTS.best_child(root)
+        if root is root1:
+            best1 = best
+        else:
+            best2 = best
+        for c in root.children:
+            acts.append(_action_of(c.state)); ns.append(c.n); ws.append(c.w); ps.append(np.float32(c.p))
+            wtypes.add(type(c.w).__name__)
+        off.append(len(acts))
+        rows.append((root.n, root.w, _action_of(best.state), int(root.state[4, 0, 0])))
+        wtypes.add(type(root.w).__name__)
+        env.step(best.state)
+    return dict(env=env, rows=rows, acts=acts, ns=ns, ws=ws, ps=ps, off=off, wtypes=wtypes)
+
+
 def gen_search(cases=((30, 0, 24), (100, 1, 10), (12, 2, 400))):
-    """Drive MCTS / MCTS_Node exactly as training_pipeline.py:353-386 does and
-    record the root statistics after every search."""
+    """Deterministic searches with the exactly summable HashNet: root statistics after every search."""
     out = {}
     for ci, (budget, salt, max_plies) in enumerate(cases):
-        env = rt.new_env()
-        env.neural_net = ref_shim.HashNet(salt)
-        MCTS(**mcts_kwargs(budget, training=False, env=env))
-        rows, acts, ns, ws, ps, off = [], [], [], [], [], [0]
-        initial = env.state
-        root1 = MCTS_Node(initial, parent=None)
-        best1 = best2 = root2 = None
-        while not env.done and env.move_count < max_plies:
-            if env.current_player(env.state) == "player1":
-                if env.move_count != 0:
-                    root1 = MCTS.new_root_node(best1)
-                root = root1
-            else:
-                if env.move_count == 1:
-                    root2 = MCTS_Node(env.state, parent=None, initial_state=initial)
-                else:
-                    root2 = MCTS.new_root_node(best2)
-                root = root2
-            MCTS.begin_tree_search(root)
-            best = MCTS.best_child(root)
-            if root is root1:
-                best1 = best
-            else:
-                best2 = best
-            for c in root.children:
-                a = (int(c.state[14, 0, 0]) - 6) * 64 + 8 * int(c.state[14, 0, 1]) + int(c.state[14, 0, 2])
-                acts.append(a); ns.append(c.n); ws.append(np.float32(c.w)); ps.append(np.float32(c.p))
-            off.append(len(acts))
-            ba = (int(best.state[14, 0, 0]) - 6) * 64 + 8 * int(best.state[14, 0, 1]) + int(best.state[14, 0, 2])
-            rows.append((root.n, np.float32(root.w), ba, int(root.state[4, 0, 0])))
-            env.step(best.state)
+        r = _drive_searches(ref_shim.HashNet(salt), budget, max_plies)
+        env, rows = r["env"], r["rows"]
         out["c%d_cfg" % ci] = np.array([budget, salt, max_plies, env.move_count,
                                          rt.OUTCOME_CODE[env.outcome]], np.int64)
-        out["c%d_root_n" % ci] = np.array([r[0] for r in rows], np.int64)
-        out["c%d_root_w" % ci] = np.array([r[1] for r in rows], np.float32)
-        out["c%d_chosen" % ci] = np.array([r[2] for r in rows], np.int64)
-        out["c%d_side" % ci] = np.array([r[3] for r in rows], np.int64)
-        out["c%d_off" % ci] = np.array(off, np.int64)
-        out["c%d_action" % ci] = np.array(acts, np.int64)
-        out["c%d_n" % ci] = np.array(ns, np.int64)
-        out["c%d_w" % ci] = np.array(ws, np.float32)
-        out["c%d_p" % ci] = np.array(ps, np.float32)
+        out["c%d_root_n" % ci] = np.array([x[0] for x in rows], np.int64)
+        out["c%d_root_w" % ci] = np.array([np.float32(x[1]) for x in rows], np.float32)
+        out["c%d_chosen" % ci] = np.array([x[2] for x in rows], np.int64)
+        out["c%d_side" % ci] = np.array([x[3] for x in rows], np.int64)
+        out["c%d_off" % ci] = np.array(r["off"], np.int64)
+        out["c%d_action" % ci] = np.array(r["acts"], np.int64)
+        out["c%d_n" % ci] = np.array(r["ns"], np.int64)
+        out["c%d_w" % ci] = np.array([np.float32(x) for x in r["ws"]], np.float32)
+        out["c%d_p" % ci] = np.array(r["ps"], np.float32)
         print("search case", ci, "budget", budget, "plies", len(rows), "outcome", env.outcome)
     out["n_cases"] = np.array(len(cases))
     np.savez_compressed(os.path.join(OUT, "search_v1.npz"), **out)
+
+
+def promotion_regime():
+    """'np1' = legacy value-based promotion (NumPy < 2: python_number op np.float32 -> float64, what the reference's pinned
+    NumPy 1.19 does, requirements.txt:68); 'np2' = NEP 50 (NumPy >= 2: stays float32)."""
+    return "np1" if type(np.float32(1) * 1) is np.float64 else "np2"
+
+
+def gen_search_inexact(cases=((25, 7, 200), (60, 3, 40), (200, 5, 16))):
+    """The same searches with InexactNet, whose outputs are not exactly summable: W then depends on the precision and
+    the order of every accumulation (MCTS.py:419-430) and q = w / n (MCTS.py:389-394) on the promotion rules of the
+    NumPy that runs the reference.  Written to search_inexact_<regime>.npz -- run under both interpreters:
+        python make_golden.py search_inexact ; /opt/conda/bin/python3.9 make_golden.py search_inexact
+    W is stored as float64 (the exact value of the reference's float32 or float64 scalar) next to its type name."""
+    out = {}
+    regime = promotion_regime()
+    for ci, (budget, salt, max_plies) in enumerate(cases):
+        r = _drive_searches(ref_shim.InexactNet(salt), budget, max_plies)
+        env, rows = r["env"], r["rows"]
+        out["c%d_cfg" % ci] = np.array([budget, salt, max_plies, env.move_count, rt.OUTCOME_CODE[env.outcome]], np.int64)
+        out["c%d_root_n" % ci] = np.array([x[0] for x in rows], np.int64)
+        out["c%d_root_w" % ci] = np.array([float(x[1]) for x in rows], np.float64)
+        out["c%d_chosen" % ci] = np.array([x[2] for x in rows], np.int64)
+        out["c%d_side" % ci] = np.array([x[3] for x in rows], np.int64)
+        out["c%d_off" % ci] = np.array(r["off"], np.int64)
+        out["c%d_action" % ci] = np.array(r["acts"], np.int64)
+        out["c%d_n" % ci] = np.array(r["ns"], np.int64)
+        out["c%d_w" % ci] = np.array([float(x) for x in r["ws"]], np.float64)
+        out["c%d_p" % ci] = np.array(r["ps"], np.float32)
+        out["c%d_wtypes" % ci] = np.array(sorted(r["wtypes"]))
+        print("inexact search case", ci, "budget", budget, "plies", len(rows), "outcome", env.outcome, "W types", sorted(r["wtypes"]))
+    out["n_cases"] = np.array(len(cases))
+    out["numpy_version"] = np.array(np.__version__)
+    np.savez_compressed(os.path.join(OUT, "search_inexact_%s.npz" % regime), **out)
+
+
+def gen_selfplay_inexact(cases=((25, 60, 1, 7), (40, 1000, 1, 2), (60, 30, 2, 3))):
+    """generate_Checkers_data._generate_data with InexactNet (the shim's load_model returns it for 'inexact' file names):
+    tuples (state, pi, q, z) with q as the reference holds it -- np.float32 under NEP 50, np.float64 under the legacy rules.
+    Written to selfplay_inexact_<regime>.npz; run under both interpreters."""
+    out = {}
+    regime = promotion_regime()
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "training_data"))
+    os.chdir(tmp)
+    try:
+        for ci, (budget, terminate, games, salt) in enumerate(cases):
+            sk = dict(NUM_SELFPLAY_GAMES=games, TRAINING_ITERATION=0, TERMINATE_CNT=terminate, NUM_CPUS=1,
+                      NN_FN="inexact_salt%d.h5" % salt)
+            mem = pickle.load(open(tp.generate_Checkers_data(sk, mcts_kwargs(budget)).generate_data(), "rb"))
+            out["c%d_cfg" % ci] = np.array([budget, terminate, games, salt], np.int64)
+            out["c%d_state" % ci] = np.array([m[0] for m in mem], np.float64)
+            out["c%d_pi" % ci] = np.array([m[1] for m in mem], np.float64)
+            out["c%d_q" % ci] = np.array([float(m[2]) for m in mem], np.float64)
+            out["c%d_q_is_int" % ci] = np.array([type(m[2]) is int for m in mem], np.bool_)
+            out["c%d_qtypes" % ci] = np.array(sorted({type(m[2]).__name__ for m in mem}))
+            out["c%d_z" % ci] = np.array([m[3] for m in mem], np.int64)
+            gen = tp.Keras_Generator(mem, 32)                              # value targets as Keras receives them (float32)
+            out["c%d_value_target" % ci] = np.concatenate([gen[b][1][1] for b in range((len(mem) + 31) // 32)]).astype(np.float32)
+    finally:
+        os.chdir(cwd)
+    out["n_cases"] = np.array(len(cases))
+    out["numpy_version"] = np.array(np.__version__)
+    np.savez_compressed(os.path.join(OUT, "selfplay_inexact_%s.npz" % regime), **out)
 
 
 # --------------------------------------------------------------------------- self-play tuples
@@ -473,12 +553,12 @@ def gen_text():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "predict", "search", "selfplay", "tournament", "rollout", "training", "text", "ttt"]
+    which = sys.argv[1:] or ["rules", "predict", "search", "search_inexact", "selfplay", "selfplay_inexact", "tournament", "rollout", "training", "text", "ttt"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:
         fn = globals()["gen_" + w]
-        sys.stdout = devnull if w in ("selfplay", "tournament", "rollout") else real_stdout   # the reference prints per game
+        sys.stdout = devnull if w in ("selfplay", "selfplay_inexact", "tournament", "rollout") else real_stdout   # the reference prints per game
         try:
             fn()
         finally:

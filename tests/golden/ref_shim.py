@@ -49,7 +49,7 @@ def install():
     _mod("tensorflow.keras.utils", Sequence=Sequence)
     _mod("tensorflow.keras.callbacks", Callback=Callback, __all__=["Callback"])
     _mod("tensorflow.keras.backend")
-    _mod("tensorflow.keras.models", load_model=lambda fn: HashNet(salt_of(fn)))
+    _mod("tensorflow.keras.models", load_model=net_of)
     _mod("keras")
     _mod("keras.callbacks", Callback=Callback)
     _mod("keras.backend")
@@ -63,6 +63,11 @@ def salt_of(fn):
     import re
     m = re.search(r"salt(\d+)", str(fn))
     return int(m.group(1)) if m else 0
+
+
+def net_of(fn):
+    """File name -> test network: '...inexact...' selects InexactNet, otherwise HashNet; salt as in salt_of."""
+    return InexactNet(salt_of(fn)) if "inexact" in str(fn) else HashNet(salt_of(fn))
 
 
 _M32 = np.uint64(0xFFFFFFFF)
@@ -110,3 +115,15 @@ class HashNet:
         vv = int(_fmix32(h ^ np.uint64(0xDEADBEEF)) & np.uint64(0xFFFF)) - 32768
         v = np.float32(vv) * np.float32(1.0 / 65536.0)
         return [p.reshape(1, 512), np.array([[v]], np.float32)]
+
+
+class InexactNet(HashNet):
+    """HashNet whose outputs are NOT exactly summable (float32 p * 0.7 + 1/3, v * 0.3): unlike HashNet's dyadic
+    rationals, sums of these values round differently in float32 and float64 and depend on the order of accumulation,
+    so fixtures made with it pin the search's accumulation arithmetic (MCTS.py:149-186,389-394,419-430) in either NumPy
+    promotion regime.  Same arithmetic as ckro_hashnet(..., inexact = 1) and ckr_hashnet_batch(..., inexact = 1)."""
+
+    def predict(self, x):
+        p, v = HashNet.predict(self, x)
+        p = (p * np.float32(0.7) + np.float32(1.0 / 3.0)).astype(np.float32)
+        return [p, (v * np.float32(0.3)).astype(np.float32)]

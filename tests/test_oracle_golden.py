@@ -107,10 +107,72 @@ def test_search_root_statistics_bit_exact(oracle, golden_dir):
             sl = slice(off[i], off[i + 1])
             assert (t["action"] == g["c%d_action" % ci][sl]).all()
             assert (t["visits"] == g["c%d_n" % ci][sl]).all()
-            assert (t["wsum"].view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert (t["wsum"].astype(np.float32).astype(np.float64) == t["wsum"]).all()       # float32 values (w_accum 0)
+            assert (t["wsum"].astype(np.float32).view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
             assert (t["prior"].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
             assert t["root_n"] == g["c%d_root_n" % ci][i] and t["root_w"] == g["c%d_root_w" % ci][i]
             assert t["chosen"] == g["c%d_chosen" % ci][i]
+
+
+# ---- the search arithmetic with a network whose outputs do NOT sum exactly, in both NumPy promotion regimes:
+# np2 = NEP 50 (MCTS_Node.w float32), np1 = the legacy rules of the reference's pinned NumPy 1.19 (w float64);
+# fixtures generated by running the reference under the matching interpreter (make_golden.gen_search_inexact)
+REGIMES = (("np2", "float32"), ("np1", "float64"))
+
+
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_inexact_hashnet_search_w_bits(oracle, golden_dir, regime, w_accum):
+    g = _load(golden_dir, "search_inexact_%s.npz" % regime)
+    assert w_accum in set(g["c1_wtypes"])                              # the reference really held that type
+    for ci in range(int(g["n_cases"])):
+        budget, salt, max_plies, moves, outcome = (int(v) for v in g["c%d_cfg" % ci])
+        w = oracle.Worker(oracle.make_config(_mk(budget, training=False), terminate_cnt=max_plies, num_games=1, w_accum=w_accum))
+        w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+        tu = [t for t in w.tuples() if t["chosen"] >= 0]
+        off = g["c%d_off" % ci]
+        assert len(tu) == len(off) - 1 == moves
+        for i, t in enumerate(tu):
+            sl = slice(off[i], off[i + 1])
+            assert (t["action"] == g["c%d_action" % ci][sl]).all()
+            assert (t["visits"] == g["c%d_n" % ci][sl]).all()
+            assert (t["wsum"].view(np.uint64) == g["c%d_w" % ci][sl].view(np.uint64)).all()          # W bits
+            assert (t["prior"].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
+            assert t["root_n"] == g["c%d_root_n" % ci][i]
+            assert np.float64(t["root_w"]).view(np.uint64) == g["c%d_root_w" % ci][i].view(np.uint64)
+            assert t["chosen"] == g["c%d_chosen" % ci][i]
+        if outcome:
+            assert w.results()[0]["outcome"] == outcome
+
+
+def test_inexact_fixtures_tell_the_regimes_apart(oracle, golden_dir):
+    """The point of the inexact network: the wrong accumulation precision is DETECTED (HashNet's fixtures cannot)."""
+    g = _load(golden_dir, "search_inexact_np1.npz")
+    budget, salt, max_plies, moves, outcome = (int(v) for v in g["c1_cfg"])
+    w = oracle.Worker(oracle.make_config(_mk(budget, training=False), terminate_cnt=max_plies, num_games=1, w_accum="float32"))
+    w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+    tu = [t for t in w.tuples() if t["chosen"] >= 0]
+    got = np.concatenate([t["wsum"] for t in tu])
+    assert len(got) == len(g["c1_w"]) and (got != g["c1_w"]).mean() > 0.5
+
+
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_inexact_selfplay_tuples_q_bits(oracle, golden_dir, regime, w_accum):
+    g = _load(golden_dir, "selfplay_inexact_%s.npz" % regime)
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games, salt = (int(v) for v in g["c%d_cfg" % ci])
+        assert w_accum in set(g["c%d_qtypes" % ci])
+        w = oracle.Worker(oracle.make_config(_mk(budget), terminate_cnt=terminate, num_games=games, w_accum=w_accum))
+        w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+        tu = w.tuples()
+        assert len(tu) == len(g["c%d_z" % ci])
+        st = codec.records_to_planes(np.array([t["board"] for t in tu]), np.array([t["mask"] for t in tu]),
+                                     np.array([t["status"] for t in tu], np.uint32))
+        assert (st == g["c%d_state" % ci]).all()
+        for i, t in enumerate(tu):
+            assert (codec.pi_planes(t["action"], t["visits"]) == g["c%d_pi" % ci][i]).all()
+            q = float(t["q"]) if (t["q_is_int"] or w_accum == "float32") else t["q64"]
+            assert np.float64(q).view(np.uint64) == g["c%d_q" % ci][i].view(np.uint64)
+            assert t["q_is_int"] == bool(g["c%d_q_is_int" % ci][i]) and t["z"] == g["c%d_z" % ci][i]
 
 
 def test_tournament_outcomes(oracle, golden_dir):
@@ -167,7 +229,7 @@ def test_tictactoe_root_statistics_bit_exact(oracle, golden_dir):
         for i, t in enumerate(tu):
             sl = slice(off[i], off[i + 1])
             assert (t["action"] == g["c%d_cell" % ci][sl]).all() and (t["visits"] == g["c%d_n" % ci][sl]).all()
-            assert (t["wsum"].view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert (t["wsum"].astype(np.float32).view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
             assert t["root_n"] == g["c%d_root_n" % ci][i] and t["root_w"] == g["c%d_root_w" % ci][i]
             assert t["chosen"] == g["c%d_chosen" % ci][i] and (int(t["board"][3]) & 1) == g["c%d_side" % ci][i]
         res = w.results()
