@@ -99,6 +99,9 @@ def parse():
     ap.add_argument("--max-sims-per-step", type=int, default=0,
                     help="cap on network-free simulations (terminal visits) a slot runs back to back in one step (0 = engine default)")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool per tree and semispace (0 = engine default)")
+    ap.add_argument("--leaf-cache-log2", type=int, default=23,
+                    help="log2 of the records of each engine's leaf cache (positions already evaluated are expanded without the "
+                         "network; results identical with and without -- tests/test_leaf_cache_gpu.py); 0 = off")
     ap.add_argument("--extra-steps", type=int, default=300,
                     help="timed steps of the extra legs (bf16 throughput mode, arena, random rollouts; N = 1 only, 0 = skip)")
     return ap.parse_args()
@@ -281,6 +284,7 @@ class Leg:
             cfg = ckengine.config_from_kwargs(kw, n_slots=n, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
                                               first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
                                               device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
+                                              leaf_cache_log2=a.leaf_cache_log2,
                                               **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
             return ckengine.Engine(cfg, feature_dtype=dtype)
 
@@ -349,7 +353,7 @@ def timed_window(leg, dev, steps, barrier=lambda: None):
     barrier()
     dt = time.perf_counter() - t0
     s1 = leg.stats()
-    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games")}
+    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves")}
 
 
 def throughput_leg(a, dev, mode):
@@ -514,6 +518,8 @@ def main():
     term_total = ckdist.sum_over_ranks(d["terminal_visits"], dev)
     plies_total = ckdist.sum_over_ranks(d["plies"], dev)
     games_window = ckdist.sum_over_ranks(d["games"], dev)
+    nn_total = ckdist.sum_over_ranks(d["nn_evals"], dev)
+    dup_total = ckdist.sum_over_ranks(d["dup_leaves"], dev)
     active_after_window = leg.stats()["active_slots"]
 
     # ---- instrumented eager pass on the first engine (its wall time is taken out of the whole-run figure): HIP events on
@@ -558,7 +564,8 @@ def main():
         gathered = ckdist.gather_rows(payload, dst=0)
         torch.cuda.synchronize(dev)
         t_gather = ckdist.max_over_ranks(time.perf_counter() - g0, dev)
-        tot = {k: ckdist.sum_over_ranks(st[k], dev) for k in ("expansions", "terminal_visits", "plies", "games", "pool_overflows")}
+        tot = {k: ckdist.sum_over_ranks(st[k], dev) for k in ("expansions", "terminal_visits", "plies", "games", "pool_overflows", "nn_evals", "dup_leaves",
+                                                                  "cache_entries", "cache_dropped")}
         if rank == 0:
             n_rows = int(gathered.shape[0])
             whole = {"games": int(tot["games"]), "games_per_slot": games_per_slot, "seconds": t_play + t_gather,
@@ -567,6 +574,9 @@ def main():
                      "plies": tot["plies"], "mean_plies_per_game": tot["plies"] / max(1.0, tot["games"]),
                      "terminal_visit_fraction": tot["terminal_visits"] / max(1.0, tot["expansions"] + tot["terminal_visits"]),
                      "pool_overflows": int(tot["pool_overflows"]),
+                     "leaf_cache": {"nn_evals": tot["nn_evals"], "dup_leaves": tot["dup_leaves"],
+                                    "duplicate_rate": tot["dup_leaves"] / max(1.0, tot["expansions"]),
+                                    "records_written": tot["cache_entries"], "records_dropped": tot["cache_dropped"]},
                      "gather": {"collective": "all_gather(sizes) + gather(padded rows) to rank 0 (%s)"
                                               % (("RCCL" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend() + ", rows staged through host memory") if world > 1 else "single rank: no collective issued"),
                                 "tuples": n_rows, "bytes": n_rows * 288, "seconds": t_gather},
@@ -612,11 +622,16 @@ def main():
                                       % (a.budget, a.slots),
                           "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": mode, "preroll_steps": pre,
                           "hip_graph": not a.no_graph, "evaluator": which,
+                          "leaf_cache": ("2^%d records per engine: positions the network has already evaluated (Checkers.predict is a "
+                                         "pure function of planes 0-13; two trees per game) are expanded from cached priors / v; results "
+                                         "identical with and without" % a.leaf_cache_log2) if a.leaf_cache_log2 else "off",
                           "streams": "2 half-batches of %d slots on 2 HIP streams" % nb if leg.split else "1",
                           "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
                "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py); rules, search, tuples "
                          "bit-exact vs the reference golden vectors (NumPy >= 2 promotion rules; the vectors regenerate bit-identically under NumPy 1.26 legacy rules)" if mode == "fp32" else
                          "throughput mode (not a parity claim)",
+               "nn_evals": nn_total, "dup_leaves": dup_total, "duplicate_rate": dup_total / max(1.0, exp_total),
+               "nn_evals_per_s": nn_total / dt,
                "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total, "games_finished_in_window": games_window,
                "active_slots_after_window": active_after_window,
                "sims_per_s": (exp_total + term_total) / dt,

@@ -7,6 +7,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
+VERSION = 110                      # CKR_VERSION of include/ckr.h this binding was written against
+Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
 class CkrError(RuntimeError):
@@ -23,18 +25,19 @@ class Config(C.Structure):
                 ("feature_dtype", C.c_int32), ("max_sims_per_step", C.c_int32),
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
                 ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
-                ("reserved", C.c_int32), ("seed", C.c_uint64)]
+                ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32)]
 
 
 class NodeInfo(C.Structure):
-    _fields_ = [("board", C.c_uint32 * 4), ("status", C.c_uint32), ("n", C.c_int32), ("w", C.c_float), ("p", C.c_float)]
+    _fields_ = [("board", C.c_uint32 * 4), ("status", C.c_uint32), ("n", C.c_int32), ("w", C.c_double), ("p", C.c_float),
+                ("reserved", C.c_int32)]
 
 
 class Tuple(C.Structure):
     _fields_ = [("board", C.c_uint32 * 4), ("mask", C.c_uint32 * 8), ("status", C.c_uint32),
                 ("worker", C.c_int32), ("game", C.c_int32), ("ply", C.c_int32), ("n_children", C.c_int32),
-                ("q", C.c_float), ("q_is_int", C.c_int32), ("z", C.c_int32), ("root_n", C.c_int32),
-                ("root_w", C.c_float), ("chosen", C.c_int32), ("reserved", C.c_int32),
+                ("q", C.c_float), ("q_kind", C.c_int32), ("z", C.c_int32), ("root_n", C.c_int32),
+                ("chosen", C.c_int32), ("root_w", C.c_double),
                 ("pi", C.c_uint32 * MAX_CHILDREN)]
 
 
@@ -46,7 +49,7 @@ class GameResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("expansions", "terminal_visits", "plies", "games", "reroot_misses",
                                           "nodes_created", "compactions", "pool_overflows", "steps",
-                                          "active_slots")]
+                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped")]
 
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",
@@ -75,13 +78,16 @@ def load():
         raise CkrError("libckr.so is missing (%s): build it with `python -m checkers_mcts_amd.build` "
                        "-- there is no CPU fallback" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    if L.ckr_version() != VERSION:
+        raise CkrError("libckr.so is version %d, this binding needs %d: rebuild with `python -m checkers_mcts_amd.build --force`"
+                       % (L.ckr_version(), VERSION))
     vp, i64 = C.c_void_p, C.c_int64
     L.ckr_last_error.restype = C.c_char_p
     L.ckr_movegen_batch.argtypes = [vp, i64, vp, vp, vp]
     L.ckr_children_batch.argtypes = [vp, i64, vp, vp, vp]
     L.ckr_features_batch.argtypes = [vp, i64, vp, vp]
     L.ckr_mask_renorm_batch.argtypes = [vp, i64, vp, vp, vp]
-    L.ckr_hashnet_batch.argtypes = [vp, i64, C.c_uint32, vp, vp, vp]
+    L.ckr_hashnet_batch.argtypes = [vp, i64, C.c_uint32, C.c_int32, vp, vp, vp]
     L.ckr_training_batch.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp]
     L.ckr_arena_partition.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, vp, vp]
     L.ckr_arena_merge.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]

@@ -23,17 +23,50 @@
 namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
-enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS, CNT_N };
+enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS,
+       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_N };
 constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
+
+// ---- leaf cache: network outputs by position.  Checkers.predict is a pure function of planes 0-13 (Checkers.py:425-438),
+// i.e. of (p1, p2, kings, side to move, draw numerator k) and of the network that evaluates it; the reference nevertheless
+// evaluates a position once per tree node: both trees of a game (training_pipeline.py:353-386) expand the continuation of the
+// same game line, and transpositions repeat inside a tree.  The cache keeps what an expansion takes from the network -- the
+// masked, renormalised priors of the children in tree order and v -- in an open-addressing table in HBM shared by all slots
+// of the engine; a leaf found there is expanded on the spot as a network-free simulation.  Results do not depend on it: a
+// cached record holds exactly the floats the expansion would compute again from the same inputs.
+//
+// Concurrency without a single fence (the per-XCD L2s are not coherent with each other; what makes the plain stores of one
+// XCD visible to the plain loads of another is a kernel boundary).  E = number of the running k_step launch, the same in
+// every wave; generation = E >> gen_shift.
+//   claim[i]  : 0 = never used, else key hash (upper 40 bits, top bit set) | launch number of the writer (24 bits).  Changed
+//               only by a device-scope compare-and-swap (atomics act on memory, beyond the L2s).
+//   record[i] : written with plain stores by the wave whose compare-and-swap installed claim[i].
+//   FRESH     : a claim whose generation is the current or the previous one.  Readers accept only fresh claims written by an
+//               EARLIER launch (claim.launch != E): that record is complete and visible.  Writers take only slots that are
+//               unused or NOT fresh -- so a record a reader may accept in this launch is never overwritten in this launch,
+//               and a record being written in this launch (claim.launch == E) is never read.  All waves of a launch agree on
+//               what is fresh, because they share E.  A record therefore serves for one to two generations; one still in
+//               demand after that is evaluated and cached again.
+struct CacheRecord {
+    uint32_t key[4];             // p1, p2, kings, side | k << 1 | network id << 8
+    float    v;
+    uint32_t n;                  // number of children
+    uint32_t pad[10];
+    float    prior[CKR_MAX_CHILDREN];
+};
+static_assert(sizeof(CacheRecord) == 256, "two 128-byte lines per record");
+constexpr int CACHE_PROBES = 4;
+constexpr unsigned long long CACHE_LAUNCH_MASK = 0xFFFFFFull;
 
 struct Dev {
     // configuration
     int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
     int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual, dynamic, total_games, neural, rollout_first, ln_n, uct_n;
+    int w64;                     // ckr_config.w_accum: n_W holds double (1) or float (0); the kernels are instantiated for either
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local
-    uint4* n_board; int32_t* n_parent; uint32_t* n_kids; int32_t* n_N; float* n_W; float* n_P; uint32_t* n_status;
+    uint4* n_board; int32_t* n_parent; uint32_t* n_kids; int32_t* n_N; void* n_W; float* n_P; uint32_t* n_status;
     // per slot
     uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
@@ -46,10 +79,13 @@ struct Dev {
     // per tree (slot*2 + tree)
     int32_t* t_cursor; int32_t* t_used; int32_t* t_half; int32_t* t_searched;
     // outputs
-    ckr_tuple* tuples; float* rs_w; float* rs_p; ckr_game_result* results;
+    ckr_tuple* tuples; double* rs_w; float* rs_p; ckr_game_result* results;
     unsigned long long* counters; const double* sqrt_tab; uint4* leaves;
     const double* ln_tab;        // rollout mode: ln(n) as the host's np.log computes it
     const double* uct_tab;       // rollout mode: pow(2 ln(N) / n, 0.5) for n <= N < uct_n, row N at N(N+1)/2
+    // leaf cache (see CacheRecord); cache == nullptr: off
+    unsigned long long* cache_claim; CacheRecord* cache; unsigned long long cache_mask; int cache_gen_shift;
+    uint32_t* g_epoch;           // [slot] number of k_step launches so far (every launch covers every slot: all equal)
 };
 
 struct WaveLds {
@@ -59,8 +95,14 @@ struct WaveLds {
     uint32_t cnt[CNT_N];                                         // per-wave event counters (lane 0), flushed once
 };
 
-struct Wave {
+// WT = the type MCTS_Node._total_reward accumulates in (MCTS.py:419-430): float under NumPy >= 2 (NEP 50), double under the
+// reference's pinned NumPy 1.19 (requirements.txt:68; python int + np.float32 -> float64); q = w / n (MCTS.py:389-394) has the
+// same type.  Every search function is a template over the wave type so that each mode is its own straight-line code.
+template <typename WT> struct WaveT {
+    using wtype = WT;
     const Dev& D; WaveLds& L; int slot, lane;
+    uint32_t epoch = 0u;         // launch number (leaf cache)
+    __device__ WT* nW() const { return static_cast<WT*>(D.n_W); }
     __device__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
     __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
     __device__ size_t tb(int t) const { return tbase(t, D.t_half[slot * 2 + t]); }
@@ -153,19 +195,19 @@ __device__ __forceinline__ double decayed_tau(const Dev& D, double tau, int move
 }
 
 // ---- backups: MCTS_Node.backpropagation + MCTS.determine_reward (MCTS.py:149-186,419-430)
-__device__ void backup_value(Wave& w, int t, int node, float v, uint32_t sim_player) {
+template <class Wave> __device__ void backup_value(Wave& w, int t, int node, float v, uint32_t sim_player) {
     const size_t tb = w.tb(t);
     const int root = w.D.t_cursor[w.slot * 2 + t];
     for (int n = node;;) {
         const uint32_t st = w.D.n_status[tb + n];
         const uint32_t mover = (st >> 4) & 1u;
         const float reward = (sim_player != mover) ? -1.0f * v : v;
-        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.D.n_W[tb + n] += reward; }
+        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.nW()[tb + n] += (typename Wave::wtype)reward; }
         if (n == root) break;
         n = w.D.n_parent[tb + n];
     }
 }
-__device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
+template <class Wave> __device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
     const size_t tb = w.tb(t);
     const int root = w.D.t_cursor[w.slot * 2 + t];
     for (int n = node;;) {
@@ -174,7 +216,7 @@ __device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
         float reward = 0.0f;
         if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
         else if (outcome == 2u) reward = mover == 1u ? 1.0f : -1.0f;
-        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.D.n_W[tb + n] += reward; }
+        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.nW()[tb + n] += (typename Wave::wtype)reward; }
         if (n == root) break;
         n = w.D.n_parent[tb + n];
     }
@@ -184,21 +226,21 @@ __device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
 // lane): every node of a path is distinct, so the read-modify-writes are independent and issue in
 // one round instead of one dependent round trip per tree level.  Per node the order of the float32
 // accumulation over simulations is unchanged.
-__device__ __forceinline__ void backup_value_path(Wave& w, int t, uint32_t entry, int len, float v, uint32_t sim_player) {
+template <class Wave> __device__ __forceinline__ void backup_value_path(Wave& w, int t, uint32_t entry, int len, float v, uint32_t sim_player) {
     if (w.lane < len) {
         const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
         const float reward = (sim_player != ((entry >> 30) & 1u)) ? -1.0f * v : v;
-        w.D.n_N[i] += 1; w.D.n_W[i] += reward;
+        w.D.n_N[i] += 1; w.nW()[i] += (typename Wave::wtype)reward;
     }
 }
-__device__ __forceinline__ void backup_outcome_path(Wave& w, int t, uint32_t entry, int len, uint32_t outcome) {
+template <class Wave> __device__ __forceinline__ void backup_outcome_path(Wave& w, int t, uint32_t entry, int len, uint32_t outcome) {
     if (w.lane < len) {
         const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
         const uint32_t mover = (entry >> 30) & 1u;
         float reward = 0.0f;
         if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
         else if (outcome == 2u) reward = mover == 1u ? 1.0f : -1.0f;
-        w.D.n_N[i] += 1; w.D.n_W[i] += reward;
+        w.D.n_N[i] += 1; w.nW()[i] += (typename Wave::wtype)reward;
     }
 }
 
@@ -229,15 +271,16 @@ template <int GAME> __device__ __forceinline__ uint4 rules_initial_board() {
 template <int GAME> __device__ __forceinline__ uint32_t rules_initial_status() { return GAME == 0 ? (7u << 8) : (9u << 8); }
 
 // ---- tree bookkeeping
-__device__ void write_node(const Dev& D, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
+template <class Wave> __device__ void write_node(const Wave& w, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
+    const Dev& D = w.D;
     st_board(&D.n_board[idx], b);
-    D.n_parent[idx] = parent; D.n_kids[idx] = 0u; D.n_N[idx] = 0; D.n_W[idx] = 0.0f; D.n_P[idx] = prior;
+    D.n_parent[idx] = parent; D.n_kids[idx] = 0u; D.n_N[idx] = 0; w.nW()[idx] = 0; D.n_P[idx] = prior;
     D.n_status[idx] = status;
 }
 
 // MCTS_Node(state) for a tree that has no node for the live game state
 // (start of the game, MCTS.py:350-376, or the reply-missing case :289-295).
-template <int GAME = 0> __device__ void fresh_root(Wave& w, int t) {
+template <int GAME = 0, class Wave> __device__ void fresh_root(Wave& w, int t) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const ckr_board b = ld_board(&D.g_board[w.slot]);
@@ -245,7 +288,7 @@ template <int GAME = 0> __device__ void fresh_root(Wave& w, int t) {
     rules_movegen<GAME>(b, m, st);
     if (w.lane == 0) {
         D.t_half[ti] = 0;
-        write_node(D, w.tbase(t, 0), b, -1, 0.0f, st | (meta_mover(b.meta) << 4));
+        write_node(w, w.tbase(t, 0), b, -1, 0.0f, st | (meta_mover(b.meta) << 4));
         D.t_cursor[ti] = 0; D.t_used[ti] = 1;
     }
     w.count(CNT_NODES);
@@ -255,7 +298,7 @@ template <int GAME = 0> __device__ void fresh_root(Wave& w, int t) {
 // Semispace copy of the subtree under the cursor (breadth first, children stay
 // contiguous).  64 nodes per pass: lane = node, wave scan assigns child blocks.
 // Returns the new index of node `track` (a node of the subtree; -1: none asked for).
-__device__ int compact(Wave& w, int t, int track = -1) {
+template <class Wave> __device__ int compact(Wave& w, int t, int track = -1) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const int half = D.t_half[ti];
@@ -263,7 +306,7 @@ __device__ int compact(Wave& w, int t, int track = -1) {
     const int root = D.t_cursor[ti];
     if (w.lane == 0) {
         D.n_board[dst] = D.n_board[src + root]; D.n_parent[dst] = -1; D.n_kids[dst] = D.n_kids[src + root];
-        D.n_N[dst] = D.n_N[src + root]; D.n_W[dst] = D.n_W[src + root]; D.n_P[dst] = D.n_P[src + root];
+        D.n_N[dst] = D.n_N[src + root]; w.nW()[dst] = w.nW()[src + root]; D.n_P[dst] = D.n_P[src + root];
         D.n_status[dst] = D.n_status[src + root];
     }
     wave_mem_fence();
@@ -285,7 +328,7 @@ __device__ int compact(Wave& w, int t, int track = -1) {
         for (int c = 0; c < nk; ++c) {
             const size_t s = src + ob + c, d = dst + nb + c;
             D.n_board[d] = D.n_board[s]; D.n_parent[d] = idx; D.n_kids[d] = D.n_kids[s];
-            D.n_N[d] = D.n_N[s]; D.n_W[d] = D.n_W[s]; D.n_P[d] = D.n_P[s]; D.n_status[d] = D.n_status[s];
+            D.n_N[d] = D.n_N[s]; w.nW()[d] = w.nW()[s]; D.n_P[d] = D.n_P[s]; D.n_status[d] = D.n_status[s];
             if (ob + c == track) moved = nb + c;
         }
         for (int c = nk; c < reserve; ++c) { D.n_kids[dst + nb + c] = 0u; D.n_status[dst + nb + c] = 0u; }
@@ -301,7 +344,7 @@ __device__ int compact(Wave& w, int t, int track = -1) {
 // Start of a ply's search for the side to move: (re)root its tree
 // (MCTS.new_root_node, MCTS.py:251-295 -- the cursor already followed every
 // ply played, see advance_cursor) and reset the rollout counter (:216-217).
-template <int GAME = 0> __device__ void start_search(Wave& w) {
+template <int GAME = 0, class Wave> __device__ void start_search(Wave& w) {
     const Dev& D = w.D;
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
@@ -315,7 +358,7 @@ template <int GAME = 0> __device__ void start_search(Wave& w) {
     wave_mem_fence();
 }
 
-template <int GAME = 0> __device__ void new_game(Wave& w) {
+template <int GAME = 0, class Wave> __device__ void new_game(Wave& w) {
     const Dev& D = w.D;
     if (w.lane == 0) {
         // Checkers.reset / init_board (Checkers.py:405-423); the mover into the
@@ -333,6 +376,77 @@ template <int GAME = 0> __device__ void new_game(Wave& w) {
     start_search<GAME>(w);
 }
 
+// ---- leaf cache probes
+__device__ __forceinline__ uint4 cache_key(const ckr_board b, uint32_t status, int net) {
+    return make_uint4(b.p1, b.p2, b.kings, (b.meta & 1u) | (st_drawk(status) << 1) | ((uint32_t)(net & 1) << 8));
+}
+__device__ __forceinline__ unsigned long long cache_hash(const uint4 k) {
+    unsigned long long a = (unsigned long long)k.x | ((unsigned long long)k.y << 32);
+    const unsigned long long b = (unsigned long long)k.z | ((unsigned long long)k.w << 32);
+    a *= 0x9E3779B97F4A7C15ull; a ^= a >> 32; a += b;
+    a *= 0xC2B2AE3D27D4EB4Full; a ^= a >> 29;
+    a *= 0x165667B19E3779F9ull; a ^= a >> 32;
+    return a;
+}
+// claim word of a key written in launch E; its table index comes from the low hash bits, its tag from the upper 40
+__device__ __forceinline__ unsigned long long cache_claim_word(unsigned long long h, uint32_t E) {
+    return ((h | 0x8000000000000000ull) & ~CACHE_LAUNCH_MASK) | ((unsigned long long)E & CACHE_LAUNCH_MASK);
+}
+__device__ __forceinline__ bool cache_fresh(const Dev& D, unsigned long long claim, uint32_t E) {
+    const uint32_t gens = (uint32_t)(CACHE_LAUNCH_MASK >> D.cache_gen_shift);                       // generation counter wraps with the 24-bit launch number
+    const uint32_t g = (uint32_t)(claim & CACHE_LAUNCH_MASK) >> D.cache_gen_shift, G = (E & (uint32_t)CACHE_LAUNCH_MASK) >> D.cache_gen_shift;
+    return claim != 0ull && ((G - g) & gens) <= 1u;
+}
+// All lanes pass the same key.  On a hit: lane l < n gets the prior of child l, every lane v and n.
+template <class Wave> __device__ __forceinline__ bool cache_lookup(const Wave& w, const uint4 key, float& prior, float& v, int& n) {
+    const Dev& D = w.D;
+    const unsigned long long h = cache_hash(key), mine = cache_claim_word(h, 0u);
+    for (int i = 0; i < CACHE_PROBES; ++i) {
+        const size_t at = (size_t)((h + (unsigned long long)i) & D.cache_mask);
+        const unsigned long long claim = D.cache_claim[at];          // same round of loads as the record
+        const CacheRecord* r = D.cache + at;
+        const uint4 k = *reinterpret_cast<const uint4*>(r->key);
+        const float rv = r->v;
+        const uint32_t rn = r->n;
+        const float pr = r->prior[w.lane < CKR_MAX_CHILDREN ? w.lane : 0];
+        if (claim == 0ull) return false;
+        if ((claim & ~CACHE_LAUNCH_MASK) != mine) continue;
+        if (!cache_fresh(D, claim, w.epoch) || (claim & CACHE_LAUNCH_MASK) == ((unsigned long long)w.epoch & CACHE_LAUNCH_MASK)) return false;
+        if (k.x != key.x || k.y != key.y || k.z != key.z || k.w != key.w) return false;   // 40-bit tag collision: not this position
+        prior = pr; v = rv; n = (int)rn;
+        return true;
+    }
+    return false;
+}
+// priors of the n children (lane l < n: child l) and v of the position `key`, just computed from the network's output
+template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, const uint4 key, int n, float prior, float v) {
+    const Dev& D = w.D;
+    const unsigned long long h = cache_hash(key), mine = cache_claim_word(h, w.epoch);
+    for (int i = 0; i < CACHE_PROBES; ++i) {
+        const size_t at = (size_t)((h + (unsigned long long)i) & D.cache_mask);
+        unsigned long long cur = D.cache_claim[at];
+        if (!cache_fresh(D, cur, w.epoch)) {                        // unused, or too old for any reader: take it
+            unsigned long long old = 0ull;
+            if (w.lane == 0) old = atomicCAS(&D.cache_claim[at], cur, mine);
+            old = ((unsigned long long)(uint32_t)bcast_i32((int)(uint32_t)(old >> 32), 0) << 32) | (uint32_t)bcast_i32((int)(uint32_t)old, 0);
+            if (old == cur) {                                       // ours: write the record
+                CacheRecord* r = D.cache + at;
+                if (w.lane < n) r->prior[w.lane] = prior;
+                if (w.lane == 0) {
+                    *reinterpret_cast<uint4*>(r->key) = key;
+                    r->v = v; r->n = (uint32_t)n;
+                }
+                w.count(CNT_CINS);
+                return;
+            }
+            cur = old;                                              // another wave was faster (or the plain load was stale)
+            if (!cache_fresh(D, cur, w.epoch)) continue;            // (only a stale load can bring us here: next slot)
+        }
+        if ((cur & ~CACHE_LAUNCH_MASK) == (mine & ~CACHE_LAUNCH_MASK)) return;   // present, or being written by another wave
+    }
+    w.count(CNT_CDROP);                                             // neighbourhood full of fresh records: not cached
+}
+
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
 // Checkers.predict's mask/renormalise (Checkers.py:435-437) and
 // set_prior_probs (:440-452).  Returns false on pool overflow.
@@ -340,7 +454,10 @@ template <int GAME = 0> __device__ void new_game(Wave& w) {
 // phase / pending leaf (one dependent round less per item than loading them where they are used).
 struct ExpandPre { int half, used, plen; uint32_t entry; };
 
-__device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre) {
+// CACHED: the priors come from the leaf cache (cached_prior: child `lane`), prow is not read.  net: the network that
+// evaluated the leaf (key of the cache record written when !CACHED).
+template <bool CACHED, class Wave> __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
+                                                           float cached_prior, int cached_n, int net) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const size_t tb = w.tbase(t, pre.half);
@@ -348,32 +465,40 @@ __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow,
     // the nodes on the recorded path (their updates are stored at the end; nothing in between touches them)
     const ckr_board b = ld_board(&D.n_board[tb + leaf]);
     const uint32_t leaf_status = D.n_status[tb + leaf];
-    const float4* src = reinterpret_cast<const float4*>(prow);
-    const float4 p0 = src[w.lane], p1 = src[w.lane + 64];
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+    if (!CACHED) {
+        const float4* src = reinterpret_cast<const float4*>(prow);
+        p0 = src[w.lane]; p1 = src[w.lane + 64];
+    }
     const bool on_path = pre.plen <= 64 && w.lane < pre.plen;
     const size_t pnode = tb + (pre.entry & 0x3FFFFFFFu);
-    int path_n = 0; float path_w = 0.0f;
-    if (on_path) { path_n = D.n_N[pnode]; path_w = D.n_W[pnode]; }
+    using WT = typename Wave::wtype;
+    int path_n = 0; WT path_w = 0;
+    if (on_path) { path_n = D.n_N[pnode]; path_w = w.nW()[pnode]; }
     uint32_t m[8], st;
     movegen(b, m, st);
-    if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
-    {
+    float total = 1.0f;
+    if (!CACHED) {
+        if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
         float4* dl = reinterpret_cast<float4*>(w.L.u.p);
         dl[w.lane] = p0; dl[w.lane + 64] = p1;
+        __builtin_amdgcn_wave_barrier();
+        total = wave_masked_sum(w.L.u.p, w.L.mask);
     }
-    __builtin_amdgcn_wave_barrier();
-    const float total = wave_masked_sum(w.L.u.p, w.L.mask);
     const int n = wave_children(b, m, w.L.kids, true);
     __builtin_amdgcn_wave_barrier();
     const int used = pre.used;
     if (used + n > D.C) return false;
+    if (CACHED && n != cached_n) return false;                // cannot happen (the successor list is a function of the key)
+    float prior = cached_prior;
     if (w.lane < n) {
         const ckr_board c = w.L.kids[w.lane];
         uint32_t cm[8], cst;
         movegen(c, cm, cst);
-        const float prior = w.L.u.p[meta_action(c.meta)] / total;
-        write_node(D, tb + used + w.lane, c, leaf, prior, cst | ((b.meta & 1u) << 4));
+        if (!CACHED) prior = w.L.u.p[meta_action(c.meta)] / total;
+        write_node(w, tb + used + w.lane, c, leaf, prior, cst | ((b.meta & 1u) << 4));
     }
+    if (!CACHED && D.cache) cache_insert(w, cache_key(b, st, net), n, prior, v);
     if (w.lane == 0) {
         D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
         D.n_status[tb + leaf] = leaf_status | ST_EXPANDED;
@@ -384,7 +509,7 @@ __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow,
     if (pre.plen <= 64) {                                     // backup along the recorded path (cf. backup_value_path)
         if (on_path) {
             const float reward = (sim_player != ((pre.entry >> 30) & 1u)) ? -1.0f * v : v;
-            D.n_N[pnode] = path_n + 1; D.n_W[pnode] = path_w + reward;
+            D.n_N[pnode] = path_n + 1; w.nW()[pnode] = path_w + (WT)reward;
         }
     } else {
         wave_mem_fence();
@@ -399,7 +524,7 @@ __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow,
 // child (:93-94).  Scores are float64 exactly as NumPy evaluates them:
 //   q32 + ((c * P') * N_parent**0.5) / (1 + N_child),
 //   P' = float32((1-eps) * P) + eps * dirichlet.
-__device__ int descend(Wave& w, int t) {
+template <class Wave> __device__ int descend(Wave& w, int t, int& plen_out, uint32_t& entry_out) {
     const Dev& D = w.D;
     const size_t tb = w.tb(t);
     int node = D.t_cursor[w.slot * 2 + t];
@@ -418,13 +543,15 @@ __device__ int descend(Wave& w, int t) {
         if (!(st & ST_EXPANDED)) {
             if (w.lane == 0) { D.g_plen[w.slot] = lvl; if (D.epsilon != 0.0) D.g_rng[w.slot] = ctr; }
             if (lvl <= 64) D.g_path[(size_t)w.slot * 64 + w.lane] = entry;
+            plen_out = lvl; entry_out = entry;
             return node;
         }
         const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
         const bool act = w.lane < n;
         const size_t ci = tb + base + (act ? w.lane : 0);
         const int cn = D.n_N[ci];
-        const float cw = D.n_W[ci], cp = D.n_P[ci];
+        const typename Wave::wtype cw = w.nW()[ci];
+        const float cp = D.n_P[ci];
         const uint32_t cst = D.n_status[ci], ckids = D.n_kids[ci];
         double dir = 0.0;
         if (D.epsilon != 0.0) {
@@ -432,7 +559,7 @@ __device__ int descend(Wave& w, int t) {
             ++ctr;
         }
         const double sqrt_n = np < D.sqrt_n ? D.sqrt_tab[np] : sqrt((double)np);
-        const float q = cn ? cw / (float)cn : 0.0f;
+        const typename Wave::wtype q = cn ? cw / (typename Wave::wtype)cn : (typename Wave::wtype)0;   // MCTS_Node.q, in W's type
         const float pf = one_minus * cp;
         const double psa = (double)pf + D.epsilon * dir;
         const double u = ((D.uct_c * psa) * sqrt_n) / (double)(1 + cn);
@@ -512,7 +639,7 @@ template <int GAME> __device__ __forceinline__ ckr_board rules_child(const ckr_b
 }
 
 // uniform random playout to the end of the game (MCTS.py:139-143); returns the outcome code
-template <int GAME> __device__ uint32_t playout(Wave& w, ckr_board b) {
+template <int GAME, class Wave> __device__ uint32_t playout(Wave& w, ckr_board b) {
     const Dev& D = w.D;
     const uint32_t ctr = D.g_rng[w.slot];
     if (w.lane == 0) D.g_rng[w.slot] = ctr + 1u;
@@ -531,7 +658,7 @@ template <int GAME> __device__ uint32_t playout(Wave& w, ckr_board b) {
 }
 
 // one simulation of the non-NN tree policy; false when the node pool is full (nothing has been changed then)
-template <int GAME> __device__ bool rollout_sim(Wave& w, int t) {
+template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const size_t tb = w.tb(t);
@@ -561,7 +688,7 @@ template <int GAME> __device__ bool rollout_sim(Wave& w, int t) {
             rules_movegen<GAME>(c, cm, cst);
             const int ci = base + created;
             if (w.lane == 0) {
-                write_node(D, tb + ci, c, node, 0.0f, cst | ((b.meta & 1u) << 4));
+                write_node(w, tb + ci, c, node, 0.0f, cst | ((b.meta & 1u) << 4));
                 D.n_kids[tb + node] = (uint32_t)base | ((uint32_t)(created + 1) << 24);
             }
             wave_mem_fence();
@@ -576,7 +703,7 @@ template <int GAME> __device__ bool rollout_sim(Wave& w, int t) {
         const bool act = w.lane < nleg;
         const size_t ci = tb + base + (act ? w.lane : 0);
         const int cn = D.n_N[ci];
-        const float cw = D.n_W[ci];
+        const double cw = (double)w.nW()[ci];                 // a python int in this mode (exact in either type)
         const uint32_t cst = D.n_status[ci];
         double root;
         if (np < D.uct_n) root = D.uct_tab[(size_t)np * (size_t)(np + 1) / 2 + (size_t)(act ? cn : 1)];
@@ -584,7 +711,7 @@ template <int GAME> __device__ bool rollout_sim(Wave& w, int t) {
             const double lnN = np < D.ln_n ? D.ln_tab[np] : log((double)np);
             root = sqrt((2.0 * lnN) / (double)cn);
         }
-        const double q = (double)cw / (double)cn;
+        const double q = cw / (double)cn;
         const double score = q + (2.0 * D.uct_c) * root;
         const int best = wave_argmax_first(score, nleg);
         const uint32_t bst = (uint32_t)bcast_i32((int)cst, best);
@@ -606,11 +733,11 @@ __device__ __forceinline__ int p1_net_of(const Dev& D, int slot) {
 }
 
 // ---- tuple helpers (training_pipeline.py:364-369,406-410,421-455)
-__device__ size_t tuple_index(const Wave& w, int ply) {
+template <class Wave> __device__ size_t tuple_index(const Wave& w, int ply) {
     return (size_t)w.D.g_gid[w.slot] * (size_t)w.D.tuples_per_game + (size_t)ply;
 }
 
-template <int GAME = 0> __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
+template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
     const Dev& D = w.D;
     const int game = D.g_game[w.slot], moves = D.g_moves[w.slot];
     int n_tuples = 0;
@@ -624,8 +751,8 @@ template <int GAME = 0> __device__ void end_game(Wave& w, uint32_t outcome, int 
             if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
             if (w.lane == 0) {
                 T->board = gb; T->status = st; T->worker = D.first_worker + w.slot; T->game = game; T->ply = moves;
-                T->n_children = 0; T->q = outcome == 3u ? 0.0f : -1.0f; T->q_is_int = 1; T->root_n = 0;
-                T->root_w = 0.0f; T->chosen = -1;
+                T->n_children = 0; T->q = outcome == 3u ? 0.0f : -1.0f; T->q_kind = CKR_Q_INT; T->root_n = 0;
+                T->root_w = 0.0; T->chosen = -1;
             }
         }
         wave_mem_fence();
@@ -672,7 +799,7 @@ template <int GAME = 0> __device__ void end_game(Wave& w, uint32_t outcome, int 
 // ---- end of a ply: MCTS.best_child (MCTS.py:227-248), Checkers.step
 // (Checkers.py:62-75), tuple emission, TERMINATE_CNT adjudication
 // (training_pipeline.py:387-405), cursor updates for both trees.
-template <int GAME = 0> __device__ void finish_ply(Wave& w) {
+template <int GAME = 0, class Wave> __device__ void finish_ply(Wave& w) {
     const Dev& D = w.D;
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
@@ -709,17 +836,20 @@ template <int GAME = 0> __device__ void finish_ply(Wave& w) {
         if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
         if (act) T->pi[w.lane] = (meta_action(ld_board(&D.n_board[tb + base + w.lane]).meta) << 23) | (uint32_t)cn;
         if (D.record_root && act) {
-            D.rs_w[tix * CKR_MAX_CHILDREN + w.lane] = D.n_W[tb + base + w.lane];
+            D.rs_w[tix * CKR_MAX_CHILDREN + w.lane] = (double)w.nW()[tb + base + w.lane];
             D.rs_p[tix * CKR_MAX_CHILDREN + w.lane] = D.n_P[tb + base + w.lane];
         }
         if (w.lane == 0) {
             const int rn = D.n_N[tb + root];
-            const float rw = D.n_W[tb + root];
-            const float q = rn ? rw / (float)rn : 0.0f;
+            using WT = typename Wave::wtype;
+            const WT rw = w.nW()[tb + root];
+            const WT q = rn ? rw / (WT)rn : (WT)0;
+            const bool neg = meta_mover(rb.meta) != (rb.meta & 1u);     // qval = -root.q / root.q, :365-368
             T->board = rb; T->status = st; T->worker = D.first_worker + w.slot; T->game = D.g_game[w.slot];
             T->ply = moves; T->n_children = n;
-            T->q = (meta_mover(rb.meta) != (rb.meta & 1u)) ? -q : q;     // :365-368
-            T->q_is_int = 0; T->z = 0; T->root_n = rn; T->root_w = rw; T->chosen = (int)meta_action(cb.meta);
+            T->q = (float)(neg ? -q : q);
+            T->q_kind = sizeof(WT) == 8 ? (neg ? CKR_Q_F64_NEG : CKR_Q_F64) : CKR_Q_F32;
+            T->z = 0; T->root_n = rn; T->root_w = (double)rw; T->chosen = (int)meta_action(cb.meta);
         }
     }
     // Checkers.step: the chosen child becomes the live state
@@ -762,7 +892,7 @@ template <int GAME = 0> __device__ void finish_ply(Wave& w) {
     else start_search<GAME>(w);
 }
 
-__device__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
+template <class Wave> __device__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
     const Dev& D = w.D;
     uint32_t m[8], st;
     movegen(b, m, st);
@@ -794,7 +924,7 @@ __device__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void flush_counters(Wave& w) {
+template <class Wave> __device__ __forceinline__ void flush_counters(Wave& w) {
     if (w.lane != 0) return;
 #pragma unroll
     for (int i = 0; i < CNT_N; ++i)
@@ -805,12 +935,12 @@ __device__ __forceinline__ void flush_counters(Wave& w) {
 // Kernels take the engine descriptor by POINTER to device memory: every field read is a
 // uniform scalar load (a by-value struct whose address is taken is copied to scratch and
 // turned ~0.5 KB/lane of private-memory traffic per launch).
-template <int GAME> __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
+template <int GAME, typename WT> __global__ __launch_bounds__(256) void k_init(const Dev* __restrict__ Dp) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id()};
+    WaveT<WT> w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     const int gid0 = D.dynamic ? slot : slot * D.games_per_slot;
     if (w.lane == 0) {
@@ -827,15 +957,19 @@ template <int GAME> __global__ __launch_bounds__(256) void k_init(const Dev* __r
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
-__global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
+template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
                                               const float* __restrict__ v, void* x, int32_t* net_out, int end_ply) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id()};
+    WaveT<WT> w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (slot == 0) w.count(CNT_STEPS);
+    if (D.cache) {                                             // launch number, kept per slot: no cross-wave word needed
+        w.epoch = D.g_epoch[slot];
+        if (w.lane == 0) D.g_epoch[slot] = w.epoch + 1u;
+    }
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
     const int row = D.g_row[slot];
@@ -847,14 +981,15 @@ __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, con
     asm volatile("" :: "v"(pre.half), "v"(pre.used), "v"(pre.plen), "v"(pre.entry));   // keep the loads up here
     if (pending >= 0 && phase0 == PH_PLAYING) {
         const int t = t0;
-        bool ok = expand(w, t, pending, p + (size_t)row * 512, v[row], pre);
+        const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
+        bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet);
         if (!ok) {
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
             // to 48 children): drop the garbage now and retry; the recorded path is stale after the move, so the
             // backup walks the parent links (plen > 64)
             const int moved = compact(w, t, pending);
             ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
-            ok = moved >= 0 && expand(w, t, moved, p + (size_t)row * 512, v[row], again);
+            ok = moved >= 0 && expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet);
         }
         if (ok) {
             if (w.lane == 0) D.g_sims[slot] += 1;
@@ -879,13 +1014,30 @@ __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, con
         }
         if (free_sims >= D.max_sims) break;
         const int t = (int)(D.g_board[slot].w & 1u);
-        leaf = descend(w, t);
+        int plen = 0; uint32_t pentry = 0u;
+        leaf = descend(w, t, plen, pentry);
         if (leaf < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
         lb = ld_board(&D.n_board[w.tb(t) + leaf]);
         if (D.tournament) {
             const int p1_net = p1_net_of(D, slot);
             net = t == 0 ? p1_net : 1 - p1_net;                          // training_pipeline.py:523-529,536,546
         } else net = 0;
+        if (D.cache) {                                                   // evaluated before (by any slot, either tree)?
+            uint32_t lm[8], lst;
+            movegen(lb, lm, lst);
+            float cprior = 0.0f, cv = 0.0f; int cn = 0;
+            if (cache_lookup(w, cache_key(lb, lst, net), cprior, cv, cn)) {
+                const ExpandPre now{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], plen, pentry};
+                if (expand<true>(w, t, leaf, nullptr, cv, now, cprior, cn, net)) {
+                    w.count(CNT_HIT);
+                    if (w.lane == 0) D.g_sims[slot] += 1;
+                    wave_mem_fence();
+                    leaf = -1; ++free_sims;
+                    continue;
+                }                                                        // pool full: let the network path compact and retry
+            }
+        }
+        w.count(CNT_NN);
         break;
     }
     if (w.lane == 0) {
@@ -904,7 +1056,7 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id()};
+    WaveT<float> w{D, lds[wave], slot, lane_id()};   // W is a python int in this mode: exact in float
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (slot == 0) w.count(CNT_STEPS);
     // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198): the wall-clock budget of the running searches is used up -- a slot
@@ -930,7 +1082,7 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
 
 // ---- interactive commands (manual_play): Checkers.step / reset and begin_tree_search
 // for the per-tree search interface of the reference (MCTS.py:211-295, Checkers.py:62-75).
-__device__ int apply_action(Wave& w, int action) {
+template <class Wave> __device__ int apply_action(Wave& w, int action) {
     const Dev& D = w.D;
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     uint32_t m[8], st;
@@ -969,13 +1121,13 @@ __device__ int apply_action(Wave& w, int action) {
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_command(const Dev* __restrict__ Dp, const int32_t* __restrict__ cmd,
+template <typename WT> __global__ __launch_bounds__(256) void k_command(const Dev* __restrict__ Dp, const int32_t* __restrict__ cmd,
                                                  const int32_t* __restrict__ arg, int32_t* __restrict__ err) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
-    Wave w{D, lds[wave], slot, lane_id()};
+    WaveT<WT> w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     const int c = cmd[slot];
     int e = 0;
@@ -1124,7 +1276,7 @@ template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool
 }
 
 static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
-static_assert(sizeof(ckr_config) == 128, "ckr_config layout is mirrored by _lib.Config (ctypes)");
+static_assert(sizeof(ckr_config) == 136, "ckr_config layout is mirrored by _lib.Config (ctypes)");
 
 extern "C" {
 
@@ -1141,6 +1293,10 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (c->feature_dtype < 0 || c->feature_dtype > 2) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1 or 2");
     if (c->alpha <= 0.0 && c->epsilon != 0.0) return fail(CKR_ERR_INVALID, "DIRICHLET_ALPHA must be > 0");
     if (c->game != 0 && c->game != 1) return fail(CKR_ERR_INVALID, "game must be 0 (Checkers) or 1 (Tic-Tac-Toe)");
+    if (c->w_accum != 0 && c->w_accum != 1) return fail(CKR_ERR_INVALID, "w_accum must be 0 (float32) or 1 (float64)");
+    if (c->leaf_cache_log2 != 0 && (c->leaf_cache_log2 < 10 || c->leaf_cache_log2 > 30))
+        return fail(CKR_ERR_INVALID, "leaf_cache_log2 must be 0 (off) or in [10, 30]");
+    if (c->leaf_cache_gen_log2 < 0 || c->leaf_cache_gen_log2 > 20) return fail(CKR_ERR_INVALID, "leaf_cache_gen_log2 must be in [0, 20]");
     if (c->game == 1 && (c->neural_net || c->manual_play || c->tournament))
         return fail(CKR_ERR_INVALID, "Tic-Tac-Toe (game = 1) is offered in the random-rollout self-play mode only (neural_net = 0)");
     CKR_HIP(hipSetDevice(c->device));
@@ -1155,6 +1311,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
     D.total_games = c->n_slots * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
+    D.w64 = (c->w_accum == 1 && c->neural_net) ? 1 : 0;
+    const int cache_log2 = c->neural_net ? c->leaf_cache_log2 : 0;       // random-rollout mode: W is a python int in the reference, exact in float
     D.tuples_per_game = (c->tournament || c->manual_play) ? 0 : c->terminate_cnt + 1;
     D.margin = c->budget > (1 << 20) ? D.C / 2 : c->budget * 16 + 64;    // unbounded (time-limited) searches: compact early
     if (D.margin > D.C / 2) D.margin = D.C / 2;
@@ -1165,7 +1323,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     int rc = CKR_OK;
 #define A(ptr, count, zero) if (rc == CKR_OK) rc = dalloc(e, &ptr, (count), (zero))
     A(D.n_board, NN, false); A(D.n_parent, NN, false); A(D.n_kids, NN, false); A(D.n_N, NN, false);
-    A(D.n_W, NN, false); A(D.n_P, NN, false); A(D.n_status, NN, false);
+    A(D.n_P, NN, false); A(D.n_status, NN, false);
+    if (D.w64) { double* nw = nullptr; A(nw, NN, false); D.n_W = nw; } else { float* nw = nullptr; A(nw, NN, false); D.n_W = nw; }
     A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
     A(D.g_path, S * 64, true); A(D.g_plen, S, true); A(D.g_row, S, true); A(e->d_row_tmp, S, true);
@@ -1177,6 +1336,14 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.results, (size_t)e->n_games_total, true);
     A(D.counters, (size_t)CNT_SHARDS * CNT_STRIDE, true);
     A(D.leaves, S, true);
+    A(D.g_epoch, S, true);
+    if (cache_log2 > 0) {
+        const size_t cap = (size_t)1 << cache_log2;
+        A(D.cache_claim, cap + CACHE_PROBES, true);
+        A(D.cache, cap + CACHE_PROBES, true);
+        D.cache_mask = (unsigned long long)(cap - 1);
+        D.cache_gen_shift = c->leaf_cache_gen_log2 > 0 ? c->leaf_cache_gen_log2 : 11;
+    }
     // node.n ** 0.5 is C pow() in the reference (python int ** float), which is
     // NOT always sqrt(): keep a host-computed table for the counts that occur.
     D.sqrt_n = 1 << 16;
@@ -1214,8 +1381,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
         }
         e->d_dev = d_dev;
     }
-    if (c->game == 1) hipLaunchKernelGGL(k_init<1>, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
-    else hipLaunchKernelGGL(k_init<0>, dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
+    if (c->game == 1) hipLaunchKernelGGL((k_init<1, float>), dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
+    else if (D.w64) hipLaunchKernelGGL((k_init<0, double>), dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
+    else hipLaunchKernelGGL((k_init<0, float>), dim3((c->n_slots + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)e->d_dev);
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
         ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "engine init kernel failed");
     }
@@ -1282,7 +1450,8 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_step drives the NEURAL_NET search; use ckr_engine_rollout");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
     note_stream(&e->last_stream, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_step, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
+    if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
+    else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
     CKR_HIP(hipGetLastError());
     e->steps++;
     return CKR_OK;
@@ -1322,6 +1491,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS]; out->active_slots = active;
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP];
     return CKR_OK;
 }
 
@@ -1391,19 +1561,19 @@ int ckr_engine_tuples(ckr_engine* e, ckr_tuple* out, int64_t cap, int64_t* n) {
     return CKR_OK;
 }
 
-int ckr_engine_root_stats(ckr_engine* e, float* w_out, float* p_out, int64_t cap) {
+int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t cap) {
     if (!e || !w_out || !p_out) return fail(CKR_ERR_INVALID, "ckr_engine_root_stats: null argument");
     if (!e->dev.record_root) return fail(CKR_ERR_STATE, "engine was created without record_root_stats");
     std::vector<ckr_game_result> all;
     if (int rc = fetch_results(e, all)) return rc;
     int64_t k = 0;
-    const size_t row = CKR_MAX_CHILDREN * sizeof(float);
+    const size_t row = CKR_MAX_CHILDREN * sizeof(float), wrow = CKR_MAX_CHILDREN * sizeof(double);
     for (size_t g = 0; g < all.size(); ++g)
         if (all[g].game >= 0 && all[g].n_tuples > 0) {
             const int64_t cnt = all[g].n_tuples;
             if (k + cnt > cap) return fail(CKR_ERR_INVALID, "ckr_engine_root_stats: buffer too small");
             const size_t s = g * (size_t)e->dev.tuples_per_game * CKR_MAX_CHILDREN;
-            CKR_HIP(hipMemcpy(w_out + k * CKR_MAX_CHILDREN, e->dev.rs_w + s, (size_t)cnt * row, hipMemcpyDeviceToHost));
+            CKR_HIP(hipMemcpy(w_out + k * CKR_MAX_CHILDREN, e->dev.rs_w + s, (size_t)cnt * wrow, hipMemcpyDeviceToHost));
             CKR_HIP(hipMemcpy(p_out + k * CKR_MAX_CHILDREN, e->dev.rs_p + s, (size_t)cnt * row, hipMemcpyDeviceToHost));
             k += cnt;
         }
@@ -1418,8 +1588,10 @@ int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, in
     CKR_HIP(hipDeviceSynchronize());
     CKR_HIP(hipMemcpy(e->d_cmd, cmd, S * sizeof(int32_t), hipMemcpyHostToDevice));
     CKR_HIP(hipMemcpy(e->d_cmd + S, arg, S * sizeof(int32_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_command, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, (const Dev*)e->d_dev,
-                       (const int32_t*)e->d_cmd, (const int32_t*)(e->d_cmd + S), e->d_cmd + 2 * S);
+    if (e->dev.w64) hipLaunchKernelGGL(k_command<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, (const Dev*)e->d_dev,
+                                       (const int32_t*)e->d_cmd, (const int32_t*)(e->d_cmd + S), e->d_cmd + 2 * S);
+    else hipLaunchKernelGGL(k_command<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, e->last_stream, (const Dev*)e->d_dev,
+                            (const int32_t*)e->d_cmd, (const int32_t*)(e->d_cmd + S), e->d_cmd + 2 * S);
     CKR_HIP(hipGetLastError());
     CKR_HIP(hipStreamSynchronize(e->last_stream));
     CKR_HIP(hipMemcpy(err, e->d_cmd + 2 * S, S * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1443,7 +1615,8 @@ static int read_node(ckr_engine* e, size_t idx, ckr_node_info* out) {
     CKR_HIP(hipMemcpy(&out->board, e->dev.n_board + idx, sizeof(ckr_board), hipMemcpyDeviceToHost));
     CKR_HIP(hipMemcpy(&out->status, e->dev.n_status + idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
     CKR_HIP(hipMemcpy(&out->n, e->dev.n_N + idx, sizeof(int32_t), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(&out->w, e->dev.n_W + idx, sizeof(float), hipMemcpyDeviceToHost));
+    if (e->dev.w64) CKR_HIP(hipMemcpy(&out->w, static_cast<const double*>(e->dev.n_W) + idx, sizeof(double), hipMemcpyDeviceToHost));
+    else { float wf = 0.0f; CKR_HIP(hipMemcpy(&wf, static_cast<const float*>(e->dev.n_W) + idx, sizeof(float), hipMemcpyDeviceToHost)); out->w = (double)wf; }
     CKR_HIP(hipMemcpy(&out->p, e->dev.n_P + idx, sizeof(float), hipMemcpyDeviceToHost));
     out->status &= ~(ST_EXPANDED | ST_MOVER);
     return CKR_OK;

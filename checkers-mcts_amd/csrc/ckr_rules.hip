@@ -129,7 +129,16 @@ __global__ __launch_bounds__(256) void k_training_batch(const ckr_tuple* __restr
         float4* dp = reinterpret_cast<float4*>(pi + r * 512);
         const float4* sp = reinterpret_cast<const float4*>(prob[wave]);
         for (int k = lane; k < 128; k += 64) dp[k] = sp[k];
-        if (lane == 0) tv[r] = ok ? (float)(((double)T->q + (double)T->z) / 2.0) : 0.0f;
+        if (lane == 0) {
+            // (qvals + zvals) / 2 in float64, cast to float32 by Keras (training_pipeline.py:304-306); qval is the float64
+            // -+ root.w / root.n when the search ran in the float64 regime (ckr_config.w_accum = 1)
+            double q = (double)T->q;
+            if (T->q_kind == CKR_Q_F64 || T->q_kind == CKR_Q_F64_NEG) {
+                q = T->root_n ? T->root_w / (double)T->root_n : 0.0;
+                if (T->q_kind == CKR_Q_F64_NEG) q = -q;
+            }
+            tv[r] = ok ? (float)((q + (double)T->z) / 2.0) : 0.0f;
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -225,7 +234,9 @@ __device__ __forceinline__ uint32_t squares_of_cells(unsigned long long b) {
     return (uint32_t)t;
 }
 
-__global__ __launch_bounds__(256) void k_hashnet(const float* __restrict__ x, int64_t n, uint32_t salt,
+// inexact != 0: tests/golden/ref_shim.InexactNet = the same outputs through p * float32(0.7) + float32(1/3), v * float32(0.3)
+// (every step rounded to float32; -ffp-contract=off): values whose sums are not exact in float32 or float64
+__global__ __launch_bounds__(256) void k_hashnet(const float* __restrict__ x, int64_t n, uint32_t salt, int inexact,
                                                  float* __restrict__ p, float* __restrict__ vout) {
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -242,10 +253,17 @@ __global__ __launch_bounds__(256) void k_hashnet(const float* __restrict__ x, in
         for (int q = 0; q < 4; ++q) h = fmix32(h ^ w[q]) + 0x7F4A7C15u;
         h = fmix32(h ^ side) + 0x7F4A7C15u;
         h = fmix32(h ^ k) + 0x7F4A7C15u;
-        for (uint32_t a = lane; a < 512; a += 64)
-            p[i * 512 + a] = (float)((fmix32(h + a * 0x9E3779B1u) >> 16) + 1u) * (1.0f / 33554432.0f);
-        if (lane == 0)
-            vout[i] = (float)((int)(fmix32(h ^ 0xDEADBEEFu) & 0xFFFFu) - 32768) * (1.0f / 65536.0f);
+        const float third = (float)(1.0 / 3.0);
+        for (uint32_t a = lane; a < 512; a += 64) {
+            float pv = (float)((fmix32(h + a * 0x9E3779B1u) >> 16) + 1u) * (1.0f / 33554432.0f);
+            if (inexact) pv = pv * 0.7f + third;
+            p[i * 512 + a] = pv;
+        }
+        if (lane == 0) {
+            float v = (float)((int)(fmix32(h ^ 0xDEADBEEFu) & 0xFFFFu) - 32768) * (1.0f / 65536.0f);
+            if (inexact) v = v * 0.3f;
+            vout[i] = v;
+        }
     }
 }
 
@@ -356,12 +374,12 @@ int ckr_arena_merge(const float* d_p_new, const float* d_v_new, const float* d_p
     return CKR_OK;
 }
 
-int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, float* d_p, float* d_v, void* stream) {
+int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, int32_t inexact, float* d_p, float* d_v, void* stream) {
     CKR_CHECK_ARGS(n >= 0, "n < 0");
     if (int rc = require_device()) return rc;
     if (n == 0) return CKR_OK;
     CKR_CHECK_ARGS(d_x && d_p && d_v, "null device pointer");
-    hipLaunchKernelGGL(k_hashnet, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, d_x, n, salt, d_p, d_v);
+    hipLaunchKernelGGL(k_hashnet, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream, d_x, n, salt, (int)inexact, d_p, d_v);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

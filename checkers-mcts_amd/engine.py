@@ -16,6 +16,7 @@ from . import _lib
 FEATURE_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 GAMES = {"checkers": 0, "tictactoe": 1}
+W_ACCUM = {"float32": 0, "float64": 1}
 
 # MCTS(**kwargs) keys (MCTS.py:43-55)
 MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOSE", "TRAINING",
@@ -25,7 +26,7 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=4, device=0,
-                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers"):
+                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -36,6 +37,13 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     endgames produce long runs of terminal visits: measured on cfg3 in steady state the tree
     kernel takes 0.035 / 0.07 / 0.10 / 0.28 ms at caps 1 / 4 / 8 / 64 while a cap of 1 leaves
     8.7 % of the network batch empty; 4 is the throughput optimum (profiles/README.md, round 2).
+
+    w_accum: "float32" (default) or "float64" -- the type MCTS_Node._total_reward / .q carry in the reference
+    (MCTS.py:389-394,419-430): float32 under NumPy >= 2, float64 under the reference's pinned NumPy 1.19
+    (requirements.txt:68).  Also read from mcts_kwargs["W_ACCUM"] (an extension key the reference ignores).
+
+    leaf_cache_log2: 0 = off (default), else log2 of the number of records (264 B each) of the engine's leaf cache
+    (include/ckr.h, ckr_config.leaf_cache_log2); also read from mcts_kwargs["LEAF_CACHE_LOG2"].  Results do not depend on it.
 
     game: "checkers", or "tictactoe" -- the reference's second environment (GAME_ENV = TicTacToe(), play_TTT.py:47-60),
     random-rollout self-play only (NEURAL_NET False): the README's known-answer validation of the search core."""
@@ -50,11 +58,23 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
         # owns the clock and ends the plies with Engine.step(..., end_ply=True)  (time_budget_of(kwargs))
         budget = 2 ** 31 - 1
         if nodes_per_tree is None:
-            nodes_per_tree = 1 << 18
+            # unbounded searches: as large a pool as a quarter of the device memory allows (44 B per node, 4 semispaces per
+            # slot), at most 2^18 nodes; a search whose live subtree outgrows it abandons the game (counted as failed)
+            try:
+                mem = torch.cuda.get_device_properties(int(device)).total_memory
+            except Exception:
+                mem = 64 << 30
+            nodes_per_tree = int(max(4096, min(1 << 18, (mem // 4) // (4 * 48 * max(1, int(n_slots))))))
     else:
         budget = int(k["BUDGET"])
     if nodes_per_tree is None:
         nodes_per_tree = max(4096, 48 * budget)
+    if w_accum is None:
+        w_accum = k.get("W_ACCUM", "float32")
+    if w_accum not in W_ACCUM:
+        raise ValueError("W_ACCUM must be 'float32' or 'float64', not %r" % (w_accum,))
+    if leaf_cache_log2 is None:
+        leaf_cache_log2 = int(k.get("LEAF_CACHE_LOG2", 0))
     return _lib.Config(n_slots=int(n_slots), games_per_slot=int(games_per_slot), first_worker_id=int(first_worker_id),
                        budget=budget, terminate_cnt=int(terminate_cnt or 0), training=int(bool(k["TRAINING"])),
                        tournament=int(bool(tournament)), tau_decay_delay=int(k["TEMP_DECAY_DELAY"]),
@@ -64,7 +84,8 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        feature_dtype=FEATURE_DTYPES[feature_dtype], max_sims_per_step=int(max_sims_per_step),
                        record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
                        device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
-                       dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], seed=int(seed))
+                       dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], w_accum=W_ACCUM[w_accum], seed=int(seed),
+                       leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2))
 
 
 def time_budget_of(mcts_kwargs):
@@ -203,8 +224,8 @@ class Engine:
         return out[:n.value]
 
     def root_stats(self, n_tuples):
-        w = np.zeros((max(1, n_tuples), _lib.MAX_CHILDREN), np.float32)
-        p = np.zeros_like(w)
+        w = np.zeros((max(1, n_tuples), _lib.MAX_CHILDREN), np.float64)      # float32 values unless w_accum = float64
+        p = np.zeros((max(1, n_tuples), _lib.MAX_CHILDREN), np.float32)
         _lib.check(self._L.ckr_engine_root_stats(self._h, w.ctypes.data, p.ctypes.data, n_tuples))
         return w[:n_tuples], p[:n_tuples]
 
@@ -234,7 +255,7 @@ class Engine:
         if n.value < 0:
             return None, None
         conv = lambda k: dict(board=np.array(k.board[:], np.uint32), status=int(k.status), n=int(k.n),
-                              w=np.float32(k.w), p=np.float32(k.p))
+                              w=(np.float64(k.w) if self.cfg.w_accum else np.float32(k.w)), p=np.float32(k.p))
         return conv(root), [conv(kids[i]) for i in range(n.value)]
 
     def leaves(self):
@@ -258,8 +279,8 @@ class Engine:
 
 TUPLE_DTYPE = np.dtype([("board", np.uint32, 4), ("mask", np.uint32, 8), ("status", np.uint32),
                         ("worker", np.int32), ("game", np.int32), ("ply", np.int32), ("n_children", np.int32),
-                        ("q", np.float32), ("q_is_int", np.int32), ("z", np.int32), ("root_n", np.int32),
-                        ("root_w", np.float32), ("chosen", np.int32), ("reserved", np.int32),
+                        ("q", np.float32), ("q_kind", np.int32), ("z", np.int32), ("root_n", np.int32),
+                        ("chosen", np.int32), ("root_w", np.float64),
                         ("pi", np.uint32, _lib.MAX_CHILDREN)])
 assert TUPLE_DTYPE.itemsize == C.sizeof(_lib.Tuple) == 288
 
@@ -270,15 +291,27 @@ def tuple_actions_visits(t):
     return (t["pi"][:k] >> 23).astype(np.int64), (t["pi"][:k] & 0x7FFFFF).astype(np.int64)
 
 
-def hashnet_evaluator(salt_new=0, salt_old=None):
-    """Evaluator using the built-in integer test network (parity tests)."""
+def tuple_q(t):
+    """qval of one compact tuple with the Python type the reference stores (training_pipeline.py:365-369,406-409):
+    python int for the terminal tuple, np.float32 (w_accum float32), np.float64 = -+ root_w / root_n (w_accum float64)."""
+    kind = int(t["q_kind"])
+    if kind == _lib.Q_INT:
+        return int(t["q"])
+    if kind == _lib.Q_F32:
+        return np.float32(t["q"])
+    q = np.float64(t["root_w"]) / int(t["root_n"]) if int(t["root_n"]) else np.float64(0.0)
+    return -q if kind == _lib.Q_F64_NEG else q
+
+
+def hashnet_evaluator(salt_new=0, salt_old=None, inexact=False):
+    """Evaluator using the built-in integer test network (parity tests); inexact: ref_shim.InexactNet."""
     from . import rules
 
     def ev(engine):
         x = engine.x if engine.x.dtype == torch.float32 else engine.x.float()
-        p, v = rules.hashnet(x, salt_new)
+        p, v = rules.hashnet(x, salt_new, inexact)
         if salt_old is not None:
-            p2, v2 = rules.hashnet(x, salt_old)
+            p2, v2 = rules.hashnet(x, salt_old, inexact)
             sel = (engine.net_id == 1)
             p = torch.where(sel[:, None], p2, p)
             v = torch.where(sel, v2, v)

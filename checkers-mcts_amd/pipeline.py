@@ -26,7 +26,7 @@ from datetime import datetime
 import numpy as np
 import torch
 
-from . import codec, dist as ckdist, engine as ckengine
+from . import _lib, codec, dist as ckdist, engine as ckengine
 from .net import NetEvaluator, PolicyValueNet, make_net
 
 
@@ -332,10 +332,8 @@ def tuples_to_memory(raw, neural_net=True):
     memory = []
     for i in range(len(raw)):
         a, n = ckengine.tuple_actions_visits(raw[i])
-        if raw["q_is_int"][i]:
-            q = int(raw["q"][i])
-        elif neural_net:
-            q = np.float32(raw["q"][i])
+        if raw["q_kind"][i] == _lib.Q_INT or neural_net:
+            q = ckengine.tuple_q(raw[i])        # python int | np.float32 | np.float64, as the reference stores it
         else:
             meta = raw["board"][i][3]
             q = float(raw["root_w"][i]) / int(raw["root_n"][i])

@@ -70,13 +70,14 @@ def mask_renorm(boards, p):
     return out
 
 
-def hashnet(x, salt=0):
-    """Deterministic integer test network: x [N,8,8,14] float32 -> (p [N,512], v [N])."""
+def hashnet(x, salt=0, inexact=False):
+    """Deterministic integer test network: x [N,8,8,14] float32 -> (p [N,512], v [N]).  inexact: the variant whose
+    outputs do not sum exactly (tests/golden/ref_shim.InexactNet)."""
     L = _lib.load()
     n = x.shape[0]
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == n * 896):
         raise ValueError("x must be a contiguous cuda float32 tensor of shape [N, 8, 8, 14]")
     p = torch.empty((n, 512), dtype=torch.float32, device=x.device)
     v = torch.empty((n,), dtype=torch.float32, device=x.device)
-    _lib.check(L.ckr_hashnet_batch(x.data_ptr(), n, int(salt) & 0xFFFFFFFF, p.data_ptr(), v.data_ptr(), _stream()))
+    _lib.check(L.ckr_hashnet_batch(x.data_ptr(), n, int(salt) & 0xFFFFFFFF, int(bool(inexact)), p.data_ptr(), v.data_ptr(), _stream()))
     return p, v

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 100          /* 0.1.0 */
+#define CKR_VERSION 110          /* 0.1.1: w_accum, leaf cache, ckr_tuple.q_kind / root_w double, ckr_hashnet_batch(inexact) */
 
 typedef enum {
     CKR_OK = 0,
@@ -86,8 +86,10 @@ int ckr_mask_renorm_batch(const ckr_board* d_boards, int64_t n, const float* d_p
                           float* d_out, void* stream);
 
 /* Deterministic integer test network (same arithmetic as the oracle's
- * ckro_hashnet and tests/golden/ref_shim.HashNet): x[n][896] -> p[n][512], v[n]. */
-int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, float* d_p, float* d_v,
+ * ckro_hashnet and tests/golden/ref_shim.HashNet): x[n][896] -> p[n][512], v[n].
+ * inexact != 0: ref_shim.InexactNet -- the same outputs through p * 0.7f + float32(1/3), v * 0.3f, i.e. values whose sums
+ * are NOT exact, so that the precision and order of the search's reward accumulation become observable. */
+int ckr_hashnet_batch(const float* d_x, int64_t n, uint32_t salt, int32_t inexact, float* d_p, float* d_v,
                       void* stream);
 
 /* ---- network body (the only MFMA user) ---------------------------------- */
@@ -228,13 +230,31 @@ typedef struct {
     int32_t  game;               /* 0 = Checkers.  1 = Tic-Tac-Toe (TicTacToe.py:25-142), the reference's second environment, for
                                     the README's validation of the search core (README:100-168): random-rollout self-play only
                                     (neural_net = 0); ckr_board p1 / p2 = X / O cells (bit 3 x + y), action = the cell taken */
-    int32_t  reserved;
+    int32_t  w_accum;            /* arithmetic of MCTS_Node._total_reward and .q (MCTS.py:389-394,419-430).  0 = float32: the
+                                    reference under NumPy >= 2 (NEP 50: np.float32 op python number stays float32).  1 = float64:
+                                    the reference under its pinned NumPy 1.19 (requirements.txt:68; legacy promotion: int +
+                                    np.float32 and -1 * np.float32 are float64), W accumulated and q = w / n evaluated in double.
+                                    Both are pinned bit for bit by fixtures generated under the matching interpreter
+                                    (tests/golden/search_inexact_np{1,2}.npz).  Ignored when neural_net = 0 (W is a python int) */
     uint64_t seed;               /* Philox key for Dirichlet noise / temperature sampling */
+    int32_t  leaf_cache_log2;    /* 0 = off; else log2 of the capacity (records of 264 bytes) of the engine's leaf cache.
+                                    Checkers.predict is a pure function of planes 0-13 (Checkers.py:425-438) and the reference
+                                    keeps two trees per game (training_pipeline.py:353-386), so the same position reaches the
+                                    network again and again; a leaf whose (pieces, side, draw numerator, network) was evaluated
+                                    in an earlier step is expanded from the cached priors / v as a network-free simulation.
+                                    Results are identical with and without (the cached floats are the ones the expansion would
+                                    recompute); only ckr_stats.nn_evals / dup_leaves and the step count change */
+    int32_t  leaf_cache_gen_log2;/* log2 of the cache's generation length in steps (0 = 11): a record is served for one to two
+                                    generations after it was written, then its place may be taken by a new one */
 } ckr_config;
 
 /* One training tuple, compact form (training_pipeline.py:364-369,406-410,
  * 421-455): root board + legal mask + status reproduce planes 0-14; pi is
  * (action, visit count) pairs in tree order; q, z as in the reference. */
+#define CKR_Q_F32      0         /* np.float32 (w_accum = 0): q */
+#define CKR_Q_INT      1         /* python int: the terminal tuple's 0 / -1 (training_pipeline.py:406-409) */
+#define CKR_Q_F64      2         /* float64 (w_accum = 1):  root_w / root_n */
+#define CKR_Q_F64_NEG  3         /* float64 (w_accum = 1): -root_w / root_n (training_pipeline.py:365-368) */
 typedef struct {
     ckr_board board;
     uint32_t  mask[8];
@@ -243,13 +263,12 @@ typedef struct {
     int32_t   game;              /* game index within the worker */
     int32_t   ply;
     int32_t   n_children;        /* 0: terminal tuple */
-    float     q;
-    int32_t   q_is_int;          /* terminal tuple carries a python int */
+    float     q;                 /* qval as float32 (exact for CKR_Q_F32 / CKR_Q_INT; rounded for the F64 kinds) */
+    int32_t   q_kind;            /* CKR_Q_*: the Python type the reference stores for qval */
     int32_t   z;
     int32_t   root_n;
-    float     root_w;
     int32_t   chosen;            /* action code played; -1: terminal tuple */
-    int32_t   reserved;          /* pads the record to 288 bytes (18 x 16) */
+    double    root_w;            /* root W after the search: a float32 value when w_accum = 0 */
     uint32_t  pi[CKR_MAX_CHILDREN];   /* action << 23 | visits */
 } ckr_tuple;
 
@@ -265,6 +284,10 @@ typedef struct {
     uint64_t nodes_created, compactions, pool_overflows;
     uint64_t steps;
     uint64_t active_slots;       /* slots still playing after the last step */
+    uint64_t nn_evals;           /* leaves handed to the network (ckr_engine_step; one Checkers.predict call each) */
+    uint64_t dup_leaves;         /* expansions served by the leaf cache: evaluations of a position the network had already seen */
+    uint64_t cache_entries;      /* records written to the leaf cache */
+    uint64_t cache_dropped;      /* records not cached because their probe neighbourhood was full */
 } ckr_stats;
 
 typedef struct ckr_engine ckr_engine;
@@ -338,7 +361,7 @@ int ckr_training_batch(const ckr_tuple* d_tuples, int64_t n_tuples, const int64_
 int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t* n, void* stream);
 /* Per-ply root child statistics (record_root_stats = 1): W and P for tuple i
  * at out[i][CKR_MAX_CHILDREN]. */
-int ckr_engine_root_stats(ckr_engine* e, float* w_out, float* p_out, int64_t cap);
+int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t cap);
 /* Leaf boards handed out by the last step (parity tests): HOST out[n_slots]. */
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out);
 
@@ -356,8 +379,9 @@ typedef struct {
     ckr_board board;
     uint32_t  status;
     int32_t   n;                 /* visits */
-    float     w;                 /* total reward */
+    double    w;                 /* total reward (a float32 value when w_accum = 0) */
     float     p;                 /* prior */
+    int32_t   reserved;
 } ckr_node_info;
 
 /* Live game of one slot: board, status word, move count, 1 if a search is still running. */

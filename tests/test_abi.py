@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.ckr_version() == 100
+    assert lib.ckr_version() == 110
     assert isinstance(lib.ckr_last_error(), bytes)
 
 
@@ -35,9 +35,9 @@ def test_struct_sizes_match_header():
     from checkers_mcts_amd import _lib
     assert C.sizeof(_lib.Tuple) == 288
     assert C.sizeof(_lib.GameResult) == 32
-    assert C.sizeof(_lib.Stats) == 80
-    assert C.sizeof(_lib.Config) == 128
-    assert C.sizeof(_lib.NodeInfo) == 32
+    assert C.sizeof(_lib.Stats) == 112
+    assert C.sizeof(_lib.Config) == 136
+    assert C.sizeof(_lib.NodeInfo) == 40
 
 
 def test_no_cpu_fallback(lib):

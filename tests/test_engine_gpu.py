@@ -26,8 +26,8 @@ def E():
     return engine
 
 
-def run_engine(E, kwargs, salts, **cfg_kw):
-    """Engine with one slot per salt (slot i evaluated by hash net salts[i])."""
+def run_engine(E, kwargs, salts, inexact=False, **cfg_kw):
+    """Engine with one slot per salt (slot i evaluated by hash net salts[i]; inexact: ref_shim.InexactNet)."""
     import torch
     from checkers_mcts_amd import rules
     cfg = E.config_from_kwargs(kwargs, n_slots=len(salts), **cfg_kw)
@@ -38,7 +38,7 @@ def run_engine(E, kwargs, salts, **cfg_kw):
     def ev(e):
         p = v = None
         for s in uniq:
-            ps, vs = rules.hashnet(e.x, s)
+            ps, vs = rules.hashnet(e.x, s, inexact)
             if p is None:
                 p, v = ps, vs
             else:
@@ -73,7 +73,7 @@ def test_selfplay_tuples_match_reference_golden(E, golden_dir):
                 a, nv = E.tuple_actions_visits(tw[i])
                 assert (codec.pi_planes(a, nv) == g["c%d_pi" % ci][i]).all()
             assert (tw["q"] == g["c%d_q" % ci]).all()
-            assert (tw["q_is_int"].astype(bool) == g["c%d_q_is_int" % ci]).all()
+            assert ((tw["q_kind"] == 1) == g["c%d_q_is_int" % ci]).all() and (tw["q_kind"] <= 1).all()
             assert (tw["z"] == g["c%d_z" % ci]).all()
         s = eng.stats()
         assert s["pool_overflows"] == 0 and s["reroot_misses"] == 0
@@ -97,7 +97,8 @@ def test_search_root_statistics_match_reference_golden(E, golden_dir):
             a, nv = E.tuple_actions_visits(t[i])
             k = len(a)
             assert (a == g["c%d_action" % ci][sl]).all() and (nv == g["c%d_n" % ci][sl]).all()
-            assert (w[i, :k].view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert (w[i, :k].astype(np.float32).view(np.uint32) == g["c%d_w" % ci][sl].view(np.uint32)).all()
+            assert (w[i, :k].astype(np.float32) == w[i, :k]).all()                   # float32 values in the default mode
             assert (p[i, :k].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
             assert t["root_n"][i] == g["c%d_root_n" % ci][i] and t["root_w"][i] == g["c%d_root_w" % ci][i]
             assert t["chosen"][i] == g["c%d_chosen" % ci][i]
@@ -125,17 +126,17 @@ def test_tournament_matches_reference_golden(E, golden_dir):
     assert checked >= 1
 
 
-def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts_old=None, **kw):
+def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts_old=None, inexact=False, w_accum="float32", **kw):
     """Engine slots and oracle workers advanced one evaluation at a time; the
     leaf every slot asks for must be the oracle's, at every step."""
     import torch
     from checkers_mcts_amd import rules
     cfg = E.config_from_kwargs(kwargs, n_slots=len(salts), games_per_slot=games, terminate_cnt=terminate,
                                tournament=tournament, record_root_stats=not tournament,
-                               max_sims_per_step=1 << 30, **kw)
+                               max_sims_per_step=1 << 30, w_accum=w_accum, **kw)
     eng = E.Engine(cfg)
-    workers = [oracle.Worker(oracle.make_config(kwargs, terminate_cnt=terminate, num_games=games, tournament=tournament))
-               for _ in salts]
+    workers = [oracle.Worker(oracle.make_config(kwargs, terminate_cnt=terminate, num_games=games, tournament=tournament,
+                                                w_accum=w_accum)) for _ in salts]
     p = v = None
     steps = 0
     while True:
@@ -154,7 +155,7 @@ def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts
                 assert (leaves[i] == w.leaf).all(), (steps, i, leaves[i], w.leaf)
                 assert (x[i].reshape(-1) == w.x).all(), (steps, i)
                 salt = salts[i] if (not tournament or w.net == 0) else salts_old[i]
-                pn[i], vn[i] = oracle.hashnet(w.x, salt)
+                pn[i], vn[i] = oracle.hashnet(w.x, salt, inexact)
                 w.submit(pn[i], vn[i])
             else:
                 assert nets[i] == -1, (steps, i)
@@ -164,7 +165,7 @@ def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts
     return eng, workers, steps
 
 
-def compare_final(E, eng, workers, tournament=False):
+def compare_final(E, eng, workers, tournament=False, w_accum="float32"):
     res = sorted(eng.results(), key=lambda r: (r["worker"], r["game"]))
     s = eng.stats()
     tot = dict(expansions=0, terminal_visits=0, plies=0, games=0, reroot_misses=0)
@@ -192,17 +193,116 @@ def compare_final(E, eng, workers, tournament=False):
             e = et[j]
             assert (e["board"] == o["board"]).all() and (e["mask"] == o["mask"]).all() and e["status"] == o["status"]
             assert e["game"] == o["game"] and e["ply"] == o["ply"] and e["z"] == o["z"]
-            assert e["q"] == o["q"] and bool(e["q_is_int"]) == o["q_is_int"] and e["chosen"] == o["chosen"]
+            assert (e["q_kind"] == 1) == o["q_is_int"] and e["chosen"] == o["chosen"]
+            if w_accum == "float64" and not o["q_is_int"]:
+                q = E.tuple_q(e)
+                assert e["q_kind"] >= 2 and type(q) is np.float64 and q.view(np.uint64) == np.float64(o["q64"]).view(np.uint64)
+            else:
+                assert e["q"] == o["q"] and e["q_kind"] <= 1
             a, nv = E.tuple_actions_visits(e)
             assert (a == o["action"]).all() and (nv == o["visits"]).all()
             k = len(a)
             if k:
                 assert e["root_n"] == o["root_n"] and e["root_w"] == o["root_w"]
-                assert (ew[j, :k].view(np.uint32) == o["wsum"].view(np.uint32)).all()
+                assert (ew[j, :k].view(np.uint64) == o["wsum"].view(np.uint64)).all()            # W bits (float64 holds either mode)
                 assert (ep[j, :k].view(np.uint32) == o["prior"].view(np.uint32)).all()
     for k, val in tot.items():
         assert s[k] == val, (k, s[k], val)
     assert s["pool_overflows"] == 0
+
+
+# ---- the search arithmetic with a network whose outputs do NOT sum exactly (ref_shim.InexactNet), in both NumPy promotion
+# regimes: np2 = NEP 50 (MCTS_Node.w float32, w_accum float32), np1 = the reference's pinned NumPy 1.19 (w float64).  The
+# fixtures come from the reference run under the matching interpreter; HashNet's exactly summable outputs cannot tell a
+# wrong accumulation precision or order apart, these can (MCTS.py:102-116,149-186,389-394,419-430).
+REGIMES = (("np2", "float32"), ("np1", "float64"))
+
+
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_inexact_search_w_bits_match_reference_golden(E, golden_dir, regime, w_accum):
+    g = np.load(os.path.join(golden_dir, "search_inexact_%s.npz" % regime))
+    for ci in range(int(g["n_cases"])):
+        budget, salt, max_plies, moves, outcome = (int(v) for v in g["c%d_cfg" % ci])
+        eng, ev = run_engine(E, mk(budget, training=False), [salt, salt, salt], inexact=True, games_per_slot=1,
+                             terminate_cnt=max_plies, record_root_stats=True, w_accum=w_accum)
+        eng.run(ev)
+        t_all = sorted_tuples(eng)
+        raw = eng.tuples_raw()
+        w_all, p_all = eng.root_stats(len(raw))
+        order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
+        w_all, p_all = w_all[order], p_all[order]
+        off = g["c%d_off" % ci]
+        for slot in range(3):
+            sel = (t_all["worker"] == slot) & (t_all["chosen"] >= 0)
+            t, w, p = t_all[sel], w_all[sel], p_all[sel]
+            assert len(t) == moves
+            for i in range(moves):
+                sl = slice(off[i], off[i + 1])
+                a, nv = E.tuple_actions_visits(t[i])
+                k = len(a)
+                assert (a == g["c%d_action" % ci][sl]).all() and (nv == g["c%d_n" % ci][sl]).all()
+                assert (w[i, :k].view(np.uint64) == g["c%d_w" % ci][sl].view(np.uint64)).all()        # child W bits
+                assert (p[i, :k].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
+                assert t["root_n"][i] == g["c%d_root_n" % ci][i]
+                assert t["root_w"][i].view(np.uint64) == g["c%d_root_w" % ci][i].view(np.uint64)
+                assert t["chosen"][i] == g["c%d_chosen" % ci][i]
+        if outcome:
+            assert [r["outcome"] for r in eng.results()] == [outcome] * 3
+        eng.close()
+
+
+def test_inexact_fixture_detects_the_wrong_accumulation_type(E, golden_dir):
+    """float32 accumulation against the float64 fixture: most W differ (the HashNet fixtures cannot see this)."""
+    g = np.load(os.path.join(golden_dir, "search_inexact_np1.npz"))
+    budget, salt, max_plies, moves, outcome = (int(v) for v in g["c1_cfg"])
+    eng, ev = run_engine(E, mk(budget, training=False), [salt], inexact=True, games_per_slot=1, terminate_cnt=max_plies,
+                         record_root_stats=True, w_accum="float32")
+    eng.run(ev)
+    t = sorted_tuples(eng)
+    w, _ = eng.root_stats(len(t))
+    got = np.concatenate([w[i, :int(t["n_children"][i])] for i in range(len(t)) if t["chosen"][i] >= 0])
+    assert len(got) == len(g["c1_w"]) and (got != g["c1_w"]).mean() > 0.5
+    eng.close()
+
+
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_inexact_selfplay_tuples_match_reference_golden(E, golden_dir, regime, w_accum):
+    """(state, pi, q, z) with q in the type the reference stores (np.float32 / np.float64), and the value targets
+    Keras receives from Keras_Generator, built on the device from the compact tuples."""
+    import torch
+    from checkers_mcts_amd import pipeline, train
+    g = np.load(os.path.join(golden_dir, "selfplay_inexact_%s.npz" % regime))
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games, salt = (int(v) for v in g["c%d_cfg" % ci])
+        eng, ev = run_engine(E, mk(budget), [salt, salt], inexact=True, games_per_slot=games, terminate_cnt=terminate,
+                             w_accum=w_accum)
+        eng.run(ev)
+        raw = eng.tuples_raw()
+        n = len(g["c%d_z" % ci])
+        for wk in range(2):
+            tw = raw[raw["worker"] == wk]
+            mem = pipeline.tuples_to_memory(tw)
+            assert len(mem) == n
+            for i, (state, pi, q, z) in enumerate(mem):
+                assert (state == g["c%d_state" % ci][i]).all() and (pi == g["c%d_pi" % ci][i]).all() and z == g["c%d_z" % ci][i]
+                assert (type(q) is int) == bool(g["c%d_q_is_int" % ci][i])
+                assert type(q) is int or type(q).__name__ == w_accum
+                assert np.float64(q).view(np.uint64) == g["c%d_q" % ci][i].view(np.uint64)
+            order = np.lexsort((tw["ply"], tw["game"]))
+            d = torch.from_numpy(tw[order].view(np.uint8).reshape(len(tw), -1).copy()).cuda()
+            _, _, tv = train.TrainingData(tuples=d).batch(torch.arange(len(tw), device="cuda"))
+            assert (tv.cpu().numpy().view(np.uint32) == g["c%d_value_target" % ci].view(np.uint32)).all()
+        eng.close()
+
+
+@pytest.mark.parametrize("w_accum", ["float32", "float64"])
+def test_lockstep_inexact_net_vs_oracle(E, oracle, w_accum):
+    """Every leaf of every step equals the oracle's with the inexact network, in either accumulation mode; final W bits,
+    q, counters equal (the oracle itself is pinned against the reference in both regimes, test_oracle_golden.py)."""
+    salts = [21, 22, 23, 24, 25, 26]
+    eng, workers, steps = lockstep(E, oracle, mk(20), salts, games=2, terminate=50, inexact=True, w_accum=w_accum)
+    compare_final(E, eng, workers, w_accum=w_accum)
+    eng.close()
 
 
 def test_lockstep_selfplay_vs_oracle(E, oracle):

@@ -106,7 +106,7 @@ def test_tuples_to_memory_matches_reference_format(oracle, golden_dir):
     for i, o in enumerate(ot):
         raw["board"][i], raw["mask"][i], raw["status"][i] = o["board"], o["mask"], o["status"]
         raw["game"][i], raw["ply"][i], raw["n_children"][i] = o["game"], o["ply"], len(o["action"])
-        raw["q"][i], raw["q_is_int"][i], raw["z"][i] = o["q"], o["q_is_int"], o["z"]
+        raw["q"][i], raw["q_kind"][i], raw["z"][i] = o["q"], int(o["q_is_int"]), o["z"]
         raw["pi"][i, :len(o["action"])] = (o["action"].astype(np.uint32) << 23) | o["visits"]
     mem = pipeline.tuples_to_memory(raw[::-1].copy())          # order must be restored by (worker, game, ply)
     assert len(mem) == len(g["c1_z"])

@@ -1,0 +1,134 @@
+"""GPU: the engine's leaf cache (ckr_config.leaf_cache_log2).  Checkers.predict is a pure function of planes 0-13
+(Checkers.py:425-438) and the reference keeps two trees per game (training_pipeline.py:353-386), so the same position is
+handed to the network repeatedly; the cache serves those repeats from HBM.  What is checked here: results are IDENTICAL with
+the cache on and off (tuples byte for byte, game results, search counters) for the hash nets, the inexact net in both
+accumulation modes (against the oracle), the arena, and the real network in the float32-grade kernels at cfg3's size; the
+accounting nn_evals + dup_leaves == expansions; and the premise the cache rests on -- the network kernels' output for a board
+does not depend on its row in the batch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_engine_gpu import E, mk, run_engine, sorted_tuples, compare_final          # noqa: F401
+from test_fullsize_gpu import checksum, check_tuples
+
+
+def play(E, kwargs, n_slots, evaluator, **cfg_kw):
+    eng = E.Engine(E.config_from_kwargs(kwargs, n_slots=n_slots, **cfg_kw))
+    eng.run(evaluator)
+    raw = sorted_tuples(eng)
+    res = sorted((tuple(sorted(r.items())) for r in eng.results()))
+    st = eng.stats()
+    eng.close()
+    return raw, res, st
+
+
+SEARCH_COUNTERS = ("expansions", "terminal_visits", "plies", "games", "reroot_misses", "nodes_created", "pool_overflows")
+
+
+@pytest.mark.parametrize("gen_log2", [0, 4])
+def test_cache_on_off_identical_hashnet_selfplay(E, gen_log2):
+    """Noise and temperature on (Philox streams keyed by worker: reproducible), two games per slot; gen_log2 = 4 makes
+    generations 16 steps long, so that records expire and their places are reused all the time."""
+    kw = mk(60, eps=0.25, tau=1.0)
+    common = dict(games_per_slot=2, terminate_cnt=80, seed=77)
+    off = play(E, kw, 96, E.hashnet_evaluator(9), **common)
+    on = play(E, kw, 96, E.hashnet_evaluator(9), leaf_cache_log2=14, leaf_cache_gen_log2=gen_log2, **common)
+    assert off[0].tobytes() == on[0].tobytes() and off[1] == on[1]
+    for k in SEARCH_COUNTERS:
+        assert off[2][k] == on[2][k], k
+    assert off[2]["dup_leaves"] == 0 and off[2]["nn_evals"] == off[2]["expansions"]
+    assert on[2]["nn_evals"] + on[2]["dup_leaves"] == on[2]["expansions"]
+    assert on[2]["dup_leaves"] > 0.05 * on[2]["expansions"]                 # the two trees of a game share their line
+    assert on[2]["cache_entries"] <= on[2]["nn_evals"]
+    assert on[2]["steps"] < off[2]["steps"]                                  # fewer network batches for the same games
+
+
+@pytest.mark.parametrize("w_accum", ["float32", "float64"])
+def test_cache_with_inexact_net_equals_oracle(E, oracle, w_accum):
+    """Cached priors / v are the floats the expansion would recompute: with the inexact net every W bit, q and counter
+    still equals the oracle's (which is pinned against the reference in both NumPy regimes)."""
+    kw = mk(24)
+    # (one network per engine: the cache is keyed by position and network id, so all slots of a run share one salt)
+    for salt in (31, 32):
+        eng, ev = run_engine(E, kw, [salt] * 3, inexact=True, games_per_slot=2, terminate_cnt=40, record_root_stats=True,
+                             w_accum=w_accum, leaf_cache_log2=12)
+        eng.run(ev)
+        workers = [oracle.Worker(oracle.make_config(kw, terminate_cnt=40, num_games=2, w_accum=w_accum)) for _ in range(3)]
+        for w in workers:
+            w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+        compare_final(E, eng, workers, w_accum=w_accum)
+        st = eng.stats()
+        assert st["dup_leaves"] > 0 and st["nn_evals"] + st["dup_leaves"] == st["expansions"]
+        eng.close()
+
+
+def test_cache_on_off_identical_arena(E):
+    """Two networks: the key carries the network id, a position evaluated by NEW is not served to OLD."""
+    kw = dict(mk(80, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    runs = []
+    for log2 in (0, 13):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=64, games_per_slot=2, tournament=True, seed=5, leaf_cache_log2=log2))
+        eng.run(E.hashnet_evaluator(3, 4))
+        runs.append((sorted(tuple(sorted(r.items())) for r in eng.results()), eng.stats()))
+        eng.close()
+    assert runs[0][0] == runs[1][0]
+    for k in SEARCH_COUNTERS:
+        assert runs[0][1][k] == runs[1][1][k], k
+    assert runs[1][1]["dup_leaves"] > 0
+
+
+def test_network_kernels_are_batch_position_independent():
+    """The premise of the cache for the real network: the same board gives the same (p, v) bits in any row of the batch
+    (conv stack: 2 boards per workgroup, float32-grade; 8 boards, bf16 -- and the heads' 16-row tiles)."""
+    import torch
+    from checkers_mcts_amd import net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from test_rules_gpu import random_boards
+    S = 4096
+    m = N.PolicyValueNet(128).keras_init(3).perturb_bn(7).eval().cuda()
+    x = rules.features(rules.boards_to_device(random_boards(S, 99))).contiguous()
+    perm = torch.from_numpy(np.random.RandomState(5).permutation(S)).cuda()
+    for mode, dt in (("f16x3", torch.float32), ("bf16", torch.bfloat16)):
+        ev = FusedEvaluator(m, S, mode=mode)
+        p, v = (t.clone() for t in ev.forward_features(x.to(dt).contiguous()))
+        p2, v2 = ev.forward_features(x[perm].to(dt).contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(p2, p[perm]) and torch.equal(v2, v[perm]), mode
+        x3 = x.clone(); x3[1::2] = x[0]                                         # one board next to 2 048 different neighbours
+        p3, v3 = ev.forward_features(x3.to(dt).contiguous())
+        torch.cuda.synchronize()
+        assert (p3[1::2] == p3[1]).all() and (v3[1::2] == v3[1]).all(), mode
+
+
+def test_cfg3_real_network_cache_on_off_identical(E, capsys):
+    """cfg3 (4 096 games, 100 sims/move, noise + temperature) with the random-init network in the float32-grade kernels
+    through the drop-in runner: tuples byte-identical with the cache on and off; reports the duplicate rate."""
+    import torch
+    from checkers_mcts_amd.pipeline import SplitRunner, make_evaluator
+    kw = mk(100, eps=0.25, tau=1.0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = []
+    for log2 in (0, 23):
+        def make_engine(offset, n):
+            return E.Engine(E.config_from_kwargs(kw, n_slots=n, first_worker_id=offset, games_per_slot=1, terminate_cnt=200,
+                                                 seed=20260929, leaf_cache_log2=log2))
+        runner = SplitRunner(make_engine, lambda n: make_evaluator("random:0", dev, torch.float32, n), 4096)
+        runner.run_to_completion()
+        st = runner.stats()
+        raw = np.frombuffer(runner.pack_tuples_device().cpu().numpy().tobytes(), dtype=E.TUPLE_DTYPE)
+        raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
+        runner.close()
+        out.append((raw, st))
+    (raw0, st0), (raw1, st1) = out
+    assert len(raw0) == len(raw1) and checksum(raw0) == checksum(raw1) and raw0.tobytes() == raw1.tobytes()
+    for k in SEARCH_COUNTERS:
+        assert st0[k] == st1[k], k
+    assert st1["nn_evals"] + st1["dup_leaves"] == st1["expansions"] and st0["dup_leaves"] == 0
+    check_tuples(E, raw1, 100)
+    rate = st1["dup_leaves"] / st1["expansions"]
+    with capsys.disabled():
+        print("\n[leaf cache] cfg3, real network: %.1f %% of %d expansions served from the cache; steps %d -> %d; dropped %d"
+              % (100 * rate, st1["expansions"], st0["steps"], st1["steps"], st1["cache_dropped"]))
+    assert rate > 0.05
