@@ -458,3 +458,282 @@ def load_keras_weights(path):
     net = PolicyValueNet(K)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     return net.eval()
+
+
+# ---- PolicyValueNet -> Keras model file --------------------------------------------------------------
+#
+# The other direction: `neural_network.save('...h5')` (training_pipeline.py:185-191, and ModelCheckpoint in train_nn,
+# :139-145) -- a file the reference's `load_model` (training_pipeline.py:345,515-516; train_Checkers.py:164;
+# play_Checkers.py:109) can open, written without h5py or TensorFlow.  `H5Writer` emits the same HDF5 subset the reader above
+# understands and that h5py 2.10 / libhdf5 1.10 produce with default settings: superblock version 0, version-1 object
+# headers, old-style groups (symbol-table message, v1 B-tree, local heap, one symbol node per group), contiguous
+# little-endian datasets, fixed-length string attributes (what h5py makes of the `bytes` tf.keras 2.2 stores:
+# hdf5_format.save_model_to_hdf5 encodes model_config / training_config / layer_names / weight_names to utf-8 bytes, and
+# its loader calls .decode() on what it reads back).  Checked against a real HDF5 library in the build container
+# (tests/test_keras_h5_cpu.py reads the written file back with /opt/conda's h5py when that interpreter is present).
+
+UNDEF = (1 << 64) - 1
+_LEAF_K, _INTERNAL_K = 32, 16          # symbol-node / B-tree fan-out parameters, recorded in the superblock
+
+
+def _pad8(b):
+    return bytes(b) + b"\0" * (-len(b) % 8)
+
+
+class _Node:
+    def __init__(self, name, data=None):
+        self.name, self.data, self.attrs, self.children = name, data, [], []      # data is None: a group
+
+
+class H5Writer:
+    """Build a tree with group() / dataset() / attr(), then write(path)."""
+
+    def __init__(self):
+        self.root = _Node("/")
+
+    def group(self, parent, name):
+        g = _Node(name)
+        parent.children.append(g)
+        return g
+
+    def dataset(self, parent, name, array):
+        """`name` may contain '/' (h5py creates the intermediate groups, as in Keras' '<layer>/kernel:0')."""
+        parts = name.split("/")
+        for p in parts[:-1]:
+            nxt = next((c for c in parent.children if c.name == p and c.data is None), None)
+            parent = nxt or self.group(parent, p)
+        a = np.asarray(array)
+        if a.dtype not in (np.dtype("<f4"), np.dtype("<f8"), np.dtype("<i8")):
+            raise H5Error("H5Writer: unsupported dataset type %s" % a.dtype)
+        d = _Node(parts[-1], np.ascontiguousarray(a))
+        parent.children.append(d)
+        return d
+
+    @staticmethod
+    def attr(node, name, value):
+        """value: bytes / str (fixed-length string scalar), a list of bytes / str (1-D fixed-length string array; an empty
+        list becomes an empty float64 array, which is what h5py makes of []), or a numpy scalar / array of f4, f8, i8."""
+        node.attrs.append((name, value))
+
+    # ---- encoders --------------------------------------------------------------------------------
+    @staticmethod
+    def _dtype_msg(dt, strlen=0):
+        if dt == "S":                                       # fixed-length string, null-padded, ASCII (numpy 'S<n>')
+            return bytes([0x13, 0x01, 0, 0]) + int(strlen).to_bytes(4, "little")
+        if dt == np.dtype("<f4"):
+            return bytes([0x11, 0x20, 31, 0]) + (4).to_bytes(4, "little") + bytes([0, 0, 32, 0, 23, 8, 0, 23]) + (127).to_bytes(4, "little")
+        if dt == np.dtype("<f8"):
+            return bytes([0x11, 0x20, 63, 0]) + (8).to_bytes(4, "little") + bytes([0, 0, 64, 0, 52, 11, 0, 52]) + (1023).to_bytes(4, "little")
+        if dt == np.dtype("<i8"):
+            return bytes([0x10, 0x08, 0, 0]) + (8).to_bytes(4, "little") + bytes([0, 0, 64, 0])
+        raise H5Error("H5Writer: unsupported type %r" % (dt,))
+
+    @staticmethod
+    def _space_msg(shape):
+        if shape is None:                                   # scalar
+            return bytes([1, 0, 0, 0, 0, 0, 0, 0])
+        return bytes([1, len(shape), 0, 0, 0, 0, 0, 0]) + b"".join(int(d).to_bytes(8, "little") for d in shape)
+
+    def _attr_msg(self, name, value):
+        if isinstance(value, str):
+            value = value.encode("utf8")
+        if isinstance(value, (bytes, bytearray)):
+            dt, sp, raw = self._dtype_msg("S", max(1, len(value))), self._space_msg(None), bytes(value) or b"\0"
+        elif isinstance(value, (list, tuple)):
+            items = [v.encode("utf8") if isinstance(v, str) else bytes(v) for v in value]
+            if not items:
+                dt, sp, raw = self._dtype_msg(np.dtype("<f8")), self._space_msg((0,)), b""
+            else:
+                n = max(1, max(len(v) for v in items))
+                dt, sp, raw = self._dtype_msg("S", n), self._space_msg((len(items),)), b"".join(v.ljust(n, b"\0") for v in items)
+        else:
+            a = np.asarray(value)
+            dt, sp, raw = self._dtype_msg(a.dtype), self._space_msg(a.shape if a.shape else None), np.ascontiguousarray(a).tobytes()
+        nm = name.encode("utf8") + b"\0"
+        body = bytes([1, 0]) + len(nm).to_bytes(2, "little") + len(dt).to_bytes(2, "little") + len(sp).to_bytes(2, "little")
+        body += _pad8(nm) + _pad8(dt) + _pad8(sp) + raw
+        if len(body) > 65528:
+            raise H5Error("attribute %r is %d bytes: above the 64-KB limit of an object header message (the same limit "
+                          "h5py / Keras hit)" % (name, len(body)))
+        return 0x0C, body
+
+    def _header(self, msgs):
+        """Version-1 object header holding all messages in its first chunk."""
+        body = b""
+        for mtype, data in msgs:
+            data = _pad8(data)
+            body += int(mtype).to_bytes(2, "little") + len(data).to_bytes(2, "little") + bytes([0, 0, 0, 0]) + data
+        return bytes([1, 0]) + len(msgs).to_bytes(2, "little") + (1).to_bytes(4, "little") + len(body).to_bytes(4, "little") + b"\0" * 4 + body
+
+    def _put(self, blob):
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        at = len(self.buf)
+        self.buf += blob
+        return at
+
+    def _write_node(self, node):
+        """Returns (object header address, B-tree address, local heap address) -- the last two 0 for a dataset."""
+        attrs = [self._attr_msg(n, v) for n, v in node.attrs]
+        if node.data is not None:
+            a = node.data
+            raw_at = self._put(a.tobytes()) if a.size else UNDEF
+            layout = bytes([3, 1]) + int(raw_at).to_bytes(8, "little") + int(a.nbytes).to_bytes(8, "little")
+            msgs = [(0x01, self._space_msg(a.shape)), (0x03, self._dtype_msg(a.dtype)), (0x05, bytes([2, 1, 0, 0])), (0x08, layout)]
+            return self._put(self._header(msgs + attrs)), 0, 0
+        if len(node.children) > 2 * _LEAF_K:
+            raise H5Error("H5Writer: more than %d links in one group" % (2 * _LEAF_K))
+        kids = sorted(node.children, key=lambda c: c.name.encode("utf8"))
+        if len({c.name for c in kids}) != len(kids):
+            raise H5Error("H5Writer: duplicate link name in group %r" % node.name)
+        placed = [(c, self._write_node(c)) for c in kids]
+        # local heap: the empty name at offset 0, then the link names
+        heap_data, offs = bytearray(8), []
+        for c in kids:
+            offs.append(len(heap_data))
+            heap_data += _pad8(c.name.encode("utf8") + b"\0")
+        data_at = self._put(bytes(heap_data))
+        heap_at = self._put(b"HEAP" + bytes(4) + len(heap_data).to_bytes(8, "little") + (1).to_bytes(8, "little") + data_at.to_bytes(8, "little"))   # free list: 1 = none (H5HL_FREE_NULL)
+        snod = bytearray(b"SNOD" + bytes([1, 0]) + len(kids).to_bytes(2, "little"))
+        for (c, (hdr, bt, hp)), off in zip(placed, offs):
+            snod += off.to_bytes(8, "little") + hdr.to_bytes(8, "little")
+            snod += ((1).to_bytes(4, "little") + bytes(4) + bt.to_bytes(8, "little") + hp.to_bytes(8, "little")) if c.data is None else bytes(24)
+        snod += bytes(8 + 2 * _LEAF_K * 40 - len(snod))
+        snod_at = self._put(bytes(snod))
+        tree = bytearray(b"TREE" + bytes([0, 0]) + (1 if kids else 0).to_bytes(2, "little") + UNDEF.to_bytes(8, "little") * 2)
+        tree += (0).to_bytes(8, "little")
+        if kids:
+            tree += snod_at.to_bytes(8, "little") + offs[-1].to_bytes(8, "little")
+        tree += bytes(24 + (2 * _INTERNAL_K + 1) * 8 + 2 * _INTERNAL_K * 8 - len(tree))
+        tree_at = self._put(bytes(tree))
+        stab = tree_at.to_bytes(8, "little") + heap_at.to_bytes(8, "little")
+        return self._put(self._header([(0x11, stab)] + attrs)), tree_at, heap_at
+
+    def write(self, path):
+        self.buf = bytearray(96)                            # the superblock is filled in last
+        hdr, tree, heap = self._write_node(self.root)
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        sb = SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + _LEAF_K.to_bytes(2, "little") + _INTERNAL_K.to_bytes(2, "little") + bytes(4)
+        sb += (0).to_bytes(8, "little") + UNDEF.to_bytes(8, "little") + len(self.buf).to_bytes(8, "little") + UNDEF.to_bytes(8, "little")
+        sb += (0).to_bytes(8, "little") + hdr.to_bytes(8, "little") + (1).to_bytes(4, "little") + bytes(4) + tree.to_bytes(8, "little") + heap.to_bytes(8, "little")
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        with open(path, "wb") as f:
+            f.write(self.buf)
+
+
+def _f32(x):
+    """A Python float that went through float32, as Keras' get_config() reports regularisation factors and Adam's settings."""
+    return float(np.float32(x))
+
+
+def keras_layer_table(num_kernels):
+    """create_nn's layers (training_pipeline.py:59-114) in tf.keras' `model.layers` order, each as (name, kind, detail,
+    inbound layer, torch module prefix).  Names: the per-class counters of a fresh Keras session in creation order.
+    Order: tf.keras sorts a functional model's layers by decreasing depth (longest path to an output) and, inside one
+    depth, by the order in which a depth-first walk from the outputs [policy_head, value_head] first meets them
+    (network._map_graph_network) -- the order in which save_weights lists `layer_names` and load_weights pairs them."""
+    K = int(num_kernels)
+    t = [("input_1", "input", None, None, None)]
+    prev = "input_1"
+    for i in range(7):
+        c, b = "conv2d" + ("_%d" % i if i else ""), "batch_normalization" + ("_%d" % i if i else "")
+        t += [(c, "conv", (K, 3), prev, "body.%d.conv" % i), (b, "bn", 3, c, "body.%d.bn" % i)]
+        prev = b
+    t += [("conv2d_7", "conv", (K, 3), prev, "pol1.conv"), ("conv2d_9", "conv", (1, 1), prev, "val1.conv"),
+          ("batch_normalization_7", "bn", 3, "conv2d_7", "pol1.bn"), ("batch_normalization_9", "bn", 3, "conv2d_9", "val1.bn"),
+          ("conv2d_8", "conv", (8, 1), "batch_normalization_7", "pol2.conv"), ("flatten_1", "flatten", None, "batch_normalization_9", None),
+          ("batch_normalization_8", "bn", 3, "conv2d_8", "pol2.bn"), ("dense", "dense", (64, "relu"), "flatten_1", "val_fc1"),
+          ("flatten", "flatten", None, "batch_normalization_8", None), ("batch_normalization_10", "bn", 1, "dense", "val_bn"),
+          ("policy_head", "dense", (512, "softmax"), "flatten", "pol_fc"), ("value_head", "dense", (1, "tanh"), "batch_normalization_10", "val_fc2")]
+    return t
+
+
+def keras_model_config(num_kernels=128, conv_reg=0.001, dense_reg=0.001):
+    """The `model_config` attribute tf.keras 2.2 (`keras_version` 2.3.0-tf) stores for create_nn's model: what load_model
+    rebuilds the architecture from.  Restated from tf.keras' layer get_config() methods (TensorFlow is absent here)."""
+    def reg(v):
+        return {"class_name": "L1L2", "config": {"l1": 0.0, "l2": _f32(v)}}
+    zeros, ones = {"class_name": "Zeros", "config": {}}, {"class_name": "Ones", "config": {}}
+    glorot = {"class_name": "GlorotUniform", "config": {"seed": None}}
+    layers = []
+    for name, kind, detail, inbound, _ in keras_layer_table(num_kernels):
+        if kind == "input":
+            cfg, cls = {"batch_input_shape": [None, 8, 8, 14], "dtype": "float32", "sparse": False, "ragged": False, "name": name}, "InputLayer"
+        elif kind == "conv":
+            cfg, cls = {"name": name, "trainable": True, "dtype": "float32", "filters": detail[0], "kernel_size": [detail[1]] * 2,
+                        "strides": [1, 1], "padding": "same", "data_format": "channels_last", "dilation_rate": [1, 1],
+                        "activation": "relu", "use_bias": True, "kernel_initializer": glorot, "bias_initializer": zeros,
+                        "kernel_regularizer": reg(conv_reg), "bias_regularizer": reg(conv_reg), "activity_regularizer": None,
+                        "kernel_constraint": None, "bias_constraint": None}, "Conv2D"
+        elif kind == "bn":
+            cfg, cls = {"name": name, "trainable": True, "dtype": "float32", "axis": [detail], "momentum": 0.99, "epsilon": 0.001,
+                        "center": True, "scale": True, "beta_initializer": zeros, "gamma_initializer": ones,
+                        "moving_mean_initializer": zeros, "moving_variance_initializer": ones, "beta_regularizer": None,
+                        "gamma_regularizer": None, "beta_constraint": None, "gamma_constraint": None}, "BatchNormalization"
+        elif kind == "flatten":
+            cfg, cls = {"name": name, "trainable": True, "dtype": "float32", "data_format": "channels_last"}, "Flatten"
+        else:
+            cfg, cls = {"name": name, "trainable": True, "dtype": "float32", "units": detail[0], "activation": detail[1], "use_bias": True,
+                        "kernel_initializer": glorot, "bias_initializer": zeros, "kernel_regularizer": reg(dense_reg),
+                        "bias_regularizer": reg(dense_reg), "activity_regularizer": None, "kernel_constraint": None,
+                        "bias_constraint": None}, "Dense"
+        layers.append({"class_name": cls, "config": cfg, "name": name, "inbound_nodes": [[[inbound, 0, 0, {}]]] if inbound else []})
+    return {"class_name": "Model", "config": {"name": "model", "layers": layers, "input_layers": [["input_1", 0, 0]],
+                                              "output_layers": [["policy_head", 0, 0], ["value_head", 0, 0]]}}
+
+
+def keras_training_config(policy_loss_weight=1.0, value_loss_weight=1.0):
+    """The `training_config` attribute of model.compile(...) in create_nn (training_pipeline.py:108-113): losses per head,
+    loss weights, Adam() with tf.keras' defaults -- what load_model compiles the rebuilt model with."""
+    return {"loss": {"policy_head": "categorical_crossentropy", "value_head": "mse"}, "metrics": None, "weighted_metrics": None,
+            "loss_weights": {"policy_head": policy_loss_weight, "value_head": value_loss_weight}, "sample_weight_mode": None,
+            "optimizer_config": {"class_name": "Adam", "config": {"name": "Adam", "learning_rate": _f32(0.001), "decay": 0.0,
+                                                                  "beta_1": _f32(0.9), "beta_2": _f32(0.999), "epsilon": 1e-07,
+                                                                  "amsgrad": False}}}
+
+
+def keras_layer_weights(state_dict):
+    """state_dict of net.PolicyValueNet -> [(layer name, [(weight name, float32 array)])] in Keras layout and `model.layers`
+    order: the inverse of keras_state_dict (Conv2D (out,in,H,W) -> (H,W,in,out); Linear (out,in) -> (in,out))."""
+    sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in state_dict.items()}
+    K = int(sd["body.0.conv.weight"].shape[0])
+    out = []
+    for name, kind, _, _, prefix in keras_layer_table(K):
+        if kind == "conv":
+            ws = [("kernel:0", sd[prefix + ".weight"].transpose(2, 3, 1, 0)), ("bias:0", sd[prefix + ".bias"])]
+        elif kind == "dense":
+            ws = [("kernel:0", sd[prefix + ".weight"].T), ("bias:0", sd[prefix + ".bias"])]
+        elif kind == "bn":
+            ws = [("gamma:0", sd[prefix + ".weight"]), ("beta:0", sd[prefix + ".bias"]),
+                  ("moving_mean:0", sd[prefix + ".running_mean"]), ("moving_variance:0", sd[prefix + ".running_var"])]
+        else:
+            ws = []
+        out.append((name, [(name + "/" + w, np.ascontiguousarray(a, dtype="<f4")) for w, a in ws]))
+    return out
+
+
+def save_keras_model(net, path, conv_reg=None, dense_reg=None, policy_loss_weight=None, value_loss_weight=None):
+    """`neural_network.save(path)` for a net.PolicyValueNet: a tf.keras 2.2 HDF5 model file (model_config,
+    training_config, /model_weights) for the reference's load_model.  Regularisation factors and loss weights default to
+    the attributes train.create_nn / train_nn put on the module (create_nn kwargs, training_pipeline.py:56-60)."""
+    import json
+    pick = lambda v, attr, dflt: float(v if v is not None else getattr(net, attr, dflt))
+    layers = keras_layer_weights(net.state_dict())
+    K = int(net.state_dict()["body.0.conv.weight"].shape[0])
+    w = H5Writer()
+    H5Writer.attr(w.root, "keras_version", b"2.3.0-tf")
+    H5Writer.attr(w.root, "backend", b"tensorflow")
+    H5Writer.attr(w.root, "model_config", json.dumps(keras_model_config(K, pick(conv_reg, "conv_reg", 0.001), pick(dense_reg, "dense_reg", 0.001))).encode("utf8"))
+    H5Writer.attr(w.root, "training_config", json.dumps(keras_training_config(pick(policy_loss_weight, "policy_loss_weight", 1.0),
+                                                                              pick(value_loss_weight, "value_loss_weight", 1.0))).encode("utf8"))
+    g = w.group(w.root, "model_weights")
+    H5Writer.attr(g, "layer_names", [n.encode("utf8") for n, _ in layers])
+    H5Writer.attr(g, "backend", b"tensorflow")
+    H5Writer.attr(g, "keras_version", b"2.3.0-tf")
+    for name, weights in layers:
+        lg = w.group(g, name)
+        H5Writer.attr(lg, "weight_names", [wn.encode("utf8") for wn, _ in weights])
+        for wn, a in weights:
+            w.dataset(lg, wn, a)
+    w.write(path)
+    return path

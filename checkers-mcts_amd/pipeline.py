@@ -59,6 +59,9 @@ def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128, netw
         spec = "random:0"
     if isinstance(spec, str) and spec.startswith("random:"):
         return make_net(num_kernels, seed=int(spec.split(":", 1)[1]), device=device, dtype=dtype)
+    if isinstance(spec, str) and spec.endswith(".keras"):
+        raise ValueError("%s: the zip-based .keras format is not supported; save the model as legacy HDF5 (.h5), the format the "
+                         "reference writes (training_pipeline.py:186-191)" % spec)
     if isinstance(spec, str) and spec.endswith((".h5", ".hdf5")):          # the reference's own model files (training_pipeline.py:185-191)
         from . import keras_h5
         net = keras_h5.load_keras_weights(spec).to(device=device, dtype=dtype)
@@ -89,15 +92,19 @@ def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None, netwo
     if networks:
         spec = networks.get(spec, spec) if isinstance(spec, str) else spec
         spec_old = networks.get(spec_old, spec_old) if isinstance(spec_old, str) else spec_old
-    if kind != "torch" and dtype in (torch.bfloat16, torch.float32) and _is_128_wide(spec, spec_old):
+    # every file is read once: the networks are loaded in float32 and their width is looked up on the loaded modules
+    want_fused = kind != "torch" and dtype in (torch.bfloat16, torch.float32)
+    first = torch.float32 if want_fused else dtype
+    new = load_network(spec, device=device, dtype=first)
+    old = load_network(spec_old, device=device, dtype=first) if spec_old is not None else None
+    if want_fused and _is_128_wide(new, old):
         from .fused import FusedEvaluator
-        new = load_network(spec, device=device, dtype=torch.float32)
-        old = load_network(spec_old, device=device, dtype=torch.float32) if spec_old is not None else None
         return FusedEvaluator(new, n_slots, net_old=old, mode="bf16" if dtype == torch.bfloat16 else "f16x3")
     if kind == "fused":
         raise ValueError("the fused conv stack needs NN_DTYPE bfloat16 or float32 and a 128-kernel network")
-    new = load_network(spec, device=device, dtype=dtype)
-    old = load_network(spec_old, device=device, dtype=dtype) if spec_old is not None else None
+    if first != dtype:
+        new = load_network(new, device=device, dtype=dtype)
+        old = load_network(old, device=device, dtype=dtype) if old is not None else None
     return NetEvaluator(new, old)
 
 
@@ -105,6 +112,8 @@ def _is_128_wide(*specs):
     """The fused kernels are built for NUM_KERNELS = 128 (training_pipeline.py:61).  Modules and
     checkpoint files are inspected (the width is the first body conv's output-channel count)."""
     for sp in specs:
+        if sp is None:
+            continue
         if isinstance(sp, HashNet) or (isinstance(sp, str) and sp.startswith("hash:")):
             return False
         if isinstance(sp, torch.nn.Module):
@@ -118,7 +127,9 @@ def _is_128_wide(*specs):
 
 def network_width(path):
     """NUM_KERNELS of a saved network (torch state_dict or Keras .h5 weights)."""
-    if path.endswith((".h5", ".hdf5", ".keras")):
+    if path.endswith(".keras"):
+        raise ValueError("%s: the zip-based .keras format is not supported; use legacy HDF5 (.h5)" % path)
+    if path.endswith((".h5", ".hdf5")):
         from . import keras_h5
         return keras_h5.num_kernels(path)
     sd = torch.load(path, map_location="cpu")

@@ -6,8 +6,10 @@ What is new relative to the reference is the data path: a training batch is buil
 DEVICE from the compact tuples the engine emits (`ckr_training_batch`, the work of
 `Keras_Generator.__getitem__`, training_pipeline.py:296-307) -- no 11.8-KB-per-tuple pickle,
 no host round trip between self-play and training.  The reference's pickled list format is
-accepted as well.  The optimisation itself (autograd, Adam, MIOpen backward kernels) is
-PyTorch: plumbing around the path, not part of it.
+accepted as well.  The optimisation step of the reference's float32 network runs in the
+hand-written kernels of csrc/ckr_train.hip (train_hip.HipTrainStep, TRAIN_BACKEND "hip", the
+default on a GPU); PyTorch autograd + torch.optim.Adam (TRAIN_BACKEND "torch") serve
+mixed-precision training, other network widths and the CPU.
 
 Keras semantics kept: loss = w_p * categorical cross-entropy(pi, p) + w_v * MSE((q+z)/2, v)
 + l2 penalties CONV_REG / DENSE_REG * sum(w^2) on every kernel AND bias of the conv / dense
@@ -80,11 +82,24 @@ def create_nn(**kwargs):
     return net
 
 
-def save_nn_to_disk(neural_network, iteration, timestamp):
-    filename = "data/model/Checkers_Model" + str(iteration) + "_" + timestamp + ".pt"     # .h5 in the reference (:186-190)
-    os.makedirs("data/model", exist_ok=True)
-    torch.save({k: v.detach().cpu() for k, v in neural_network.state_dict().items()}, filename)
+def save_network(neural_network, filename):
+    """Model file by suffix: '.h5' = a tf.keras 2.2 HDF5 model file, the reference's own format (`neural_network.save`,
+    training_pipeline.py:186-191; readable by its load_model and by pipeline.load_network / train.load_model here);
+    anything else = a torch state_dict."""
+    if str(filename).endswith((".h5", ".hdf5")):
+        from . import keras_h5
+        keras_h5.save_keras_model(neural_network, filename)
+    else:
+        torch.save({k: v.detach().cpu() for k, v in neural_network.state_dict().items()}, filename)
     return filename
+
+
+def save_nn_to_disk(neural_network, iteration, timestamp, suffix=".h5"):
+    """training_pipeline.save_nn_to_disk (:185-191): 'data/model/Checkers_Model<iteration>_<timestamp>.h5', a Keras model
+    file (suffix='.pt': a torch state_dict instead)."""
+    filename = "data/model/Checkers_Model" + str(iteration) + "_" + timestamp + suffix
+    os.makedirs("data/model", exist_ok=True)
+    return save_network(neural_network, filename)
 
 
 class CyclicLR:
@@ -245,7 +260,8 @@ def _as_training_data(training_data, device):
 def train_nn(training_data, neural_network, **kwargs):
     """Trains the network (training_pipeline.py:123-179).  training_data: the reference's list, a
     device tensor of compact tuples (generate_Checkers_data.generate_tuples()), or a TrainingData.
-    Returns (history, filepath of the best model: a torch state_dict readable by NN_FN)."""
+    Returns (history, filepath of the best model: a Keras .h5 model file as in the reference, usable as NN_FN here and
+    by the reference's load_model)."""
     PATIENCE, MIN_DELTA, VAL_SPLIT = kwargs["PATIENCE"], kwargs["MIN_DELTA"], kwargs["VAL_SPLIT"]
     TRAINING_ITERATION, BATCH_SIZE = kwargs["TRAINING_ITERATION"], kwargs["BATCH_SIZE"]
     CLR_SS_COEFF, NN_BASE_LR, NN_MAX_LR, EPOCHS = kwargs["CLR_SS_COEFF"], kwargs["NN_BASE_LR"], kwargs["NN_MAX_LR"], kwargs["EPOCHS"]
@@ -273,7 +289,8 @@ def train_nn(training_data, neural_network, **kwargs):
     lr_t = torch.tensor(float(clr.on_train_begin()), dtype=torch.float32, device=dev)
     opt = torch.optim.Adam(net.parameters(), lr=lr_t if dev.type == "cuda" else float(lr_t), betas=(0.9, 0.999), eps=1e-7,
                            **({"fused": True, "capturable": True} if dev.type == "cuda" else {}))
-    filepath = "data/model/Checkers_Model" + str(TRAINING_ITERATION + 1) + "_" + create_timestamp() + ".pt"
+    # ModelCheckpoint's file, training_pipeline.py:139-141 (MODEL_SUFFIX '.pt': a torch state_dict instead of Keras HDF5)
+    filepath = "data/model/Checkers_Model" + str(TRAINING_ITERATION + 1) + "_" + create_timestamp() + kwargs.get("MODEL_SUFFIX", ".h5")
     os.makedirs("data/model", exist_ok=True)
     history, best, es_best, wait, saved = History(), np.inf, np.inf, 0, False
     lr = clr.on_train_begin()
@@ -281,10 +298,14 @@ def train_nn(training_data, neural_network, **kwargs):
     use_graph = dev.type == "cuda" and kwargs.get("USE_GRAPH", True)
     captured = {}                            # "train": (graph, static x / pi / tv, static sums); lr lives in a device tensor
     # TRAIN_BACKEND "hip" (default on a GPU for the reference's 128-kernel network in float32): forward, backward and Adam
-    # of full batches run in the hand-written kernels of csrc/ckr_train.hip (train_hip.HipTrainStep); "torch": autograd +
-    # torch.optim.Adam (also used for the last, ragged batch of an epoch and for mixed-precision training)
+    # run in the hand-written kernels of csrc/ckr_train.hip (train_hip.HipTrainStep), which work on full batches -- the
+    # epoch's last, ragged batch is filled up with randomly drawn training rows (see run()); "torch": autograd +
+    # torch.optim.Adam (mixed-precision training, other network widths, and training sets smaller than one batch, which
+    # the HIP step cannot fill)
     backend = kwargs.get("TRAIN_BACKEND", "hip" if (dev.type == "cuda" and amp == torch.float32 and net.num_kernels == 128
                                                      and BATCH_SIZE % 2 == 0) else "torch")
+    if backend == "hip" and n_train < BATCH_SIZE:
+        backend = "torch"               # fewer rows than one batch: every step would take the torch path and leave the HIP weights untouched
     hip = None
     if backend == "hip":
         from .train_hip import HipTrainStep
@@ -333,10 +354,14 @@ def train_nn(training_data, neural_network, **kwargs):
         rows_seen = 0
         for b in batches:
             sel = idx[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
-            if train and hip is not None and int(sel.shape[0]) < BATCH_SIZE <= int(idx.shape[0]):
-                # the HIP step works on full batches: the epoch's last, ragged batch is filled up with its first samples
-                sel = torch.cat([sel, idx[:BATCH_SIZE - int(sel.shape[0])]])
-            rows_seen += int(sel.shape[0])
+            n_real = int(sel.shape[0])
+            if train and hip is not None and n_real < BATCH_SIZE:
+                # the HIP step works on full batches (the reference's Keras_Generator trains on the short one,
+                # training_pipeline.py:296): the ragged batch is filled up with rows drawn at random from the training set,
+                # anew every epoch, and enters the reported epoch losses with the weight of its real rows
+                fill = torch.randint(0, int(idx.shape[0]), (BATCH_SIZE - n_real,), generator=g).to(idx.device)
+                sel = torch.cat([sel, idx[fill]])
+            rows_seen += n_real
             if train:
                 lr_t.fill_(float(lr))
                 if dev.type != "cuda":
@@ -346,13 +371,13 @@ def train_nn(training_data, neural_network, **kwargs):
                     if "graph" not in captured:
                         captured["graph"], captured["static"] = capture_train_step(acc)
                         data.batch(sel, out=captured["static"])
-                        train_batch(*captured["static"], acc, BATCH_SIZE)       # this batch itself runs eagerly
+                        train_batch(*captured["static"], acc, n_real)           # this batch itself runs eagerly
                     else:
                         data.batch(sel, out=captured["static"])
                         captured["graph"].replay()
                 else:
                     x, pi, tv = data.batch(sel)
-                    train_batch(x, pi, tv, acc, int(sel.shape[0]))
+                    train_batch(x, pi, tv, acc, n_real)
                     captured["warm"] = captured.get("warm", 0) + 1
                 lr = clr.on_batch_end(float(lr))
             else:
@@ -376,7 +401,7 @@ def train_nn(training_data, neural_network, **kwargs):
             if kwargs.get("VERBOSE", False):
                 print("Epoch %d/%d loss %.4f val_loss %.4f lr %.2e" % (epoch + 1, EPOCHS, tl, vl, lr))
             if vl < best:                                                      # ModelCheckpoint(save_best_only), :139-145
-                torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, filepath)
+                save_network(net, filepath)
                 saved = True
             best = min(best, vl)
             if vl - MIN_DELTA < es_best:                                        # EarlyStopping(min_delta, patience), :133-135
@@ -386,7 +411,7 @@ def train_nn(training_data, neural_network, **kwargs):
             if wait >= PATIENCE:
                 break
     if not saved:
-        torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, filepath)
+        save_network(net, filepath)
     net.eval()
     for p in net.parameters():
         p.requires_grad_(False)

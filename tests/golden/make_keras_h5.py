@@ -26,10 +26,14 @@ beta, moving_mean, moving_variance).
 import json
 import os
 
+import sys
+
 import h5py
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "checkers-mcts_amd"))
+import keras_h5 as product_h5            # numpy-only at import time: the config generators of the product's exporter
 K = 8
 OFFSET = 10          # layer-name counter offset of a second model built in the same session
 
@@ -77,10 +81,13 @@ def main():
 
     path = os.path.join(HERE, "keras_model_k8.h5")
     with h5py.File(path, "w") as f:
-        f.attrs["keras_version"] = "2.4.0"
+        f.attrs["keras_version"] = "2.3.0-tf"                # python str -> variable-length string (global heap), as h5py stores it
         f.attrs["backend"] = "tensorflow"
-        f.attrs["model_config"] = json.dumps({"class_name": "Functional", "config": {"name": "model_1"}})
-        f.attrs["training_config"] = json.dumps({"loss": {"policy_head": "categorical_crossentropy", "value_head": "mse"}})
+        # tf.keras 2.2 encodes the two configs to utf-8 bytes (hdf5_format.save_model_to_hdf5): fixed-length string attributes of
+        # their full size -- 17 KB for this model -- which do not fit the root object header's first chunk and go to a
+        # continuation block: the path a genuine model.save() file takes through the reader
+        f.attrs["model_config"] = json.dumps(product_h5.keras_model_config(K, 0.001, 0.001)).encode("utf8")
+        f.attrs["training_config"] = json.dumps(product_h5.keras_training_config(1.0, 1.0)).encode("utf8")
         g = f.create_group("model_weights")
         g.attrs["layer_names"] = np.array([n.encode("utf8") for n, _ in layers])     # fixed-length strings, as h5py 2.10 wrote lists of bytes
         g.attrs["backend"] = "tensorflow".encode("utf8")

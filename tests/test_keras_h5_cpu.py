@@ -24,8 +24,12 @@ def test_reader_returns_every_array_bit_for_bit():
     exp = json.load(open(EXPECTED))
     f = keras_h5.H5File(H5)
     assert set(f.root.links) == {"model_weights", "optimizer_weights"}
-    assert f.root.attrs["keras_version"] == "2.4.0" and f.root.attrs["backend"] == "tensorflow"
-    assert json.loads(f.root.attrs["model_config"])["class_name"] == "Functional"
+    assert f.root.attrs["keras_version"] == "2.3.0-tf" and f.root.attrs["backend"] == "tensorflow"    # variable-length strings
+    # the two configs as tf.keras 2.2 stores them: utf-8 bytes -> fixed-length string attributes of 17 KB / 0.4 KB, which h5py
+    # places in a continuation block of the root object header
+    mc = json.loads(f.root.attrs["model_config"])
+    assert mc["class_name"] == "Model" and len(mc["config"]["layers"]) == 27 and len(f.root.attrs["model_config"]) > 16000
+    assert json.loads(f.root.attrs["training_config"])["optimizer_config"]["class_name"] == "Adam"
     mw = f.get("model_weights")
     assert list(mw.attrs["layer_names"]) == exp["layer_order"]                    # fixed-length string array attribute
     assert list(f.get("optimizer_weights").attrs["weight_names"]) == ["Adam/iter:0"]   # variable-length string array
@@ -119,3 +123,92 @@ def test_not_hdf5_raises(tmp_path):
     bad.write_bytes(b"not an hdf5 file" * 10)
     with pytest.raises(keras_h5.H5Error):
         keras_h5.H5File(str(bad))
+
+
+# ---- export: PolicyValueNet -> a Keras model file (training_pipeline.save_nn_to_disk, :185-191) -------------------------
+CONDA_PY = "/opt/conda/bin/python3.9"          # the build container's interpreter with h5py (a real HDF5 library)
+
+
+def test_keras_export_roundtrip_and_layer_order(tmp_path):
+    """save_keras_model -> load_keras_weights returns every tensor bit for bit; the file lists the layers in tf.keras'
+    model.layers order (depth, then first visit from the outputs) and carries the configs load_model needs."""
+    from checkers_mcts_amd import keras_h5
+    from checkers_mcts_amd.net import PolicyValueNet
+    for K in (8, 128):
+        net = PolicyValueNet(K).keras_init(11).perturb_bn(5).eval()
+        net.conv_reg, net.dense_reg, net.policy_loss_weight, net.value_loss_weight = 2e-3, 5e-4, 1.0, 0.5
+        path = str(tmp_path / ("m%d.h5" % K))
+        keras_h5.save_keras_model(net, path)
+        back = keras_h5.load_keras_weights(path)
+        for k, v in net.state_dict().items():
+            if not k.endswith("num_batches_tracked"):
+                assert torch.equal(v, back.state_dict()[k]), k
+        f = keras_h5.H5File(path)
+        names = list(f.get("model_weights").attrs["layer_names"])
+        assert names[:3] == ["input_1", "conv2d", "batch_normalization"]
+        assert names[15:] == ["conv2d_7", "conv2d_9", "batch_normalization_7", "batch_normalization_9", "conv2d_8", "flatten_1",
+                              "batch_normalization_8", "dense", "flatten", "batch_normalization_10", "policy_head", "value_head"]
+        mc = json.loads(f.root.attrs["model_config"])
+        assert [l["name"] for l in mc["config"]["layers"]] == names and mc["class_name"] == "Model"
+        by = {l["name"]: l for l in mc["config"]["layers"]}
+        assert by["conv2d"]["config"]["filters"] == K and by["conv2d"]["config"]["kernel_regularizer"]["config"]["l2"] == float(np.float32(2e-3))
+        assert by["policy_head"]["config"]["activation"] == "softmax" and by["policy_head"]["inbound_nodes"] == [[["flatten", 0, 0, {}]]]
+        assert by["value_head"]["config"]["kernel_regularizer"]["config"]["l2"] == float(np.float32(5e-4))
+        assert by["batch_normalization_10"]["config"]["axis"] == [1] and by["batch_normalization_9"]["config"]["axis"] == [3]
+        assert mc["config"]["output_layers"] == [["policy_head", 0, 0], ["value_head", 0, 0]]
+        tc = json.loads(f.root.attrs["training_config"])
+        assert tc["loss_weights"] == {"policy_head": 1.0, "value_head": 0.5} and tc["loss"]["value_head"] == "mse"
+        assert len(f.root.attrs["model_config"]) < 65000                         # one object-header message, as h5py needs it
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="no interpreter with h5py in this image")
+def test_keras_export_is_read_by_a_real_hdf5_library(tmp_path):
+    """The written file through h5py 3.3 / libhdf5 1.10 exactly as tf.keras' loader walks it (attrs -> layer_names ->
+    weight_names -> datasets): every array crc-equal, string attributes come back as bytes (what the loader .decode()s)."""
+    import subprocess
+    from checkers_mcts_amd import keras_h5
+    from checkers_mcts_amd.net import PolicyValueNet
+    net = PolicyValueNet(128).keras_init(2).perturb_bn(9).eval()
+    path = str(tmp_path / "m128.h5")
+    keras_h5.save_keras_model(net, path)
+    script = (
+        "import h5py, json, sys, zlib, numpy as np\n"
+        "f = h5py.File(sys.argv[1], 'r')\n"
+        "out = {'types': [type(f.attrs[k]).__name__ for k in ('model_config', 'training_config')]}\n"
+        "out['n_layers'] = len(json.loads(f.attrs['model_config'].decode('utf-8'))['config']['layers'])\n"
+        "g = f['model_weights']\n"
+        "out['kv'] = g.attrs['keras_version'].decode('utf8')\n"
+        "names = [n.decode('utf8') for n in g.attrs['layer_names']]\n"
+        "arr = {}\n"
+        "for n in names:\n"
+        "    for w in g[n].attrs['weight_names']:\n"
+        "        a = np.asarray(g[n][w.decode('utf8')])\n"
+        "        arr[w.decode('utf8')] = [list(a.shape), str(a.dtype), zlib.crc32(np.ascontiguousarray(a).tobytes())]\n"
+        "out['names'], out['arrays'] = names, arr\n"
+        "items = []\n"
+        "f.visititems(lambda name, obj: items.append(name))\n"
+        "out['n_objects'] = len(items)\n"
+        "print(json.dumps(out))\n")
+    res = json.loads(subprocess.check_output([CONDA_PY, "-c", script, path], env={"PATH": "/usr/bin:/bin"}).decode())
+    assert res["types"] == ["bytes_", "bytes_"] and res["n_layers"] == 27 and res["kv"] == "2.3.0-tf"
+    want = keras_h5.keras_layer_weights(net.state_dict())
+    assert res["names"] == [n for n, _ in want] and res["n_objects"] == 1 + 27 + 24 + 70
+    assert len(res["arrays"]) == 70
+    for _, ws in want:
+        for wn, a in ws:
+            assert res["arrays"][wn] == [list(a.shape), "float32", zlib.crc32(np.ascontiguousarray(a).tobytes())], wn
+
+
+def test_save_nn_to_disk_writes_the_reference_file_name_and_format(tmp_path, monkeypatch):
+    from checkers_mcts_amd import train as T
+    from checkers_mcts_amd.pipeline import load_network, network_width
+    monkeypatch.chdir(tmp_path)
+    net = T.create_nn(NUM_KERNELS=8, CONV_REG=1e-3, DENSE_REG=1e-3, POLICY_LOSS_WEIGHT=1.0, VALUE_LOSS_WEIGHT=1.0)
+    fn = T.save_nn_to_disk(net, 3, "29-Jan-2021(16:46:13)")
+    assert fn == "data/model/Checkers_Model3_29-Jan-2021(16:46:13).h5"            # training_pipeline.py:188-190
+    assert open(fn, "rb").read(8) == b"\x89HDF\r\n\x1a\n" and network_width(fn) == 8
+    back = load_network(fn, device="cpu")
+    assert all(torch.equal(a, b) for (k, a), b in zip(net.state_dict().items(), back.state_dict().values()) if "tracked" not in k)
+    assert T.save_nn_to_disk(net, 3, "x", suffix=".pt").endswith(".pt")
+    with pytest.raises(ValueError):
+        load_network("model.keras", device="cpu")

@@ -110,5 +110,5 @@ def test_lr_finder_schedule_and_restore(tmp_path, monkeypatch):
     net = T.create_nn(**kw)
     path = T.save_nn_to_disk(net, 7, "stamp")
     back = T.load_model(path, CONV_REG=2e-3)
-    assert path == "data/model/Checkers_Model7_stamp.pt" and back.conv_reg == 2e-3
+    assert path == "data/model/Checkers_Model7_stamp.h5" and back.conv_reg == 2e-3
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), back.state_dict().values()))

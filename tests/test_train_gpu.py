@@ -74,3 +74,30 @@ def test_selfplay_train_arena_loop_without_pickles(tmp_path, monkeypatch):
     t = tournament_Checkers(dict(NEW_NN_FN=fn, OLD_NN_FN="random:0", TOURNEY_GAMES=2, NUM_CPUS=4, SEED=3), mk_)
     out = t._start_tournament()
     assert len(out) == 8 and all(r[3] in ("player1_wins", "player2_wins", "draw") for r in out)
+
+
+def test_training_set_smaller_than_one_batch_still_trains(tmp_path, monkeypatch):
+    """Fewer training rows than BATCH_SIZE (the HIP step needs full batches): train_nn falls back to the torch step
+    instead of silently returning the initial weights, and the returned / saved network has moved."""
+    import torch
+    from checkers_mcts_amd import train as T
+    from checkers_mcts_amd.pipeline import load_network
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(0)
+    mem = []
+    for i in range(60):
+        st = np.zeros((15, 8, 8)); st[rng.integers(0, 4), rng.integers(0, 8), rng.integers(0, 8)] = 1
+        pi = np.zeros((8, 8, 8)); pi[i % 8, 1, 2] = 0.75; pi[(i + 1) % 8, 3, 4] = 0.25
+        mem.append([st, pi, np.float32(0.2), 1 if i % 2 else -1])
+    tk = dict(PATIENCE=5, MIN_DELTA=0.0, VAL_SPLIT=0.2, TRAINING_ITERATION=0, BATCH_SIZE=128, CLR_SS_COEFF=4,
+              NN_BASE_LR=1e-3, NN_MAX_LR=1e-2, EPOCHS=3, NUM_KERNELS=128, CONV_REG=1e-3, DENSE_REG=1e-3,
+              POLICY_LOSS_WEIGHT=1.0, VALUE_LOSS_WEIGHT=1.0, SEED=2)
+    net = T.create_nn(**tk)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    hist, fn = T.train_nn(mem, net, **tk)
+    after = net.state_dict()
+    moved = [k for k in before if before[k].dtype.is_floating_point and not torch.equal(before[k].to(after[k].device), after[k])]
+    assert any(k.endswith("conv.weight") for k in moved) and any("running_mean" in k for k in moved)
+    saved = load_network(fn, device="cuda").state_dict()
+    assert not torch.equal(saved["body.0.conv.weight"].cpu(), before["body.0.conv.weight"].cpu())
+    assert hist.history["loss"][-1] < hist.history["loss"][0]
