@@ -99,7 +99,10 @@ def parse():
     ap.add_argument("--max-sims-per-step", type=int, default=0,
                     help="cap on network-free simulations (terminal visits) a slot runs back to back in one step (0 = engine default)")
     ap.add_argument("--nodes-per-tree", type=int, default=0, help="node pool per tree and semispace (0 = engine default)")
-    ap.add_argument("--leaf-cache-log2", type=int, default=23,
+    ap.add_argument("--no-dense-rows", action="store_true",
+                    help="keep every slot's leaf in the batch row of its slot number (idle rows are evaluated too) instead of packing the "
+                         "step's leaves into rows [0, n) and bounding the conv launch by n")
+    ap.add_argument("--leaf-cache-log2", type=int, default=25,
                     help="log2 of the records of each engine's leaf cache (positions already evaluated are expanded without the "
                          "network; results identical with and without -- tests/test_leaf_cache_gpu.py); 0 = off")
     ap.add_argument("--extra-steps", type=int, default=300,
@@ -284,7 +287,7 @@ class Leg:
             cfg = ckengine.config_from_kwargs(kw, n_slots=n, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
                                               first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
                                               device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
-                                              leaf_cache_log2=a.leaf_cache_log2,
+                                              leaf_cache_log2=a.leaf_cache_log2, dense_rows=not a.no_dense_rows,
                                               **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
             return ckengine.Engine(cfg, feature_dtype=dtype)
 
@@ -622,6 +625,7 @@ def main():
                                       % (a.budget, a.slots),
                           "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": mode, "preroll_steps": pre,
                           "hip_graph": not a.no_graph, "evaluator": which,
+                          "dense_rows": not a.no_dense_rows,
                           "leaf_cache": ("2^%d records per engine: positions the network has already evaluated (Checkers.predict is a "
                                          "pure function of planes 0-13; two trees per game) are expanded from cached priors / v; results "
                                          "identical with and without" % a.leaf_cache_log2) if a.leaf_cache_log2 else "off",

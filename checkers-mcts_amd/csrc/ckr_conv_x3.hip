@@ -30,6 +30,7 @@
 // buffer_load ... lds and one s_barrier per k-chunk; the barrier + DMA issue cost 9 % of the
 // kernel, its epilogues another 7 % with the matrix pipe idle.)
 #include "ckr_host.h"
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 namespace ckrx {
@@ -67,7 +68,7 @@ struct Args {
     long long n_boards;
     int n_layers;
     int has_heads;
-    float xs, inv_xs;
+    float xs, inv_xs_val, inv_xs_pol;   // input-plane scale; 1 / (scale of the stored activations the value / policy 1x1 conv reads)
     int32_t* overflow;         // optional DEVICE flag: set when an activation leaves the fp16 range of the hi terms
     const int32_t* range;      // optional DEVICE [lo, hi): only tiles overlapping these boards are computed
     ckr_conv_heads H;
@@ -327,10 +328,10 @@ __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
         }
         if (A.has_heads) {
             if (l == A.n_layers - 2 && A.H.val_out)
-                head_1x1<1>(act, stage, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid, A.inv_xs);
+                head_1x1<1>(act, stage, A.H.val_w, A.H.val_b, A.H.val_scale, A.H.val_shift, A.H.val_out, board0, rows_valid, tid, A.inv_xs_val);
             if (l == A.n_layers - 1 && A.H.pol_out)
                 head_1x1<8>(act, stage, A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift,
-                            A.H.pol_out, board0, rows_valid, tid, A.inv_xs);
+                            A.H.pol_out, board0, rows_valid, tid, A.inv_xs_pol);
         }
     }
 }
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
 using namespace ckrx;
 
 extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
-                                    const ckr_conv_heads* heads, float x_scale, const int32_t* d_board_range, int32_t* d_overflow,
-                                    void* stream) {
+                                    const ckr_conv_heads* heads, float x_scale, const float* act_scales,
+                                    const int32_t* d_board_range, int32_t* d_overflow, void* stream) {
     if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: bad n_boards / n_layers");
     if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: x_scale must be positive");
@@ -349,7 +350,13 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     if (n_boards == 0) return CKR_OK;
     if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
     Args A;
-    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale; A.inv_xs = 1.0f / x_scale;
+    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale;
+    // the scale of each layer's stored output (folded into its bias / scale / shift by the host) matters to the kernel only
+    // where float32 values leave the stack: the two 1x1 head convolutions
+    for (int i = 0; act_scales && i < n_layers; ++i)
+        if (!(act_scales[i] > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: act_scales[%d] must be positive", i);
+    A.inv_xs_val = 1.0f / (act_scales && n_layers >= 2 ? act_scales[n_layers - 2] : x_scale);
+    A.inv_xs_pol = 1.0f / (act_scales ? act_scales[n_layers - 1] : x_scale);
     A.range = d_board_range; A.overflow = d_overflow;
     A.has_heads = heads ? 1 : 0;
     if (heads) {
@@ -379,6 +386,25 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     A.w = (const uint4*)layers[0].weights;
     A.w_bytes = (long long)(expect - (const char*)layers[0].weights) + (long long)(RING - 1) * SLOT_BYTES;
     const int grid = (int)((n_boards + TILE - 1) / TILE);
+    // Kernel experiments (tools/slp_probe.py): CKR_X3_CODE_OBJECT names a gfx950 code object whose k_conv_stack_x3 -- the same
+    // source built with other compiler flags, or its assembly with instructions inserted -- is launched instead of the
+    // linked kernel.  Unset in production.
+    static hipFunction_t alt = nullptr;
+    static bool alt_tried = false;
+    if (!alt_tried) {
+        alt_tried = true;
+        if (const char* co = getenv("CKR_X3_CODE_OBJECT")) {
+            hipModule_t mod = nullptr;
+            if (hipModuleLoad(&mod, co) != hipSuccess || hipModuleGetFunction(&alt, mod, "_ZN4ckrx15k_conv_stack_x3ENS_4ArgsE") != hipSuccess)
+                return ckr::fail(CKR_ERR_HIP, "CKR_X3_CODE_OBJECT=%s: cannot load k_conv_stack_x3 from it", co);
+        }
+    }
+    if (alt) {
+        size_t bytes = sizeof(A);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+        CKR_HIP(hipModuleLaunchKernel(alt, (unsigned)grid, 1, 1, NT, 1, 1, 0, (hipStream_t)stream, nullptr, cfg));
+        return CKR_OK;
+    }
     hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());
     return CKR_OK;

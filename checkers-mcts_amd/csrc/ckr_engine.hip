@@ -86,6 +86,8 @@ struct Dev {
     // leaf cache (see CacheRecord); cache == nullptr: off
     unsigned long long* cache_claim; CacheRecord* cache; unsigned long long cache_mask; int cache_gen_shift;
     uint32_t* g_epoch;           // [slot] number of k_step launches so far (every launch covers every slot: all equal)
+    // dense rows (ckr_config.dense_rows): a slot that hands out a leaf takes the next free row of the network batch
+    int dense_rows; int32_t* row_count;          // DEVICE counter = d_range[1] of ckr_engine_set_row_range, zeroed before every step
 };
 
 struct WaveLds {
@@ -1040,12 +1042,18 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
         w.count(CNT_NN);
         break;
     }
+    int out_row = row;
+    if (D.dense_rows && leaf >= 0) {                          // rows [0, number of leaves) of this step's batch, in arrival order
+        int r = 0;
+        if (w.lane == 0) { r = atomicAdd(D.row_count, 1); D.g_row[slot] = r; }
+        out_row = bcast_i32(r, 0);
+    }
     if (w.lane == 0) {
         D.g_pending[slot] = leaf;
         D.leaves[slot] = make_uint4(lb.p1, lb.p2, lb.kings, lb.meta);
-        if (net_out) net_out[row] = leaf >= 0 ? net : -1;
+        if (net_out && (leaf >= 0 || !D.dense_rows)) net_out[out_row] = leaf >= 0 ? net : -1;   // dense: idle rows preset to -1
     }
-    if (leaf >= 0) write_features(w, lb, x, row);
+    if (leaf >= 0) write_features(w, lb, x, out_row);
     flush_counters(w);
 }
 
@@ -1263,6 +1271,7 @@ struct ckr_engine {
     int32_t* d_cmd = nullptr;
     int32_t* d_row_tmp = nullptr; float* d_tmp_p = nullptr; float* d_tmp_v = nullptr;   // ckr_engine_compact_rows
     Dev* d_dev = nullptr;              // device copy of `dev` (owned by allocs)
+    int32_t* d_range = nullptr;        // dense rows: the caller's DEVICE int32[2] = {0, leaves of the last step}
 };
 
 template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool zero = true) {
@@ -1276,7 +1285,7 @@ template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool
 }
 
 static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
-static_assert(sizeof(ckr_config) == 136, "ckr_config layout is mirrored by _lib.Config (ctypes)");
+static_assert(sizeof(ckr_config) == 144, "ckr_config layout is mirrored by _lib.Config (ctypes)");
 
 extern "C" {
 
@@ -1307,12 +1316,13 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.n_slots = c->n_slots; D.games_per_slot = c->games_per_slot; D.first_worker = c->first_worker_id;
     D.budget = c->budget; D.terminate_cnt = c->terminate_cnt; D.training = c->training; D.tournament = c->tournament;
     D.tau_decay_delay = c->tau_decay_delay; D.reset_tau = c->reset_tau_each_game; D.C = c->nodes_per_tree;
-    D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : 4;
+    D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : (c->leaf_cache_log2 > 0 && c->neural_net ? 2 : 4);
     D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
     D.total_games = c->n_slots * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
     D.w64 = (c->w_accum == 1 && c->neural_net) ? 1 : 0;
-    const int cache_log2 = c->neural_net ? c->leaf_cache_log2 : 0;       // random-rollout mode: W is a python int in the reference, exact in float
+    const int cache_log2 = c->neural_net ? c->leaf_cache_log2 : 0;
+    D.dense_rows = (c->dense_rows && c->neural_net && !c->manual_play) ? 1 : 0;       // random-rollout mode: W is a python int in the reference, exact in float
     D.tuples_per_game = (c->tournament || c->manual_play) ? 0 : c->terminate_cnt + 1;
     D.margin = c->budget > (1 << 20) ? D.C / 2 : c->budget * 16 + 64;    // unbounded (time-limited) searches: compact early
     if (D.margin > D.C / 2) D.margin = D.C / 2;
@@ -1450,6 +1460,11 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_step drives the NEURAL_NET search; use ckr_engine_rollout");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
     note_stream(&e->last_stream, (hipStream_t)stream);
+    if (e->dev.dense_rows) {
+        if (!e->dev.row_count) return fail(CKR_ERR_STATE, "dense_rows: call ckr_engine_set_row_range before the first step");
+        CKR_HIP(hipMemsetAsync(e->d_range, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
+        if (d_net) CKR_HIP(hipMemsetAsync(d_net, 0xFF, (size_t)e->cfg.n_slots * sizeof(int32_t), (hipStream_t)stream));
+    }
     if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
     else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
     CKR_HIP(hipGetLastError());
@@ -1457,9 +1472,20 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     return CKR_OK;
 }
 
+int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range) {
+    if (!e || !d_range) return fail(CKR_ERR_INVALID, "ckr_engine_set_row_range: null argument");
+    if (!e->dev.dense_rows) return fail(CKR_ERR_STATE, "ckr_engine_set_row_range needs an engine created with dense_rows = 1");
+    CKR_HIP(hipDeviceSynchronize());
+    e->d_range = d_range;
+    e->dev.row_count = d_range + 1;
+    CKR_HIP(hipMemcpy(e->d_dev, &e->dev, sizeof(Dev), hipMemcpyHostToDevice));
+    return CKR_OK;
+}
+
 int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_net, int32_t* d_range, void* stream) {
     if (!e || !d_p || !d_v || !d_range) return fail(CKR_ERR_INVALID, "ckr_engine_compact_rows: null argument");
     if (!e->dev.neural || e->dev.manual) return fail(CKR_ERR_STATE, "ckr_engine_compact_rows: batched NEURAL_NET engines only");
+    if (e->dev.dense_rows) return fail(CKR_ERR_STATE, "ckr_engine_compact_rows: a dense_rows engine keeps its batch compact at every step");
     const int S = e->cfg.n_slots;
     if (!e->d_tmp_p) {
         if (int rc = dalloc(e, &e->d_tmp_p, (size_t)S * 512, false)) return rc;

@@ -47,12 +47,13 @@ def shard_range(n_workers, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
-def gather_rows(local, dst=0):
+def gather_rows(local, dst=0, force_collective=False):
     """Gather variable-length row blocks (2-D tensors with equal row width) to
     `dst`: sizes via one all_gather, payload via one gather of padded blocks.
     Returns the concatenation on dst, None elsewhere.  Works on the device the
-    backend expects (cuda for RCCL, cpu for gloo)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    backend expects (cuda for RCCL, cpu for gloo).  A single-rank job issues no
+    collective unless force_collective is set (tests: the RCCL branch on a 1-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     home = local.device

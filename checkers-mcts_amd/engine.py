@@ -25,8 +25,8 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
-                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=4, device=0,
-                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0):
+                       reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=0, device=0,
+                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0, dense_rows=False):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -36,7 +36,8 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     result, is the same for any value.  A step lasts as long as its longest slot, and won / lost
     endgames produce long runs of terminal visits: measured on cfg3 in steady state the tree
     kernel takes 0.035 / 0.07 / 0.10 / 0.28 ms at caps 1 / 4 / 8 / 64 while a cap of 1 leaves
-    8.7 % of the network batch empty; 4 is the throughput optimum (profiles/README.md, round 2).
+    8.7 % of the network batch empty; 4 is the throughput optimum (profiles/README.md, round 2).  With the leaf cache, whose hits
+    are network-free simulations as well, and dense rows the optimum is 2 (round 3).  0 = the engine's choice: 4, or 2 with the cache.
 
     w_accum: "float32" (default) or "float64" -- the type MCTS_Node._total_reward / .q carry in the reference
     (MCTS.py:389-394,419-430): float32 under NumPy >= 2, float64 under the reference's pinned NumPy 1.19
@@ -44,6 +45,9 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
 
     leaf_cache_log2: 0 = off (default), else log2 of the number of records (264 B each) of the engine's leaf cache
     (include/ckr.h, ckr_config.leaf_cache_log2); also read from mcts_kwargs["LEAF_CACHE_LOG2"].  Results do not depend on it.
+
+    dense_rows: the network batch holds the step's leaves in rows [0, n) (arrival order) and Engine.row_range tells the
+    evaluator n, so a step costs what its leaves cost (include/ckr.h, ckr_config.dense_rows).  Results do not depend on it.
 
     game: "checkers", or "tictactoe" -- the reference's second environment (GAME_ENV = TicTacToe(), play_TTT.py:47-60),
     random-rollout self-play only (NEURAL_NET False): the README's known-answer validation of the search core."""
@@ -85,7 +89,8 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        record_root_stats=int(bool(record_root_stats)), manual_play=int(bool(manual_play)),
                        device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
                        dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], w_accum=W_ACCUM[w_accum], seed=int(seed),
-                       leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2))
+                       leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2),
+                       dense_rows=int(bool(dense_rows)))
 
 
 def time_budget_of(mcts_kwargs):
@@ -112,6 +117,9 @@ class Engine:
         self.net_id = torch.full((S,), -1, dtype=torch.int32, device=self.device)
         # board range of the network batch: [0, S) until compact_rows() moves the active slots to the front
         self.row_range = torch.tensor([0, S], dtype=torch.int32, device=self.device)
+        self.dense_rows = bool(cfg.dense_rows) and bool(cfg.neural_net) and not bool(cfg.manual_play)
+        if self.dense_rows:
+            _lib.check(self._L.ckr_engine_set_row_range(self._h, self.row_range.data_ptr()))
         self._first = True
 
     def close(self):

@@ -51,11 +51,48 @@ def pack_conv_weights(w, first):
     return img.reshape(36, cout, 40).to(torch.bfloat16).contiguous()
 
 
-XS, WS = 8.0, 1024.0         # power-of-two operand scales of the split-fp16 path (ckr_conv_x3.hip): |activation| < 7 500, |w| < 58
+XS = 8.0                     # scale of the input planes (0 / 1 and k / 80) in the split-fp16 path
+HI_TARGET = 16384.0          # operands are scaled by powers of two so that the largest magnitude seen lands in [8 192, 16 384]: four
+                             # times below the largest fp16 (the hi term), and small values keep their lo terms out of the subnormals
 
 
-def pack_split_weights(w, first):
-    """One layer of ckr_conv_stack_f16x3's weight stream: fp16 [n_slots][4 waves][hi | lo][64 lanes][8] of w * WS in
+def pow2_scale(amax, target=HI_TARGET):
+    """Largest power of two s with amax * s <= target (float32-representable; 1.0 for amax == 0)."""
+    import math
+    if not (amax > 0.0) or not math.isfinite(amax):
+        return 1.0
+    return float(2.0 ** max(-100, min(100, math.floor(math.log2(target / amax)))))
+
+
+def calibration_boards(n, device, seed=1234):
+    """n synthetic positions as 16-byte board records (uint32[n, 4]) for the one-pass range calibration of the split-fp16
+    path: per side 1-12 pieces on distinct squares, men never on their promotion row, a random share of kings, random side
+    to move.  Not games: only the MAGNITUDE of the activations they cause is used, with a fourfold margin."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    out = np.zeros((n, 4), np.uint32)
+    for i in range(n):
+        sq = rng.permutation(32)
+        n1, n2 = rng.randint(1, 13), rng.randint(1, 13)
+        kf = rng.rand()
+        p1 = p2 = kings = 0
+        for j, s_ in enumerate(sq[:n1 + n2]):
+            side = 0 if j < n1 else 1
+            x = int(s_) // 4
+            king = rng.rand() < kf or (side == 0 and x == 7) or (side == 1 and x == 0)
+            if side == 0:
+                p1 |= 1 << int(s_)
+            else:
+                p2 |= 1 << int(s_)
+            if king:
+                kings |= 1 << int(s_)
+        stm = int(rng.randint(0, 2))
+        out[i] = (p1, p2, kings, stm | ((1 - stm) << 1) | (1 << 19))          # side, mover = the other player, history length 1
+    return torch.from_numpy(out.view(np.int32)).to(device)
+
+
+def pack_split_weights(w, first, ws):
+    """One layer of ckr_conv_stack_f16x3's weight stream: fp16 [n_slots][4 waves][hi | lo][64 lanes][8] of w * ws in
     MFMA A-fragment order -- slot = tap (first layer: 14 planes in one 16-channel slice) or tap*8 + slice; wave wc
     owns output channels [32 wc, +32); lane l holds channel 32 wc + (l & 31), input channels 16 slice + 8 (l >> 5) + 0..7.
     Every (slot, wave, hi | lo) block is one contiguous 1-KB buffer_load_dwordx4 of the wave that consumes it."""
@@ -63,9 +100,9 @@ def pack_split_weights(w, first):
     assert cout == 128 and w.shape[2:] == (3, 3) and cin <= (16 if first else 128)
     q = 1 if first else 8
     t = torch.zeros((9, cout, 16 * q), dtype=torch.float32, device=w.device)
-    t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin) * WS
-    if float(t.abs().max()) > 6e4:
-        raise OverflowError("conv weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
+    t[:, :, :cin] = w.float().permute(2, 3, 0, 1).reshape(9, cout, cin) * ws
+    if not bool(torch.isfinite(t).all()) or float(t.abs().max()) > 6e4:
+        raise OverflowError("conv weights are not finite or exceed %g: outside the range of the split-fp16 path" % (6e4 / ws))
     hi = t.to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
     both = torch.stack([hi, lo], dim=0).reshape(2, 9, 4, 32, q, 2, 8)          # [hl][tap][wc][row][slice][k-half][8]
@@ -76,26 +113,29 @@ def pack_split_weights(w, first):
 STREAM_PAD_SLOTS = 3         # the kernel's register ring requests weight fragments three slots ahead, also past the last layer
 
 
-def pack_split_stream(weights):
-    """[layer 0 conv weight, layer 1, ...] -> (one contiguous fp16 stream, element offset of every layer): the layers'
-    images back to back + STREAM_PAD_SLOTS slots of zero padding."""
-    imgs = [pack_split_weights(w, i == 0).reshape(-1) for i, w in enumerate(weights)]
+def pack_split_stream(weights, ws=None):
+    """[layer 0 conv weight, layer 1, ...] -> (one contiguous fp16 stream, element offset of every layer, weight scale
+    of every layer): the layers' images back to back + STREAM_PAD_SLOTS slots of zero padding.  ws: per-layer power-of-two
+    weight scales (default: from each layer's largest weight, pow2_scale)."""
+    if ws is None:
+        ws = [pow2_scale(float(w.abs().max())) for w in weights]
+    imgs = [pack_split_weights(w, i == 0, ws[i]).reshape(-1) for i, w in enumerate(weights)]
     offs, n = [], 0
     for im in imgs:
         offs.append(n)
         n += im.numel()
     pad = torch.zeros(STREAM_PAD_SLOTS * 4 * 2 * 64 * 8, dtype=torch.float16, device=imgs[0].device)
-    return torch.cat(imgs + [pad]).contiguous(), offs
+    return torch.cat(imgs + [pad]).contiguous(), offs, ws
 
 
-def pack_dense_weights(w):
+def pack_dense_weights(w, ws):
     """Dense(512) kernel [512 out][512 in] (torch Linear layout) -> the fragment-ordered image of
-    ckr_policy_head: fp16 [32 out-tiles][16 k-steps][hi, lo][64 lanes][8] of w * WS,
+    ckr_policy_head: fp16 [32 out-tiles][16 k-steps][hi, lo][64 lanes][8] of w * ws,
     lane = 16 * ((in % 32) // 8) + out % 16, element = in % 8."""
     assert tuple(w.shape) == (512, 512)
-    t = w.float() * WS
-    if float(t.abs().max()) > 6e4:
-        raise OverflowError("dense weight magnitude above %g: outside the range of the split-fp16 path" % (6e4 / WS))
+    t = w.float() * ws
+    if not bool(torch.isfinite(t).all()) or float(t.abs().max()) > 6e4:
+        raise OverflowError("dense weights are not finite or exceed %g: outside the range of the split-fp16 path" % (6e4 / ws))
     hi = t.to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
 
@@ -129,7 +169,7 @@ class FusedEvaluator:
         vp = C.c_void_p
         self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp, vp]
         self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
-                                                 C.c_float, vp, vp, vp]
+                                                 C.c_float, vp, vp, vp, vp]
         self.overflow = None
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -143,18 +183,46 @@ class FusedEvaluator:
         self.supports_row_range = net_old is None   # single network: honours Engine.compact_rows() (tail of a run)
 
     def _prepare(self, net):
+        if self.mode == "f16x3":
+            # one-pass range calibration at weight-pack time: the network runs once, in these same kernels, on synthetic
+            # positions with deliberately small activation scales (room for magnitudes up to 4e6; up to 1e16 after the
+            # retries); the largest magnitude each layer produced then fixes its power-of-two scale.  The device flag stays
+            # armed as an assertion (check_range): it fires only if play meets activations four times beyond these.
+            dev = next(net.parameters()).device
+            boards = calibration_boards(256, dev)
+            from . import rules
+            xcal = rules.features(boards.view(torch.int32)).contiguous()
+            act = None
+            for attempt in range(4):
+                trial = [2.0 ** (-6 - 10 * attempt)] * (len(net.body) + 1)
+                cal = self._build(net, xcal.shape[0], trial, 1.0, debug_all=True)
+                self._forward(cal, xcal)
+                torch.cuda.synchronize(dev)
+                if not int(self.overflow.item()):
+                    act = [float(o.abs().max()) / xs_ for o, xs_ in zip(cal["outs"], trial)]
+                    feat = float(cal["pol_feat"].abs().max())
+                    break
+                self.overflow.zero_()
+            if act is None:
+                raise OverflowError("split-fp16 kernels: the network's activations exceed 1e16 (or are not finite) on the calibration positions")
+            return self._build(net, self.S, [pow2_scale(a) for a in act], pow2_scale(feat), debug_all=False)
+        return self._build(net, self.S, None, None, debug_all=False)
+
+    def _build(self, net, S, act_scales, feat_scale, debug_all):
+        """Device images of one network for batches of S rows.  act_scales: the power-of-two scale XS_i of every conv layer's
+        stored output (float32-grade mode); feat_scale: that of the 512 policy features entering the Dense(512) tail."""
         dev = next(net.parameters()).device
-        S = self.S
         blocks = list(net.body) + [net.pol1]
         keep = []                                                          # keep device tensors alive
         layers = (ConvLayer * len(blocks))()
         split = self.mode == "f16x3"
         odt = torch.float32 if split else torch.bfloat16
-        y_body = torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if self.debug else None
-        y_pol = torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if self.debug else None
-        stream = offs = None
+        outs = [torch.empty((S, 8, 8, 128), dtype=odt, device=dev) if (debug_all or (self.debug and i >= len(blocks) - 2)) else None
+                for i in range(len(blocks))]
+        y_body, y_pol = outs[-2], outs[-1]
+        stream = offs = ws = None
         if split:                                                          # all layers' weights in one fragment-ordered stream
-            stream, offs = pack_split_stream([_f32(blk["conv"].weight) for blk in blocks])
+            stream, offs, ws = pack_split_stream([_f32(blk["conv"].weight) for blk in blocks])
             keep.append(stream)
         for i, blk in enumerate(blocks):
             cin_pad = 32 if i == 0 else 128
@@ -162,15 +230,15 @@ class FusedEvaluator:
             sc, sh = bn_affine(blk["bn"])
             if split:                                                      # power-of-two scalings: exact
                 wptr = stream.data_ptr() + 2 * offs[i]
-                b, sc, sh = (b * (XS * WS)).contiguous(), (sc / WS).contiguous(), (sh * XS).contiguous()
+                xin = XS if i == 0 else act_scales[i - 1]
+                b, sc, sh = (b * (ws[i] * xin)).contiguous(), (sc * (act_scales[i] / (ws[i] * xin))).contiguous(), (sh * act_scales[i]).contiguous()
             else:
                 w = pack_conv_weights(_f32(blk["conv"].weight), i == 0)
                 keep.append(w)
                 wptr = w.data_ptr()
             keep += [b, sc, sh]
-            out = y_body if i == len(blocks) - 2 else (y_pol if i == len(blocks) - 1 else None)
             layers[i] = ConvLayer(wptr, b.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                  out.data_ptr() if out is not None else None, cin_pad)
+                                  outs[i].data_ptr() if outs[i] is not None else None, cin_pad)
         pol_feat = torch.zeros((S, 512), dtype=torch.float32, device=dev)
         val_feat = torch.zeros((S, 64), dtype=torch.float32, device=dev)
         t = dict(pol_w=_f32(net.pol2["conv"].weight).reshape(8, 128).contiguous(), pol_b=_f32(net.pol2["conv"].bias),
@@ -181,12 +249,16 @@ class FusedEvaluator:
                           pol_feat.data_ptr(), t["val_w"].data_ptr(), t["val_b"].data_ptr(), t["val_scale"].data_ptr(),
                           t["val_shift"].data_ptr(), val_feat.data_ptr())
         vsc, vsh = bn_affine(net.val_bn)
-        tail = dict(fc_b=_f32(net.pol_fc.bias),
-                    fc_packed=pack_dense_weights(_f32(net.pol_fc.weight)),
+        fc_w = _f32(net.pol_fc.weight)
+        fc_ws = pow2_scale(float(fc_w.abs().max()))
+        tail = dict(fc_b=_f32(net.pol_fc.bias), fc_packed=pack_dense_weights(fc_w, fc_ws), fc_ws=fc_ws,
+                    fc_xs=float(feat_scale) if feat_scale is not None else XS,
                     w1t=_f32(net.val_fc1.weight).t().contiguous(), b1=_f32(net.val_fc1.bias), sc=vsc, sh=vsh,
                     w2=_f32(net.val_fc2.weight).reshape(64).contiguous(), b2=float(net.val_fc2.bias.detach().float().item()))
-        return dict(layers=layers, n=len(blocks), heads=heads, keep=keep + list(t.values()), y_body=y_body, y_pol=y_pol,
-                    pol_feat=pol_feat, val_feat=val_feat, tail=tail,
+        xs_arr = (C.c_float * len(blocks))(*[float(a) for a in act_scales]) if split else None
+        return dict(layers=layers, n=len(blocks), heads=heads, keep=keep + list(t.values()), y_body=y_body, y_pol=y_pol, outs=outs,
+                    pol_feat=pol_feat, val_feat=val_feat, tail=tail, S=S, act_scales=list(act_scales) if split else None, xs_arr=xs_arr,
+                    xs_body=act_scales[-2] if split else 1.0, xs_pol=act_scales[-1] if split else 1.0,
                     p=torch.zeros((S, 512), dtype=torch.float32, device=dev),
                     v=torch.zeros((S,), dtype=torch.float32, device=dev))
 
@@ -198,18 +270,18 @@ class FusedEvaluator:
     def _conv(self, n, x, stream, board_range=None):
         rng = board_range.data_ptr() if board_range is not None else None
         if self.mode == "f16x3":
-            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), XS, rng,
+            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), n["S"], n["layers"], n["n"], C.byref(n["heads"]), XS, n["xs_arr"], rng,
                                                     self._overflow_ptr(x.device), stream))
         else:
-            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self.S, n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
+            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), n["S"], n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
 
     def _forward(self, n, x, board_range=None):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         self._conv(n, x, stream, board_range)
         t = n["tail"]
         # Dense(512) + softmax and the value MLP: one launch
-        _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), self.S, t["fc_packed"].data_ptr(),
-                                          t["fc_b"].data_ptr(), XS, WS, t["w1t"].data_ptr(), t["b1"].data_ptr(), t["sc"].data_ptr(),
+        _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), n["S"], t["fc_packed"].data_ptr(),
+                                          t["fc_b"].data_ptr(), t["fc_xs"], t["fc_ws"], t["w1t"].data_ptr(), t["b1"].data_ptr(), t["sc"].data_ptr(),
                                           t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"], n["p"].data_ptr(), n["v"].data_ptr(),
                                           self._overflow_ptr(x.device), stream))
         return n["p"], n["v"]
@@ -244,12 +316,13 @@ class FusedEvaluator:
         return self._p, self._v
 
     def check_range(self):
-        """Raises if the float32-grade kernel met an activation outside its range (|a| * XS > 6e4): the
-        split-fp16 terms saturate there, so results since the last check are not to be used."""
+        """Assertion on the float32-grade kernels' operand range: raises if an activation exceeded the fp16 range of its hi
+        term at the layer's calibrated scale (four times the largest magnitude the calibration saw): the split terms
+        saturate there, so results since the last check are not to be used."""
         if self.overflow is not None and int(self.overflow.item()):
             self.overflow.zero_()
-            raise OverflowError("split-fp16 kernels: activation magnitude above %g; use the PyTorch evaluator "
-                                "(kind='torch') for this network" % (6e4 / XS))
+            raise OverflowError("split-fp16 kernels: an activation left the calibrated range (layer scales %s); results since the "
+                                "last check are invalid" % (self.nets[0]["act_scales"],))
 
     CONV_FLOPS_PER_BOARD = 2 * (64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128)      # the 8 convs of the stack
 

@@ -202,7 +202,8 @@ class StepRunner:
             self.warmup()
         S = self.eng.cfg.n_slots
         rows = S
-        can_compact = compact_tail and getattr(self.evaluator, "supports_row_range", False)
+        can_compact = (compact_tail and getattr(self.evaluator, "supports_row_range", False)
+                       and not getattr(self.eng, "dense_rows", False))      # a dense-rows engine is compact at every step
         while True:
             if self.time_budget is None:
                 self.step(check_every)
@@ -301,7 +302,8 @@ class SplitRunner:
                     S = eng.cfg.n_slots
                     if active == 0:
                         live.remove(part)
-                    elif getattr(runner.evaluator, "supports_row_range", False) and active <= rows[id(eng)] - max(6, S // 32):
+                    elif (getattr(runner.evaluator, "supports_row_range", False) and not getattr(eng, "dense_rows", False)
+                          and active <= rows[id(eng)] - max(6, S // 32)):
                         rows[id(eng)] = eng.compact_rows(runner.p, runner.v)
                 total += active
             if trace is not None:
@@ -317,6 +319,20 @@ class SplitRunner:
     def close(self):
         for e in self.engines:
             e.close()
+
+
+def default_leaf_cache_log2(n_slots, device=None):
+    """Size of an engine's leaf cache for n_slots concurrent games: a record serves for 2 048 - 4 096 steps (one to two
+    generations) and about half of a step's slots write one, so 2^(log2(slots) + 14) records keep the table below a quarter
+    full -- 264 B each: 8.9 GB for 2 048 slots; never more than 1/8 of the device's memory."""
+    log2 = min(26, max(16, int(np.ceil(np.log2(max(1, int(n_slots))))) + 14))
+    try:
+        mem = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).total_memory
+    except Exception:
+        return log2
+    while log2 > 16 and (264 << log2) > mem // 8:
+        log2 -= 1
+    return log2
 
 
 def _warn_pool_overflows(stats, what):
@@ -375,6 +391,12 @@ class generate_Checkers_data:
         self.networks = selfplay_kwargs.get("NETWORKS")                  # {file name: replacement spec / module}
         # two half-batches on two HIP streams (SplitRunner) once each half still fills the chip; results are identical
         self.split_streams = selfplay_kwargs.get("SPLIT_STREAMS", True)
+        # leaf cache (positions the network has already evaluated are expanded from cached priors / v) and dense network
+        # batches (a step costs what its leaves cost): on by default, results identical with and without
+        # (tests/test_leaf_cache_gpu.py).  LEAF_CACHE_LOG2: log2 of the records per engine, 0 = off, None = by slot count
+        self.leaf_cache_log2 = selfplay_kwargs.get("LEAF_CACHE_LOG2")
+        self.dense_rows = selfplay_kwargs.get("DENSE_ROWS", True)
+        self.evaluator_kind = selfplay_kwargs.get("EVALUATOR")           # None = the hand-written kernels where they apply; "torch"
         self.stats = None
         self.results = None
 
@@ -387,12 +409,9 @@ class generate_Checkers_data:
         dev = ckdist.local_device(local_rank) if world > 1 else torch.device("cuda", torch.cuda.current_device())
         raw_dev = torch.zeros((0, ckengine.TUPLE_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         if count > 0:
-            try:
-                raw_dev = self._play(dev, first, count, None)
-            except OverflowError as e:                 # an activation left the range of the split-fp16 kernels: the steps
-                import warnings                        # since the last check are tainted, so the job is replayed (same seed,
-                warnings.warn("%s -- replaying the job with the PyTorch float32 evaluator" % e, RuntimeWarning)   # same games)
-                raw_dev = self._play(dev, first, count, "torch")
+            # (an OverflowError from the float32-grade kernels' range assertion propagates: their operand scales are calibrated
+            # per layer when the weights are packed, fused.FusedEvaluator; EVALUATOR="torch" selects the PyTorch module)
+            raw_dev = self._play(dev, first, count, self.evaluator_kind)
         return ckdist.gather_rows(raw_dev, dst=0)           # the ONE collective of the job
 
     def _play(self, dev, first, count, kind):
@@ -401,7 +420,10 @@ class generate_Checkers_data:
             cfg = ckengine.config_from_kwargs(
                 self.mcts_kwargs, n_slots=n, games_per_slot=self.NUM_SELFPLAY_GAMES,
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree,
-                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue)
+                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue,
+                leaf_cache_log2=(default_leaf_cache_log2(n, dev) if self.leaf_cache_log2 is None else self.leaf_cache_log2)
+                if self.mcts_kwargs["NEURAL_NET"] else 0,
+                dense_rows=bool(self.dense_rows) and bool(self.mcts_kwargs["NEURAL_NET"]))
             return ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
 
         if not self.mcts_kwargs["NEURAL_NET"]:     # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
@@ -475,6 +497,8 @@ class tournament_Checkers:
         self.nodes_per_tree = tourney_kwargs.get("NODES_PER_TREE")
         self.use_graph = tourney_kwargs.get("USE_GRAPH", True)
         self.networks = tourney_kwargs.get("NETWORKS")                   # {file name: replacement spec / module}
+        self.leaf_cache_log2 = tourney_kwargs.get("LEAF_CACHE_LOG2")     # as in generate_Checkers_data (the key carries the network id)
+        self.dense_rows = tourney_kwargs.get("DENSE_ROWS", True)
         self.stats = None
 
     def start_tournament(self):
@@ -495,7 +519,9 @@ class tournament_Checkers:
             cfg = ckengine.config_from_kwargs(
                 self.mcts_kwargs, n_slots=count, games_per_slot=self.NUM_GAMES, tournament=True,
                 first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
-                seed=self.seed, device=dev.index)
+                seed=self.seed, device=dev.index,
+                leaf_cache_log2=default_leaf_cache_log2(count, dev) if self.leaf_cache_log2 is None else self.leaf_cache_log2,
+                dense_rows=bool(self.dense_rows) and ckengine.time_budget_of(self.mcts_kwargs) is None)
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
             runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn,
                                                     networks=self.networks), use_graph=self.use_graph,

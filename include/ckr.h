@@ -152,13 +152,15 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
  * 32 wc + (l & 31), input channels 16 slice + 8 (l >> 5) + 0..7.  The layers' images must follow one
  * another in memory with 3 slots (24 KB) of readable padding behind the last (the kernel requests
  * fragments three slots ahead; checked); bias / scale / shift pre-scaled
- * by the host (bias*XS*WS, scale/WS, shift*XS) so that the stored activation is
- * y * XS = hi + lo; x_scale = XS (a power of two).  layers[i].out (tests): float32
- * [n_boards][8][8][128] = activation * XS.  Head outputs are unscaled float32.
- * d_overflow (may be NULL): DEVICE int32 set to 1 when an activation * XS exceeds the fp16
+ * by the host so that layer i stores y * XS_i = hi + lo, XS_i = act_scales[i] (a power of two chosen per layer from the
+ * magnitudes the network produces, fused.py): with XS_in = x_scale for the input planes and WS_i the layer's weight scale,
+ * bias * WS_i * XS_(i-1), scale * XS_i / (WS_i * XS_(i-1)), shift * XS_i -- all exact.  act_scales: HOST float[n_layers]
+ * (NULL: every layer uses x_scale).  layers[i].out (tests): float32 [n_boards][8][8][128] = activation * XS_i.  Head
+ * outputs are unscaled float32.
+ * d_overflow (may be NULL): DEVICE int32 set to 1 when an activation * XS_i exceeds the fp16
  * range of the hi terms (6e4): such results are saturated and must be discarded. */
 int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers,
-                         int32_t n_layers, const ckr_conv_heads* heads, float x_scale,
+                         int32_t n_layers, const ckr_conv_heads* heads, float x_scale, const float* act_scales,
                          const int32_t* d_board_range, int32_t* d_overflow, void* stream);
 
 /* Arena batches (tournament_Checkers swaps game_env.neural_net per side, training_pipeline.py:
@@ -217,7 +219,8 @@ typedef struct {
     int32_t  nodes_per_tree;     /* semispace capacity of one search tree */
     int32_t  feature_dtype;      /* 0 float32, 1 float16, 2 bfloat16 */
     int32_t  max_sims_per_step;  /* cap on NN-free simulations (terminal visits) a slot runs back to back in one step before it
-                                    hands out a leaf; results do not depend on it (<= 0: 4, the measured throughput optimum) */
+                                    hands out a leaf; results do not depend on it (<= 0: the measured throughput optimum -- 4, or 2 with the
+                                    leaf cache, whose hits are network-free simulations too) */
     int32_t  record_root_stats;  /* 1: keep per-ply child W / P next to the tuples (tests) */
     int32_t  manual_play;        /* 1: interactive search API (MCTS / MCTS_Node facade): slots park after
                                     BUDGET simulations and moves are applied by ckr_engine_command */
@@ -246,6 +249,14 @@ typedef struct {
                                     recompute); only ckr_stats.nn_evals / dup_leaves and the step count change */
     int32_t  leaf_cache_gen_log2;/* log2 of the cache's generation length in steps (0 = 11): a record is served for one to two
                                     generations after it was written, then its place may be taken by a new one */
+    int32_t  dense_rows;         /* 1: the network batch is kept dense -- a slot that hands out a leaf takes the next free row of
+                                    d_x / d_net (and finds its answer in the same row of d_p / d_v at the next step) instead of
+                                    the row of its slot number, and every step leaves {0, number of leaves} in the DEVICE range
+                                    registered with ckr_engine_set_row_range, which ckr_conv_stack_* take as d_board_range: a
+                                    step costs what its leaves cost (slots that found no leaf within max_sims_per_step, finished
+                                    games, cache-served expansions leave no hole).  Row order varies from run to run; results do
+                                    not (the network kernels evaluate every row on its own: tests/test_leaf_cache_gpu.py) */
+    int32_t  reserved;
 } ckr_config;
 
 /* One training tuple, compact form (training_pipeline.py:364-369,406-410,
@@ -337,6 +348,9 @@ int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t count);
  * games cost.  Call between steps, on the stream of the steps.  No reference counterpart (the
  * reference's worker processes simply exit, training_pipeline.py:349-417). */
 int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_net, int32_t* d_range, void* stream);
+/* dense_rows engines: d_range = DEVICE int32[2]; every ckr_engine_step first zeroes it (and presets d_net to -1) on the
+ * step's stream, the tree kernel then counts the leaves it hands out in d_range[1].  Call once before the first step. */
+int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range);
 
 /* Counters (synchronises the stream the last step ran on). */
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out);

@@ -36,7 +36,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Tuple) == 288
     assert C.sizeof(_lib.GameResult) == 32
     assert C.sizeof(_lib.Stats) == 112
-    assert C.sizeof(_lib.Config) == 136
+    assert C.sizeof(_lib.Config) == 144
     assert C.sizeof(_lib.NodeInfo) == 40
 
 

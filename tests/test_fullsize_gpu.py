@@ -164,3 +164,67 @@ def test_fused_evaluator_full_batch_rows_vs_float64(oracle):
     pb, vb = FusedEvaluator(m, S, mode="bf16").forward_features(x.to(torch.bfloat16).contiguous())
     torch.cuda.synchronize()
     assert np.abs(pb[rows].cpu().numpy() - rp).max() < 5e-3 and np.abs(vb[rows].cpu().numpy() - rv).max() < 5e-2
+
+
+def test_cfg4_per_gpu_share_with_the_real_network(E):
+    """BASELINE cfg4 as one GPU of the 8 sees it: 4 096 of the 32 768 games, 400 sims/move, the random-init network in the
+    float32-grade kernels, played to the end through the drop-in runner (two half-batch engines, leaf cache, dense rows).
+    Accounting identities, well-formed tuples, and independence of the sharding: workers [0, 1 024) replayed as a shard
+    of their own (another engine size, one stream) give the same tuples byte for byte."""
+    import torch
+    from checkers_mcts_amd.pipeline import SplitRunner, StepRunner, make_evaluator, default_leaf_cache_log2
+    kw = mk(400, eps=0.25, tau=1.0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def make_engine(offset, n):
+        return E.Engine(E.config_from_kwargs(kw, n_slots=n, first_worker_id=offset, games_per_slot=1, terminate_cnt=200,
+                                             seed=4, leaf_cache_log2=default_leaf_cache_log2(n, dev), dense_rows=True))
+    runner = SplitRunner(make_engine, lambda n: make_evaluator("random:0", dev, torch.float32, n), 4096)
+    runner.run_to_completion()
+    st, res = runner.stats(), runner.results()
+    raw = np.frombuffer(runner.pack_tuples_device().cpu().numpy().tobytes(), dtype=E.TUPLE_DTYPE)
+    raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
+    runner.close()
+    assert len(res) == 4096 and st["games"] == 4096 and st["pool_overflows"] == 0 and all(r["failed"] == 0 for r in res)
+    plies = sum(r["move_count"] for r in res)
+    assert st["plies"] == plies and st["expansions"] + st["terminal_visits"] == 400 * plies
+    assert st["nn_evals"] + st["dup_leaves"] == st["expansions"] and st["dup_leaves"] > 0.2 * st["expansions"]
+    assert len(raw) == plies + 4096 - sum(r["adjudicated"] for r in res)
+    check_tuples(E, raw, 400)
+    eng = make_engine(0, 1024)
+    StepRunner(eng, make_evaluator("random:0", dev, torch.float32, 1024)).run_to_completion()
+    part = eng.tuples_raw()
+    part = part[np.lexsort((part["ply"], part["game"], part["worker"]))]
+    eng.close()
+    assert checksum(part) == checksum(raw[raw["worker"] < 1024])
+
+
+def test_cfg5_arena_share_with_two_real_networks(tmp_path, monkeypatch, capsys):
+    """BASELINE cfg5's shape on one GPU through the drop-in class: tournament_Checkers, 1 024 workers x 2 games, 800
+    sims/move, two different random-init networks in the float32-grade kernels, every game to its natural end
+    (training_pipeline.py:505-560); colours swap for each worker's second game; win / loss / draw bookkeeping adds up and
+    the reference's result file is written."""
+    import torch
+    from checkers_mcts_amd.pipeline import tournament_Checkers
+    monkeypatch.chdir(tmp_path)
+    kw = dict(mk(800, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    t = tournament_Checkers(dict(NEW_NN_FN="random:0", OLD_NN_FN="random:1", TOURNEY_GAMES=2, NUM_CPUS=1024, SEED=5), kw)
+    out = t._start_tournament()
+    st = t.stats
+    assert len(out) == 2048 and st["games"] == 2048 and st["pool_overflows"] == 0
+    assert all(r[3] in ("player1_wins", "player2_wins", "draw") for r in out)
+    assert [r[0] for r in out] == list(range(1, 2049))
+    assert all(out[i][1] == "random:0" and out[i + 1][1] == "random:1" for i in range(0, 2048, 2))      # :523-531
+    plies = sum(r[4] for r in out)
+    assert st["plies"] == plies and st["expansions"] + st["terminal_visits"] == 800 * plies
+    assert st["nn_evals"] + st["dup_leaves"] == st["expansions"]
+    new = sum((r[3] == "player1_wins" and r[1] == "random:0") or (r[3] == "player2_wins" and r[2] == "random:0") for r in out)
+    old = sum((r[3] == "player1_wins" and r[1] == "random:1") or (r[3] == "player2_wins" and r[2] == "random:1") for r in out)
+    draws = sum(r[3] == "draw" for r in out)
+    assert new + old + draws == 2048
+    fn = t._save_tourney_results(out)
+    assert t.summary == dict(new="random:0", old="random:1", new_wins=new, old_wins=old, draws=draws)
+    assert "%d/%d/%d" % (new, old, draws) in open(fn, encoding="utf-8").read()
+    with capsys.disabled():
+        print("\n[cfg5 share] 2 048 arena games, 800 sims/move: new %d, old %d, draws %d; %d plies (max %d); cache served %.1f %%"
+              % (new, old, draws, plies, max(r[4] for r in out), 100.0 * st["dup_leaves"] / st["expansions"]))

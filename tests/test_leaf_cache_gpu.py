@@ -1,10 +1,11 @@
-"""GPU: the engine's leaf cache (ckr_config.leaf_cache_log2).  Checkers.predict is a pure function of planes 0-13
+"""GPU: the engine's leaf cache (ckr_config.leaf_cache_log2) and dense network batches (ckr_config.dense_rows).  Checkers.predict is a pure function of planes 0-13
 (Checkers.py:425-438) and the reference keeps two trees per game (training_pipeline.py:353-386), so the same position is
 handed to the network repeatedly; the cache serves those repeats from HBM.  What is checked here: results are IDENTICAL with
 the cache on and off (tuples byte for byte, game results, search counters) for the hash nets, the inexact net in both
 accumulation modes (against the oracle), the arena, and the real network in the float32-grade kernels at cfg3's size; the
 accounting nn_evals + dup_leaves == expansions; and the premise the cache rests on -- the network kernels' output for a board
-does not depend on its row in the batch."""
+does not depend on its row in the batch.  The same identities hold with dense_rows, where the row a leaf occupies in the
+batch is whatever the arrival order of the step makes it."""
 import numpy as np
 import pytest
 
@@ -27,14 +28,14 @@ def play(E, kwargs, n_slots, evaluator, **cfg_kw):
 SEARCH_COUNTERS = ("expansions", "terminal_visits", "plies", "games", "reroot_misses", "nodes_created", "pool_overflows")
 
 
-@pytest.mark.parametrize("gen_log2", [0, 4])
-def test_cache_on_off_identical_hashnet_selfplay(E, gen_log2):
+@pytest.mark.parametrize("gen_log2,dense", [(0, False), (4, False), (0, True)])
+def test_cache_on_off_identical_hashnet_selfplay(E, gen_log2, dense):
     """Noise and temperature on (Philox streams keyed by worker: reproducible), two games per slot; gen_log2 = 4 makes
     generations 16 steps long, so that records expire and their places are reused all the time."""
     kw = mk(60, eps=0.25, tau=1.0)
     common = dict(games_per_slot=2, terminate_cnt=80, seed=77)
     off = play(E, kw, 96, E.hashnet_evaluator(9), **common)
-    on = play(E, kw, 96, E.hashnet_evaluator(9), leaf_cache_log2=14, leaf_cache_gen_log2=gen_log2, **common)
+    on = play(E, kw, 96, E.hashnet_evaluator(9), leaf_cache_log2=14, leaf_cache_gen_log2=gen_log2, dense_rows=dense, **common)
     assert off[0].tobytes() == on[0].tobytes() and off[1] == on[1]
     for k in SEARCH_COUNTERS:
         assert off[2][k] == on[2][k], k
@@ -68,15 +69,43 @@ def test_cache_on_off_identical_arena(E):
     """Two networks: the key carries the network id, a position evaluated by NEW is not served to OLD."""
     kw = dict(mk(80, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
     runs = []
-    for log2 in (0, 13):
-        eng = E.Engine(E.config_from_kwargs(kw, n_slots=64, games_per_slot=2, tournament=True, seed=5, leaf_cache_log2=log2))
+    for log2, dense in ((0, False), (13, False), (13, True), (0, True)):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=64, games_per_slot=2, tournament=True, seed=5, leaf_cache_log2=log2,
+                                            dense_rows=dense))
         eng.run(E.hashnet_evaluator(3, 4))
         runs.append((sorted(tuple(sorted(r.items())) for r in eng.results()), eng.stats()))
         eng.close()
-    assert runs[0][0] == runs[1][0]
-    for k in SEARCH_COUNTERS:
-        assert runs[0][1][k] == runs[1][1][k], k
-    assert runs[1][1]["dup_leaves"] > 0
+    for other in runs[1:]:
+        assert runs[0][0] == other[0]
+        for k in SEARCH_COUNTERS:
+            assert runs[0][1][k] == other[1][k], k
+    assert runs[1][1]["dup_leaves"] > 0 and runs[2][1]["dup_leaves"] > 0 and runs[3][1]["dup_leaves"] == 0
+
+
+def test_dense_rows_batch_is_compact(E):
+    """dense_rows: after a step the leaves sit in rows [0, n) of the batch (n = Engine.row_range[1]), idle rows carry net id
+    -1, and a slot finds the network's answer in the row it was given."""
+    import torch
+    from checkers_mcts_amd import rules
+    kw = mk(30, eps=0.25, tau=1.0)
+    eng = E.Engine(E.config_from_kwargs(kw, n_slots=128, games_per_slot=1, terminate_cnt=20, seed=3, dense_rows=True,
+                                        leaf_cache_log2=12, max_sims_per_step=1))
+    p = v = None
+    seen_partial = False
+    for step in range(4000):
+        eng.step(p, v)
+        n = int(eng.row_range[1].item())
+        ids = eng.net_id.cpu().numpy()
+        assert int(eng.row_range[0].item()) == 0 and (ids[:n] == 0).all() and (ids[n:] == -1).all()
+        st = eng.stats()
+        seen_partial |= 0 < n < 128
+        x = eng.x[:n].float().cpu().numpy()
+        assert n == 0 or (np.abs(x).reshape(n, -1).sum(1) > 0).all()             # every row in range holds a real position
+        if st["active_slots"] == 0:
+            break
+        p, v = rules.hashnet(eng.x, 5)
+    assert seen_partial and eng.stats()["active_slots"] == 0
+    eng.close()
 
 
 def test_network_kernels_are_batch_position_independent():
@@ -110,10 +139,10 @@ def test_cfg3_real_network_cache_on_off_identical(E, capsys):
     kw = mk(100, eps=0.25, tau=1.0)
     dev = torch.device("cuda", torch.cuda.current_device())
     out = []
-    for log2 in (0, 23):
+    for log2, dense in ((0, False), (23, False), (25, True)):
         def make_engine(offset, n):
             return E.Engine(E.config_from_kwargs(kw, n_slots=n, first_worker_id=offset, games_per_slot=1, terminate_cnt=200,
-                                                 seed=20260929, leaf_cache_log2=log2))
+                                                 seed=20260929, leaf_cache_log2=log2, dense_rows=dense))
         runner = SplitRunner(make_engine, lambda n: make_evaluator("random:0", dev, torch.float32, n), 4096)
         runner.run_to_completion()
         st = runner.stats()
@@ -121,14 +150,18 @@ def test_cfg3_real_network_cache_on_off_identical(E, capsys):
         raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
         runner.close()
         out.append((raw, st))
-    (raw0, st0), (raw1, st1) = out
+    (raw0, st0), (raw1, st1), (raw2, st2) = out
     assert len(raw0) == len(raw1) and checksum(raw0) == checksum(raw1) and raw0.tobytes() == raw1.tobytes()
+    assert raw0.tobytes() == raw2.tobytes()                                     # cache + dense rows: still byte-identical
     for k in SEARCH_COUNTERS:
-        assert st0[k] == st1[k], k
+        assert st0[k] == st1[k] == st2[k], k
+    assert st2["nn_evals"] + st2["dup_leaves"] == st2["expansions"]
     assert st1["nn_evals"] + st1["dup_leaves"] == st1["expansions"] and st0["dup_leaves"] == 0
     check_tuples(E, raw1, 100)
     rate = st1["dup_leaves"] / st1["expansions"]
     with capsys.disabled():
         print("\n[leaf cache] cfg3, real network: %.1f %% of %d expansions served from the cache; steps %d -> %d; dropped %d"
               % (100 * rate, st1["expansions"], st0["steps"], st1["steps"], st1["cache_dropped"]))
+        print("[leaf cache] 2^25 records + dense rows: %.1f %%; steps %d; dropped %d"
+              % (100.0 * st2["dup_leaves"] / st2["expansions"], st2["steps"], st2["cache_dropped"]))
     assert rate > 0.05

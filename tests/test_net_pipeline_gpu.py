@@ -194,7 +194,7 @@ def test_split_fp16_conv_stack_within_1e5_of_float64(oracle):
     import torch
     import net_ref
     from checkers_mcts_amd import net as N, rules
-    from checkers_mcts_amd.fused import FusedEvaluator, XS
+    from checkers_mcts_amd.fused import FusedEvaluator
     for n_boards, seed, perturb in ((96, 0, False), (191, 3, True), (7, 4, True), (1, 5, True), (770, 6, True)):
         m = N.PolicyValueNet(128).keras_init(seed)
         if perturb:
@@ -212,11 +212,13 @@ def test_split_fp16_conv_stack_within_1e5_of_float64(oracle):
             for blk in m.body:
                 h = m._block(blk, h)
             body_ref = h.permute(0, 2, 3, 1)
-        body = fe.nets[0]["y_body"] / XS
+        body = fe.nets[0]["y_body"] / fe.nets[0]["xs_body"]
         assert float((body - body_ref).abs().max()) < 1e-5 * max(1.0, float(body_ref.abs().max()))
     # large activations (BatchNorm gains x2.5 per layer: |activation| in the hundreds, toward the fp16 range of the
     # hi terms) and tiny ones (gains x0.05: lo terms in fp16's subnormal range): relative accuracy holds
-    for gain in (2.5, 0.05):
+    # ... and the x8-gain network (|activation| up to ~1e5), which the fixed operand scale of round 2 could not hold: the
+    # per-layer scales calibrated at weight-pack time keep it in range -- no PyTorch replay, the flag stays an assertion
+    for gain in (2.5, 0.05, 8.0):
         m = N.PolicyValueNet(128).keras_init(11).perturb_bn(11)
         with torch.no_grad():
             for blk in list(m.body)[:6]:
@@ -234,18 +236,25 @@ def test_split_fp16_conv_stack_within_1e5_of_float64(oracle):
                 h = md._block(blk, h)
             body_ref = h.permute(0, 2, 3, 1)
             pr, vr = md(x.double().permute(0, 3, 1, 2))
-        body = fe.nets[0]["y_body"].double() / XS
+        body = fe.nets[0]["y_body"].double() / fe.nets[0]["xs_body"]
         scale = float(body_ref.abs().max())
         assert float((body - body_ref).abs().max()) < 2e-6 * max(scale, 1e-30), (gain, scale)
-        assert float((p.double() - pr).abs().max()) < 1e-5 and float((v.double() - vr).abs().max()) < 1e-5
+        if gain == 8.0:
+            # logits of this network are in the thousands: ANY float32 evaluation is 1e-4-ish from float64 after the softmax
+            # (the PyTorch float32 module included) -- float32-grade here means no worse than that module
+            with torch.no_grad():
+                p32, v32 = m(x.permute(0, 3, 1, 2))
+            tol_p = max(1e-5, 2.0 * float((p32.double() - pr).abs().max()))
+            tol_v = max(1e-5, 2.0 * float((v32.double() - vr).abs().max()))
+        else:
+            tol_p = tol_v = 1e-5
+        assert float((p.double() - pr).abs().max()) < tol_p and float((v.double() - vr).abs().max()) < tol_v, gain
         fe.check_range()
-    # out of range (|activation| * XS beyond fp16): flagged, not silently saturated
-    m = N.PolicyValueNet(128).keras_init(11).perturb_bn(11)
-    with torch.no_grad():
-        for blk in list(m.body)[:6]:
-            blk["bn"].weight.mul_(8.0)
-    fe = FusedEvaluator(m.eval().cuda(), 48, mode="f16x3")
-    fe.forward_features(x)
+        if gain == 8.0:
+            assert float(body_ref.abs().max()) > 7500.0                 # beyond what XS = 8 could represent
+    # far outside the calibrated range (inputs 1 000 times larger than any position's planes): flagged, never silently saturated
+    fe = FusedEvaluator(m, 48, mode="f16x3")
+    fe.forward_features((x * 1000.0).contiguous())
     with pytest.raises(OverflowError):
         fe.check_range()
 

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 import numpy as np, torch
 import net_ref
 from checkers_mcts_amd import net as N, rules
-from checkers_mcts_amd.fused import FusedEvaluator, XS
+from checkers_mcts_amd.fused import FusedEvaluator
 from test_rules_gpu import random_boards
 
 for n_boards, seed, perturb in ((96, 0, False), (191, 3, True), (7, 4, True)):
@@ -27,7 +27,7 @@ for n_boards, seed, perturb in ((96, 0, False), (191, 3, True), (7, 4, True)):
             h = mm._block(blk, h)
         body_ref = h.permute(0, 2, 3, 1).contiguous()
         pt, vt = mm(x.permute(0, 3, 1, 2))
-    body = fe.nets[0]["y_body"] / XS
+    body = fe.nets[0]["y_body"] / fe.nets[0]["xs_body"]
     print("boards %d: body max|err| vs torch fp32 %.3e (max|act| %.2f) | p err %.3e v err %.3e | torch-fp32 p err %.3e v err %.3e" % (
         n_boards, float((body - body_ref).abs().max()), float(body_ref.abs().max()),
         np.abs(p.cpu().numpy() - rp).max(), np.abs(v.cpu().numpy() - rv).max(),
