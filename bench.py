@@ -387,13 +387,15 @@ def arena_leg(a, dev):
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.float32,
-                                      seed=20260929, device=dev.index, dynamic_queue=True)
+                                      seed=20260929, device=dev.index, dynamic_queue=True,
+                                      leaf_cache_log2=min(26, a.leaf_cache_log2 + 1) if a.leaf_cache_log2 else 0,
+                                      dense_rows=not a.no_dense_rows)
     eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
     ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
                         net_old=make_net(128, seed=1, device=dev, dtype=torch.float32), mode="f16x3")
     runner = StepRunner(eng, ev, use_graph=not a.no_graph)
     runner.warmup(3)
-    runner.step(30)
+    runner.step(1600)                                     # two plies into the games: the second tree of every game has started
 
     class _One:                                           # single engine, single stream
         step = staticmethod(runner.step)
@@ -403,7 +405,7 @@ def arena_leg(a, dev):
     return {"sims_per_s": (d["expansions"] + d["terminal_visits"]) / dt, "ms_per_step": dt / a.extra_steps * 1e3,
             "steps": a.extra_steps, "budget": 800, "dtype": DTYPE_LABEL["fp32"],
             "note": "each leaf is evaluated by its own network only (batch partitioned by network id on the device); "
-                    "sample from the start of the games"}
+                    "sample from the third ply of the games; leaf cache (keyed by position AND network) and dense rows as in the headline"}
 
 
 def rollout_leg(a, dev):
@@ -470,7 +472,14 @@ def training_leg(dev, batch=128, reps=30):
         opt.step()
     torch_ms = graph_ms(torch_step)
     flops = 2.0 * 64 * batch * 128 * (3 * 7 * 1152 + 2 * 126)
-    return {"batch": batch, "samples_per_s": batch / hip_ms * 1e3, "ms_per_step": hip_ms, "dtype": "f32 (conv GEMMs: float32 operands as 3 bfloat16 pieces, 6 products, float32 accumulate)",
+    tf = flops / hip_ms / 1e9
+    roof = {"bound": "mfma", "kernel": "the step's convolution GEMMs (k_gemm_nt6 / k_wgrad_tn6: forward, data gradient, weight gradient of "
+                                       "7 x [8192 B/128 x 128 x 1152] + the 14-plane first layer) over the WHOLE step's time (heads, BatchNorm, "
+                                       "Adam and launch gaps included)",
+            "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+            "flops_per_step": flops, "note": "float32-grade arithmetic priced against the float32 matrix peak; executed on the bf16 "
+                                             "matrix instruction as 6 products of 3 bfloat16 pieces per operand"}
+    return {"batch": batch, "roofline": roof, "samples_per_s": batch / hip_ms * 1e3, "ms_per_step": hip_ms, "dtype": "f32 (conv GEMMs: float32 operands as 3 bfloat16 pieces, 6 products, float32 accumulate)",
             "conv_gemm_tflops_over_whole_step": flops / hip_ms / 1e9, "fp32_matrix_peak_tflops": 157.3,
             "torch_miopen_ms_per_step": torch_ms, "speedup_vs_torch_miopen": torch_ms / hip_ms}
 
@@ -613,6 +622,7 @@ def main():
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
             extra["random_rollout_mode"] = rollout_leg(a, dev)
             extra["training_step"] = training_leg(dev)
+            extra["training_step_batch_1024"] = training_leg(dev, batch=1024, reps=10)
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(a.budget, a.cpu_seconds)

@@ -521,7 +521,7 @@ class tournament_Checkers:
                 first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
                 seed=self.seed, device=dev.index,
                 leaf_cache_log2=default_leaf_cache_log2(count, dev) if self.leaf_cache_log2 is None else self.leaf_cache_log2,
-                dense_rows=bool(self.dense_rows) and ckengine.time_budget_of(self.mcts_kwargs) is None)
+                dense_rows=bool(self.dense_rows))
             eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
             runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn,
                                                     networks=self.networks), use_graph=self.use_graph,

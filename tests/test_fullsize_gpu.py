@@ -143,9 +143,12 @@ def test_cfg3_with_the_real_network_float32_grade(E):
 
 
 def test_fused_evaluator_full_batch_rows_vs_float64(oracle):
-    """Both precision modes of the fused evaluator on the bench's batch (4 096 rows of real leaf-like features): rows
-    sampled from every part of the batch (first / last workgroup tiles, both boards of a tile) against the float64
-    restatement -- float32-grade mode within 1e-5 (pi, v), bf16 mode within its throughput-mode tolerance."""
+    """Both precision modes of the fused evaluator on the bench's batch (4 096 rows of leaf-like features), EVERY row against
+    a float64 evaluation of the same network (the module in double precision on the device; a sample of rows also against
+    the independent NumPy restatement oracle/net_ref.py): float32-grade mode within 1e-5 (pi, v), bf16 mode within its
+    throughput-mode tolerance.  This is the regression test of the packed-float32 wrong-result (build.py,
+    profiles/r03_slp_finding.md): it showed in ~12 % of the rows of this very batch and in no smaller one."""
+    import copy
     import torch
     import net_ref
     from checkers_mcts_amd import net as N, rules
@@ -154,16 +157,49 @@ def test_fused_evaluator_full_batch_rows_vs_float64(oracle):
     S = 4096
     m = N.PolicyValueNet(128).keras_init(3).perturb_bn(7).eval().cuda()
     x = rules.features(rules.boards_to_device(random_boards(S, 4242))).contiguous()
+    with torch.no_grad():
+        p64, v64 = copy.deepcopy(m).double()(x.permute(0, 3, 1, 2).double())
     rows = np.unique(np.concatenate([np.arange(0, 8), np.arange(S - 8, S), np.random.RandomState(1).randint(0, S, 48)]))
     sd = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
     rp, rv = net_ref.forward(sd, x[torch.from_numpy(rows).cuda()].cpu().numpy())
+    assert np.abs(p64[rows].cpu().numpy() - rp).max() < 1e-8 and np.abs(v64[rows].cpu().numpy().reshape(-1) - rv.reshape(-1)).max() < 1e-7
     p, v = FusedEvaluator(m, S, mode="f16x3").forward_features(x)
     torch.cuda.synchronize()
-    assert np.abs(p[rows].cpu().numpy() - rp).max() < 1e-5 and np.abs(v[rows].cpu().numpy() - rv).max() < 1e-5
+    ep, evv = (p.double() - p64).abs().max(1).values, (v.double() - v64.reshape(-1)).abs()
+    assert int((ep >= 1e-5).sum()) == 0 and int((evv >= 1e-5).sum()) == 0, (int((ep >= 1e-5).sum()), float(ep.max()), float(evv.max()))
     assert torch.allclose(p.sum(1), torch.ones(S, device="cuda"), atol=1e-5)
     pb, vb = FusedEvaluator(m, S, mode="bf16").forward_features(x.to(torch.bfloat16).contiguous())
     torch.cuda.synchronize()
-    assert np.abs(pb[rows].cpu().numpy() - rp).max() < 5e-3 and np.abs(vb[rows].cpu().numpy() - rv).max() < 5e-2
+    assert float((pb.double() - p64).abs().max()) < 5e-3 and float((vb.double() - v64.reshape(-1)).abs().max()) < 5e-2
+
+
+def test_fused_evaluator_two_concurrent_launches_all_rows():
+    """The condition that triggered the packed-float32 wrong result -- workgroups of different phases sharing a CU -- at its
+    worst: two evaluators on two HIP streams, their conv launches in flight together, several rounds; every row of both
+    against the float64 network."""
+    import copy
+    import torch
+    from checkers_mcts_amd import net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from test_rules_gpu import random_boards
+    S = 2048
+    nets = [N.PolicyValueNet(128).keras_init(s_).perturb_bn(s_ + 1).eval().cuda() for s_ in (3, 8)]
+    xs = [rules.features(rules.boards_to_device(random_boards(S, 77 + i))).contiguous() for i in range(2)]
+    with torch.no_grad():
+        refs = [copy.deepcopy(n_).double()(x_.permute(0, 3, 1, 2).double()) for n_, x_ in zip(nets, xs)]
+    evs = [FusedEvaluator(n_, S, mode="f16x3") for n_ in nets]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        outs = []
+        for ev, x_, st in zip(evs, xs, streams):
+            with torch.cuda.stream(st):
+                for _ in range(3):                                   # a queue of launches per stream: the two kernels overlap
+                    p, v = ev.forward_features(x_)
+                outs.append((p, v))
+        torch.cuda.synchronize()
+        for (p, v), (p64, v64) in zip(outs, refs):
+            assert float((p.double() - p64).abs().max()) < 1e-5 and float((v.double() - v64.reshape(-1)).abs().max()) < 1e-5, rnd
 
 
 def test_cfg4_per_gpu_share_with_the_real_network(E):

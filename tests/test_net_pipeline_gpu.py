@@ -240,12 +240,15 @@ def test_split_fp16_conv_stack_within_1e5_of_float64(oracle):
         scale = float(body_ref.abs().max())
         assert float((body - body_ref).abs().max()) < 2e-6 * max(scale, 1e-30), (gain, scale)
         if gain == 8.0:
-            # logits of this network are in the thousands: ANY float32 evaluation is 1e-4-ish from float64 after the softmax
-            # (the PyTorch float32 module included) -- float32-grade here means no worse than that module
+            # logits of this network are in the thousands: a float32 evaluation -- any, the PyTorch float32 module included
+            # (1.2e-4 here) -- carries a few ulps of the largest logit into the softmax, and d p / d logit <= 1/4:
+            # float32-grade means within 8 float32 ulps of the largest logit, a quarter of that on p
             with torch.no_grad():
-                p32, v32 = m(x.permute(0, 3, 1, 2))
-            tol_p = max(1e-5, 2.0 * float((p32.double() - pr).abs().max()))
-            tol_v = max(1e-5, 2.0 * float((v32.double() - vr).abs().max()))
+                hp = md._block(md.pol2, md._block(md.pol1, h))
+                logits = md.pol_fc(hp.permute(0, 2, 3, 1).reshape(hp.shape[0], -1))
+            lmax = float(logits.abs().max())
+            assert lmax > 500.0
+            tol_p, tol_v = max(1e-5, 0.25 * 8 * 2.0 ** -23 * lmax), 1e-5
         else:
             tol_p = tol_v = 1e-5
         assert float((p.double() - pr).abs().max()) < tol_p and float((v.double() - vr).abs().max()) < tol_v, gain

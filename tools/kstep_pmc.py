@@ -12,7 +12,10 @@ STEPS = int(os.environ.get("KSTEP_STEPS", "9000"))
 S = int(os.environ.get("KSTEP_SLOTS", "4096"))
 kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=100, MULTIPROC=False, NEURAL_NET=True, VERBOSE=False,
           TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25, TEMPERATURE_TAU=1.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
-eng = E.Engine(E.config_from_kwargs(kw, n_slots=S, games_per_slot=8, terminate_cnt=200, seed=20260929))
+CACHE = int(os.environ.get("KSTEP_CACHE_LOG2", "0"))          # round 3: leaf cache (records = 2^CACHE) and dense rows
+DENSE = os.environ.get("KSTEP_DENSE", "0") == "1"
+eng = E.Engine(E.config_from_kwargs(kw, n_slots=S, games_per_slot=8, terminate_cnt=200, seed=20260929, leaf_cache_log2=CACHE,
+                                    dense_rows=DENSE))
 runner = StepRunner(eng, make_evaluator("random:0", eng.device, torch.float32, S), use_graph=False)
 runner.step(STEPS)
 torch.cuda.synchronize()

@@ -87,6 +87,20 @@ def build():
     }
     for k, c in enumerate(cl):
         variants["slp_nop7_after_pk_cluster%d" % k] = dict(where=c, after="s_nop 7")
+    # second round: WHICH counter, and WHERE.  head = from the first packed operation of the policy-head clusters to the end
+    # of the kernel; body = everything before it
+    INSTR = re.compile(r"^\s*(v_|ds_|global_|buffer_|s_(?!waitcnt|nop|endpgm|cbranch|branch|barrier))")
+    VALU, DS, VMEM = re.compile(r"^\s*v_"), re.compile(r"^\s*ds_"), re.compile(r"^\s*(global_|buffer_)")
+    head, body = (cl[-2][0] - 40, cl[-1][1]), (0, cl[-2][0] - 41)
+    variants.update({
+        "slp2_head_all_counters_before_every_instr": dict(where=head, before="s_waitcnt vmcnt(0) lgkmcnt(0)", match=INSTR),
+        "slp2_body_all_counters_before_every_instr": dict(where=body, before="s_waitcnt vmcnt(0) lgkmcnt(0)", match=INSTR),
+        "slp2_head_lgkm0_after_ds": dict(where=head, after="s_waitcnt lgkmcnt(0)", match=DS),
+        "slp2_head_lgkm0_before_valu": dict(where=head, before="s_waitcnt lgkmcnt(0)", match=VALU),
+        "slp2_head_vm0_before_every_instr": dict(where=head, before="s_waitcnt vmcnt(0)", match=INSTR),
+        "slp2_head_vm0_after_vmem": dict(where=head, after="s_waitcnt vmcnt(0)", match=VMEM),
+        "slp2_head_nop3_before_valu": dict(where=head, before="s_nop 3", match=VALU),
+    })
     for name, v in variants.items():
         with open(os.path.join(OUT, name + ".s"), "w") as f:
             f.writelines(edit(lines, **v))
