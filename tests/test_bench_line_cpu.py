@@ -1,4 +1,4 @@
-"""CPU: the committed bench line of the round (profiles/r02_final_bench_default.json, written by `python bench.py` on an
+"""CPU: the committed bench line of the round (profiles/r03_final_bench_default.json, written by `python bench.py` on an
 MI355X) carries every field of the driver's contract, with the hot path's own metric and roofline / cpu_baseline objects."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r02_final_bench_default.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r03_final_bench_default.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
