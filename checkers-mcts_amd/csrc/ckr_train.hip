@@ -532,17 +532,24 @@ __global__ void k_tall_tn(const float* __restrict__ A, const float* __restrict__
 // Pass 1: a (in place over z) and per-block partial sums of a, a^2 per channel: part[blk][2][C].
 // blockDim = 256 threads = (256 / C) row lanes x C channels (C <= 256, power of two); ROWS rows per block.
 constexpr int ROWS = 64;
-__global__ void k_bias_relu_stats(float* __restrict__ z, const float* __restrict__ bias, int P, int Cc, int relu, float* __restrict__ part) {
+// The sums are SHIFTED by the channel's moving mean (shift; a good estimate of the batch mean once training runs): sum (a - c0)
+// and sum (a - c0)^2, so that var = E[(a - c0)^2] - (E[a - c0])^2 does not cancel when |mean| >> std.  Block 0 leaves the
+// shift it used behind the partials (part[2 C nblk + c]) for the finalising pass -- the moving mean itself is updated there.
+__global__ void k_bias_relu_stats(float* __restrict__ z, const float* __restrict__ bias, int P, int Cc, int relu, float* __restrict__ part,
+                                  const float* __restrict__ shift) {
     __shared__ float red[2][256];
     const int c = threadIdx.x % Cc, rl = threadIdx.x / Cc, nrl = blockDim.x / Cc;
     const int r0 = blockIdx.x * ROWS;
     float s = 0.0f, s2 = 0.0f;
     const float b = bias ? bias[c] : 0.0f;
+    const float c0 = shift ? shift[c] : 0.0f;
+    if (blockIdx.x == 0 && rl == 0) part[(size_t)gridDim.x * 2 * Cc + c] = c0;
     for (int r = r0 + rl; r < min(P, r0 + ROWS); r += nrl) {
         float v = z[(size_t)r * Cc + c] + b;
         if (relu) v = fmaxf(v, 0.0f);
         z[(size_t)r * Cc + c] = v;
-        s += v; s2 += v * v;
+        const float d = v - c0;
+        s += d; s2 += d * d;
     }
     red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
     __syncthreads();
@@ -572,22 +579,25 @@ __device__ inline void sum_partials(const float* __restrict__ part, int nblk, in
     __syncthreads();
 }
 
-// Pass 2 (one block): mean, biased variance, 1 / sqrt(var + eps); moving statistics with torch's
-// convention (momentum, unbiased variance).  stats[0][C] = mean, stats[1][C] = inv_std.  C <= 128.
+// Pass 2 (one block): mean, biased variance, 1 / sqrt(var + eps); moving statistics (momentum; the moving variance takes the
+// UNBIASED batch variance -- what tf.keras' fused BatchNormalization of 4-D inputs and torch do -- or, biased_moving_var != 0,
+// the biased one: tf.keras' non-fused BatchNormalization behind a Dense layer, training_pipeline.py:109).
+// stats[0][C] = mean, stats[1][C] = inv_std.  C <= 128.
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int nblk, int P, int Cc, float eps, float momentum,
-                              float* __restrict__ stats, float* __restrict__ run_mean, float* __restrict__ run_var) {
+                              float* __restrict__ stats, float* __restrict__ run_mean, float* __restrict__ run_var, int biased_moving_var) {
     __shared__ double red[256];
     sum_partials(part, nblk, 2 * Cc, red);
     const int c = threadIdx.x;
     if (c >= Cc) return;
-    const double mean = red[c] / P;
-    double var = red[Cc + c] / P - mean * mean;
+    const double d1 = red[c] / P, mean = (double)part[(size_t)nblk * 2 * Cc + c] + d1;          // shift + E[a - shift]
+    double var = red[Cc + c] / P - d1 * d1;
     if (var < 0.0) var = 0.0;
     stats[c] = (float)mean;
     stats[Cc + c] = (float)(1.0 / sqrt(var + (double)eps));
     if (run_mean) {
+        const double corr = biased_moving_var ? 1.0 : (double)P / (double)(P > 1 ? P - 1 : 1);
         run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
-        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(var * (double)P / (double)(P > 1 ? P - 1 : 1));
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)(var * corr);
     }
 }
 
@@ -678,13 +688,16 @@ __global__ __launch_bounds__(256) void k_sum_rows(const float* __restrict__ part
 // of the previous pass in their prologue (every block repeats the small sum; block 0 stores the results).
 //
 // Forward pass 1: a = ReLU(sum_z ws[z] + bias) and the partial sums of a, a^2: part[blk][2][128]
+// (shifted sums as in k_bias_relu_stats: part[256 nblk + c] = the shift)
 __global__ __launch_bounds__(1024) void k_fwd_reduce128(const float* __restrict__ ws, int slices, const float* __restrict__ bias, int P, int rpb,
-                                                       float* __restrict__ a, float* __restrict__ part) {
+                                                       float* __restrict__ a, float* __restrict__ part, const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float red[2][32][128];
     const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int r0 = blockIdx.x * rpb, r1 = min(P, r0 + rpb);
     const size_t n = (size_t)P * 128;
     const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    const float4 c0 = *reinterpret_cast<const float4*>(shift + 4 * c4);
+    if (blockIdx.x == 0 && rl == 0) *reinterpret_cast<float4*>(part + (size_t)gridDim.x * 256 + 4 * c4) = c0;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
     for (int r = r0 + rl; r < r1; r += 32) {
         const size_t i = (size_t)r * 128 + 4 * c4;
@@ -693,8 +706,9 @@ __global__ __launch_bounds__(1024) void k_fwd_reduce128(const float* __restrict_
         for (int z = 0; z < slices; ++z) { const float4 w = *reinterpret_cast<const float4*>(ws + z * n + i); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         *reinterpret_cast<float4*>(a + i) = v;
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+        const float4 d = make_float4(v.x - c0.x, v.y - c0.y, v.z - c0.z, v.w - c0.w);
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+        s2.x += d.x * d.x; s2.y += d.y * d.y; s2.z += d.z * d.z; s2.w += d.w * d.w;
     }
     *reinterpret_cast<float4*>(&red[0][rl][4 * c4]) = s;
     *reinterpret_cast<float4*>(&red[1][rl][4 * c4]) = s2;
@@ -717,8 +731,8 @@ __global__ __launch_bounds__(1024) void k_bn_apply128(const float* __restrict__ 
     sum_partials(part, npart, 256, red);
     if (threadIdx.x < 128) {
         const int c = threadIdx.x;
-        const double mean = red[c] / P;
-        double var = red[128 + c] / P - mean * mean;
+        const double d1 = red[c] / P, mean = (double)part[(size_t)npart * 256 + c] + d1;      // shift + E[a - shift]
+        double var = red[128 + c] / P - d1 * d1;
         if (var < 0.0) var = 0.0;
         const float mf = (float)mean, inv = (float)(1.0 / sqrt(var + (double)eps));
         sc[c] = inv; sh[c] = mf;
@@ -1004,14 +1018,14 @@ int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float
 
 // Forward half of a conv block after its GEMM: a = ReLU(sum of the workspace slices + bias) (kept for the backward pass),
 // batch statistics -> stats[2][128] (mean, 1 / sqrt(var + eps)), moving statistics updated, out = BatchNorm(a).
-// part: workspace of 256 * ceil(P / 128) floats.  The slices may alias a (slices == 1, workspace == a).
+// part: workspace of 256 * ceil(P / 128) + 128 floats.  The slices may alias a (slices == 1, workspace == a).
 int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* bias, int32_t P, const float* gamma, const float* beta, float eps,
                           float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part, void* stream) {
     if (!workspace || slices < 1 || !bias || !gamma || !beta || !run_mean || !run_var || !stats || !a || !out || !part || P <= 0)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bias_relu_bn: bad argument");
     if (int rc = ckr::require_device()) return rc;
     const int rpb = rows_per_block(P), nblk = (P + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_fwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, bias, (int)P, rpb, a, part);
+    hipLaunchKernelGGL(k_fwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, bias, (int)P, rpb, a, part, (const float*)run_mean);
     hipLaunchKernelGGL(k_bn_apply128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, (const float*)a, (const float*)part, nblk, (int)P, rpb, gamma, beta,
                        eps, momentum, run_mean, run_var, stats, out);
     CKR_HIP(hipGetLastError());
@@ -1080,14 +1094,16 @@ int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col,
 static bool chan_ok(int Cc) { return Cc >= 1 && Cc <= 128 && (128 % Cc) == 0; }
 
 // a = act(z + bias) in place, batch statistics -> stats[2][C], moving statistics updated, out = BatchNorm(a).
-// part: workspace of 2 * C * ceil(P / 64) floats.  (The heads' small layers; the conv blocks use ckr_conv_bias_relu_bn.)
+// part: workspace of 2 * C * ceil(P / 64) + C floats.  (The heads' small layers; the conv blocks use ckr_conv_bias_relu_bn.)
 int ckr_bn_forward(float* z, const float* bias, int32_t P, int32_t Cc, int32_t relu, const float* gamma, const float* beta, float eps,
-                   float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part, void* stream) {
+                   float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part, int32_t biased_moving_var,
+                   void* stream) {
     if (!z || !gamma || !beta || !stats || !out || !part || P <= 0 || !chan_ok(Cc)) return ckr::fail(CKR_ERR_INVALID, "ckr_bn_forward: bad argument");
     if (int rc = ckr::require_device()) return rc;
     const int nblk = (P + ROWS - 1) / ROWS;
-    hipLaunchKernelGGL(k_bias_relu_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z, bias, (int)P, (int)Cc, (int)relu, part);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, (int)P, (int)Cc, eps, momentum, stats, run_mean, run_var);
+    hipLaunchKernelGGL(k_bias_relu_stats, dim3(nblk), dim3(256), 0, (hipStream_t)stream, z, bias, (int)P, (int)Cc, (int)relu, part, (const float*)run_mean);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)part, nblk, (int)P, (int)Cc, eps, momentum, stats, run_mean, run_var,
+                       (int)biased_moving_var);
     LAUNCH1D(k_bn_apply, (long long)P * Cc, stream, (const float*)z, (const float*)stats, gamma, beta, (long long)P * Cc, (int)Cc, out);
     CKR_HIP(hipGetLastError());
     return CKR_OK;

@@ -40,7 +40,7 @@ class HipTrainStep:
         L.ckr_gemm_small.argtypes = [vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp]
         L.ckr_gemm_tall.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
         L.ckr_im2col.argtypes = [vp, i32, i32, i32, vp, vp]
-        L.ckr_bn_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
+        L.ckr_bn_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, i32, vp]
         L.ckr_bn_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
         L.ckr_policy_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
         L.ckr_value_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
@@ -177,7 +177,7 @@ class HipTrainStep:
         _lib.check(self._L.ckr_bn_forward(z.data_ptr(), bias.data_ptr() if bias is not None else None, P, Cc, relu,
                                           self.w(gname).data_ptr(), self.w(bname).data_ptr(), self.bn_eps, self.bn_mom,
                                           rm.data_ptr(), rv.data_ptr(), self.stats[key].data_ptr(), out.data_ptr(),
-                                          part.data_ptr(), self._s()))
+                                          part.data_ptr(), 1 if key == "vbn" else 0, self._s()))     # Dense BN: biased moving variance (Keras, non-fused)
 
     def _bn_bwd(self, dout, a, P, Cc, relu, key, gname, bname, biasname, part, sums):
         _lib.check(self._L.ckr_bn_backward(dout.data_ptr(), a.data_ptr(), self.stats[key].data_ptr(), self.w(gname).data_ptr(), P, Cc, relu,

@@ -432,7 +432,7 @@ int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int
 int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float* wt, void* stream);
 /* Forward of a conv block after its GEMM: a = ReLU(sum of `slices` workspace slices + bias) (kept for the backward pass),
  * stats[2][128] = batch mean, 1 / sqrt(biased variance + eps), moving statistics updated (torch convention: momentum,
- * unbiased variance), out = gamma * (a - mean) * inv_std + beta.  part: >= 256 ceil(P / 128) floats of workspace. */
+ * unbiased variance), out = gamma * (a - mean) * inv_std + beta.  part: >= 256 ceil(P / 128) + 128 floats of workspace. */
 int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* bias, int32_t P, const float* gamma, const float* beta,
                           float eps, float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part,
                           void* stream);
@@ -453,9 +453,12 @@ int ckr_gemm_tall(const float* A, const float* B, int32_t P, int32_t M, int32_t 
 /* col[p][tap * cin + c] = x[p + off(tap)][c] ('same' zero padding per 8x8 board; columns >= 9 cin zero): the first layer. */
 int ckr_im2col(const float* x, int32_t P, int32_t cin, int32_t kpad, float* col, void* stream);
 /* Keras block "activation -> BatchNormalization" in training mode for the heads' small layers (C | 128):
- * z := act(z + bias) in place (relu != 0: ReLU), stats, moving statistics, out as above.  part: >= 2 C ceil(P / 64) floats. */
+ * z := act(z + bias) in place (relu != 0: ReLU), stats, moving statistics, out as above.  part: >= 2 C ceil(P / 64) + C floats.
+ * biased_moving_var != 0: the moving variance takes the biased batch variance (tf.keras' non-fused BatchNormalization, i.e. the
+ * one behind the value head's Dense(64), training_pipeline.py:109) instead of the unbiased one (fused, 4-D inputs). */
 int ckr_bn_forward(float* z, const float* bias, int32_t P, int32_t C, int32_t relu, const float* gamma, const float* beta,
-                   float eps, float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part, void* stream);
+                   float eps, float momentum, float* run_mean, float* run_var, float* stats, float* out, float* part,
+                   int32_t biased_moving_var, void* stream);
 /* dout (gradient w.r.t. out) -> gradient w.r.t. the pre-activation, in place; dgamma, dbeta, dbias (may be NULL). */
 int ckr_bn_backward(float* dout, const float* a, const float* stats, const float* gamma, int32_t P, int32_t C, int32_t relu,
                     float* dgamma, float* dbeta, float* dbias, float* part, float* sums, void* stream);

@@ -189,6 +189,14 @@ def test_one_step_gradients_match_autograd(B, pipe):
     close(hs.g("fc.b") + two_reg["dense"] * ref.pol_fc.bias.detach(), ref.pol_fc.bias.grad, 5e-4, "policy dense bias")
     close(hs.g("f1.w").reshape(64, 64) + two_reg["dense"] * ref.val_fc1.weight.detach(), ref.val_fc1.weight.grad, 5e-4, "value dense 1 kernel")
     close(hs.g("f1.b") + two_reg["dense"] * ref.val_fc1.bias.detach(), ref.val_fc1.bias.grad, 5e-4, "value dense 1 bias")
+    for key, blk in (("p2", ref.pol2), ("v1", ref.val1)):                   # 4-D BatchNormalization: unbiased moving variance (Keras fused, torch)
+        close(hs.run[key][0], blk["bn"].running_mean, 1e-4, key + " moving mean")
+        close(hs.run[key][1], blk["bn"].running_var, 1e-4, key + " moving variance")
+    # the BatchNormalization behind Dense(64) is Keras' non-fused one: its moving variance takes the BIASED batch variance
+    mom = ref.val_bn.momentum
+    var_unbiased = (ref.val_bn.running_var - (1.0 - mom) * 1.0) / mom
+    close(hs.run["vbn"][0], ref.val_bn.running_mean, 1e-4, "value bn moving mean")
+    close(hs.run["vbn"][1], (1.0 - mom) * 1.0 + mom * var_unbiased * (B - 1) / B, 1e-4, "value bn moving variance (biased)")
     close(hs.g("vbn.g"), ref.val_bn.weight.grad, 5e-4, "value bn gamma")
     close(hs.g("vbn.beta"), ref.val_bn.bias.grad, 5e-4, "value bn beta")
     close(hs.g("f2.w").reshape(1, 64) + two_reg["dense"] * ref.val_fc2.weight.detach(), ref.val_fc2.weight.grad, 5e-4, "value dense 2 kernel")
@@ -236,3 +244,34 @@ def test_adam_trajectory_matches_float64():
         r32 = copy.deepcopy(ref).float()
         p2, v2 = r32(x.permute(0, 3, 1, 2))
     assert float((p1 - p2).abs().max()) < 1e-3 and float((v1 - v2).abs().max()) < 1e-2          # six Adam steps apart (see above)
+
+
+def test_batchnorm_statistics_do_not_cancel_with_a_large_mean():
+    """Batch variance from sums shifted by the moving mean: a channel whose mean is 10 000 standard deviations away from 0
+    (E[x^2] - mean^2 in float32 partial sums would lose every digit of the variance) still gets its inverse standard
+    deviation to 1e-3; and the Dense-layer flag switches the moving variance between the biased and the unbiased estimate."""
+    import ctypes as C
+    from checkers_mcts_amd import _lib
+    L = _lib.load()
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    L.ckr_bn_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, i32, vp]
+    P, Cc = 4096, 8
+    g = torch.Generator().manual_seed(1)
+    x64 = 100.0 + 0.01 * torch.randn(P, Cc, generator=g, dtype=torch.float64)
+    for biased in (0, 1):
+        z = x64.float().cuda().contiguous()
+        x_seen = z.double().cpu()                                                  # the float32 values the kernel sees
+        gamma, beta = torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        rm, rv = torch.full((Cc,), 99.99, device="cuda"), torch.ones(Cc, device="cuda")
+        stats, out = torch.zeros(2, Cc, device="cuda"), torch.zeros(P, Cc, device="cuda")
+        part = torch.zeros(2 * Cc * (P // 64 + 1) + Cc, device="cuda")
+        _lib.check(L.ckr_bn_forward(z.data_ptr(), None, P, Cc, 0, gamma.data_ptr(), beta.data_ptr(), 1e-9, 0.01, rm.data_ptr(), rv.data_ptr(),
+                                    stats.data_ptr(), out.data_ptr(), part.data_ptr(), biased, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        mean, var = x_seen.mean(0), x_seen.var(0, unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-9)
+        assert float(((stats[0].double().cpu() - mean).abs()).max()) < 1e-5
+        assert float(((stats[1].double().cpu() - inv).abs() / inv).max()) < 1e-3
+        want = 0.99 * 1.0 + 0.01 * var * (1.0 if biased else P / (P - 1.0))
+        assert float((rv.double().cpu() - want).abs().max()) < 1e-7
+        assert float((rm.double().cpu() - (0.99 * 99.99 + 0.01 * mean)).abs().max()) < 1e-4
