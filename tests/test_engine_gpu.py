@@ -467,7 +467,8 @@ def test_rollout_mode_vs_oracle_and_random_playouts(E, oracle, golden_dir):
     eng.close()
 
 
-def test_time_constrained_search(E):
+@pytest.mark.parametrize("fast", [False, True])
+def test_time_constrained_search(E, fast):
     """CONSTRAINT == 'time' (MCTS.computational_budget, MCTS.py:196-198): every ply is searched for BUDGET seconds of wall
     clock, then all running games move.  Results depend on the machine's speed (as in the reference), so the checks are
     structural: one ply per time window, searches of more than one simulation, well-formed tuples, games that end."""
@@ -475,7 +476,8 @@ def test_time_constrained_search(E):
     import torch
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(mk(1, eps=0.25, tau=1.0), CONSTRAINT="time", BUDGET=0.02)
-    cfg = E.config_from_kwargs(kw, n_slots=64, games_per_slot=1, terminate_cnt=12, seed=3)
+    cfg = E.config_from_kwargs(kw, n_slots=64, games_per_slot=1, terminate_cnt=12, seed=3,       # fast: leaf cache + dense rows too
+                               leaf_cache_log2=14 if fast else 0, dense_rows=fast)
     eng = E.Engine(cfg)
     runner = StepRunner(eng, E.hashnet_evaluator(4), use_graph=False, time_budget=E.time_budget_of(kw))
     t0 = time.perf_counter()

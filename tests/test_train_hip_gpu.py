@@ -193,10 +193,10 @@ def test_one_step_gradients_match_autograd(B, pipe):
         close(hs.run[key][0], blk["bn"].running_mean, 1e-4, key + " moving mean")
         close(hs.run[key][1], blk["bn"].running_var, 1e-4, key + " moving variance")
     # the BatchNormalization behind Dense(64) is Keras' non-fused one: its moving variance takes the BIASED batch variance
-    mom = ref.val_bn.momentum
-    var_unbiased = (ref.val_bn.running_var - (1.0 - mom) * 1.0) / mom
+    mom, rv0 = ref.val_bn.momentum, net.val_bn.running_var.detach().double()          # net: the module's value before the step
+    var_unbiased = (ref.val_bn.running_var - (1.0 - mom) * rv0) / mom
     close(hs.run["vbn"][0], ref.val_bn.running_mean, 1e-4, "value bn moving mean")
-    close(hs.run["vbn"][1], (1.0 - mom) * 1.0 + mom * var_unbiased * (B - 1) / B, 1e-4, "value bn moving variance (biased)")
+    close(hs.run["vbn"][1], (1.0 - mom) * rv0 + mom * var_unbiased * (B - 1) / B, 1e-4, "value bn moving variance (biased)")
     close(hs.g("vbn.g"), ref.val_bn.weight.grad, 5e-4, "value bn gamma")
     close(hs.g("vbn.beta"), ref.val_bn.bias.grad, 5e-4, "value bn beta")
     close(hs.g("f2.w").reshape(1, 64) + two_reg["dense"] * ref.val_fc2.weight.detach(), ref.val_fc2.weight.grad, 5e-4, "value dense 2 kernel")
