@@ -60,7 +60,7 @@ EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_bat
            "ckr_probe_dirichlet", "ckr_probe_temperature", "ckr_probe_tau_schedule",
            "ckr_gemm_nt", "ckr_conv_gemm", "ckr_conv_wgrad", "ckr_conv_wflip", "ckr_conv_bias_relu_bn", "ckr_conv_bn_relu_backward", "ckr_conv_bias_grad",
            "ckr_gemm_small", "ckr_gemm_tall", "ckr_im2col", "ckr_bn_forward", "ckr_bn_backward",
-           "ckr_policy_loss", "ckr_value_loss", "ckr_loss_sums", "ckr_adam_step", "ckr_sum_rows"]
+           "ckr_policy_loss", "ckr_value_loss", "ckr_loss_sums", "ckr_adam_step", "ckr_sum_rows", "ckr_value_head_step", "ckr_policy_head_step"]
 
 _lib = None
 

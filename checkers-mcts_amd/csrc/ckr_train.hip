@@ -21,6 +21,7 @@
 //   * everything else (1x1 convolutions and the dense layers of the two heads, losses, Adam with the l2 terms)
 //     is bandwidth- or latency-bound elementwise / reduction work in plain float32.
 #include "ckr_host.h"
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 namespace ckrt {
@@ -905,6 +906,7 @@ __global__ __launch_bounds__(256) void k_loss_sums(const float* __restrict__ ce,
 }
 
 // ------------------------------------------------------------------------------------------------ Adam + l2
+struct LossArgs { const float* ce; const float* se; double* acc; double n_rows; int B; float wp, wv; int pad; };
 // One flat parameter vector; reg[i] = the l2 coefficient of element i (CONV_REG / DENSE_REG on kernels and biases,
 // 0 on BatchNorm parameters).  g = grad + 2 reg w;  torch.optim.Adam arithmetic (bias-corrected step size,
 // eps outside the square root), lr and the step counter read from device memory (captured in a HIP graph).
@@ -912,9 +914,10 @@ __global__ __launch_bounds__(256) void k_loss_sums(const float* __restrict__ ce,
 // weights BEFORE the update (Keras adds it to the loss it prints) in penalty_parts[b].
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ w, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                        const float* __restrict__ reg, long long n, const float* __restrict__ lr, float beta1, float beta2, float eps,
-                       const float* __restrict__ step, double* __restrict__ penalty_parts) {
+                       float* __restrict__ step, double* __restrict__ penalty_parts, const LossArgs la) {
     __shared__ double red[256];
-    const float t = *step + 1.0f;                                 // k_step_inc runs after this kernel
+    __shared__ unsigned last;
+    const float t = *step + 1.0f;                                 // the last block to finish stores it (every block has read *step by then)
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     const float rate = *lr / bc1, rs = sqrtf(bc2);
     double pen = 0.0;
@@ -928,14 +931,523 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ w, const float
         const float denom = sqrtf(vi) / rs + eps;
         w[i] = wi - rate * (mi / denom);
     }
-    if (!penalty_parts) return;
-    red[threadIdx.x] = pen;
+    if (penalty_parts) {
+        red[threadIdx.x] = pen;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    }
+    // the block that finishes last advances the step counter and adds the batch's losses to the running sums: the work of
+    // two more launches at the end of the step's critical path.  step[1] holds the ticket (an unsigned, left at 0).
+    // (No agent-scope release / acquire fences: each would write back and invalidate the XCD's L2, 512 times -- measured
+    // 21 us instead of 11.  The partial sums travel as device-scope atomic stores / loads, which go to the coherent level
+    // themselves; the wait between the store and the ticket keeps their order.)
+    if (!threadIdx.x) {
+        if (penalty_parts) {
+            __hip_atomic_store(penalty_parts + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);                        // the store has been acknowledged before the ticket is taken
+        }
+        const unsigned ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(step + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = ticket == gridDim.x - 1;
+    }
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
-    if (!threadIdx.x) penalty_parts[blockIdx.x] = red[0];
+    if (!last) return;
+    if (!threadIdx.x) { step[0] = t; __hip_atomic_store(reinterpret_cast<unsigned*>(step + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (!la.acc) return;
+    __shared__ double red3[3][256];
+    double c = 0.0, q = 0.0, pn = 0.0;
+    for (int b = threadIdx.x; b < la.B; b += 256) { c += la.ce[b]; q += la.se[b]; }
+    if (penalty_parts)
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) pn += __hip_atomic_load(penalty_parts + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red3[0][threadIdx.x] = c; red3[1][threadIdx.x] = q; red3[2][threadIdx.x] = pn;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) for (int j = 0; j < 3; ++j) red3[j][threadIdx.x] += red3[j][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x) return;
+    c = red3[0][0] / la.B; q = red3[1][0] / la.B;
+    la.acc[0] += la.n_rows * ((double)la.wp * c + (double)la.wv * q + red3[2][0]);
+    la.acc[1] += la.n_rows * c;
+    la.acc[2] += la.n_rows * q;
 }
 
-__global__ void k_step_inc(float* step) { if (!threadIdx.x && !blockIdx.x) *step += 1.0f; }
+
+// ------------------------------------------------------------------------------------------------ the value head in four launches
+// 1x1 conv (1 kernel) + ReLU + BN -> flatten -> Dense(64) + ReLU + BN -> Dense(1) -> tanh, its loss and its whole backward pass
+// (training_pipeline.py:102-112).  At the reference's batch (128) every matrix here is tiny and the 26 launches of the
+// layer-by-layer sequence cost 4.5 us each whatever they compute (profiles/r03_train_step_timeline_before.txt: the graph issues
+// ~119 nodes per step at ~8 us per node); so: k_vh_conv (positions in parallel: the 1x1 convolution, ReLU, BatchNorm partial
+// sums), k_vh_mlp (ONE workgroup walks the rest of the forward pass, the loss and the backward pass down to the gradient w.r.t.
+// the convolution's output; the arithmetic and its order follow the layer kernels above), k_vh_conv_bwd (positions in parallel:
+// gradient w.r.t. the body's output, partial sums of the 1x1 kernel's gradient) + k_sum_rows.
+struct ValueHead {
+    const float* body; const float* target;                       // [P][128], [B]
+    const float* v1_w; const float* v1_b; const float* v1_g; const float* v1_beta;       // [128], [1], [1], [1]
+    const float* f1_w; const float* f1_b; const float* vbn_g; const float* vbn_beta;     // [64 out][64 in], [64], [64], [64]
+    const float* f2_w; const float* f2_b;                         // [64], [1]
+    float* v1_rm; float* v1_rv; float* vbn_rm; float* vbn_rv;      // moving statistics
+    float* stats_v1; float* stats_vbn;                            // [2][1], [2][64]: mean, 1 / sqrt(var + eps)
+    float* g_v1_w; float* g_v1_b; float* g_v1_g; float* g_v1_beta; float* g_f1_w; float* g_f1_b; float* g_vbn_g; float* g_vbn_beta;
+    float* g_f2_w; float* g_f2_b;
+    float* a_v1; float* out_v1; float* a_f1; float* out_f1; float* dz_f2; float* d_f1; float* d_v1;      // kept activations / scratch
+    float* d_body; float* se; float* part;                        // [P][128] gradient w.r.t. the body's output; [B]; workspace
+    int P, B; float eps, momentum, weight;
+};
+
+__global__ __launch_bounds__(256) void k_vh_conv(const ValueHead A) {                 // 64 positions per block, 4 lanes (32 channels each) per position
+    __shared__ float red[2][64];
+    const int tid = threadIdx.x, pos = tid >> 2, q = tid & 3, p = blockIdx.x * 64 + pos;
+    const float c0 = *A.v1_rm;
+    const float4* x = reinterpret_cast<const float4*>(A.body + (size_t)p * 128 + 32 * q);
+    const float4* w = reinterpret_cast<const float4*>(A.v1_w + 32 * q);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 xv = x[k], wv = w[k];
+        s = fmaf(xv.x, wv.x, s); s = fmaf(xv.y, wv.y, s); s = fmaf(xv.z, wv.z, s); s = fmaf(xv.w, wv.w, s);
+    }
+    const float s1 = __shfl(s, (tid & ~3) + 1), s2 = __shfl(s, (tid & ~3) + 2), s3 = __shfl(s, (tid & ~3) + 3);
+    if (q == 0) {
+        const float a = fmaxf((((s + s1) + s2) + s3) + *A.v1_b, 0.0f), d = a - c0;
+        A.a_v1[p] = a;
+        red[0][pos] = d; red[1][pos] = d * d;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        float t = red[tid][0];
+        for (int k = 1; k < 64; ++k) t += red[tid][k];
+        A.part[blockIdx.x * 2 + tid] = t;
+        if (blockIdx.x == 0 && tid == 0) A.part[gridDim.x * 2] = c0;
+    }
+}
+
+// sums of two per-thread doubles over the workgroup (1 024 threads); every thread gets both totals
+__device__ inline void vh_block_sum2(double& a, double& b, double* red) {
+    __syncthreads();
+    red[threadIdx.x] = a; red[1024 + threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[1024 + threadIdx.x] += red[1024 + threadIdx.x + o]; }
+        __syncthreads();
+    }
+    a = red[0]; b = red[1024];
+    __syncthreads();
+}
+
+// B <= 128.  Everything between the two convolution-sized passes lives in LDS (dynamic, VH_MLP_LDS bytes): the flattened
+// BatchNorm output f [B][64] (later the gradient w.r.t. it), the Dense(64) activations a [B][64] and their gradient d [B][64].
+constexpr int VH_MLP_LDS = 2048 * 8 + (3 * 128 * 64 + 64 * 65 + 128 + 6 * 64) * 4;
+__global__ __launch_bounds__(1024) void k_vh_mlp(const ValueHead A, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vh_lds[];
+    double* red = reinterpret_cast<double*>(vh_lds);               // [2048]
+    float* f = reinterpret_cast<float*>(red + 2048);               // [128][64]
+    float* a = f + 128 * 64;                                       // [128][64]
+    float* d = a + 128 * 64;                                       // [128][64]
+    float* w1 = d + 128 * 64;                                      // Dense(64) kernel, rows padded to 65: lane = output unit reads conflict-free
+    float* dz2 = w1 + 64 * 65;                                     // [128]
+    float (*cst)[64] = reinterpret_cast<float (*)[64]>(dz2 + 128); // per hidden unit: mean, inv_std, gamma, beta, dbeta / B, dgamma / B
+    const int tid = threadIdx.x, P = A.P, B = A.B;
+    const int j = tid & 63, g = tid >> 6;                          // 64 units x 16 row groups
+    for (int i = tid; i < 4096; i += 1024) w1[(i >> 6) * 65 + (i & 63)] = A.f1_w[i];
+    if (tid < 64) { cst[2][tid] = A.vbn_g[tid]; cst[3][tid] = A.vbn_beta[tid]; }
+    // ---- BatchNorm of the convolution's output: statistics from k_vh_conv's partial sums, apply
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = tid; b < nblk; b += 1024) { s1 += (double)A.part[2 * b]; s2 += (double)A.part[2 * b + 1]; }
+    vh_block_sum2(s1, s2, red);
+    const double d1 = s1 / P, mean_d = (double)A.part[2 * nblk] + d1;
+    double var = s2 / P - d1 * d1;
+    if (var < 0.0) var = 0.0;
+    const float mean1 = (float)mean_d, inv1 = (float)(1.0 / sqrt(var + (double)A.eps));
+    if (tid == 0) {
+        A.stats_v1[0] = mean1; A.stats_v1[1] = inv1;
+        *A.v1_rm = (1.0f - A.momentum) * *A.v1_rm + A.momentum * mean1;
+        *A.v1_rv = (1.0f - A.momentum) * *A.v1_rv + A.momentum * (float)(var * (double)P / (double)(P > 1 ? P - 1 : 1));
+    }
+    const float g1 = *A.v1_g, be1 = *A.v1_beta;
+    for (int p = tid; p < P; p += 1024) f[p] = g1 * ((A.a_v1[p] - mean1) * inv1) + be1;
+    __syncthreads();
+    // ---- Dense(64) + bias + ReLU
+    {
+        const float bj = A.f1_b[j];
+        for (int b = g; b < B; b += 16) {
+            const float* fb = f + b * 64;
+            float s = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < 64; ++k) s = fmaf(fb[k], w1[j * 65 + k], s);
+            const float av = fmaxf(s + bj, 0.0f);
+            a[b * 64 + j] = av; A.a_f1[b * 64 + j] = av;           // kept post-ReLU activations (global copy: for inspection)
+        }
+    }
+    __syncthreads();
+    // ---- BatchNorm behind the Dense layer (Keras non-fused: biased moving variance)
+    {
+        const float c0 = A.vbn_rm[j];
+        float s = 0.0f, q = 0.0f;
+        for (int b = g; b < B; b += 16) { const float e = a[b * 64 + j] - c0; s += e; q += e * e; }
+        red[tid] = s; red[1024 + tid] = q;
+        __syncthreads();
+        if (tid < 64) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int k = 0; k < 16; ++k) { t1 += red[k * 64 + tid]; t2 += red[1024 + k * 64 + tid]; }
+            const double e1 = t1 / B, m = (double)c0 + e1;
+            double v = t2 / B - e1 * e1;
+            if (v < 0.0) v = 0.0;
+            const float mf = (float)m, inv = (float)(1.0 / sqrt(v + (double)A.eps));
+            cst[0][tid] = mf; cst[1][tid] = inv;
+            A.stats_vbn[tid] = mf; A.stats_vbn[64 + tid] = inv;
+            A.vbn_rm[tid] = (1.0f - A.momentum) * c0 + A.momentum * mf;
+            A.vbn_rv[tid] = (1.0f - A.momentum) * A.vbn_rv[tid] + A.momentum * (float)v;
+        }
+        __syncthreads();
+    }
+    // ---- Dense(1) + tanh, squared error, gradient w.r.t. the pre-activation: 8 lanes per row, 8 units each, added in order
+    //      h = BatchNorm output, recomputed from a where it is needed
+    {
+        const int b = tid >> 3, q = tid & 7;
+        float s = 0.0f;
+        if (b < B) {
+#pragma unroll
+            for (int k = 8 * q; k < 8 * q + 8; ++k) s = fmaf(cst[2][k] * ((a[b * 64 + k] - cst[0][k]) * cst[1][k]) + cst[3][k], A.f2_w[k], s);
+        }
+        float t = s;                                               // ordered sum of the eight partial dot products
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const float o = __shfl(s, (tid & ~7) + k); if (q == 0) t += o; }
+        if (b < B && q == 0) {
+            const float v = tanhf(t + *A.f2_b), e = v - A.target[b];
+            A.se[b] = e * e;
+            const float dzb = A.weight * 2.0f * e / (float)B * (1.0f - v * v);
+            dz2[b] = dzb; A.dz_f2[b] = dzb;
+        }
+    }
+    __syncthreads();
+    // ---- backward: Dense(1); BatchNorm (64 units) statistics
+    {
+        const float w2 = A.f2_w[j];
+        float sw = 0.0f, s = 0.0f, q = 0.0f;
+        for (int b = g; b < B; b += 16) {
+            const float ah = (a[b * 64 + j] - cst[0][j]) * cst[1][j], h = cst[2][j] * ah + cst[3][j], dh = dz2[b] * w2;
+            sw = fmaf(dz2[b], h, sw);
+            d[b * 64 + j] = dh;
+            s += dh; q += dh * ah;
+        }
+        red[tid] = s; red[1024 + tid] = q;
+        __syncthreads();
+        if (tid < 64) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int k = 0; k < 16; ++k) { t1 += red[k * 64 + tid]; t2 += red[1024 + k * 64 + tid]; }
+            const float db = (float)t1, dg = (float)t2;
+            A.g_vbn_beta[tid] = db; A.g_vbn_g[tid] = dg;
+            cst[4][tid] = db / (float)B; cst[5][tid] = dg / (float)B;
+        }
+        __syncthreads();
+        red[tid] = sw;
+        __syncthreads();
+        if (tid < 64) {
+            double t = 0.0;
+            for (int k = 0; k < 16; ++k) t += red[k * 64 + tid];
+            A.g_f2_w[tid] = (float)t;
+        } else if (tid == 64) {
+            double t = 0.0;
+            for (int b = 0; b < B; ++b) t += (double)dz2[b];
+            *A.g_f2_b = (float)t;
+        }
+        __syncthreads();
+        // ---- BatchNorm + ReLU backward; bias gradient of Dense(64)
+        float sb = 0.0f;
+        for (int b = g; b < B; b += 16) {
+            const int i = b * 64 + j;
+            const float av = a[i];
+            float e = (cst[2][j] * cst[1][j]) * (d[i] - cst[4][j] - ((av - cst[0][j]) * cst[1][j]) * cst[5][j]);
+            if (!(av > 0.0f)) e = 0.0f;
+            d[i] = e;
+            sb += e;
+        }
+        red[tid] = sb;
+        __syncthreads();
+        if (tid < 64) {
+            double t = 0.0;
+            for (int k = 0; k < 16; ++k) t += red[k * 64 + tid];
+            A.g_f1_b[tid] = (float)t;
+        }
+        __syncthreads();
+    }
+    // ---- backward: Dense(64): kernel gradient dW1[jj][i] = sum_b dz[b][jj] f[b][i] (4 per thread); then the gradient w.r.t. f, written over f
+    {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = 0; b < B; ++b) {
+            const float fv = f[b * 64 + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(d[b * 64 + g + 16 * q], fv, acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A.g_f1_w[(g + 16 * q) * 64 + j] = acc[q];
+    }
+    __syncthreads();
+    for (int b = g; b < B; b += 16) {
+        const float* db = d + b * 64;
+        float s = 0.0f;
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) s = fmaf(db[k], w1[k * 65 + j], s);
+        f[b * 64 + j] = s;
+    }
+    __syncthreads();
+    // ---- backward: BatchNorm (1 channel, P values) + ReLU of the convolution; its bias gradient
+    double t1 = 0.0, t2 = 0.0;
+    for (int p = tid; p < P; p += 1024) { const float e = f[p]; t1 += (double)e; t2 += (double)(e * ((A.a_v1[p] - mean1) * inv1)); }
+    vh_block_sum2(t1, t2, red);
+    const float dbeta = (float)t1, dgamma = (float)t2;
+    if (tid == 0) { *A.g_v1_beta = dbeta; *A.g_v1_g = dgamma; }
+    const float gi = g1 * inv1, dbp = dbeta / (float)P, dgp = dgamma / (float)P;
+    double sb = 0.0, zero = 0.0;
+    for (int p = tid; p < P; p += 1024) {
+        const float av = A.a_v1[p];
+        float e = gi * (f[p] - dbp - ((av - mean1) * inv1) * dgp);
+        if (!(av > 0.0f)) e = 0.0f;
+        A.d_v1[p] = e;
+        sb += (double)e;
+    }
+    vh_block_sum2(sb, zero, red);
+    if (tid == 0) *A.g_v1_b = (float)sb;
+}
+
+// d_body[p][c] = dz[p] w[c]; part[blk][c] = sum over the block's 64 positions of dz[p] body[p][c] (256 threads = 2 row lanes x 128)
+__global__ __launch_bounds__(256) void k_vh_conv_bwd(const ValueHead A, float* __restrict__ part) {
+    __shared__ float red[256];
+    const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    const int r0 = blockIdx.x * 64, r1 = min(A.P, r0 + 64);
+    const float w = A.v1_w[c];
+    const float* __restrict__ body = A.body;
+    const float* __restrict__ dv = A.d_v1;
+    float* __restrict__ dbody = A.d_body;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int r = r0 + rl; r < r1; r += 2) {
+        const float dz = dv[r];
+        dbody[(size_t)r * 128 + c] = dz * w;
+        acc = fmaf(dz, body[(size_t)r * 128 + c], acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) part[(size_t)blockIdx.x * 128 + c] = acc + red[128 + c];
+}
+
+
+// ------------------------------------------------------------------------------------------------ the policy head in few launches
+// 1x1 conv (8 kernels) + ReLU + BN -> flatten (H, W, C) -> Dense(512) -> softmax, Keras' clipped cross-entropy, backward
+// (training_pipeline.py:93-100).  It sits ON the step's critical path (between the policy conv block's forward and backward
+// pass): seven launches there instead of seventeen -- k_ph_conv, k_ph_bn_apply, the logits GEMM (split-K partials left in the
+// workspace), k_policy_loss (adds the partials), the GEMM of the gradient w.r.t. the features (on the transposed kernel),
+// k_ph_bn_bwd_stats (adds its partials), k_ph_bn_bwd_conv -- and the parameter gradients nobody waits for (Dense kernel and
+// bias, 1x1 kernel and bias) on the side stream.  Arithmetic and summation orders of the layer kernels above.
+struct PolicyHead {
+    const float* x; const float* pi;                              // [P][128] policy conv block output; [B][512] targets
+    const float* p2_w; const float* p2_b; const float* p2_g; const float* p2_beta;       // [8][128], [8], [8], [8]
+    const float* fc_w; const float* fc_b;                         // [512 out][512 in], [512]
+    float* fc_wt;                                                 // [512 in][512 out]: transposed copy (phase 3)
+    float* p2_rm; float* p2_rv; float* stats_p2;                  // moving statistics; [2][8]
+    float* g_p2_w; float* g_p2_b; float* g_p2_g; float* g_p2_beta; float* g_fc_w; float* g_fc_b;
+    float* a_p2; float* out_p2; float* dlogits; float* d_f; float* ce;       // [P][8], [P][8], [B][512], [B][512] = [P][8], [B]
+    float* d_x;                                                   // [P][128] gradient w.r.t. x
+    float* ws; float* part; float* tall;                          // split-K workspace (4 B 512); 48 P / 64 + 64 floats; 16 P floats
+    int P, B; float eps, momentum, weight;
+};
+
+__global__ __launch_bounds__(256) void k_ph_conv(const PolicyHead A) {
+    __shared__ __attribute__((aligned(16))) float w[8 * 128];
+    __shared__ float red[2][8][64];
+    const int tid = threadIdx.x, pos = tid >> 2, og = tid & 3, p = blockIdx.x * 64 + pos;
+    for (int i = tid; i < 1024; i += 256) w[i] = A.p2_w[i];
+    __syncthreads();
+    const float4* x = reinterpret_cast<const float4*>(A.x + (size_t)p * 128);
+    const float4* w0 = reinterpret_cast<const float4*>(w + (2 * og) * 128);
+    const float4* w1 = reinterpret_cast<const float4*>(w + (2 * og + 1) * 128);
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+        const float4 xv = x[k], a = w0[k], b = w1[k];
+        s0 = fmaf(xv.x, a.x, s0); s0 = fmaf(xv.y, a.y, s0); s0 = fmaf(xv.z, a.z, s0); s0 = fmaf(xv.w, a.w, s0);
+        s1 = fmaf(xv.x, b.x, s1); s1 = fmaf(xv.y, b.y, s1); s1 = fmaf(xv.z, b.z, s1); s1 = fmaf(xv.w, b.w, s1);
+    }
+    const int o = 2 * og;
+    const float a0 = fmaxf(s0 + A.p2_b[o], 0.0f), a1 = fmaxf(s1 + A.p2_b[o + 1], 0.0f);
+    *reinterpret_cast<float2*>(A.a_p2 + (size_t)p * 8 + o) = make_float2(a0, a1);
+    const float d0 = a0 - A.p2_rm[o], d1 = a1 - A.p2_rm[o + 1];               // sums shifted by the moving mean
+    red[0][o][pos] = d0; red[1][o][pos] = d0 * d0; red[0][o + 1][pos] = d1; red[1][o + 1][pos] = d1 * d1;
+    __syncthreads();
+    if (tid < 16) {
+        const int st = tid >> 3, c = tid & 7;
+        float t = red[st][c][0];
+        for (int j = 1; j < 64; ++j) t += red[st][c][j];
+        A.part[((size_t)blockIdx.x * 2 + st) * 8 + c] = t;
+        if (blockIdx.x == 0 && st == 0) A.part[(size_t)gridDim.x * 16 + c] = A.p2_rm[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ph_bn_apply(const PolicyHead A, int nblk) {
+    __shared__ double red[256];
+    __shared__ float mi[2][8];
+    sum_partials(A.part, nblk, 16, red);
+    if (threadIdx.x < 8) {
+        const int c = threadIdx.x;
+        const double d1 = red[c] / A.P, mean = (double)A.part[(size_t)nblk * 16 + c] + d1;
+        double var = red[8 + c] / A.P - d1 * d1;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean, inv = (float)(1.0 / sqrt(var + (double)A.eps));
+        mi[0][c] = mf; mi[1][c] = inv;
+        if (blockIdx.x == 0) {
+            A.stats_p2[c] = mf; A.stats_p2[8 + c] = inv;
+            A.p2_rm[c] = (1.0f - A.momentum) * A.p2_rm[c] + A.momentum * mf;
+            A.p2_rv[c] = (1.0f - A.momentum) * A.p2_rv[c] + A.momentum * (float)(var * (double)A.P / (double)(A.P > 1 ? A.P - 1 : 1));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const size_t t = (size_t)blockIdx.x * 512 + i;
+        const int c = i & 7;
+        A.out_p2[t] = A.p2_g[c] * ((A.a_p2[t] - mi[0][c]) * mi[1][c]) + A.p2_beta[c];
+    }
+}
+
+// k_policy_loss on split-K partial logits: logits = sum of `slices` partials of [B][512] + bias
+template <int SLICES>
+__global__ __launch_bounds__(256) void k_policy_loss_s(const float* __restrict__ parts, const float* __restrict__ bias,
+                                                       const float* __restrict__ pi, int B, float weight,
+                                                       float* __restrict__ dlogits, float* __restrict__ ce_out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const size_t n = (size_t)B * 512;
+    float z[8], t[8];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        float l = parts[(size_t)b * 512 + i];
+#pragma unroll
+        for (int q = 1; q < SLICES; ++q) l += parts[q * n + (size_t)b * 512 + i];
+        z[j] = l + bias[i];
+        t[j] = pi[(size_t)b * 512 + i];
+        mx = fmaxf(mx, z[j]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { z[j] = expf(z[j] - mx); sum += z[j]; }
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    float ce = 0.0f, tu = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        z[j] = z[j] / sum;
+        const bool u = z[j] > 1e-7f && z[j] < 1.0f - 1e-7f;
+        const float pc = fminf(fmaxf(z[j], 1e-7f), 1.0f - 1e-7f);
+        ce -= t[j] * logf(pc);
+        tu += u ? t[j] : 0.0f;
+        t[j] = u ? t[j] : 0.0f;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { ce += __shfl_xor(ce, d); tu += __shfl_xor(tu, d); }
+    const float sc = weight / (float)B;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dlogits[(size_t)b * 512 + lane + 64 * j] = sc * (z[j] * tu - t[j]);
+    if (lane == 0) ce_out[b] = ce;
+}
+
+// d_f = sum of the split-K partials of dlogits . W (kept: the gradient w.r.t. the BatchNorm output, [P][8]); partial sums of
+// d_f and d_f * ahat per channel: partB[blk][2][8]
+template <int SLICES>
+__global__ __launch_bounds__(256) void k_ph_bn_bwd_stats(const PolicyHead A, float* __restrict__ partB) {
+    __shared__ float red[2][8][64];
+    const size_t n = (size_t)A.P * 8;
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const size_t t = (size_t)blockIdx.x * 512 + i;
+        float d = A.ws[t];
+#pragma unroll
+        for (int q = 1; q < SLICES; ++q) d += A.ws[q * n + t];
+        A.d_f[t] = d;
+        const int c = i & 7, pos = i >> 3;
+        red[0][c][pos] = d; red[1][c][pos] = d * ((A.a_p2[t] - A.stats_p2[c]) * A.stats_p2[8 + c]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int st = threadIdx.x >> 3, c = threadIdx.x & 7;
+        float t = red[st][c][0];
+        for (int j = 1; j < 64; ++j) t += red[st][c][j];
+        partB[((size_t)blockIdx.x * 2 + st) * 8 + c] = t;
+    }
+}
+
+// BatchNorm + ReLU backward (sums finished in the prologue), then, with the block's dz[64][8] in LDS: d_x[p][c] = sum_o dz[p][o] W[o][c],
+// partial kernel gradient tall[blk][o][c] = sum_p dz[p][o] x[p][c], partial bias gradient part2[blk][o] = sum_p dz[p][o]
+__global__ __launch_bounds__(256) void k_ph_bn_bwd_conv(const PolicyHead A, int nblk, const float* __restrict__ partB, float* __restrict__ part2) {
+    __shared__ double red[256];
+    __shared__ float cs[4][8];                                    // mean, g * inv, dbeta / P, dgamma / P
+    __shared__ float dz[64][8];
+    __shared__ float w[8][128];
+    __shared__ float acc2[8][128];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 1024; i += 256) w[i >> 7][i & 127] = A.p2_w[i];
+    sum_partials(partB, nblk, 16, red);
+    if (tid < 8) {
+        const float db = (float)red[tid], dg = (float)red[8 + tid];
+        if (blockIdx.x == 0) { A.g_p2_beta[tid] = db; A.g_p2_g[tid] = dg; }
+        cs[0][tid] = A.stats_p2[tid]; cs[1][tid] = A.stats_p2[8 + tid];
+        cs[2][tid] = db / (float)A.P; cs[3][tid] = dg / (float)A.P;
+    }
+    __syncthreads();
+    for (int i = tid; i < 512; i += 256) {
+        const size_t t = (size_t)blockIdx.x * 512 + i;
+        const int c = i & 7;
+        const float av = A.a_p2[t], inv = cs[1][c];
+        float d = (A.p2_g[c] * inv) * (A.d_f[t] - cs[2][c] - ((av - cs[0][c]) * inv) * cs[3][c]);
+        if (!(av > 0.0f)) d = 0.0f;
+        A.d_f[t] = d;
+        dz[i >> 3][c] = d;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        float t = 0.0f;
+        for (int j = 0; j < 64; ++j) t += dz[j][tid];
+        part2[(size_t)blockIdx.x * 8 + tid] = t;
+    }
+    const int c = tid & 127, rl = tid >> 7;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+    float wc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) wc[o] = w[o][c];
+    const float* __restrict__ xin = A.x + (size_t)blockIdx.x * 64 * 128 + c;
+    float* __restrict__ dx = A.d_x + (size_t)blockIdx.x * 64 * 128 + c;
+    for (int r0 = rl; r0 < 64; r0 += 16) {                         // 8 rows per pass: the loads first
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = xin[(size_t)(r0 + 2 * u) * 128];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 2 * u;
+            float s = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) { const float d = dz[r][o]; s = fmaf(d, wc[o], s); acc[o] = fmaf(d, xv[u], acc[o]); }
+            dx[(size_t)r * 128] = s;
+        }
+    }
+    if (rl == 1) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc2[o][c] = acc[o];
+    }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) A.tall[((size_t)blockIdx.x * 8 + o) * 128 + c] = acc[o] + acc2[o][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_transpose512(const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x & 15, by = blockIdx.x >> 4, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) t[j][tx] = in[(size_t)(by * 32 + j) * 512 + bx * 32 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) out[(size_t)(bx * 32 + j) * 512 + by * 32 + tx] = t[tx][j];
+}
+
 
 }  // namespace ckrt
 
@@ -949,13 +1461,13 @@ static int rows_per_block(int P) { return P <= 16384 ? 128 : 128 * ((P + 16383) 
 
 int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                 int32_t slices, float* workspace, const float* add, void* stream) {
-    if (!A || !Bt || !C || M <= 0 || N <= 0 || K <= 0 || M % BM || N % BN || slices < 1 || K % (BK * slices) || (ldc % 4) || (lda % 4) || (ldb % 4))
+    if (!A || !Bt || (!C && slices < 2) || M <= 0 || N <= 0 || K <= 0 || M % BM || N % BN || slices < 1 || K % (BK * slices) || (ldc % 4) || (lda % 4) || (ldb % 4))
         return ckr::fail(CKR_ERR_INVALID, "ckr_gemm_nt: M, N multiples of 128, K a multiple of 32 * slices, leading dimensions of 4");
     if (slices > 1 && (!workspace || ldc != N)) return ckr::fail(CKR_ERR_INVALID, "ckr_gemm_nt: split-K needs a workspace and ldc == N");
     if (int rc = ckr::require_device()) return rc;
     float* dst = slices > 1 ? workspace : C;
     hipLaunchKernelGGL(k_gemm_nt<0>, dim3(N / BN, M / BM, slices), dim3(GT), 0, (hipStream_t)stream, A, (int)lda, Bt, (int)ldb, dst, (int)ldc, (int)M, (int)K);
-    if (slices > 1 || add) {
+    if (C && (slices > 1 || add)) {                                 // C == NULL: the caller's next kernel adds the slices
         const long long n4 = (long long)M * N / 4;
         if (slices == 1) {                                        // C = C + add
             hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float4*)C, 1, n4, (const float4*)add, (float4*)C);
@@ -1149,14 +1661,84 @@ int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float w
     return CKR_OK;
 }
 
-// d_penalty_parts: 512 doubles (or null): the l2 penalty of the weights before this update, in 512 partial sums
+// d_penalty_parts: 512 doubles (or null): the l2 penalty of the weights before this update, in 512 partial sums.
+// d_step: 2 floats -- the step counter and a scratch word that is 0 between calls.  losses (may be null): the sums of
+// ckr_loss_sums, added by the same launch.
 int ckr_adam_step(float* w, const float* grad, float* m, float* v, const float* reg, int64_t n, const float* d_lr, float beta1, float beta2,
-                  float eps, float* d_step, double* d_penalty_parts, void* stream) {
+                  float eps, float* d_step, double* d_penalty_parts, const ckr_loss_args* losses, void* stream) {
     if (!w || !grad || !m || !v || !reg || !d_lr || !d_step || n <= 0) return ckr::fail(CKR_ERR_INVALID, "ckr_adam_step: bad argument");
+    if (losses && (!losses->ce || !losses->se || !losses->acc || losses->B <= 0)) return ckr::fail(CKR_ERR_INVALID, "ckr_adam_step: bad loss arguments");
     if (int rc = ckr::require_device()) return rc;
+    static_assert(sizeof(ckr_loss_args) == sizeof(LossArgs), "ckr_loss_args mirrors LossArgs");
+    LossArgs la;
+    memset(&la, 0, sizeof(la));
+    if (losses) memcpy(&la, losses, sizeof(la));
     hipLaunchKernelGGL(k_adam, dim3(ADAM_BLOCKS), dim3(256), 0, (hipStream_t)stream, w, grad, m, v, reg, (long long)n, d_lr, beta1, beta2, eps,
-                       (const float*)d_step, d_penalty_parts);
-    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(64), 0, (hipStream_t)stream, d_step);
+                       d_step, d_penalty_parts, la);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_value_head_step(const ckr_value_head* h, void* stream) {
+    if (!h) return ckr::fail(CKR_ERR_INVALID, "ckr_value_head_step: null argument");
+    const void* const* ptrs = reinterpret_cast<const void* const*>(h);
+    for (int i = 0; i < 38; ++i)
+        if (!ptrs[i]) return ckr::fail(CKR_ERR_INVALID, "ckr_value_head_step: null pointer (field %d)", i);
+    if (h->B <= 0 || h->B > 128 || h->P != 64 * h->B) return ckr::fail(CKR_ERR_INVALID, "ckr_value_head_step: 1 <= B <= 128, P = 64 B");
+    if (int rc = ckr::require_device()) return rc;
+    static_assert(sizeof(ckr_value_head) == sizeof(ValueHead), "ckr_value_head mirrors ValueHead");
+    ValueHead A;
+    memcpy(&A, h, sizeof(A));
+    const int nblk = h->P / 64, nb2 = nblk;
+    float* part2 = h->part + 2 * nblk + 8;
+    static bool lds_set = false;                                  // one workgroup keeps three [128][64] float arrays in LDS
+    if (!lds_set) {
+        CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_vh_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, VH_MLP_LDS));
+        lds_set = true;
+    }
+    hipLaunchKernelGGL(k_vh_conv, dim3(nblk), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_vh_mlp, dim3(1), dim3(1024), VH_MLP_LDS, (hipStream_t)stream, A, nblk);
+    hipLaunchKernelGGL(k_vh_conv_bwd, dim3(nb2), dim3(256), 0, (hipStream_t)stream, A, part2);
+    hipLaunchKernelGGL(k_sum_rows, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)part2, nb2, 128, h->g_v1_w);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_policy_head_step(const ckr_train_policy_head* h, int32_t phase, void* stream) {
+    if (!h) return ckr::fail(CKR_ERR_INVALID, "ckr_policy_head_step: null argument");
+    const void* const* ptrs = reinterpret_cast<const void* const*>(h);
+    for (int i = 0; i < 27; ++i)
+        if (!ptrs[i]) return ckr::fail(CKR_ERR_INVALID, "ckr_policy_head_step: null pointer (field %d)", i);
+    if (h->B <= 0 || h->B % 128 || h->P != 64 * h->B) return ckr::fail(CKR_ERR_INVALID, "ckr_policy_head_step: B a multiple of 128, P = 64 B");
+    if (int rc = ckr::require_device()) return rc;
+    static_assert(sizeof(ckr_train_policy_head) == sizeof(PolicyHead), "ckr_train_policy_head mirrors PolicyHead");
+    PolicyHead A;
+    memcpy(&A, h, sizeof(A));
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int SL = 4;
+    const int nblk = h->P / 64;
+    float* partB = h->part + (size_t)nblk * 16 + 16;
+    float* part2 = partB + (size_t)nblk * 16;
+    if (phase == 3) {                                             // the Dense kernel transposed (it is fixed during a step)
+        hipLaunchKernelGGL(k_transpose512, dim3(256), dim3(256), 0, st, h->fc_w, h->fc_wt);
+    } else if (phase == 0) {                                      // forward + loss
+        hipLaunchKernelGGL(k_ph_conv, dim3(nblk), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(k_ph_bn_apply, dim3(nblk), dim3(256), 0, st, A, nblk);
+        if (int rc = ckr_gemm_nt(h->out_p2, 512, h->fc_w, 512, nullptr, 512, h->B, 512, 512, SL, h->ws, nullptr, stream)) return rc;
+        hipLaunchKernelGGL(k_policy_loss_s<SL>, dim3((h->B + 3) / 4), dim3(256), 0, st, (const float*)h->ws, h->fc_b, h->pi, (int)h->B, h->weight,
+                           h->dlogits, h->ce);
+    } else if (phase == 1) {                                      // backward, critical path: down to the gradient w.r.t. x
+        if (int rc = ckr_gemm_nt(h->dlogits, 512, h->fc_wt, 512, nullptr, 512, h->B, 512, 512, SL, h->ws, nullptr, stream)) return rc;
+        hipLaunchKernelGGL(k_ph_bn_bwd_stats<SL>, dim3(nblk), dim3(256), 0, st, A, partB);
+        hipLaunchKernelGGL(k_ph_bn_bwd_conv, dim3(nblk), dim3(256), 0, st, A, nblk, (const float*)partB, part2);
+    } else if (phase == 2) {                                      // parameter gradients (off the critical path)
+        hipLaunchKernelGGL(k_sum_rows, dim3(8), dim3(256), 0, st, (const float*)h->dlogits, (int)h->B, 512, h->g_fc_b);
+        LAUNCH1D(k_gemm_small, 512ll * 512, stream, (const float*)h->dlogits, 1ll, 512ll, (const float*)h->out_p2, 512ll, 1ll, h->g_fc_w, 512ll, 512, 512, (int)h->B, 0);
+        hipLaunchKernelGGL(k_sum_rows, dim3(16), dim3(256), 0, st, (const float*)h->tall, nblk, 1024, h->g_p2_w);
+        hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, st, (const float*)part2, nblk, 8, h->g_p2_b);
+    } else {
+        return ckr::fail(CKR_ERR_INVALID, "ckr_policy_head_step: phase must be 0 .. 3");
+    }
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

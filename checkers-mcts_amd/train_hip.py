@@ -21,6 +21,31 @@ from . import _lib
 KPAD0 = 128                      # 9 taps x 14 planes = 126 columns of the first layer's im2col matrix, padded to the GEMM's K granule
 
 
+class ValueHeadArgs(C.Structure):
+    """ckr_value_head (include/ckr.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "body", "target", "v1_w", "v1_b", "v1_g", "v1_beta", "f1_w", "f1_b", "vbn_g", "vbn_beta", "f2_w", "f2_b",
+        "v1_rm", "v1_rv", "vbn_rm", "vbn_rv", "stats_v1", "stats_vbn",
+        "g_v1_w", "g_v1_b", "g_v1_g", "g_v1_beta", "g_f1_w", "g_f1_b", "g_vbn_g", "g_vbn_beta", "g_f2_w", "g_f2_b",
+        "a_v1", "out_v1", "a_f1", "out_f1", "dz_f2", "d_f1", "d_v1", "d_body", "se", "part")] + \
+        [("P", C.c_int32), ("B", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float), ("weight", C.c_float)]
+
+
+class PolicyHeadArgs(C.Structure):
+    """ckr_train_policy_head (include/ckr.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "x", "pi", "p2_w", "p2_b", "p2_g", "p2_beta", "fc_w", "fc_b", "fc_wt", "p2_rm", "p2_rv", "stats_p2",
+        "g_p2_w", "g_p2_b", "g_p2_g", "g_p2_beta", "g_fc_w", "g_fc_b", "a_p2", "out_p2", "dlogits", "d_f", "ce", "d_x",
+        "ws", "part", "tall")] + \
+        [("P", C.c_int32), ("B", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float), ("weight", C.c_float)]
+
+
+class LossArgs(C.Structure):
+    """ckr_loss_args (include/ckr.h)."""
+    _fields_ = [("ce", C.c_void_p), ("se", C.c_void_p), ("acc", C.c_void_p), ("n_rows", C.c_double), ("B", C.c_int32),
+                ("wp", C.c_float), ("wv", C.c_float), ("reserved", C.c_int32)]
+
+
 class HipTrainStep:
     def __init__(self, net, batch_size, conv_reg, dense_reg, policy_loss_weight=1.0, value_loss_weight=1.0,
                  betas=(0.9, 0.999), eps=1e-7, bn_eps=1e-3, bn_momentum=0.01, pipe=None):
@@ -45,8 +70,10 @@ class HipTrainStep:
         L.ckr_policy_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
         L.ckr_value_loss.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp]
         L.ckr_loss_sums.argtypes = [vp, vp, i32, f32, f32, vp, C.c_double, vp, vp]
-        L.ckr_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, vp]
+        L.ckr_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, vp, vp, C.POINTER(LossArgs), vp]
         L.ckr_sum_rows.argtypes = [vp, i32, i32, vp, vp]
+        L.ckr_value_head_step.argtypes = [C.POINTER(ValueHeadArgs), vp]
+        L.ckr_policy_head_step.argtypes = [C.POINTER(PolicyHeadArgs), i32, vp]
         self.net = net
         # matrix pipe of the conv GEMMs: "f32" = float32 MFMA, "bf16x6" = float32 operands as three bfloat16 pieces, six products
         # per multiply-add on the bf16 MFMA (float32-grade results, 2.65 x the rate); see include/ckr.h
@@ -56,6 +83,7 @@ class HipTrainStep:
         # the weight gradient (9 tap tiles) over the positions, never fewer than 4 chunks of 32 per slice on average
         self.slices = int(os.environ.get("CKR_TRAIN_SLICES", 0)) or next((s for s in (1, 2, 3, 4, 6, 9) if (P // 128) * s >= 256), 9)
         self.wgrad_slices = int(os.environ.get("CKR_TRAIN_WGRAD_SLICES", 0)) or max(1, min(28, P // 128))   # 9 x 28 = 252 workgroups
+        self.wgrad_slices0 = max(1, min(9 * self.wgrad_slices, P // 64))                                       # first layer: 1 tap tile
         self.dev = dev = next(net.parameters()).device
         self.B, self.P = int(batch_size), 64 * int(batch_size)
         self.wp, self.wv = float(policy_loss_weight), float(value_loss_weight)
@@ -82,7 +110,7 @@ class HipTrainStep:
         self.W, self.G, self.M, self.V, self.reg = z(off), z(off), z(off), z(off), z(off)
         for name, (o, n, reg) in self.slices_map.items():
             self.reg[o:o + n] = reg
-        self.step_t = z(1)
+        self.step_t = z(2)                                # the step counter; a scratch word of ckr_adam_step
         self.penalty = torch.zeros(512, dtype=torch.float64, device=dev)
         self.w_offsets = (C.c_int64 * 7)(*[self.slices_map["c%d.w" % l][0] for l in range(1, 8)])
         # ---- BatchNorm moving statistics (not optimised): conv blocks, p2, v1, vbn
@@ -109,6 +137,13 @@ class HipTrainStep:
         self.wt = z(7, 128, 1152)                          # flipped kernels of layers 1..7 for the data-gradient GEMMs
         self.d_act, self.d_act_b, self.d_act2 = z(P, 128), z(P, 128), z(P, 128)
         self.d_p2, self.d_f, self.d_v1, self.d_f1 = z(P, 8), z(B, 512), z(P, 1), z(B, 64)
+        # the heads' tiny layers as a few fused launches (a step of <= 256 boards is bound by the launch count of its critical path);
+        # CKR_TRAIN_FUSED_HEADS=0: the layer-by-layer sequence (also what other batch sizes use)
+        fused = os.environ.get("CKR_TRAIN_FUSED_HEADS", "1") != "0"
+        self.fused_value = fused and self.B <= 128                 # ckr_value_head_step keeps the head's activations in LDS
+        self.fused_policy = fused and self.B in (128, 256)         # ckr_policy_head_step: logits GEMMs on 128-row tiles
+        self._vh = self._ph = None
+        self.part_p, self.fc_wt = z(48 * (P // 64) + 64), z(512, 512)
         self.load_from_module()
 
     # ---- parameter views --------------------------------------------------------------------------------
@@ -198,6 +233,38 @@ class HipTrainStep:
         ev.record(main)
         self.side.wait_event(ev)
 
+    def _value_head_fused(self, tv):
+        """The value head in four launches (ckr_value_head_step): at small batches a step is bound by its launch count."""
+        if self._vh is None:
+            w, g = self.w, self.g
+            ptr = lambda t: t.data_ptr()
+            self._vh = ValueHeadArgs(
+                ptr(self.out[6]), 0, ptr(w("v1.w")), ptr(w("v1.b")), ptr(w("v1.g")), ptr(w("v1.beta")),
+                ptr(w("f1.w")), ptr(w("f1.b")), ptr(w("vbn.g")), ptr(w("vbn.beta")), ptr(w("f2.w")), ptr(w("f2.b")),
+                ptr(self.run["v1"][0]), ptr(self.run["v1"][1]), ptr(self.run["vbn"][0]), ptr(self.run["vbn"][1]),
+                ptr(self.stats["v1"]), ptr(self.stats["vbn"]),
+                ptr(g("v1.w")), ptr(g("v1.b")), ptr(g("v1.g")), ptr(g("v1.beta")), ptr(g("f1.w")), ptr(g("f1.b")), ptr(g("vbn.g")), ptr(g("vbn.beta")),
+                ptr(g("f2.w")), ptr(g("f2.b")),
+                ptr(self.a_v1), ptr(self.out_v1), ptr(self.a_f1), ptr(self.out_f1), ptr(self.dz_f2), ptr(self.d_f1), ptr(self.d_v1),
+                ptr(self.d_act2), ptr(self.se), ptr(self.part_v), self.P, self.B, self.bn_eps, self.bn_mom, self.wv)
+        self._vh.target = tv.data_ptr()
+        _lib.check(self._L.ckr_value_head_step(C.byref(self._vh), self._s()))
+
+    def _policy_head_fused(self, pi, phase):
+        """ckr_policy_head_step: 3 = transposed Dense kernel, 0 = forward + loss, 1 = backward to d_act (critical path),
+        2 = parameter gradients (side stream)."""
+        if self._ph is None:
+            w, g = self.w, self.g
+            ptr = lambda t: t.data_ptr()
+            self._ph = PolicyHeadArgs(
+                ptr(self.out[7]), 0, ptr(w("p2.w")), ptr(w("p2.b")), ptr(w("p2.g")), ptr(w("p2.beta")), ptr(w("fc.w")), ptr(w("fc.b")), ptr(self.fc_wt),
+                ptr(self.run["p2"][0]), ptr(self.run["p2"][1]), ptr(self.stats["p2"]),
+                ptr(g("p2.w")), ptr(g("p2.b")), ptr(g("p2.g")), ptr(g("p2.beta")), ptr(g("fc.w")), ptr(g("fc.b")),
+                ptr(self.a_p2), ptr(self.out_p2), ptr(self.dlogits), ptr(self.d_f), ptr(self.ce), ptr(self.d_act),
+                ptr(self.ws), ptr(self.part_p), ptr(self.tall), self.P, self.B, self.bn_eps, self.bn_mom, self.wp)
+        self._ph.pi = pi.data_ptr()
+        _lib.check(self._L.ckr_policy_head_step(C.byref(self._ph), phase, self._s()))
+
     def _value_head(self, tv):
         """Forward, loss and backward of the value head on the CURRENT stream; leaves d loss / d body in d_act2.
         1x1 conv (1) + ReLU + BN -> flatten -> Dense(64) + ReLU + BN -> Dense(1) -> tanh (training_pipeline.py:102-112)."""
@@ -265,17 +332,36 @@ class HipTrainStep:
         self._conv_fwd_tail(0, self.a[0], 1)
         for l in range(1, 8):
             inp = self.out[6] if l == 7 else self.out[l - 1]      # pol1 (l = 7) reads the body's output
-            if l == 7:                                            # the value head, beside the policy conv block and the policy head
-                self._fork(main)
+            if l == 7:                                            # the value head hangs off the body's output, beside the policy conv block
+                body_done = torch.cuda.Event()
+                body_done.record(main)
+            _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.pipe, self.ws.data_ptr(), s))
+            if l == 7:
+                # A side branch is issued AFTER the main chain's next kernel: the graph keeps a node's first-captured child in
+                # the parent's hardware queue and hands the others to another queue behind a signal (measured: ~10 us for every
+                # child when the side branch comes first, ~50 us when that moves the main chain into a queue that was idle).
+                self.side.wait_event(body_done)
                 with torch.cuda.stream(self.side):
-                    self._value_head(tv)
+                    ss = self.side.cuda_stream
+                    # re-laid copies of kernels that are fixed during the step, off the critical path: the flipped conv kernels
+                    # of the data-gradient GEMMs, the transposed Dense(512) kernel
+                    _lib.check(L.ckr_conv_wflip(self.W.data_ptr(), self.w_offsets, 7, self.wt.data_ptr(), ss))
+                    if self.fused_policy:
+                        self._policy_head_fused(pi, 3)
+                    prep_done = torch.cuda.Event()
+                    prep_done.record(self.side)
+                    (self._value_head_fused if self.fused_value else self._value_head)(tv)
                     value_done = torch.cuda.Event()
                     value_done.record(self.side)
-            _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.pipe, self.ws.data_ptr(), s))
             self._conv_fwd_tail(l, self.ws, self.slices)
-        self._policy_head(pi)
+        if self.fused_policy:
+            self._policy_head_fused(pi, 0)
+            main.wait_event(prep_done)
+            self._policy_head_fused(pi, 1)
+        else:
+            self._policy_head(pi)
+            main.wait_event(prep_done)
         # ---------------- backward: conv blocks 7 (policy conv) .. 0
-        _lib.check(L.ckr_conv_wflip(self.W.data_ptr(), self.w_offsets, 7, self.wt.data_ptr(), s))
         bufs = (self.d_act, self.d_act_b)                          # dz of block l lives in bufs[(7 - l) % 2] while its weight gradient runs
         nslices, wgrad_done = 0, {}
         for l in range(7, -1, -1):
@@ -290,27 +376,34 @@ class HipTrainStep:
                                                    self.a[l].data_ptr(), self.stats[key].data_ptr(), self.w(key + ".g").data_ptr(), P,
                                                    self.g(key + ".g").data_ptr(), self.g(key + ".beta").data_ptr(), None,
                                                    part.data_ptr(), s))                                   # d := dz
-            self._fork(main)
+            dz_done = torch.cuda.Event()
+            dz_done.record(main)
+            if l > 0:                                             # the critical path first (see the forward pass): gradient w.r.t. the block's input
+                _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.pipe, self.ws.data_ptr(), s))
+            # the side branch is issued AFTER the main chain's next kernel: in the captured graph the node that continues the
+            # critical path then follows its predecessor directly (a node with two children otherwise delays both by ~10 us)
+            self.side.wait_event(dz_done)
             with torch.cuda.stream(self.side):
                 ss = self.side.cuda_stream
+                if l == 7 and self.fused_policy:
+                    self._policy_head_fused(pi, 2)
+                if l == 0:                                        # the step's tail: one tap tile only, so many position slices
+                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices0, self.pipe, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
                 _lib.check(L.ckr_conv_bias_grad(part.data_ptr(), P, self.g(key + ".b").data_ptr(), ss))
-                if l == 0:
-                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices, self.pipe, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
-                else:
+                if l > 0:
                     inp = self.out[6] if l == 7 else self.out[l - 1]
                     _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.pipe, self.ws_w.data_ptr(), self.g(key + ".w").data_ptr(), ss))
                 wgrad_done[l] = torch.cuda.Event()
                 wgrad_done[l].record(self.side)
             if l == 0:
                 break
-            _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.pipe, self.ws.data_ptr(), s))   # gradient w.r.t. the block's input
             nslices = self.slices
         main.wait_event(wgrad_done[1])
         main.wait_event(wgrad_done[0])
         # ---------------- Adam with the l2 terms; losses of the batch (before the update)
+        losses = None
+        if acc is not None:
+            losses = C.byref(LossArgs(self.ce.data_ptr(), self.se.data_ptr(), acc.data_ptr(), float(n_rows if n_rows is not None else B), B, self.wp, self.wv, 0))
         _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
                                    lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(),
-                                   self.penalty.data_ptr() if acc is not None else None, s))
-        if acc is not None:
-            _lib.check(L.ckr_loss_sums(self.ce.data_ptr(), self.se.data_ptr(), B, self.wp, self.wv, self.penalty.data_ptr(),
-                                       float(n_rows if n_rows is not None else B), acc.data_ptr(), s))
+                                   self.penalty.data_ptr() if acc is not None else None, losses, s))

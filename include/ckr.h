@@ -412,7 +412,8 @@ int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* ro
  * channels last, arithmetic float32 throughout (what Keras computes in).  csrc/ckr_train.hip. */
 /* C[M][N] = sum_k A[m][k] Bt[n][k] (+ add[M][N]) on the float32 matrix pipe (v_mfma_f32_32x32x2_f32): the first
  * layer's forward GEMM on its im2col matrix (the 14-plane input: K = 126 -> 128).  M, N multiples of 128; K a multiple of
- * 32 * slices; slices > 1: split-K through workspace[slices][M][N], ldc == N. */
+ * 32 * slices; slices > 1: split-K through workspace[slices][M][N], ldc == N (C == NULL: the partial products stay in the
+ * workspace for the caller's next kernel to add). */
 int ckr_gemm_nt(const float* A, int32_t lda, const float* Bt, int32_t ldb, float* C, int32_t ldc, int32_t M, int32_t N,
                 int32_t K, int32_t slices, float* workspace, const float* add, void* stream);
 /* The 3x3 convolutions with 128 input and 128 output planes as IMPLICIT GEMMs on act[P][128] (no im2col matrix):
@@ -463,6 +464,45 @@ int ckr_bn_forward(float* z, const float* bias, int32_t P, int32_t C, int32_t re
 int ckr_bn_backward(float* dout, const float* a, const float* stats, const float* gamma, int32_t P, int32_t C, int32_t relu,
                     float* dgamma, float* dbeta, float* dbias, float* part, float* sums, void* stream);
 int ckr_sum_rows(const float* in, int32_t rows, int32_t cols, float* out, void* stream);
+/* The value head of one training step -- 1x1 conv (1) + ReLU + BN -> flatten -> Dense(64) + ReLU + BN -> Dense(1) -> tanh
+ * (training_pipeline.py:102-112), its squared-error loss and its whole backward pass -- in four launches instead of the 26 of
+ * the layer-by-layer calls above (at the reference's batch of 128 a step is bound by the number of launches, not by their
+ * work): positions in parallel for the 1x1 convolution, ONE workgroup for everything between its output and the gradient
+ * w.r.t. that output, positions in parallel again for the gradient w.r.t. the body.  Same arithmetic as the layer calls.
+ * All pointers DEVICE float; P = 64 B; part: >= P / 128 + 8 + 2 P floats of workspace.  Meant for B <= 256. */
+typedef struct {
+    const float* body; const float* target;                  /* [P][128] the body's output; [B] (q + z) / 2 */
+    const float* v1_w; const float* v1_b; const float* v1_g; const float* v1_beta;       /* conv 1x1: [128], [1]; its BN: [1], [1] */
+    const float* f1_w; const float* f1_b; const float* vbn_g; const float* vbn_beta;     /* Dense(64): [64 out][64 in], [64]; BN: [64], [64] */
+    const float* f2_w; const float* f2_b;                    /* Dense(1): [64], [1] */
+    float* v1_rm; float* v1_rv; float* vbn_rm; float* vbn_rv; /* moving statistics (updated; the Dense BN with the biased variance) */
+    float* stats_v1; float* stats_vbn;                       /* [2][1], [2][64]: batch mean, 1 / sqrt(var + eps) */
+    float* g_v1_w; float* g_v1_b; float* g_v1_g; float* g_v1_beta; float* g_f1_w; float* g_f1_b; float* g_vbn_g; float* g_vbn_beta;
+    float* g_f2_w; float* g_f2_b;                            /* gradients, same shapes as the parameters */
+    float* a_v1; float* out_v1; float* a_f1; float* out_f1; float* dz_f2; float* d_f1; float* d_v1;   /* [P], [P], [B][64], [B][64], [B], [B][64], [P] */
+    float* d_body; float* se; float* part;                   /* [P][128] d loss / d body (value path); [B] squared errors; workspace */
+    int32_t P, B; float eps, momentum, weight;               /* BN epsilon / momentum; VALUE_LOSS_WEIGHT */
+} ckr_value_head;
+int ckr_value_head_step(const ckr_value_head* h, void* stream);
+/* The policy head of one training step -- 1x1 conv (8) + ReLU + BN -> flatten (H, W, C) -> Dense(512) -> softmax
+ * (training_pipeline.py:93-100), Keras' clipped categorical cross-entropy, backward -- as four groups of launches:
+ *   phase 3: fc_wt = the Dense kernel transposed (any time before phase 1; the kernel does not change during a step)
+ *   phase 0: forward and loss (4 launches): a_p2, out_p2, dlogits, ce
+ *   phase 1: backward on the step's critical path (3 launches): d_x = d loss / d x; leaves partial sums for phase 2
+ *   phase 2: the parameter gradients nothing waits for (4 launches; run them on another stream after phase 1)
+ * B a multiple of 128 (the logits GEMMs run on ckr_gemm_nt's tiles).  ws: >= 4 B 512 floats; part: >= 48 P / 64 + 64; tall: >= 16 P. */
+typedef struct {
+    const float* x; const float* pi;                          /* [P][128] output of the policy conv block; [B][512] */
+    const float* p2_w; const float* p2_b; const float* p2_g; const float* p2_beta;       /* [8][128], [8], [8], [8] */
+    const float* fc_w; const float* fc_b; float* fc_wt;       /* [512 out][512 in], [512], [512 in][512 out] */
+    float* p2_rm; float* p2_rv; float* stats_p2;              /* moving statistics (updated); [2][8] */
+    float* g_p2_w; float* g_p2_b; float* g_p2_g; float* g_p2_beta; float* g_fc_w; float* g_fc_b;
+    float* a_p2; float* out_p2; float* dlogits; float* d_f; float* ce;       /* [P][8], [P][8], [B][512], [B][512], [B] */
+    float* d_x;                                               /* [P][128] */
+    float* ws; float* part; float* tall;                      /* workspaces */
+    int32_t P, B; float eps, momentum, weight;                /* BN epsilon / momentum; POLICY_LOSS_WEIGHT */
+} ckr_train_policy_head;
+int ckr_policy_head_step(const ckr_train_policy_head* h, int32_t phase, void* stream);
 /* Keras categorical cross-entropy of softmax(logits + bias) (clipped to [1e-7, 1 - 1e-7] after renormalisation) against
  * pi: ce[B]; dlogits = weight / B * d(sum ce)/dlogits.  Value head: v = tanh(z + *bias), se[B] = (v - target)^2,
  * dz = weight / B * d(sum se)/dz. */
@@ -472,10 +512,16 @@ int ckr_value_loss(const float* z, const float* bias, const float* target, int32
  * partial sums ckr_adam_step left in penalty_parts (NULL: 0). */
 int ckr_loss_sums(const float* ce, const float* se, int32_t B, float wp, float wv, const double* penalty_parts, double n_rows, double* acc, void* stream);
 /* Adam (torch.optim.Adam arithmetic, Keras epsilon) on the flat parameter vector with the l2 terms folded in:
- * g = grad + 2 reg[i] w[i]; step number = *d_step + 1, then *d_step += 1; lr read from the device; d_penalty_parts (512 doubles,
- * may be NULL) = sum reg w^2 before the update, in 512 partial sums. */
+ * g = grad + 2 reg[i] w[i]; step number = d_step[0] + 1, then d_step[0] += 1 (d_step: 2 floats, the second a scratch word that
+ * is 0 between calls); lr read from the device; d_penalty_parts (512 doubles, may be NULL) = sum reg w^2 before the update, in
+ * 512 partial sums; losses (may be NULL): what ckr_loss_sums would add afterwards from the same penalty, done by this launch. */
+typedef struct {
+    const float* ce; const float* se;                         /* [B] per-sample losses (ckr_policy_loss / ckr_value_loss) */
+    double* acc;                                              /* [3] running sums */
+    double n_rows; int32_t B; float wp, wv; int32_t reserved;
+} ckr_loss_args;
 int ckr_adam_step(float* w, const float* grad, float* m, float* v, const float* reg, int64_t n, const float* d_lr, float beta1,
-                  float beta2, float eps, float* d_step, double* d_penalty_parts, void* stream);
+                  float beta2, float eps, float* d_step, double* d_penalty_parts, const ckr_loss_args* losses, void* stream);
 
 /* ---- probes of the stochastic paths (parity tests only) ------------------ *
  * The reference draws from NumPy's MT19937 (np.random.dirichlet, MCTS.py:107-108; np.random.choice,

@@ -26,12 +26,17 @@ def graph_of(fn):
     return g
 
 
+HOST = []
+
+
 def timeit(g, reps=50):
     g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    t0 = time.perf_counter()
     for _ in range(reps):
         g.replay()
+    HOST.append((time.perf_counter() - t0) / reps)                # host time to ISSUE one replay (the queue runs ahead if this is smaller)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 
@@ -60,7 +65,7 @@ def main():
     # the conv layers' GEMMs alone: forward + data gradient + weight gradient of the seven 128 -> 128 layers and the first layer
     P = 64 * B
     flops = 2.0 * P * 128 * (3 * 7 * 1152 + 2 * 126)
-    out = dict(batch=B, hip_ms_per_step=t_hip * 1e3, hip_samples_per_s=B / t_hip, torch_ms_per_step=t_torch * 1e3,
+    out = dict(batch=B, hip_host_issue_ms_per_replay=HOST[0] * 1e3, torch_host_issue_ms_per_replay=HOST[1] * 1e3, hip_ms_per_step=t_hip * 1e3, hip_samples_per_s=B / t_hip, torch_ms_per_step=t_torch * 1e3,
                torch_samples_per_s=B / t_torch, speedup=t_torch / t_hip, conv_gemm_flops_per_step=flops,
                conv_gemm_tflops_if_whole_step=flops / t_hip / 1e12, fp32_matrix_peak_tflops=157.3)
     print(json.dumps(out))
