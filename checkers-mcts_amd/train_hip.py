@@ -129,13 +129,16 @@ class HipTrainStep:
         self.ce, self.se = z(B), z(B)
         part_n, tall_n = 4 * 128 * (P // 64 + 1), 8 * 128 * (P // 64 + 1)
         self.part, self.tall, self.sums = z(part_n), z(tall_n), z(2, 128)            # main stream's reduction workspaces
-        self.part_b = z(part_n)                                                      # conv blocks alternate part / part_b (the bias gradient reads them on the side stream)
+        self.parts_bwd = [z(part_n) for _ in range(8)]                               # one per conv block: the bias gradient reads them on the side stream
         self.part_v, self.tall_v, self.sums_v = z(part_n), z(tall_n), z(2, 128)      # the value head's (side stream)
         self.ws = z(max(self.slices * P * 128, 4 * B * 512))                         # split-K partial products: forward / data gradient
         self.ws_w = z(self.wgrad_slices * 128 * 1152)                                # ... and weight gradient (side stream)
         self.side = torch.cuda.Stream(device=dev)
         self.wt = z(7, 128, 1152)                          # flipped kernels of layers 1..7 for the data-gradient GEMMs
-        self.d_act, self.d_act_b, self.d_act2 = z(P, 128), z(P, 128), z(P, 128)
+        self.d_act, self.d_act2 = z(P, 128), z(P, 128)
+        # dz of every conv block in its own buffer: reusing two would make each block's first backward kernel wait for the weight
+        # gradient two blocks up -- a node with two parents in the captured graph, ~6 us on the critical path each
+        self.dz = [z(P, 128) for _ in range(7)] + [self.d_act]
         self.d_p2, self.d_f, self.d_v1, self.d_f1 = z(P, 8), z(B, 512), z(P, 1), z(B, 64)
         # the heads' tiny layers as a few fused launches (a step of <= 256 boards is bound by the launch count of its critical path);
         # CKR_TRAIN_FUSED_HEADS=0: the layer-by-layer sequence (also what other batch sizes use)
@@ -226,6 +229,12 @@ class HipTrainStep:
         _lib.check(self._L.ckr_conv_bias_relu_bn(ws.data_ptr(), slices, self.w(key + ".b").data_ptr(), self.P, self.w(key + ".g").data_ptr(),
                                                  self.w(key + ".beta").data_ptr(), self.bn_eps, self.bn_mom, rm.data_ptr(), rv.data_ptr(),
                                                  self.stats[key].data_ptr(), self.a[l].data_ptr(), self.out[l].data_ptr(), self.part.data_ptr(), self._s()))
+
+    def _join(self, main):
+        """The main stream continues when the side stream's work so far is done."""
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        main.wait_event(ev)
 
     def _fork(self, main):
         """The side stream continues from this point of the main stream."""
@@ -362,16 +371,13 @@ class HipTrainStep:
             self._policy_head(pi)
             main.wait_event(prep_done)
         # ---------------- backward: conv blocks 7 (policy conv) .. 0
-        bufs = (self.d_act, self.d_act_b)                          # dz of block l lives in bufs[(7 - l) % 2] while its weight gradient runs
-        nslices, wgrad_done = 0, {}
+        nslices = 0
         for l in range(7, -1, -1):
-            key, d = "c%d" % l, bufs[(7 - l) % 2]
+            key, d = "c%d" % l, self.dz[l]
             if l == 6:
                 main.wait_event(value_done)                       # the body's output feeds both heads
-            if l + 2 in wgrad_done:
-                main.wait_event(wgrad_done[l + 2])                # this buffer was read by the weight gradient two blocks up
             add = self.d_act2 if l == 6 else None
-            part = (self.part, self.part_b)[(7 - l) % 2]
+            part = self.parts_bwd[l]
             _lib.check(L.ckr_conv_bn_relu_backward(self.ws.data_ptr(), nslices, add.data_ptr() if add is not None else None, d.data_ptr(),
                                                    self.a[l].data_ptr(), self.stats[key].data_ptr(), self.w(key + ".g").data_ptr(), P,
                                                    self.g(key + ".g").data_ptr(), self.g(key + ".beta").data_ptr(), None,
@@ -393,13 +399,10 @@ class HipTrainStep:
                 if l > 0:
                     inp = self.out[6] if l == 7 else self.out[l - 1]
                     _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.pipe, self.ws_w.data_ptr(), self.g(key + ".w").data_ptr(), ss))
-                wgrad_done[l] = torch.cuda.Event()
-                wgrad_done[l].record(self.side)
             if l == 0:
                 break
             nslices = self.slices
-        main.wait_event(wgrad_done[1])
-        main.wait_event(wgrad_done[0])
+        self._join(main)                                          # every gradient is in place (the side stream runs in order)
         # ---------------- Adam with the l2 terms; losses of the batch (before the update)
         losses = None
         if acc is not None:
