@@ -102,9 +102,11 @@ def parse():
     ap.add_argument("--no-dense-rows", action="store_true",
                     help="keep every slot's leaf in the batch row of its slot number (idle rows are evaluated too) instead of packing the "
                          "step's leaves into rows [0, n) and bounding the conv launch by n")
-    ap.add_argument("--leaf-cache-log2", type=int, default=25,
+    ap.add_argument("--leaf-cache-log2", type=int, default=27,
                     help="log2 of the records of each engine's leaf cache (positions already evaluated are expanded without the "
                          "network; results identical with and without -- tests/test_leaf_cache_gpu.py); 0 = off")
+    ap.add_argument("--leaf-cache-gen-log2", type=int, default=0,
+                    help="launches per leaf-cache generation = 2^this (0 = engine default: log2(records) - 14, at least 11); records of the current and the previous generation are served")
     ap.add_argument("--extra-steps", type=int, default=300,
                     help="timed steps of the extra legs (bf16 throughput mode, arena, random rollouts; N = 1 only, 0 = skip)")
     return ap.parse_args()
@@ -287,7 +289,7 @@ class Leg:
             cfg = ckengine.config_from_kwargs(kw, n_slots=n, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
                                               first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
                                               device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
-                                              leaf_cache_log2=a.leaf_cache_log2, dense_rows=not a.no_dense_rows,
+                                              leaf_cache_log2=a.leaf_cache_log2, leaf_cache_gen_log2=a.leaf_cache_gen_log2, dense_rows=not a.no_dense_rows,
                                               **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
             return ckengine.Engine(cfg, feature_dtype=dtype)
 
@@ -388,7 +390,7 @@ def arena_leg(a, dev):
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.float32,
                                       seed=20260929, device=dev.index, dynamic_queue=True,
-                                      leaf_cache_log2=min(26, a.leaf_cache_log2 + 1) if a.leaf_cache_log2 else 0,
+                                      leaf_cache_log2=min(27, a.leaf_cache_log2 + 1) if a.leaf_cache_log2 else 0,
                                       dense_rows=not a.no_dense_rows)
     eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
     ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,

@@ -1352,7 +1352,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
         A(D.cache_claim, cap + CACHE_PROBES, true);
         A(D.cache, cap + CACHE_PROBES, true);
         D.cache_mask = (unsigned long long)(cap - 1);
-        D.cache_gen_shift = c->leaf_cache_gen_log2 > 0 ? c->leaf_cache_gen_log2 : 11;
+        // default: a generation = 2^(log2(records) - 14) launches, at least 2^11 (a launch of <= 4 096 slots writes <= 2^12 records:
+        // two live generations then fill at most half of the table)
+        D.cache_gen_shift = c->leaf_cache_gen_log2 > 0 ? c->leaf_cache_gen_log2 : (cache_log2 - 14 > 11 ? cache_log2 - 14 : 11);
     }
     // node.n ** 0.5 is C pow() in the reference (python int ** float), which is
     // NOT always sqrt(): keep a host-computed table for the counts that occur.

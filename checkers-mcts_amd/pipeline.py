@@ -322,10 +322,12 @@ class SplitRunner:
 
 
 def default_leaf_cache_log2(n_slots, device=None):
-    """Size of an engine's leaf cache for n_slots concurrent games: a record serves for 2 048 - 4 096 steps (one to two
-    generations) and about half of a step's slots write one, so 2^(log2(slots) + 14) records keep the table below a quarter
-    full -- 264 B each: 8.9 GB for 2 048 slots; never more than 1/8 of the device's memory."""
-    log2 = min(26, max(16, int(np.ceil(np.log2(max(1, int(n_slots))))) + 14))
+    """Size of an engine's leaf cache for n_slots concurrent games: 2^(log2(slots) + 16) records, at most 2^27 (264 B each:
+    35 GB for >= 2 048 slots) and never more than 1/8 of the device's memory.  A record serves for one to two generations of
+    2^(log2(records) - 14) steps -- 8 192 - 16 384 steps at 2^27, one to two games' length -- and about half of a step's slots
+    write one.  Measured on cfg3 (profiles/r03_leaf_cache_size_sweep.txt): 2^25 / 2^26 / 2^27 records serve 48.7 / 49.2 /
+    51.0 % of the leaves (51.0 % = every position seen since the start of the run), 6.74 / 6.96 / 7.09 M expansions/s."""
+    log2 = min(27, max(16, int(np.ceil(np.log2(max(1, int(n_slots))))) + 16))
     try:
         mem = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).total_memory
     except Exception:

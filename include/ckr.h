@@ -247,7 +247,7 @@ typedef struct {
                                     in an earlier step is expanded from the cached priors / v as a network-free simulation.
                                     Results are identical with and without (the cached floats are the ones the expansion would
                                     recompute); only ckr_stats.nn_evals / dup_leaves and the step count change */
-    int32_t  leaf_cache_gen_log2;/* log2 of the cache's generation length in steps (0 = 11): a record is served for one to two
+    int32_t  leaf_cache_gen_log2;/* log2 of the cache's generation length in steps (0 = max(11, leaf_cache_log2 - 14)): a record is served for one to two
                                     generations after it was written, then its place may be taken by a new one */
     int32_t  dense_rows;         /* 1: the network batch is kept dense -- a slot that hands out a leaf takes the next free row of
                                     d_x / d_net (and finds its answer in the same row of d_p / d_v at the next step) instead of
