@@ -594,7 +594,8 @@ def main():
                      "gather": {"collective": "all_gather(sizes) + gather(padded rows) to rank 0 (%s)"
                                               % (("RCCL" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend() + ", rows staged through host memory") if world > 1 else "single rank: no collective issued"),
                                 "tuples": n_rows, "bytes": n_rows * 288, "seconds": t_gather},
-                     "active_slots_trace": trace[:: max(1, len(trace) // 40)],
+                     "active_slots_trace": [[st_, act_, round(t_ - t_run0, 3)] for st_, act_, t_ in trace[:: max(1, len(trace) // 40)]],
+                     "active_slots_trace_columns": "step, slots still playing, seconds since the start of the run",
                      "semantics": "fixed number of games per worker slot, played back to back (training_pipeline.py:349); "
                                   "includes pre-roll, timed window and the tail in which slots run dry"}
 

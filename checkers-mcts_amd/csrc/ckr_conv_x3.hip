@@ -42,17 +42,23 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int MAX_LAYERS = 9;
 constexpr int NT = 256;                                          // 4 waves
-constexpr int TILE = 2;                                          // boards per workgroup
-constexpr int XP = 64 * TILE;                                    // positions per workgroup
-constexpr int PT = XP / 32;                                      // position tiles per wave
 constexpr int AROW = 512;                                        // [128 hi | 128 lo] fp16, swizzled, no padding
 constexpr int LO = 256;                                          // byte offset of the lo half of a row
-constexpr int ZBASE = XP * AROW;                                 // 512-B zero region for out-of-board taps
-constexpr int ACT_BYTES = ZBASE + 512;
 constexpr int PRM_BYTES = 2 * 128 * 4;                           // BatchNorm scale | shift of the running layer (wave-private quarters)
 constexpr int STAGE_BYTES = 8 * 131 * 4 + 32;                    // staging of the 1x1 heads' weights
-constexpr int LDS_BYTES = ACT_BYTES + PRM_BYTES + STAGE_BYTES;   // 71 296 B: two workgroups per CU
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+// TL = boards per workgroup.  2: the throughput kernel.  1: the LATENCY kernel for launches of <= SMALL_BOARDS boards (the
+// tail of a run, a single interactive search): half the MFMA chain per wave, so a launch that cannot fill the chip anyway
+// returns in about half the time.  Same instruction order per output element: the two produce identical bits.
+template <int TL> struct Cfg {
+    static constexpr int TILE = TL;
+    static constexpr int XP = 64 * TL;                           // positions per workgroup
+    static constexpr int PT = XP / 32;                           // position tiles per wave
+    static constexpr int ZBASE = XP * AROW;                      // 512-B zero region for out-of-board taps
+    static constexpr int ACT_BYTES = ZBASE + 512;
+    static constexpr int LDS_BYTES = ACT_BYTES + PRM_BYTES + STAGE_BYTES;   // TL = 2: 71 296 B, two workgroups per CU
+};
+static_assert(2 * Cfg<2>::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+constexpr int SMALL_BOARDS = 256;                                // one single-board workgroup per CU
 constexpr int SLOT_BYTES = 4 * 2 * 64 * 16;                      // one 16-input-channel slice of a tap: [wave][hi | lo][lane] x 16 B
 constexpr int RING = 4;                                          // register ring of A fragments: RING - 1 slots ahead of the MFMAs
 
@@ -79,7 +85,7 @@ struct Args {
 __device__ __forceinline__ int act_addr(int r, int ks) { return r * AROW + ((ks ^ (r & 15)) << 4); }
 
 struct AF { f16x8 h, l; };                                       // this lane's A fragment (32 channels x 16 k): hi, lo
-struct BF { f16x8 h[PT], l[PT]; };                               // B fragments of the wave's four position tiles
+template <int PT> struct BF { f16x8 h[PT], l[PT]; };             // B fragments of the wave's position tiles
 
 // A fragments of global slot g: two fully coalesced 1-KB loads per wave (buffer addressing: the slot offset
 // lives in an SGPR, hi / lo are immediate offsets)
@@ -91,7 +97,7 @@ __device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rsrc, int voff, in
 }
 
 // the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half)
-__device__ __forceinline__ void load_b(const char* __restrict__ act, int c8, const int (&rowaddr)[PT], BF& f) {
+template <int PT> __device__ __forceinline__ void load_b(const char* __restrict__ act, int c8, const int (&rowaddr)[PT], BF<PT>& f) {
     const int kc = (2 * c8) << 4;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -100,7 +106,7 @@ __device__ __forceinline__ void load_b(const char* __restrict__ act, int c8, con
     }
 }
 
-__device__ __forceinline__ void mfma_block(const AF& a, const BF& b, f32x16 (&acc)[PT]) {
+template <int PT> __device__ __forceinline__ void mfma_block(const AF& a, const BF<PT>& b, f32x16 (&acc)[PT]) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
 #pragma unroll
@@ -111,7 +117,7 @@ __device__ __forceinline__ void mfma_block(const AF& a, const BF& b, f32x16 (&ac
 
 // one k-chunk: 12 MFMAs with the next chunk's 8 ds_read_b128 and the two weight loads of the chunk RING - 1 ahead
 // spread between them
-__device__ __forceinline__ void interleave() {
+template <int PT> __device__ __forceinline__ void interleave() {
 #pragma unroll
     for (int i = 0; i < 2 * PT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
@@ -122,12 +128,13 @@ __device__ __forceinline__ void interleave() {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // 1 VMEM read
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 3 * PT - 2 * PT - 2, 0);
+    if constexpr (PT > 2) __builtin_amdgcn_sched_group_barrier(0x008, 3 * PT - 2 * PT - 2, 0);
 }
 
 // Row addresses (k-slot `half`) of the B-tile rows this lane reads for tap (dy, dx); out-of-board taps read the
 // zero region with the swizzle of the row they replace (conflict-free).
-__device__ __forceinline__ void tap_rows(int prow0, int tap, int half, int (&rowaddr)[PT]) {
+template <int PT> __device__ __forceinline__ void tap_rows(int prow0, int tap, int half, int (&rowaddr)[PT]) {
+    constexpr int ZBASE = 32 * PT * AROW;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -146,7 +153,7 @@ __device__ __forceinline__ void split1(float y, _Float16& h, _Float16& l, float&
 }
 
 // ReLU + BatchNorm affine (bias already in the accumulators, constants pre-scaled), split, store in place
-__device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, const f32x16 (&acc)[PT], int32_t* overflow) {
+template <int PT> __device__ __forceinline__ void epilogue(char* act, const float* prm, int wc, int lane, const f32x16 (&acc)[PT], int32_t* overflow) {
 #pragma clang fp contract(fast)
     asm volatile("" : "+v"(lane));                 // compute the store addresses here, not at kernel entry
     const int prow0 = lane & 31;
@@ -218,7 +225,7 @@ __device__ __forceinline__ void head_1x1(const char* act, float* stage, const fl
 // (the ring holds slots s .. s + RING - 2 when step s starts, also across layers).  CPT = slots (16-channel slices)
 // per tap: 1 (first layer: 14 planes in one slice) or 8.  Per step: weight fragments of slot s + RING - 1 requested,
 // activation fragments of slot s + 1 read, 12 MFMAs of slot s.
-template <int CPT, int R0>
+template <int PT, int CPT, int R0>
 __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float* prm, __amdgpu_buffer_rsrc_t rsrc, int voff,
                                           int g0, AF (&ring)[RING], int wc, int lane) {
     constexpr int NSLOTS = 9 * CPT;
@@ -237,19 +244,19 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
     }
     // the wave's own 32 channels of the BatchNorm constants: written and read by this wave only (no barrier)
     if (lane < 32) { prm[32 * wc + lane] = L.scale[32 * wc + lane]; prm[128 + 32 * wc + lane] = L.shift[32 * wc + lane]; }
-    BF b0, b1;
+    BF<PT> b0, b1;
     int rowaddr[PT];
     tap_rows(prow0, 0, half, rowaddr);
     load_b(act, 0, rowaddr, b0);
     __builtin_amdgcn_sched_barrier(0);
-    auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BF& bc, BF& bn) {
+    auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BF<PT>& bc, BF<PT>& bn) {
         load_a(rsrc, voff, g0 + s + RING - 1, apf);               // beyond the layer: the next layer's first slots / the padding
         if (s + 1 < NSLOTS) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
             load_b(act, c8 == CPT - 1 ? 0 : c8 + 1, rowaddr, bn);
         }
-        mfma_block(ac, bc, acc);
-        interleave();
+        mfma_block<PT>(ac, bc, acc);
+        interleave<PT>();
     };
     if constexpr (CPT == 1) {
 #pragma unroll
@@ -268,19 +275,22 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
         }
     }
     lds_barrier();                                 // every wave has read its last activation fragments
-    epilogue(act, prm, wc, lane, acc, A.overflow);
+    epilogue<PT>(act, prm, wc, lane, acc, A.overflow);
     lds_barrier();                                 // the layer's output is complete
 }
 
-__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+template <int TL>
+__device__ __forceinline__ void conv_stack_body(const Args& A, char* smem) {
+    typedef Cfg<TL> K;
+    constexpr int TILE = K::TILE, XP = K::XP, PT = K::PT, ACT_BYTES = K::ACT_BYTES;
     char* act = smem;
     float* prm = reinterpret_cast<float*>(smem + ACT_BYTES);
     float* stage = reinterpret_cast<float*>(smem + ACT_BYTES + PRM_BYTES);
     const int tid = threadIdx.x, wc = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const long long board0 = (long long)blockIdx.x * TILE;
-    const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
     if (A.range && (board0 >= A.range[1] || board0 + TILE <= A.range[0])) return;   // arena / tail: not this launch's share
+    const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
+    if (rows_valid <= 0) return;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, (int)A.w_bytes, 0x00020000);
     const int voff = wc * 2048 + lane * 16;
@@ -315,8 +325,8 @@ __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
     }
     lds_barrier();
     for (int l = 0; l < A.n_layers; ++l) {
-        if (l == 0) run_layer<1, 0>(A, l, act, prm, rsrc, voff, 0, ring, wc, lane);
-        else run_layer<8, 9 % RING>(A, l, act, prm, rsrc, voff, 9 + 72 * (l - 1), ring, wc, lane);
+        if (l == 0) run_layer<PT, 1, 0>(A, l, act, prm, rsrc, voff, 0, ring, wc, lane);
+        else run_layer<PT, 8, 9 % RING>(A, l, act, prm, rsrc, voff, 9 + 72 * (l - 1), ring, wc, lane);
         float* out = A.L[l].out;
         if (out) {                                                // (tests) activation * XS as float32
             float* dst = out + board0 * 64 * 128;
@@ -334,6 +344,15 @@ __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
                             A.H.pol_out, board0, rows_valid, tid, A.inv_xs_pol);
         }
     }
+}
+
+__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
+    __shared__ __attribute__((aligned(16))) char smem[Cfg<2>::LDS_BYTES];
+    conv_stack_body<2>(A, smem);
+}
+__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_small(const Args A) {
+    __shared__ __attribute__((aligned(16))) char smem[Cfg<1>::LDS_BYTES];
+    conv_stack_body<1>(A, smem);
 }
 
 }  // namespace ckrx
@@ -385,7 +404,12 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     }
     A.w = (const uint4*)layers[0].weights;
     A.w_bytes = (long long)(expect - (const char*)layers[0].weights) + (long long)(RING - 1) * SLOT_BYTES;
-    const int grid = (int)((n_boards + TILE - 1) / TILE);
+    // n_boards <= SMALL_BOARDS: the single-board kernel (callers that know only few rows of a larger batch are in use -- the
+    // tail of a run -- pass that bound as n_boards).  CKR_X3_SMALL=0 keeps everything on the two-board kernel.
+    // (Launching both and letting the device range decide which computes was measured: the idle launch costs 7 us per step.)
+    static const bool small_ok = !(getenv("CKR_X3_SMALL") && getenv("CKR_X3_SMALL")[0] == '0');
+    const bool small_only = small_ok && n_boards <= SMALL_BOARDS;
+    const int grid = (int)((n_boards + 1) / 2);
     // Kernel experiments (tools/slp_probe.py): CKR_X3_CODE_OBJECT names a gfx950 code object whose k_conv_stack_x3 -- the same
     // source built with other compiler flags, or its assembly with instructions inserted -- is launched instead of the
     // linked kernel.  Unset in production.
@@ -405,7 +429,8 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
         CKR_HIP(hipModuleLaunchKernel(alt, (unsigned)grid, 1, 1, NT, 1, 1, 0, (hipStream_t)stream, nullptr, cfg));
         return CKR_OK;
     }
-    hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
+    if (small_only) hipLaunchKernelGGL(k_conv_stack_x3_small, dim3((unsigned)n_boards), dim3(NT), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

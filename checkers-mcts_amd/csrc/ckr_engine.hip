@@ -62,6 +62,7 @@ struct Dev {
     // configuration
     int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
     int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual, dynamic, total_games, neural, rollout_first, ln_n, uct_n;
+    int tail_sims, tail_shift;   // network-free simulations per step once <= n_slots >> tail_shift slots still play (0: max_sims throughout)
     int w64;                     // ckr_config.w_accum: n_W holds double (1) or float (0); the kernels are instantiated for either
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
@@ -76,6 +77,7 @@ struct Dev {
                                  // ckr_engine_compact_rows moves the active slots to the front
     int32_t* g_gid;              // storage index of the slot's current game (results / tuple region)
     int32_t* next_game;          // dynamic queue: next unclaimed game index
+    int32_t* n_finished;         // slots whose games are all played (the tail of a run: see tail_sims)
     // per tree (slot*2 + tree)
     int32_t* t_cursor; int32_t* t_used; int32_t* t_half; int32_t* t_searched;
     // outputs
@@ -793,7 +795,7 @@ template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t o
         wave_mem_fence();
         new_game<GAME>(w);
     } else {
-        if (w.lane == 0) D.g_phase[w.slot] = PH_FINISHED;
+        if (w.lane == 0) { D.g_phase[w.slot] = PH_FINISHED; atomicAdd(D.n_finished, 1); }
         wave_mem_fence();
     }
 }
@@ -949,6 +951,7 @@ template <int GAME, typename WT> __global__ __launch_bounds__(256) void k_init(c
         D.g_game[slot] = 0; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; D.g_gid[slot] = gid0;
         D.g_row[slot] = slot;
         D.g_phase[slot] = gid0 < D.total_games ? PH_PLAYING : PH_FINISHED;
+        if (gid0 >= D.total_games) atomicAdd(D.n_finished, 1);
     }
     wave_mem_fence();
     if (gid0 < D.total_games) new_game<GAME>(w);
@@ -1005,6 +1008,9 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
     // B. advance until a leaf needs the network
     int leaf = -1, net = -1, free_sims = 0;
     ckr_board lb{0u, 0u, 0u, 0u};
+    // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
+    // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
+    const int max_sims = D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
     while (D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
         const int sims_done = D.g_sims[slot];
@@ -1014,7 +1020,7 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
             finish_ply(w); continue;
         }
-        if (free_sims >= D.max_sims) break;
+        if (free_sims >= max_sims) break;
         const int t = (int)(D.g_board[slot].w & 1u);
         int plen = 0; uint32_t pentry = 0u;
         leaf = descend(w, t, plen, pentry);
@@ -1318,6 +1324,10 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.tau_decay_delay = c->tau_decay_delay; D.reset_tau = c->reset_tau_each_game; D.C = c->nodes_per_tree;
     D.feature_dtype = c->feature_dtype; D.max_sims = c->max_sims_per_step > 0 ? c->max_sims_per_step : (c->leaf_cache_log2 > 0 && c->neural_net ? 2 : 4);
     D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
+    D.tail_sims = c->max_sims_per_step > 0 || !c->neural_net ? 0 : 4;
+    D.tail_shift = 1;                                             // tail = at most n_slots >> 1 slots still play
+    if (const char* t = getenv("CKR_TAIL_SIMS")) D.tail_sims = D.tail_sims ? atoi(t) : 0;      // tuning experiments (profiles/r03_tail_sweep.txt)
+    if (const char* t = getenv("CKR_TAIL_SHIFT")) D.tail_shift = atoi(t);
     D.total_games = c->n_slots * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
     D.w64 = (c->w_accum == 1 && c->neural_net) ? 1 : 0;
@@ -1338,7 +1348,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
     A(D.g_path, S * 64, true); A(D.g_plen, S, true); A(D.g_row, S, true); A(e->d_row_tmp, S, true);
-    A(D.g_gid, S, true); A(D.next_game, (size_t)1, true);
+    A(D.g_gid, S, true); A(D.next_game, (size_t)1, true); A(D.n_finished, (size_t)1, true);
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
     A(D.tuples, NT ? NT : 1, true);

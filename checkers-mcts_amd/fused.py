@@ -171,6 +171,7 @@ class FusedEvaluator:
         self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
                                                  C.c_float, vp, vp, vp, vp]
         self.overflow = None
+        self.row_cap = None                     # set_row_cap()
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         self._L.ckr_heads_tail.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]
@@ -267,20 +268,29 @@ class FusedEvaluator:
             self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
         return self.overflow.data_ptr()
 
+    def set_row_cap(self, cap):
+        """Only rows [0, cap) of the batch can be in use from now on (the tail of a run: Engine dense rows / compact_rows with
+        few slots still playing): the kernels are launched for that many boards -- <= 256 puts the float32-grade conv stack on
+        its low-latency single-board kernel.  None: the whole batch again."""
+        self.row_cap = None if cap is None else max(1, int(cap))
+
+    def _rows(self, n):
+        return n["S"] if self.row_cap is None else min(n["S"], self.row_cap)
+
     def _conv(self, n, x, stream, board_range=None):
         rng = board_range.data_ptr() if board_range is not None else None
         if self.mode == "f16x3":
-            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), n["S"], n["layers"], n["n"], C.byref(n["heads"]), XS, n["xs_arr"], rng,
+            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self._rows(n), n["layers"], n["n"], C.byref(n["heads"]), XS, n["xs_arr"], rng,
                                                     self._overflow_ptr(x.device), stream))
         else:
-            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), n["S"], n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
+            _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self._rows(n), n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
 
     def _forward(self, n, x, board_range=None):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         self._conv(n, x, stream, board_range)
         t = n["tail"]
         # Dense(512) + softmax and the value MLP: one launch
-        _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), n["S"], t["fc_packed"].data_ptr(),
+        _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), self._rows(n), t["fc_packed"].data_ptr(),
                                           t["fc_b"].data_ptr(), t["fc_xs"], t["fc_ws"], t["w1t"].data_ptr(), t["b1"].data_ptr(), t["sc"].data_ptr(),
                                           t["sh"].data_ptr(), t["w2"].data_ptr(), t["b2"], n["p"].data_ptr(), n["v"].data_ptr(),
                                           self._overflow_ptr(x.device), stream))

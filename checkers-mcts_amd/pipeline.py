@@ -21,6 +21,7 @@ Differences a user can observe (all documented in DESIGN.md):
 """
 import os
 import pickle
+import time
 from datetime import datetime
 
 import numpy as np
@@ -166,6 +167,23 @@ class StepRunner:
         self._eval_into_buffers()
         self.steps += 1
 
+    TAIL_ROWS = 256                                       # the float32-grade conv stack's low-latency kernel takes <= 256 boards
+
+    def set_row_cap(self, cap):
+        """The tail of a run: at most `cap` rows of the batch can be in use from now on (dense rows: a step's leaves occupy rows
+        [0, number of leaves) and no more slots play than that).  The evaluator launches its kernels for that many boards and
+        the step's graph is captured again (None: the whole batch; the graph is captured again at the next step, if any)."""
+        ev = self.evaluator
+        if not hasattr(ev, "set_row_cap") or getattr(ev, "row_cap", None) == cap:
+            return False
+        ev.set_row_cap(cap)
+        if self.graph is not None:
+            torch.cuda.synchronize(self.eng.device)
+            self.graph = None
+            if cap is not None:
+                self.warmup(0)
+        return True
+
     def warmup(self, n=3):
         for _ in range(n):
             self._eager_step()
@@ -208,7 +226,6 @@ class StepRunner:
             if self.time_budget is None:
                 self.step(check_every)
             else:                                            # one ply of every running game: search for the budget, then move
-                import time
                 t0 = time.perf_counter()
                 while True:
                     self.step(8)
@@ -220,11 +237,14 @@ class StepRunner:
                 self.steps += 1
             active = self.eng.stats()["active_slots"]
             if trace is not None:
-                trace.append((self.steps, active))
+                trace.append((self.steps, active, time.perf_counter()))
             if hasattr(self.evaluator, "check_range"):
                 self.evaluator.check_range()
             if active == 0:
+                self.set_row_cap(None)
                 return self.steps
+            if getattr(self.eng, "dense_rows", False) and active <= self.TAIL_ROWS < S and self.time_budget is None:
+                self.set_row_cap(self.TAIL_ROWS)
             if can_compact and active <= rows - max(6, S // 32):
                 rows = self.eng.compact_rows(self.p, self.v)
 
@@ -301,13 +321,17 @@ class SplitRunner:
                         runner.evaluator.check_range()
                     S = eng.cfg.n_slots
                     if active == 0:
+                        runner.set_row_cap(None)
                         live.remove(part)
+                    elif getattr(eng, "dense_rows", False):
+                        if active <= runner.TAIL_ROWS < S:
+                            runner.set_row_cap(runner.TAIL_ROWS)
                     elif (getattr(runner.evaluator, "supports_row_range", False) and not getattr(eng, "dense_rows", False)
                           and active <= rows[id(eng)] - max(6, S // 32)):
                         rows[id(eng)] = eng.compact_rows(runner.p, runner.v)
                 total += active
             if trace is not None:
-                trace.append((self.steps, total))
+                trace.append((self.steps, total, time.perf_counter()))
         return self.steps
 
     def results(self):

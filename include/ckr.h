@@ -220,7 +220,8 @@ typedef struct {
     int32_t  feature_dtype;      /* 0 float32, 1 float16, 2 bfloat16 */
     int32_t  max_sims_per_step;  /* cap on NN-free simulations (terminal visits) a slot runs back to back in one step before it
                                     hands out a leaf; results do not depend on it (<= 0: the measured throughput optimum -- 4, or 2 with the
-                                    leaf cache, whose hits are network-free simulations too) */
+                                    leaf cache, whose hits are network-free simulations too -- and 4 once half of the slots have played
+                                    all their games: the step's time then approaches the latency of one small network launch) */
     int32_t  record_root_stats;  /* 1: keep per-ply child W / P next to the tuples (tests) */
     int32_t  manual_play;        /* 1: interactive search API (MCTS / MCTS_Node facade): slots park after
                                     BUDGET simulations and moves are applied by ckr_engine_command */

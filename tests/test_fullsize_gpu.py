@@ -142,6 +142,38 @@ def test_cfg3_with_the_real_network_float32_grade(E):
     assert 40 < lens.mean() < 160 and lens.max() <= 200                       # games of a random-init net: SURVEY 88 plies
 
 
+def test_small_launch_kernel_produces_the_throughput_kernels_bits():
+    """Launches of <= 256 boards (the tail of a run, one interactive search) go to k_conv_stack_x3_small -- one board per workgroup,
+    half the MFMA chain per wave: the host passes the number of rows that can be in use (FusedEvaluator.set_row_cap).  Same instruction order
+    per output element: pi / v are bit-identical to the two-board kernel's, and also within 1e-5 of float64."""
+    import copy
+    import torch
+    from checkers_mcts_amd import net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from test_rules_gpu import random_boards
+    S = 1024
+    m = N.PolicyValueNet(128).keras_init(5).perturb_bn(9).eval().cuda()
+    x = rules.features(rules.boards_to_device(random_boards(S, 777))).contiguous()
+    big = FusedEvaluator(m, S, mode="f16x3")
+    p, v = [t.clone() for t in big.forward_features(x)]                     # 1 024 boards, no range: the two-board kernel
+    with torch.no_grad():
+        p64, v64 = copy.deepcopy(m).double()(x.permute(0, 3, 1, 2).double())
+    assert float((p.double() - p64).abs().max()) < 1e-5 and float((v.double() - v64.reshape(-1)).abs().max()) < 1e-5
+    for n in (1, 7, 200, 256):                                              # host-side choice: n <= 256 boards
+        ps, vs = FusedEvaluator(m, n, mode="f16x3").forward_features(x[:n].contiguous())
+        assert torch.equal(ps, p[:n]) and torch.equal(vs, v[:n]), n
+    for cap, lo, hi in ((256, 0, 1), (256, 3, 250), (200, 0, 200), (None, 300, 500), (None, 0, 600)):   # a row cap on the big batch's evaluator
+        n0 = big.nets[0]                                                    # (what the runners set in the tail of a run) + a device range
+        n0["p"].zero_(); n0["v"].zero_(); n0["pol_feat"].fill_(float("nan")); n0["val_feat"].fill_(float("nan"))
+        rng = torch.tensor([lo, hi], dtype=torch.int32, device="cuda")
+        big.set_row_cap(cap)
+        pr, vr = big._forward(n0, x, rng)
+        torch.cuda.synchronize()
+        assert torch.equal(pr[lo:hi], p[lo:hi]) and torch.equal(vr[lo:hi], v[lo:hi]), (cap, lo, hi)
+    big.set_row_cap(None)
+    big.check_range()
+
+
 def test_fused_evaluator_full_batch_rows_vs_float64(oracle):
     """Both precision modes of the fused evaluator on the bench's batch (4 096 rows of leaf-like features), EVERY row against
     a float64 evaluation of the same network (the module in double precision on the device; a sample of rows also against

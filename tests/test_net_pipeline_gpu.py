@@ -343,3 +343,39 @@ def test_tail_compaction_keeps_results():
     for f in ("board", "mask", "status", "worker", "game", "ply", "n_children", "q", "z", "root_n", "root_w", "chosen", "pi"):
         assert (a[f] == b[f]).all(), f
     assert sa["expansions"] == sb["expansions"] and sa["plies"] == sb["plies"]
+
+
+def test_tail_row_cap_keeps_results(monkeypatch):
+    """The runners' tail handling for dense-rows engines -- once <= 256 slots still play, the evaluator launches its kernels for
+    256 rows (the float32-grade conv stack then runs its low-latency single-board kernel) and the step graph is captured again --
+    changes nothing but the cost of the last steps: identical tuples, results and counters with and without it, noise and
+    temperature on, leaf cache on."""
+    import torch
+    from checkers_mcts_amd import engine as E, net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(KW, BUDGET=8)
+    net = N.make_net(128, seed=3)
+    out = []
+    for tail_rows in (0, 256):
+        monkeypatch.setattr(StepRunner, "TAIL_ROWS", tail_rows)
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=384, games_per_slot=1, terminate_cnt=200, seed=78, feature_dtype=torch.float32,
+                                            leaf_cache_log2=16, dense_rows=True), feature_dtype=torch.float32)
+        ev = FusedEvaluator(net, 384, mode="f16x3")
+        runner = StepRunner(eng, ev)
+        caps = []
+        orig = ev.set_row_cap
+        monkeypatch.setattr(ev, "set_row_cap", lambda cap, orig=orig, caps=caps: (caps.append(cap), orig(cap))[1])
+        runner.run_to_completion(check_every=20)
+        ev.check_range()
+        raw = eng.tuples_raw()
+        raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
+        res = sorted((r["worker"], r["game"], r["outcome"], r["move_count"], r["n_tuples"]) for r in eng.results())
+        out.append((raw, res, caps, eng.stats()))
+        eng.close()
+    (a, ra, caps_a, sa), (b, rb, caps_b, sb) = out
+    assert caps_a == [] and caps_b[:1] == [256] and caps_b[-1] is None and ev.row_cap is None
+    assert ra == rb and len(a) == len(b) and len(a) > 384 * 20
+    for f in ("board", "mask", "status", "worker", "game", "ply", "n_children", "q", "z", "root_n", "root_w", "chosen", "pi"):
+        assert (a[f] == b[f]).all(), f
+    assert sa["expansions"] == sb["expansions"] and sa["plies"] == sb["plies"]
