@@ -410,6 +410,34 @@ def arena_leg(a, dev):
                     "sample from the third ply of the games; leaf cache (keyed by position AND network) and dense rows as in the headline"}
 
 
+def single_game_leg(a, dev):
+    """The reference's own mode of use -- ONE game, one search at a time (play_Checkers.py, MCTS.begin_tree_search): the latency
+    of a simulation when nothing can be batched.  One slot, float32-grade network, BUDGET 400 (play_Checkers.py:73)."""
+    from checkers_mcts_amd import engine as ckengine
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.net import make_net
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(MCTS_KWARGS, BUDGET=400, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    cfg = ckengine.config_from_kwargs(kw, n_slots=1, games_per_slot=64, terminate_cnt=TERMINATE_CNT, feature_dtype=torch.float32,
+                                      seed=20260929, device=dev.index, leaf_cache_log2=20, dense_rows=True)
+    eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
+    runner = StepRunner(eng, FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), 1, mode="f16x3"), use_graph=not a.no_graph)
+    runner.warmup(3)
+    runner.step(500)
+
+    class _One:
+        step = staticmethod(runner.step)
+        stats = staticmethod(eng.stats)
+    steps = 4000
+    dt, d = timed_window(_One, dev, steps)
+    eng.close()
+    sims = d["expansions"] + d["terminal_visits"]
+    return {"sims_per_s": sims / dt, "us_per_step": dt / steps * 1e6, "us_per_simulation": dt / max(1, sims) * 1e6, "steps": steps, "budget": 400,
+            "dtype": DTYPE_LABEL["fp32"],
+            "note": "one game, one tree search at a time: a step = tree kernel + the single-board conv kernel (k_conv_stack_x3_small) + heads, "
+                    "one graph replay; leaves already evaluated come from the leaf cache"}
+
+
 def rollout_leg(a, dev):
     """NEURAL_NET=False (iteration-0 data, train_Checkers.py:78, BUDGET 400 as in README:284): whole
     simulations incl. uniform random playouts to the end of the game inside the tree kernel."""
@@ -624,6 +652,7 @@ def main():
             extra["bf16_throughput_mode" if other == "bf16" else "fp32_grade_mode"] = throughput_leg(a, dev, other)
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
             extra["random_rollout_mode"] = rollout_leg(a, dev)
+            extra["single_game_search"] = single_game_leg(a, dev)
             extra["training_step"] = training_leg(dev)
             extra["training_step_batch_1024"] = training_leg(dev, batch=1024, reps=10)
         cpu = None
