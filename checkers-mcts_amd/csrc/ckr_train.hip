@@ -244,6 +244,130 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef CKR_NT6_STAGE
 }
 
+// k_gemm_nt6 with the operand splitting UNDER the MFMAs (round 3).  In k_gemm_nt6 a chunk is split and staged between two
+// barriers while the matrix pipe idles (PMC: busy 46-50 %).  Here LDS holds two chunk buffers: while the 48 MFMAs of chunk c
+// run out of one, the registers holding chunk c + 1 (fetched an iteration ago) are split and stored into the other, piece by
+// piece between the MFMAs, and each register is refilled with its part of chunk c + 2 as soon as it has been staged -- every
+// global load has a whole iteration to arrive.  One barrier per chunk.  106 KB of LDS: one workgroup per CU, as before.
+template <int GATHER>
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_nt6p(const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb,
+                                                 float* __restrict__ C, int ldc, int M, int K) {
+    extern __shared__ __attribute__((aligned(16))) uint2 lds6[];  // [2][As | Bs]
+    constexpr int BUF = (BM + BN) * P6;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kper = K / gridDim.z, kbeg = blockIdx.z * kper, kend = kbeg + kper;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;                // named scalars: see k_gemm_nt
+    const int frow = tid >> 3, fc4 = tid & 7;
+    unsigned on_board = 0xf;
+    auto load_a = [&](int k0, int i) -> float4 {
+        const int row = frow + 32 * i;
+        if (GATHER == 0) return *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 4 * fc4);
+        const int tap = k0 >> 7, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int p = m0 + row, y = ((p >> 3) & 7) + GATHER * dy, x = (p & 7) + GATHER * dx;
+        const bool in = (unsigned)y < 8u && (unsigned)x < 8u;
+        on_board = (on_board & ~(1u << i)) | ((unsigned)in << i);
+        return *reinterpret_cast<const float4*>(A + (size_t)(p + (in ? GATHER * (8 * dy + dx) : 0)) * 128 + (k0 & 127) + 4 * fc4);
+    };
+    auto load_b = [&](int k0, int i) -> float4 {
+        return *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + frow + 32 * i) * ldb + k0 + 4 * fc4);
+    };
+#define CKR_P6_STAGE(buf, r, i, keep)                                                                 \
+    { const bool in = keep;                                                                           \
+      const Split4 sp = split3(make_float4(in ? r.x : 0.f, in ? r.y : 0.f, in ? r.z : 0.f, in ? r.w : 0.f)); \
+      uint2* dst = buf + (frow + 32 * i) * P6 + fc4;                                                  \
+      dst[0] = sp.p1; dst[8] = sp.p2; dst[16] = sp.p3; }
+#define CKR_P6_STAGE_A(buf, r, i) CKR_P6_STAGE(buf, r, i, GATHER == 0 || (on_board & (1u << i)))
+    // prologue: chunk 0 staged into buffer 0, chunk 1 in the registers
+    ra0 = load_a(kbeg, 0); ra1 = load_a(kbeg, 1); ra2 = load_a(kbeg, 2); ra3 = load_a(kbeg, 3);
+    rb0 = load_b(kbeg, 0); rb1 = load_b(kbeg, 1); rb2 = load_b(kbeg, 2); rb3 = load_b(kbeg, 3);
+    {
+        uint2* As = lds6; uint2* Bs = lds6 + BM * P6;
+        const int k1 = min(kbeg + BK, kend - BK);
+        CKR_P6_STAGE_A(As, ra0, 0) ra0 = load_a(k1, 0); CKR_P6_STAGE_A(As, ra1, 1) ra1 = load_a(k1, 1);
+        CKR_P6_STAGE_A(As, ra2, 2) ra2 = load_a(k1, 2); CKR_P6_STAGE_A(As, ra3, 3) ra3 = load_a(k1, 3);
+        CKR_P6_STAGE(Bs, rb0, 0, true) rb0 = load_b(k1, 0); CKR_P6_STAGE(Bs, rb1, 1, true) rb1 = load_b(k1, 1);
+        CKR_P6_STAGE(Bs, rb2, 2, true) rb2 = load_b(k1, 2); CKR_P6_STAGE(Bs, rb3, 3, true) rb3 = load_b(k1, 3);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, cur ^= 1) {
+        const uint2* As = lds6 + cur * BUF; const uint2* Bs = As + BM * P6;
+        uint2* An = lds6 + (cur ^ 1) * BUF; uint2* Bn = An + BM * P6;
+        // (the last iteration stages the clamped re-fetch of the last chunk into the idle buffer: no branch in the loop body,
+        // so that the splitting can be scheduled between the MFMAs)
+        const int k2 = min(k0 + 2 * BK, kend - BK);
+        bf16x8 fa[2][3], fb[2][3], ga[2][3], gb[2][3];
+#define CKR_P6_FRAGS(fa, fb, kk)                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                 \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                               \
+            fa[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half); \
+            fb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half); }
+        // the six products of the four accumulators, product-major: consecutive MFMAs are independent
+#define CKR_P6_MFMAS(fa, fb)                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                               \
+            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};                    \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                             \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[b][QB[q]], acc[a][b], 0, 0, 0); }
+        CKR_P6_FRAGS(fa, fb, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        // Eight sub-blocks of 6 MFMAs (one accumulator pair's three products each) with one staged piece of the next chunk, its
+        // refill and -- in the first half -- three of the second half's fragment reads between them; fenced, so that each keeps
+        // its share of the VALU work under its own MFMAs.
+#define CKR_P6_SUB(fa, fb, a, qlo, WORK)                                                              \
+        { WORK                                                                                        \
+          _Pragma("unroll") for (int q = qlo; q < qlo + 3; ++q) {                                     \
+              constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};                  \
+              acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[0][QB[q]], acc[a][0], 0, 0, 0); \
+              acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[1][QB[q]], acc[a][1], 0, 0, 0); } \
+          _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                             \
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+              __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);                                      \
+              __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                                      \
+              if (i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }                        \
+          __builtin_amdgcn_sched_barrier(0); }
+#define CKR_P6_GREAD(t, q) ga[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 + 2 * half); \
+                           gb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 + 2 * half);
+        CKR_P6_SUB(fa, fb, 0, 0, CKR_P6_GREAD(0, 0) CKR_P6_GREAD(0, 1) CKR_P6_STAGE_A(An, ra0, 0) ra0 = load_a(k2, 0);)
+        CKR_P6_SUB(fa, fb, 0, 3, CKR_P6_GREAD(0, 2) CKR_P6_STAGE_A(An, ra1, 1) ra1 = load_a(k2, 1);)
+        CKR_P6_SUB(fa, fb, 1, 0, CKR_P6_GREAD(1, 0) CKR_P6_GREAD(1, 1) CKR_P6_STAGE_A(An, ra2, 2) ra2 = load_a(k2, 2);)
+        CKR_P6_SUB(fa, fb, 1, 3, CKR_P6_GREAD(1, 2) CKR_P6_STAGE_A(An, ra3, 3) ra3 = load_a(k2, 3);)
+        CKR_P6_SUB(ga, gb, 0, 0, CKR_P6_STAGE(Bn, rb0, 0, true) rb0 = load_b(k2, 0);)
+        CKR_P6_SUB(ga, gb, 0, 3, CKR_P6_STAGE(Bn, rb1, 1, true) rb1 = load_b(k2, 1);)
+        CKR_P6_SUB(ga, gb, 1, 0, CKR_P6_STAGE(Bn, rb2, 2, true) rb2 = load_b(k2, 2);)
+        CKR_P6_SUB(ga, gb, 1, 3, CKR_P6_STAGE(Bn, rb3, 3, true) rb3 = load_b(k2, 3);)
+        __syncthreads();
+    }
+    float* Cz = C + (size_t)blockIdx.z * (size_t)M * ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
+                    Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
+                }
+#undef CKR_P6_STAGE
+#undef CKR_P6_STAGE_A
+#undef CKR_P6_FRAGS
+#undef CKR_P6_MFMAS
+#undef CKR_P6_SUB
+#undef CKR_P6_GREAD
+}
+constexpr int GEMM6P_LDS = 2 * (BM + BN) * P6 * 8;
+
 // Weight gradient of a 3x3 convolution with 128 kernels: C[z][o][n0 + c] = sum_{p in slice z} dZ[p][o] * X[p + off(tap)][c]
 // (0 outside the board); gridDim = (taps, 1, slices), n0 = 128 * blockIdx.x, tap = tap0 + blockIdx.x (tap0 = 4 and one
 // block column: a plain dZ^T . X).  Both operands arrive as rows of 128 floats (one position); a thread loads the same
@@ -1493,8 +1617,27 @@ int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction
         if (direction > 0) hipLaunchKernelGGL(k_gemm_nt<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
         else hipLaunchKernelGGL(k_gemm_nt<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
     } else {
-        if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
-        else hipLaunchKernelGGL(k_gemm_nt6<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+        // CKR_TRAIN_GEMM6=staged: round 2's kernel (operands split between two barriers) instead of the pipelined one
+        // k_gemm_nt6p (operand splitting under the MFMAs, 106 KB of LDS, one workgroup per CU) is an EXPERIMENT kept selectable
+        // (CKR_TRAIN_GEMM6=pipelined): alone it wins where the grid puts one workgroup on a CU anyway (batch 128: 18.2 against
+        // 21.2 us) and loses where two staged workgroups per CU overlap each other (batch 1 024: 127 against 110 us); inside the
+        // training step, where the weight-gradient GEMM of the side stream shares the CUs, it gains nothing (0.733-0.745 ms
+        // either way, three runs each) -- profiles/r03_train_gemm_pipelined.txt.
+        static const char* force = getenv("CKR_TRAIN_GEMM6");
+        const bool pipelined = force && !strcmp(force, "pipelined");
+        static bool lds_set = false;
+        if (pipelined && !lds_set) {
+            CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt6p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM6P_LDS));
+            CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt6p<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM6P_LDS));
+            lds_set = true;
+        }
+        if (pipelined) {
+            if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6p<1>, grid, dim3(GT), GEMM6P_LDS, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+            else hipLaunchKernelGGL(k_gemm_nt6p<-1>, grid, dim3(GT), GEMM6P_LDS, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+        } else {
+            if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+            else hipLaunchKernelGGL(k_gemm_nt6<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+        }
     }
     CKR_HIP(hipGetLastError());
     return CKR_OK;
