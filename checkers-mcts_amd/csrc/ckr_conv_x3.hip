@@ -31,6 +31,7 @@
 // kernel, its epilogues another 7 % with the matrix pipe idle.)
 #include "ckr_host.h"
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 namespace ckrx {
@@ -408,7 +409,8 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     // tail of a run -- pass that bound as n_boards).  CKR_X3_SMALL=0 keeps everything on the two-board kernel.
     // (Launching both and letting the device range decide which computes was measured: the idle launch costs 7 us per step.)
     static const bool small_ok = !(getenv("CKR_X3_SMALL") && getenv("CKR_X3_SMALL")[0] == '0');
-    const bool small_only = small_ok && n_boards <= SMALL_BOARDS;
+    static const bool small_all = getenv("CKR_X3_SMALL") && !strcmp(getenv("CKR_X3_SMALL"), "all");      // experiment: every launch on the single-board kernel
+    const bool small_only = small_ok && (n_boards <= SMALL_BOARDS || small_all);
     const int grid = (int)((n_boards + 1) / 2);
     // Kernel experiments (tools/slp_probe.py): CKR_X3_CODE_OBJECT names a gfx950 code object whose k_conv_stack_x3 -- the same
     // source built with other compiler flags, or its assembly with instructions inserted -- is launched instead of the

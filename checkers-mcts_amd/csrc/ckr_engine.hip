@@ -959,6 +959,13 @@ template <int GAME, typename WT> __global__ __launch_bounds__(256) void k_init(c
     flush_counters(w);
 }
 
+// dense rows: before every step the row counter {0, 0} and (arena) every row's network id -1 = no leaf in this row
+__global__ __launch_bounds__(256) void k_step_prologue(int32_t* __restrict__ range, int32_t* __restrict__ net, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2) range[i] = 0;
+    if (net && i < n) net[i] = -1;
+}
+
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
@@ -1474,8 +1481,10 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     note_stream(&e->last_stream, (hipStream_t)stream);
     if (e->dev.dense_rows) {
         if (!e->dev.row_count) return fail(CKR_ERR_STATE, "dense_rows: call ckr_engine_set_row_range before the first step");
-        CKR_HIP(hipMemsetAsync(e->d_range, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
-        if (d_net) CKR_HIP(hipMemsetAsync(d_net, 0xFF, (size_t)e->cfg.n_slots * sizeof(int32_t), (hipStream_t)stream));
+        // One small kernel, not two hipMemsetAsync: captured into a HIP graph (ROCm 7.2) the 0xFF memset node left rows that look
+        // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
+        // past the rows in use); it is also one graph node instead of two.
+        hipLaunchKernelGGL(k_step_prologue, dim3((e->cfg.n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->d_range, d_net, (int)e->cfg.n_slots);
     }
     if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
     else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);

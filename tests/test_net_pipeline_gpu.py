@@ -345,23 +345,26 @@ def test_tail_compaction_keeps_results():
     assert sa["expansions"] == sb["expansions"] and sa["plies"] == sb["plies"]
 
 
-def test_tail_row_cap_keeps_results(monkeypatch):
+@pytest.mark.parametrize("arena", [False, True])
+def test_tail_row_cap_keeps_results(monkeypatch, arena):
     """The runners' tail handling for dense-rows engines -- once <= 256 slots still play, the evaluator launches its kernels for
     256 rows (the float32-grade conv stack then runs its low-latency single-board kernel) and the step graph is captured again --
     changes nothing but the cost of the last steps: identical tuples, results and counters with and without it, noise and
-    temperature on, leaf cache on."""
+    temperature on, leaf cache on; self-play (one network) and arena (two networks, the batch partitioned by network id)."""
     import torch
     from checkers_mcts_amd import engine as E, net as N
     from checkers_mcts_amd.fused import FusedEvaluator
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(KW, BUDGET=8)
-    net = N.make_net(128, seed=3)
+    if arena:
+        kw = dict(kw, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    net, old = N.make_net(128, seed=3), N.make_net(128, seed=4)
     out = []
     for tail_rows in (0, 256):
         monkeypatch.setattr(StepRunner, "TAIL_ROWS", tail_rows)
         eng = E.Engine(E.config_from_kwargs(kw, n_slots=384, games_per_slot=1, terminate_cnt=200, seed=78, feature_dtype=torch.float32,
-                                            leaf_cache_log2=16, dense_rows=True), feature_dtype=torch.float32)
-        ev = FusedEvaluator(net, 384, mode="f16x3")
+                                            tournament=arena, leaf_cache_log2=16, dense_rows=True), feature_dtype=torch.float32)
+        ev = FusedEvaluator(net, 384, net_old=old if arena else None, mode="f16x3")
         runner = StepRunner(eng, ev)
         caps = []
         orig = ev.set_row_cap
@@ -370,12 +373,41 @@ def test_tail_row_cap_keeps_results(monkeypatch):
         ev.check_range()
         raw = eng.tuples_raw()
         raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
-        res = sorted((r["worker"], r["game"], r["outcome"], r["move_count"], r["n_tuples"]) for r in eng.results())
+        res = sorted((r["worker"], r["game"], r["outcome"], r["move_count"], r["n_tuples"], r["p1_net"]) for r in eng.results())
         out.append((raw, res, caps, eng.stats()))
         eng.close()
     (a, ra, caps_a, sa), (b, rb, caps_b, sb) = out
     assert caps_a == [] and caps_b[:1] == [256] and caps_b[-1] is None and ev.row_cap is None
-    assert ra == rb and len(a) == len(b) and len(a) > 384 * 20
+    assert ra == rb and len(a) == len(b) and len(ra) == 384 and (arena or len(a) > 384 * 20)
     for f in ("board", "mask", "status", "worker", "game", "ply", "n_children", "q", "z", "root_n", "root_w", "chosen", "pi"):
         assert (a[f] == b[f]).all(), f
     assert sa["expansions"] == sb["expansions"] and sa["plies"] == sb["plies"]
+
+
+def test_dense_rows_network_ids_match_leaf_count_in_graph_mode():
+    """A dense-rows arena step leaves a network id in exactly the rows that hold a leaf -- also when the step is replayed from a
+    HIP graph.  (Regression: the per-step reset of the ids used to be a hipMemsetAsync(0xFF); as a captured memset node under
+    ROCm 7.2 it left stale rows looking live, the two networks' shares grew past the rows in use -- wasted evaluations, and wrong
+    ones once the tail of a run bounded the launches by the number of playing slots.)"""
+    import torch
+    from checkers_mcts_amd import engine as E, net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import StepRunner
+    kw = dict(KW, BUDGET=8, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    S = 384
+    eng = E.Engine(E.config_from_kwargs(kw, n_slots=S, games_per_slot=1, terminate_cnt=200, seed=78, feature_dtype=torch.float32,
+                                        tournament=True, leaf_cache_log2=16, dense_rows=True), feature_dtype=torch.float32)
+    ev = FusedEvaluator(N.make_net(128, seed=3), S, net_old=N.make_net(128, seed=4), mode="f16x3")
+    runner = StepRunner(eng, ev)
+    runner.warmup()
+    assert runner.graph is not None
+    counts = []
+    for it in range(450):
+        runner.step(1)
+        if it % 10 == 0:
+            torch.cuda.synchronize()
+            count, live = int(eng.row_range[1]), int((eng.net_id >= 0).sum())
+            assert live == count and ev._ranges.tolist()[3] == count and bool((eng.net_id[:count] >= 0).all()), (it, count, live)
+            counts.append(count)
+    assert max(counts) == S and min(counts[5:]) < S                       # full batches, then slots running dry
+    eng.close()
