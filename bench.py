@@ -107,6 +107,9 @@ def parse():
                          "network; results identical with and without -- tests/test_leaf_cache_gpu.py); 0 = off")
     ap.add_argument("--leaf-cache-gen-log2", type=int, default=0,
                     help="launches per leaf-cache generation = 2^this (0 = engine default: log2(records) - 14, at least 11); records of the current and the previous generation are served")
+    ap.add_argument("--dynamic-queue", action="store_true",
+                    help="a slot that finishes a game takes the next unplayed game of its engine (DYNAMIC_QUEUE) instead of the "
+                         "reference's fixed number of games per worker: no idle tail")
     ap.add_argument("--extra-steps", type=int, default=300,
                     help="timed steps of the extra legs (bf16 throughput mode, arena, random rollouts; N = 1 only, 0 = skip)")
     return ap.parse_args()
@@ -290,6 +293,7 @@ class Leg:
                                               first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
                                               device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
                                               leaf_cache_log2=a.leaf_cache_log2, leaf_cache_gen_log2=a.leaf_cache_gen_log2, dense_rows=not a.no_dense_rows,
+                                              dynamic_queue=a.dynamic_queue,
                                               **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
             return ckengine.Engine(cfg, feature_dtype=dtype)
 
@@ -432,7 +436,22 @@ def single_game_leg(a, dev):
     dt, d = timed_window(_One, dev, steps)
     eng.close()
     sims = d["expansions"] + d["terminal_visits"]
-    return {"sims_per_s": sims / dt, "us_per_step": dt / steps * 1e6, "us_per_simulation": dt / max(1, sims) * 1e6, "steps": steps, "budget": 400,
+    # the same through the reference's search API (MCTS.begin_tree_search on the facade, play_Checkers.py:125-160)
+    from checkers_mcts_amd.mcts import MCTS, MCTS_Node, Checkers
+    env = Checkers(make_net(128, seed=0, device=dev, dtype=torch.float32).eval())
+    MCTS(**dict(kw, GAME_ENV=env))
+    root = MCTS_Node(env.state, parent=None)
+    MCTS.begin_tree_search(root)                          # builds the evaluator, captures the step graph
+    t_api = []
+    for _ in range(5):
+        best = MCTS.best_child(root)
+        env.step(best.state)
+        root = MCTS.new_root_node(best)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        MCTS.begin_tree_search(root)
+        t_api.append(time.perf_counter() - t1)
+    return {"sims_per_s": sims / dt, "us_per_step": dt / steps * 1e6, "search_api_ms_per_400_simulations": float(np.median(t_api)) * 1e3, "us_per_simulation": dt / max(1, sims) * 1e6, "steps": steps, "budget": 400,
             "dtype": DTYPE_LABEL["fp32"],
             "note": "one game, one tree search at a time: a step = tree kernel + the single-board conv kernel (k_conv_stack_x3_small) + heads, "
                     "one graph replay; leaves already evaluated come from the leaf cache"}

@@ -167,6 +167,7 @@ class MCTS:
     """Class-level search controller (reference: MCTS.py:35-342)."""
     game_env = None
     _engine = None
+    _runner = _runner_key = _evaluator_kind = None
 
     @classmethod
     def __init__(cls, **kwargs):
@@ -192,6 +193,8 @@ class MCTS:
         cls._engine = ckengine.Engine(cfg)
         if not cls.neural_net:
             cls._engine.set_ln_table(kwargs.get("LN_TABLE"))     # np.log of this host for the UCT term (MCTS.py:114)
+        cls._runner = cls._runner_key = None
+        cls._evaluator_kind = kwargs.get("EVALUATOR")        # None / 'fused' / 'torch' (see _search_runner)
         cls._applied = []                  # board records of the plies the engine has been told about
         cls.rollout_count = 0
         cls.reroot_misses = 0
@@ -219,6 +222,32 @@ class MCTS:
             return net                                      # device evaluator: engine -> (p, v)
         return lambda eng: _evaluate_features(net, eng.x)
 
+    @classmethod
+    def _search_runner(cls):
+        """pipeline.StepRunner for the interactive slot: tree kernel + network per simulation step, issued without a host
+        round trip per step.  The reference's own network class (net.PolicyValueNet, 128 kernels, on the device) is evaluated by
+        the hand-written float32-grade kernels (pi, v within 1e-5 of the module; a one-board launch runs the low-latency conv
+        kernel) and the step is replayed from a HIP graph: ~0.12 ms per simulation step.  EVALUATOR='torch' in the MCTS kwargs,
+        any other module, a .predict object or a device evaluator: that evaluator, eagerly.  Rebuilt when the network object or
+        (in-place) its weights change."""
+        from .net import PolicyValueNet
+        from .pipeline import StepRunner
+        net = cls.game_env.neural_net
+        fused = (isinstance(net, PolicyValueNet) and net.num_kernels == 128 and cls._evaluator_kind != "torch"
+                 and next(net.parameters()).is_cuda and not net.training)
+        version = (sum(int(t._version) for t in list(net.parameters()) + list(net.buffers())) if isinstance(net, torch.nn.Module) else 0)
+        key = (id(net), fused, version, id(cls._engine))
+        if cls._runner is None or cls._runner_key != key:
+            if fused:
+                from .fused import FusedEvaluator
+                ev = FusedEvaluator(net, 1, mode="f16x3")
+            else:
+                ev = cls._evaluator()
+            cls._runner = StepRunner(cls._engine, ev, use_graph=fused)
+            cls._runner.steps = 1                           # the engine has stepped before: p / v are always passed
+            cls._runner_key = key
+        return cls._runner
+
     # -- reference API ---------------------------------------------------
     @classmethod
     def begin_tree_search(cls, root_node):
@@ -237,14 +266,14 @@ class MCTS:
                 if not cls._engine.game(0)[3] or out_of_time():
                     break
         else:
-            ev = cls._evaluator()
-            dev = cls._engine.device                         # nothing is pending when a search starts: p, v unused
-            p, v = torch.zeros((1, 512), device=dev), torch.zeros((1,), device=dev)
-            while True:
-                cls._engine.step(p, v)
+            runner = cls._search_runner()                    # nothing is pending when a search starts: p, v unused
+            chunk = 1 if timed else 32                       # steps issued per look at the slot (steps after the search has
+            while True:                                      # parked are no-ops in the tree kernel)
+                runner.step(chunk)
                 if not cls._engine.game(0)[3] or out_of_time():
                     break
-                p, v = ev(cls._engine)
+            if hasattr(runner.evaluator, "check_range"):
+                runner.evaluator.check_range()
         n_before = int(getattr(root_node, "_number_of_visits", 0) or 0)
         root_node._load()
         cls.rollout_count = max(0, int(root_node.n) - n_before) if timed else cls.budget
