@@ -19,11 +19,12 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tournament", action="store_true")
     ap.add_argument("--dynamic", action="store_true", help="dynamic game queue instead of a fixed count per slot")
+    ap.add_argument("--no-cache", action="store_true", help="without the leaf cache / dense network batches (the round-2 configuration)")
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many steps (throughput sample of a long run)")
     a = ap.parse_args()
     from checkers_mcts_amd import dist as ckdist, engine as E
     from checkers_mcts_amd.net import NetEvaluator, make_net
-    from checkers_mcts_amd.pipeline import StepRunner
+    from checkers_mcts_amd.pipeline import StepRunner, default_leaf_cache_log2
     rank, local_rank, world = ckdist.init_from_env()
     dev = ckdist.local_device(local_rank)
     torch.cuda.set_device(dev)
@@ -36,7 +37,8 @@ def main():
     cfg = E.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=a.games_per_slot,
                                terminate_cnt=0 if a.tournament else a.terminate, tournament=a.tournament,
                                first_worker_id=first, feature_dtype=dt, seed=a.seed, device=local_rank,
-                               dynamic_queue=a.dynamic)
+                               dynamic_queue=a.dynamic,
+                               leaf_cache_log2=0 if a.no_cache else default_leaf_cache_log2(a.slots, dev), dense_rows=not a.no_cache)
     eng = E.Engine(cfg, feature_dtype=dt)
     from checkers_mcts_amd.pipeline import make_evaluator
     runner = StepRunner(eng, make_evaluator("random:0", dev, dt, a.slots, spec_old="random:1" if a.tournament else None))
