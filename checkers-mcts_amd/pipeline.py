@@ -261,10 +261,11 @@ class SplitRunner:
 
     make_engine(first_worker_offset, n_slots) -> Engine; make_evaluator(n_slots) -> evaluator."""
 
-    def __init__(self, make_engine, make_evaluator, n_slots, use_graph=True, device=None):
-        h0 = (n_slots + 1) // 2
+    def __init__(self, make_engine, make_evaluator, n_slots, use_graph=True, device=None, n_parts=None):
+        n_parts = int(n_parts or os.environ.get("CKR_SPLIT_PARTS", 2))      # 2 measured best (3: -1.4 %, 4: -16 %; profiles/r03_split_parts.txt)
+        bounds = [n_slots * i // n_parts for i in range(n_parts + 1)]
         self.parts = []
-        for first, cnt in ((0, h0), (h0, n_slots - h0)):
+        for first, cnt in ((bounds[i], bounds[i + 1] - bounds[i]) for i in range(n_parts)):
             if cnt <= 0:
                 continue
             eng = make_engine(first, cnt)
