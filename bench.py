@@ -60,8 +60,8 @@ HBM_PEAK_GBS = 8000.0
 # per-dispatch means; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), keyed by boards per launch: see
 # profiles/README.md.  Not re-measured by this script; launches of another size are scaled from the nearest entry.
 PMC_TRAFFIC = {
-    "fp32": {4096: (2 * 86088.9 + 9216.0) * 1024.0, 2048: (2 * 36175.1 + 4608.0) * 1024.0,
-             "source": "profiles/r02_pmc_conv_4096_boards.csv / r02_pmc_conv_2048_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
+    "fp32": {4096: (2 * 92311.8 + 9216.0) * 1024.0, 2048: (2 * 41613.4 + 4608.0) * 1024.0,
+             "source": "profiles/r03_pmc_conv_4096_boards.csv / r03_pmc_conv_2048_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
     "bf16": {4096: (2 * 15114.1 + 9216.0) * 1024.0,
              "source": "profiles/r02_pmc_conv_4096_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
 }
