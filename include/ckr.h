@@ -158,7 +158,11 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
  * (NULL: every layer uses x_scale).  layers[i].out (tests): float32 [n_boards][8][8][128] = activation * XS_i.  Head
  * outputs are unscaled float32.
  * d_overflow (may be NULL): DEVICE int32 set to 1 when an activation * XS_i exceeds the fp16
- * range of the hi terms (6e4): such results are saturated and must be discarded. */
+ * range of the hi terms (6e4): such results are saturated and must be discarded.
+ * n_boards <= 256 launches the kernel's single-board instantiation (one board per workgroup: half the MFMA chain per
+ * wave, about half the latency when the launch cannot fill the chip anyway -- the tail of a run, one interactive search);
+ * same instruction order per output element, bit-identical results.  A caller that knows only the first r rows of a
+ * larger batch are in use (dense rows) passes r as n_boards. */
 int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers,
                          int32_t n_layers, const ckr_conv_heads* heads, float x_scale, const float* act_scales,
                          const int32_t* d_board_range, int32_t* d_overflow, void* stream);
