@@ -332,6 +332,23 @@ class Leg:
                 out[k] = out.get(k, 0) + v
         return out
 
+    def mark(self):
+        """Engine.mark() on the stream each engine steps on."""
+        if self.split:
+            for eng, _, stream in self.runner.parts:
+                with torch.cuda.stream(stream):
+                    eng.mark()
+        else:
+            for e in self.engines:
+                e.mark()
+
+    def stats_at_mark(self):
+        out = {}
+        for e in self.engines:
+            for k, v in e.stats_at_mark().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
     def check_range(self):
         for ev in self.evaluators:
             if hasattr(ev, "check_range"):
@@ -352,16 +369,25 @@ class Leg:
 
 
 def timed_window(leg, dev, steps, barrier=lambda: None):
+    """EXACTLY `steps` steps between barrier + synchronize pairs.  The counters at the start of the window are copied on the
+    device, in stream order, as the window's first operation (Leg.mark): reading them on the host before t0 would leave the GPU
+    idle for a moment, and the first ~10 steps after an idle gap run 5-15 % slower while the chip's power controller settles --
+    noise in a window of 20 steps (profiles/r03_window_transient.txt)."""
+    marked = hasattr(leg, "mark")
     torch.cuda.synchronize(dev)
-    s0 = leg.stats()
+    s0 = None if marked else leg.stats()
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    if marked:
+        leg.mark()
     leg.step(steps)
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
     s1 = leg.stats()
+    if marked:
+        s0 = leg.stats_at_mark()
     return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves")}
 
 

@@ -1285,6 +1285,7 @@ struct ckr_engine {
     int32_t* d_row_tmp = nullptr; float* d_tmp_p = nullptr; float* d_tmp_v = nullptr;   // ckr_engine_compact_rows
     Dev* d_dev = nullptr;              // device copy of `dev` (owned by allocs)
     int32_t* d_range = nullptr;        // dense rows: the caller's DEVICE int32[2] = {0, leaves of the last step}
+    unsigned long long* d_mark = nullptr;   // ckr_engine_mark: copy of the event counters taken in stream order
 };
 
 template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool zero = true) {
@@ -1361,7 +1362,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.tuples, NT ? NT : 1, true);
     if (D.record_root) { A(D.rs_w, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); A(D.rs_p, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); }
     A(D.results, (size_t)e->n_games_total, true);
-    A(D.counters, (size_t)CNT_SHARDS * CNT_STRIDE, true);
+    A(D.counters, (size_t)CNT_SHARDS * CNT_STRIDE, true); A(e->d_mark, (size_t)CNT_SHARDS * CNT_STRIDE, true);
     A(D.leaves, S, true);
     A(D.g_epoch, S, true);
     if (cache_log2 > 0) {
@@ -1521,6 +1522,28 @@ int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_ne
     CKR_HIP(hipMemcpyAsync(d_v, e->d_tmp_v, (size_t)S * sizeof(float), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_rows_commit, dim3((S + 255) / 256), dim3(256), 0, st, (const Dev*)e->d_dev, (const int32_t*)e->d_row_tmp);
     CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_engine_mark(ckr_engine* e, void* stream) {
+    if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_mark: null engine");
+    note_stream(&e->last_stream, (hipStream_t)stream);
+    CKR_HIP(hipMemcpyAsync(e->d_mark, e->dev.counters, sizeof(unsigned long long) * CNT_SHARDS * CNT_STRIDE, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CKR_OK;
+}
+
+int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out) {
+    if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_stats_at_mark: null argument");
+    CKR_HIP(hipDeviceSynchronize());
+    unsigned long long shards[CNT_SHARDS * CNT_STRIDE], c[CNT_N] = {0};
+    CKR_HIP(hipMemcpy(shards, e->d_mark, sizeof(shards), hipMemcpyDeviceToHost));
+    for (int s = 0; s < CNT_SHARDS; ++s)
+        for (int i = 0; i < CNT_N; ++i) c[i] += shards[s * CNT_STRIDE + i];
+    memset(out, 0, sizeof(*out));
+    out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
+    out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
+    out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP];
     return CKR_OK;
 }
 

@@ -205,6 +205,16 @@ class Engine:
         _lib.check(self._L.ckr_engine_stats(self._h, C.byref(s)))
         return {n: int(getattr(s, n)) for n, _ in _lib.Stats._fields_}
 
+    def mark(self):
+        """Copy the event counters in stream order (current stream); stats_at_mark() reads the copy later -- the counters at a
+        point of the stream without a host round trip there."""
+        _lib.check(self._L.ckr_engine_mark(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+
+    def stats_at_mark(self):
+        s = _lib.Stats()
+        _lib.check(self._L.ckr_engine_stats_at_mark(self._h, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in _lib.Stats._fields_}
+
     def results(self):
         n = C.c_int64(0)
         _lib.check(self._L.ckr_engine_results(self._h, None, 0, C.byref(n)))

@@ -359,6 +359,12 @@ int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range);
 
 /* Counters (synchronises the stream the last step ran on). */
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out);
+/* The event counters at a point of a stream, without idling the device: ckr_engine_mark copies them on `stream` (in order with
+ * the steps issued there), ckr_engine_stats_at_mark reads that copy later (counters only: active_slots is 0).  bench.py marks the
+ * start of its timed window this way -- a host read there idles the GPU for a moment, and the first steps after an idle gap run
+ * slower while the power controller settles (profiles/r03_window_transient.txt). */
+int ckr_engine_mark(ckr_engine* e, void* stream);
+int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out);
 
 /* Finished games and their tuples, copied to HOST buffers (synchronises).
  * Pass NULL buffers to query counts. */

@@ -512,3 +512,26 @@ def test_time_constrained_rollout_search(E):
             a, nv = E.tuple_actions_visits(e)
             assert int(nv.sum()) in (int(e["root_n"]), int(e["root_n"]) - 1) and e["chosen"] in a
         eng.close()
+
+
+def test_counter_mark_is_taken_in_stream_order(E):
+    """Engine.mark() copies the event counters on the stream, in order with the steps issued there; stats_at_mark() later returns
+    the counters of THAT point (bench.py marks the start of its timed window this way instead of reading them on the host)."""
+    import torch
+    eng, ev = run_engine(E, mk(30, training=True, eps=0.25, tau=1.0), [3] * 64, games_per_slot=2, terminate_cnt=60, seed=5)
+    p = v = None
+    for _ in range(50):
+        eng.step(p, v)
+        p, v = ev(eng)
+    torch.cuda.synchronize()
+    before = eng.stats()
+    eng.mark()                                             # no host synchronisation between the mark and the next steps
+    for _ in range(50):
+        eng.step(p, v)
+        p, v = ev(eng)
+    after = eng.stats()
+    at_mark = eng.stats_at_mark()
+    keys = ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves", "steps", "nodes_created")
+    assert all(at_mark[k] == before[k] for k in keys), (at_mark, before)
+    assert after["expansions"] > before["expansions"] and after["steps"] == before["steps"] + 50
+    eng.close()
