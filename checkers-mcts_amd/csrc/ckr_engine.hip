@@ -970,9 +970,15 @@ __global__ __launch_bounds__(256) void k_step_prologue(int32_t* __restrict__ ran
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
 template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
-                                              const float* __restrict__ v, void* x, int32_t* net_out, int end_ply) {
+                                              const float* __restrict__ v, void* x, int32_t* net_out, int flags) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
+    int end_ply = flags & 1;
+    if (flags & 2) {                                           // dense rows, one workgroup (<= 4 slots): k_step_prologue's work, here
+        if (threadIdx.x < 2) (D.row_count - 1)[threadIdx.x] = 0;
+        if (net_out && (int)threadIdx.x < D.n_slots) net_out[threadIdx.x] = -1;
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     WaveT<WT> w{D, lds[wave], slot, lane_id()};
@@ -1482,13 +1488,15 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     note_stream(&e->last_stream, (hipStream_t)stream);
     if (e->dev.dense_rows) {
         if (!e->dev.row_count) return fail(CKR_ERR_STATE, "dense_rows: call ckr_engine_set_row_range before the first step");
+        // (a single-workgroup engine -- one interactive search -- resets them inside k_step: one launch less per simulation)
         // One small kernel, not two hipMemsetAsync: captured into a HIP graph (ROCm 7.2) the 0xFF memset node left rows that look
         // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
         // past the rows in use); it is also one graph node instead of two.
-        hipLaunchKernelGGL(k_step_prologue, dim3((e->cfg.n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->d_range, d_net, (int)e->cfg.n_slots);
+        if (e->cfg.n_slots > 4) hipLaunchKernelGGL(k_step_prologue, dim3((e->cfg.n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->d_range, d_net, (int)e->cfg.n_slots);
     }
-    if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
-    else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, end_ply);
+    const int flags = (end_ply ? 1 : 0) | (e->dev.dense_rows && e->cfg.n_slots <= 4 ? 2 : 0);
+    if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
+    else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     CKR_HIP(hipGetLastError());
     e->steps++;
     return CKR_OK;

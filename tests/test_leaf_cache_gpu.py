@@ -165,3 +165,28 @@ def test_cfg3_real_network_cache_on_off_identical(E, capsys):
         print("[leaf cache] 2^25 records + dense rows: %.1f %%; steps %d; dropped %d"
               % (100.0 * st2["dup_leaves"] / st2["expansions"], st2["steps"], st2["cache_dropped"]))
     assert rate > 0.05
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5])
+def test_tiny_engines_reset_their_rows_inside_the_tree_kernel(E, n):
+    """Engines of <= 4 slots (one workgroup: an interactive search, bench's single-game leg) reset the dense-rows counter and
+    the rows' network ids inside k_step instead of in k_step_prologue; 5 slots take the two-kernel path.  Tuples equal the plain
+    engine's (no cache, rows by slot number) either way."""
+    from test_engine_gpu import mk, run_engine, sorted_tuples
+    res = []
+    for dense, cache in ((False, 0), (True, 14)):
+        eng, ev = run_engine(E, mk(40, training=True, eps=0.25, tau=1.0), [7] * n, games_per_slot=2, terminate_cnt=80, seed=11,
+                             dense_rows=dense, leaf_cache_log2=cache)
+        p = v = None
+        for i in range(20000):
+            eng.step(p, v)
+            p, v = ev(eng)
+            if i % 200 == 0 and eng.stats()["active_slots"] == 0:
+                break
+        assert eng.stats()["active_slots"] == 0
+        res.append(sorted_tuples(eng))
+        eng.close()
+    a, b = res
+    assert len(a) == len(b) > 50 * n
+    for f in ("board", "mask", "pi", "q", "z", "chosen", "root_n", "n_children"):
+        assert (a[f] == b[f]).all(), f
