@@ -959,6 +959,11 @@ template <int GAME, typename WT> __global__ __launch_bounds__(256) void k_init(c
     flush_counters(w);
 }
 
+__global__ void k_epoch_advance(uint32_t* __restrict__ epoch, int n, uint32_t by) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) epoch[i] += by;
+}
+
 // dense rows: before every step the row counter {0, 0} and (arena) every row's network id -1 = no leaf in this row
 __global__ __launch_bounds__(256) void k_step_prologue(int32_t* __restrict__ range, int32_t* __restrict__ net, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1655,6 +1660,17 @@ int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t ca
             CKR_HIP(hipMemcpy(p_out + k * CKR_MAX_CHILDREN, e->dev.rs_p + s, (size_t)cnt * row, hipMemcpyDeviceToHost));
             k += cnt;
         }
+    return CKR_OK;
+}
+
+int ckr_engine_cache_flush(ckr_engine* e, void* stream) {
+    if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_cache_flush: null engine");
+    if (!e->dev.cache) return CKR_OK;
+    note_stream(&e->last_stream, (hipStream_t)stream);
+    // two generations ahead: every record written so far is older than anything a reader accepts (cache_fresh)
+    hipLaunchKernelGGL(k_epoch_advance, dim3((e->cfg.n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dev.g_epoch, (int)e->cfg.n_slots,
+                       2u << e->dev.cache_gen_shift);
+    CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
 

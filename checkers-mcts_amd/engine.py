@@ -205,6 +205,10 @@ class Engine:
         _lib.check(self._L.ckr_engine_stats(self._h, C.byref(s)))
         return {n: int(getattr(s, n)) for n, _ in _lib.Stats._fields_}
 
+    def cache_flush(self):
+        """Forget the leaf cache's contents: the network behind the evaluator has changed."""
+        _lib.check(self._L.ckr_engine_cache_flush(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+
     def mark(self):
         """Copy the event counters in stream order (current stream); stats_at_mark() reads the copy later -- the counters at a
         point of the stream without a host round trip there."""

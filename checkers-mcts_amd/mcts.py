@@ -189,6 +189,9 @@ class MCTS:
         cfg = ckengine.config_from_kwargs(kwargs, n_slots=1, games_per_slot=1, manual_play=True,
                                           seed=int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))),
                                           max_sims_per_step=1 << 30, nodes_per_tree=kwargs.get("NODES_PER_TREE"),
+                                          # both players' trees (and transpositions) ask for the same positions again: 2^18 records
+                                          # (69 MB) served for 16 384 - 32 768 simulation steps; flushed when the network changes
+                                          leaf_cache_log2=kwargs.get("LEAF_CACHE_LOG2", 18) if kwargs["NEURAL_NET"] else 0, leaf_cache_gen_log2=14,
                                           rollout_first=bool(kwargs.get("ROLLOUT_FIRST", False)))   # test hook
         cls._engine = ckengine.Engine(cfg)
         if not cls.neural_net:
@@ -237,6 +240,8 @@ class MCTS:
                  and next(net.parameters()).is_cuda and not net.training)
         version = (sum(int(t._version) for t in list(net.parameters()) + list(net.buffers())) if isinstance(net, torch.nn.Module) else 0)
         key = (id(net), fused, version, id(cls._engine))
+        if cls._runner_key != key or not isinstance(net, torch.nn.Module):
+            cls._engine.cache_flush()                       # another network, other weights, or an object whose changes cannot be seen
         if cls._runner is None or cls._runner_key != key:
             if fused:
                 from .fused import FusedEvaluator

@@ -363,6 +363,9 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out);
  * the steps issued there), ckr_engine_stats_at_mark reads that copy later (counters only: active_slots is 0).  bench.py marks the
  * start of its timed window this way -- a host read there idles the GPU for a moment, and the first steps after an idle gap run
  * slower while the power controller settles (profiles/r03_window_transient.txt). */
+/* Forget the leaf cache's contents (no-op without a cache): the network behind the evaluator has changed.  The search façade
+ * (mcts.py) calls it when the game environment's neural_net object or its weights change between searches. */
+int ckr_engine_cache_flush(ckr_engine* e, void* stream);
 int ckr_engine_mark(ckr_engine* e, void* stream);
 int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out);
 
