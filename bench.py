@@ -87,7 +87,14 @@ def parse():
                     help="untimed steps before the warm-up that bring the slots to a desynchronised steady state "
                          "(-1 = 90 x BUDGET: about one mean game)")
     ap.add_argument("--games-per-slot", type=int, default=4,
-                    help="games every slot plays back to back in the run (reference semantics: NUM_SELFPLAY_GAMES per worker)")
+                    help="size of the complete run: slots x this many games")
+    ap.add_argument("--static-workers", action="store_true",
+                    help="one worker per slot playing --games-per-slot games back to back (NUM_CPUS = slots, NUM_SELFPLAY_GAMES = games per "
+                         "slot: slots run dry at the end of the run) instead of the default: NUM_CPUS = slots x games-per-slot workers of "
+                         "one game each, hosted on the slots one after the other (virtual workers: same per-worker semantics, "
+                         "training_pipeline.py:323-349, results keyed by worker id, no idle tail until the queue is empty)")
+    ap.add_argument("--park", action="store_true",
+                    help="leaf_cache_park: a leaf whose position is being evaluated for another slot right now waits for that evaluation")
     ap.add_argument("--no-complete", action="store_true", help="skip leg 3 (play the run to its end; M2)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-split", action="store_true",
@@ -102,9 +109,11 @@ def parse():
     ap.add_argument("--no-dense-rows", action="store_true",
                     help="keep every slot's leaf in the batch row of its slot number (idle rows are evaluated too) instead of packing the "
                          "step's leaves into rows [0, n) and bounding the conv launch by n")
-    ap.add_argument("--leaf-cache-log2", type=int, default=27,
-                    help="log2 of the records of each engine's leaf cache (positions already evaluated are expanded without the "
-                         "network; results identical with and without -- tests/test_leaf_cache_gpu.py); 0 = off")
+    ap.add_argument("--leaf-cache-log2", type=int, default=-1,
+                    help="log2 of the records of the GPU's leaf cache, shared by the half-batch engines (positions already evaluated are "
+                         "expanded without the network; results identical with and without -- tests/test_leaf_cache_gpu.py); 0 = off; "
+                         "-1 = pipeline.default_leaf_cache_log2: by slot count, capped by the device's total and free memory divided by "
+                         "the ranks that share the device")
     ap.add_argument("--leaf-cache-gen-log2", type=int, default=0,
                     help="launches per leaf-cache generation = 2^this (0 = engine default: log2(records) - 14, at least 11); records of the current and the previous generation are served")
     ap.add_argument("--dynamic-queue", action="store_true",
@@ -274,28 +283,36 @@ def conv_roofline(mode, conv_flops, slots, t_conv):
     return out
 
 
+def cache_log2_of(a, dev):
+    from checkers_mcts_amd.pipeline import default_leaf_cache_log2
+    return a.leaf_cache_log2 if a.leaf_cache_log2 >= 0 else default_leaf_cache_log2(a.slots, dev)
+
+
 class Leg:
     """The engine(s) + evaluator(s) + step runner of one precision mode on this rank: one engine on one stream, or
-    (split) two half-batch engines on two streams (pipeline.SplitRunner)."""
+    (split) two half-batch engines on two streams (pipeline.SplitRunner) that share the GPU's leaf cache.  The leg plays
+    `n_workers` reference workers (global ids from first_worker) of `games_per_worker` games each on a.slots slots."""
 
-    def __init__(self, a, dev, mode, first_worker, games_per_slot, split):
+    def __init__(self, a, dev, mode, first_worker, n_workers, games_per_worker, split, cache_log2=None):
         from checkers_mcts_amd import engine as ckengine
         from checkers_mcts_amd.net import NetEvaluator, make_net
-        from checkers_mcts_amd.pipeline import SplitRunner, StepRunner
+        from checkers_mcts_amd.pipeline import SplitRunner, StepRunner, make_leaf_cache
         dtype = DTYPES[mode]
         kw = dict(MCTS_KWARGS, BUDGET=a.budget)
         self.which = a.evaluator or ("fused" if mode in ("bf16", "fp32") else "torch")
         if self.which == "fused" and mode not in ("bf16", "fp32"):
             raise SystemExit("--evaluator fused needs --nn-dtype bf16 or fp32")
+        self.cache_log2 = cache_log2_of(a, dev) if cache_log2 is None else cache_log2
+        self.cache = make_leaf_cache(self.cache_log2, dev, n_engines=2 if split else 1)
 
-        def make_engine(offset, n):
-            cfg = ckengine.config_from_kwargs(kw, n_slots=n, games_per_slot=games_per_slot, terminate_cnt=TERMINATE_CNT,
+        def make_engine(offset, workers, n):
+            cfg = ckengine.config_from_kwargs(kw, n_slots=n, n_workers=workers, games_per_slot=games_per_worker, terminate_cnt=TERMINATE_CNT,
                                               first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
                                               device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
-                                              leaf_cache_log2=a.leaf_cache_log2, leaf_cache_gen_log2=a.leaf_cache_gen_log2, dense_rows=not a.no_dense_rows,
-                                              dynamic_queue=a.dynamic_queue,
+                                              leaf_cache_log2=0, dense_rows=not a.no_dense_rows,
+                                              dynamic_queue=a.dynamic_queue, leaf_cache_park=a.park,
                                               **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
-            return ckengine.Engine(cfg, feature_dtype=dtype)
+            return ckengine.Engine(cfg, feature_dtype=dtype, cache=self.cache)
 
         def make_evaluator(n):
             if self.which == "fused":
@@ -306,12 +323,12 @@ class Leg:
 
         self.dev, self.split = dev, bool(split)
         if split:
-            self.runner = SplitRunner(make_engine, make_evaluator, a.slots, use_graph=not a.no_graph)
+            self.runner = SplitRunner(make_engine, make_evaluator, n_workers, use_graph=not a.no_graph, n_slots=a.slots)
             self.engines = self.runner.engines
             self.evaluators = [r.evaluator for _, r, _ in self.runner.parts]
         else:
-            eng = make_engine(0, a.slots)
-            self.runner = StepRunner(eng, make_evaluator(a.slots), use_graph=not a.no_graph)
+            eng = make_engine(0, n_workers, min(a.slots, n_workers))
+            self.runner = StepRunner(eng, make_evaluator(min(a.slots, n_workers)), use_graph=not a.no_graph)
             self.engines, self.evaluators = [eng], [self.runner.evaluator]
         self.boards_per_launch = self.engines[0].cfg.n_slots
 
@@ -364,8 +381,16 @@ class Leg:
         return torch.cat([e.pack_tuples_device() for e in self.engines], dim=0)
 
     def close(self):
+        """Engines, their node pools, and the leaf cache: everything this leg holds in device memory."""
         for e in self.engines:
             e.close()
+        self.engines = []
+        if self.cache is not None:
+            self.cache.close()
+            self.cache = None
+        self.runner = None
+        self.evaluators = []
+        torch.cuda.empty_cache()
 
 
 def timed_window(leg, dev, steps, barrier=lambda: None):
@@ -388,21 +413,25 @@ def timed_window(leg, dev, steps, barrier=lambda: None):
     s1 = leg.stats()
     if marked:
         s0 = leg.stats_at_mark()
-    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves")}
+    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves", "parked")}
 
 
-def throughput_leg(a, dev, mode):
-    """extra: the same workload in the other precision mode (steady state after a pre-roll)."""
-    leg = Leg(a, dev, mode, 0, 64, not a.no_split)
+def throughput_leg(a, dev, mode, cache_log2=None):
+    """extra: the same workload in the other precision mode, or (cache_log2 = 0) without the leaf cache: steady state after a
+    pre-roll of its own."""
+    leg = Leg(a, dev, mode, 0, a.slots, 64, not a.no_split, cache_log2=cache_log2)
     leg.warmup(3)
     leg.step(preroll_steps(a))
     dt, d = timed_window(leg, dev, a.extra_steps)
     t_conv = time_conv(leg.evaluators[0], leg.engines[0].x, dev) if leg.which == "fused" else 0.0
     out = {"value": d["expansions"] / dt, "unit": "node-expansions/s", "steps": a.extra_steps,
            "ms_per_step": dt / a.extra_steps * 1e3, "dtype": DTYPE_LABEL[mode], "plies": d["plies"],
-           "terminal_visits": d["terminal_visits"], "preroll_steps": preroll_steps(a)}
+           "terminal_visits": d["terminal_visits"], "preroll_steps": preroll_steps(a),
+           "nn_evals": d["nn_evals"], "dup_leaves": d["dup_leaves"], "nn_evals_per_s": d["nn_evals"] / dt,
+           "leaf_cache_log2": leg.cache_log2}
     if leg.which == "fused":
         out["roofline"] = conv_roofline(mode, leg.evaluators[0].CONV_FLOPS_PER_BOARD, leg.boards_per_launch, t_conv)
+        out["roofline"]["basis"] = "the kernel alone on a full launch of %d boards (HIP events around a graph of 10 launches)" % leg.boards_per_launch
     leg.close()
     if mode == "bf16":
         out["note"] = ("throughput mode, NOT a parity mode: bf16 operands (pi within 5e-3, v within 5e-2 of the float32 network); "
@@ -420,7 +449,7 @@ def arena_leg(a, dev):
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
     cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.float32,
                                       seed=20260929, device=dev.index, dynamic_queue=True,
-                                      leaf_cache_log2=min(27, a.leaf_cache_log2 + 1) if a.leaf_cache_log2 else 0,
+                                      leaf_cache_log2=cache_log2_of(a, dev),
                                       dense_rows=not a.no_dense_rows)
     eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
     ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
@@ -434,6 +463,8 @@ def arena_leg(a, dev):
         stats = staticmethod(eng.stats)
     dt, d = timed_window(_One, dev, a.extra_steps)
     eng.close()
+    del ev, runner
+    torch.cuda.empty_cache()
     return {"sims_per_s": (d["expansions"] + d["terminal_visits"]) / dt, "ms_per_step": dt / a.extra_steps * 1e3,
             "steps": a.extra_steps, "budget": 800, "dtype": DTYPE_LABEL["fp32"],
             "note": "each leaf is evaluated by its own network only (batch partitioned by network id on the device); "
@@ -582,12 +613,20 @@ def main():
     dev = ckdist.local_device(local_rank)
     torch.cuda.set_device(dev)
     mode = a.nn_dtype
-    first, _ = ckdist.shard_range(a.slots * world, rank, world)
     pre = preroll_steps(a)
-    # enough games per slot that no slot runs dry before the timed window is over when leg 3 is skipped
-    games_per_slot = a.games_per_slot if not a.no_complete else max(2, (pre + a.steps + a.warmup) // (a.budget * 30) + 2)
-    leg = Leg(a, dev, mode, first, games_per_slot, not a.no_split)
+    # the job: slots x games-per-slot games per GPU.  Default: that many WORKERS of one game each, hosted on the slots one after
+    # the other (virtual workers); --static-workers / --dynamic-queue / --no-complete: one worker per slot
+    virtual = not (a.static_workers or a.dynamic_queue or a.no_complete)
+    if virtual:
+        n_workers, games_per_worker = a.slots * a.games_per_slot, 1
+    else:
+        # --no-complete: enough games per slot that no slot runs dry before the timed window is over
+        n_workers = a.slots
+        games_per_worker = a.games_per_slot if not a.no_complete else max(2, (pre + a.steps + a.warmup) // (a.budget * 30) + 2)
+    first = rank * n_workers
+    leg = Leg(a, dev, mode, first, n_workers, games_per_worker, not a.no_split)
     which = leg.which
+    n_parts = len(leg.engines)
 
     # ---- 1. pre-roll (untimed for `value`, timed for the whole run)
     ckdist.barrier()
@@ -601,24 +640,33 @@ def main():
     leg.step(a.warmup)
     dt_local, d = timed_window(leg, dev, a.steps, ckdist.barrier)
     dt = ckdist.max_over_ranks(dt_local, dev)
-    exp_total = ckdist.sum_over_ranks(d["expansions"], dev)
+    dt_by_rank = ckdist.all_ranks(dt_local, dev)
+    exp_by_rank = ckdist.all_ranks(d["expansions"], dev)
+    exp_total = sum(exp_by_rank)
     term_total = ckdist.sum_over_ranks(d["terminal_visits"], dev)
     plies_total = ckdist.sum_over_ranks(d["plies"], dev)
     games_window = ckdist.sum_over_ranks(d["games"], dev)
-    nn_total = ckdist.sum_over_ranks(d["nn_evals"], dev)
+    nn_by_rank = ckdist.all_ranks(d["nn_evals"], dev)
+    nn_total = sum(nn_by_rank)
     dup_total = ckdist.sum_over_ranks(d["dup_leaves"], dev)
+    parked_total = ckdist.sum_over_ranks(d["parked"], dev)
     active_after_window = leg.stats()["active_slots"]
 
-    # ---- instrumented eager pass on the first engine (its wall time is taken out of the whole-run figure): HIP events on
-    # the launch stream around the tree kernel and the network launches of single steps
+    # ---- instrumented eager pass on the first engine (its wall time is taken out of the whole-run figure): the SAME engines go on
+    # stepping, one at a time, with HIP events on the launch stream around the tree kernel, the conv-stack launch and the heads of
+    # each step -- the conv kernel alone on the chip, on the rows real steps produce
     t_probe0 = time.perf_counter()
     t_tree = t_nn = t_conv = 0.0
+    rows_alone = 0.0
     if a.profile_steps > 0:
         eng0, ev0 = leg.engines[0], leg.evaluators[0]
         r0 = leg.runner.parts[0][1] if leg.split else leg.runner
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.profile_steps)]
+        rows_log = torch.zeros(a.profile_steps, dtype=torch.int32, device=dev)
+        if hasattr(ev0, "timing"):
+            ev0.timing = []
         with torch.no_grad():
-            for e0, e1, e2 in ev:
+            for i, (e0, e1, e2) in enumerate(ev):
                 e0.record()
                 eng0.step(r0.p, r0.v)
                 e1.record()
@@ -626,12 +674,14 @@ def main():
                 if not getattr(ev0, "static_outputs", False):
                     r0.p.copy_(p); r0.v.copy_(v)
                 e2.record()
+                rows_log[i:i + 1].copy_(eng0.row_range[1:2])
         torch.cuda.synchronize(dev)
         t_tree = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in ev])) / 1e3
         t_nn = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in ev])) / 1e3
-        # the dominant kernel on its own: one launch per step (and half-batch), against the engine's current leaf features
-        if which == "fused":
-            t_conv = time_conv(ev0, eng0.x, dev, groups=max(3, a.profile_steps // 4))
+        if which == "fused" and ev0.timing:
+            t_conv = float(np.mean([c0.elapsed_time(c1) for c0, c1 in ev0.timing])) / 1e3
+            rows_alone = float(rows_log.float().mean().item())
+            ev0.timing = None
     torch.cuda.synchronize(dev)
     t_probe = time.perf_counter() - t_probe0
 
@@ -641,58 +691,105 @@ def main():
         trace = []
         leg.run_to_completion(trace)
         torch.cuda.synchronize(dev)
+        t_play_local = time.perf_counter() - t_run0 - t_probe
         ckdist.barrier()
         t_play = ckdist.max_over_ranks(time.perf_counter() - t_run0 - t_probe, dev)
+        play_by_rank = ckdist.all_ranks(t_play_local, dev)
         st = leg.stats()
         payload = leg.pack_tuples_device()
         torch.cuda.synchronize(dev)
         ckdist.barrier()
         g0 = time.perf_counter()
-        gathered = ckdist.gather_rows(payload, dst=0)
+        gathered = ckdist.gather_rows(payload, dst=0, force_collective=bool(os.environ.get("CKR_FORCE_COLLECTIVE")))
         torch.cuda.synchronize(dev)
         t_gather = ckdist.max_over_ranks(time.perf_counter() - g0, dev)
+        bytes_by_rank = ckdist.all_ranks(payload.shape[0] * payload.shape[1], dev)
         tot = {k: ckdist.sum_over_ranks(st[k], dev) for k in ("expansions", "terminal_visits", "plies", "games", "pool_overflows", "nn_evals", "dup_leaves",
-                                                                  "cache_entries", "cache_dropped")}
+                                                                  "cache_entries", "cache_dropped", "parked")}
         if rank == 0:
             n_rows = int(gathered.shape[0])
-            whole = {"games": int(tot["games"]), "games_per_slot": games_per_slot, "seconds": t_play + t_gather,
-                     "play_seconds": t_play, "steps": leg.steps,
+            issued = torch.distributed.is_initialized() and (world > 1 or bool(os.environ.get("CKR_FORCE_COLLECTIVE")))
+            whole = {"games": int(tot["games"]), "games_per_slot": a.games_per_slot, "workers_per_gpu": n_workers, "games_per_worker": games_per_worker,
+                     "seconds": t_play + t_gather, "play_seconds": t_play, "seconds_by_rank": play_by_rank, "steps": leg.steps,
                      "expansions": tot["expansions"], "expansions_per_s": tot["expansions"] / (t_play + t_gather),
                      "plies": tot["plies"], "mean_plies_per_game": tot["plies"] / max(1.0, tot["games"]),
                      "terminal_visit_fraction": tot["terminal_visits"] / max(1.0, tot["expansions"] + tot["terminal_visits"]),
                      "pool_overflows": int(tot["pool_overflows"]),
                      "leaf_cache": {"nn_evals": tot["nn_evals"], "dup_leaves": tot["dup_leaves"],
                                     "duplicate_rate": tot["dup_leaves"] / max(1.0, tot["expansions"]),
-                                    "records_written": tot["cache_entries"], "records_dropped": tot["cache_dropped"]},
+                                    "records_written": tot["cache_entries"], "records_dropped": tot["cache_dropped"], "parked_slot_steps": tot["parked"]},
                      "gather": {"collective": "all_gather(sizes) + gather(padded rows) to rank 0 (%s)"
-                                              % (("RCCL" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend() + ", rows staged through host memory") if world > 1 else "single rank: no collective issued"),
-                                "tuples": n_rows, "bytes": n_rows * 288, "seconds": t_gather},
+                                              % (("RCCL" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend() + ", rows staged through host memory") if issued else "single rank: no collective issued"),
+                                "tuples": n_rows, "bytes": n_rows * 288, "bytes_by_rank": bytes_by_rank, "seconds": t_gather},
                      "active_slots_trace": [[st_, act_, round(t_ - t_run0, 3)] for st_, act_, t_ in trace[:: max(1, len(trace) // 40)]],
                      "active_slots_trace_columns": "step, slots still playing, seconds since the start of the run",
-                     "semantics": "fixed number of games per worker slot, played back to back (training_pipeline.py:349); "
-                                  "includes pre-roll, timed window and the tail in which slots run dry"}
+                     "semantics": ("%d workers of %d game(s) each per GPU hosted on %d slots: a slot whose worker is done takes the next unplayed "
+                                   "worker (training_pipeline.py:323-349: NUM_CPUS workers x NUM_SELFPLAY_GAMES; noise / temperature streams and tau "
+                                   "keyed by worker id); " % (n_workers, games_per_worker, a.slots) if virtual else
+                                   "fixed number of games per worker slot, played back to back (training_pipeline.py:349); ")
+                                  + "includes pre-roll, timed window and the tail in which slots run dry"}
+
+    # the main leg's engines, node pools and leaf cache are released before anything else is measured
+    conv_flops = leg.evaluators[0].CONV_FLOPS_PER_BOARD if which == "fused" else FLOPS_PER_EVAL
+    nb = leg.boards_per_launch
+    cache_log2 = leg.cache_log2
+    leg.close()
+    ckdist.barrier()
 
     out = None
     if rank == 0:
         peak = MFMA_PEAK_TFLOPS[mode]
-        nb = leg.boards_per_launch
-        nn_tflops = FLOPS_PER_EVAL * nb / t_nn / 1e12 if t_nn else None
+        nn_tflops = FLOPS_PER_EVAL * (rows_alone or nb) / t_nn / 1e12 if t_nn else None
         tree = {"kernel": "k_step", "ms_per_launch": t_tree * 1e3, "slots_per_launch": nb, "bound": "latency",
                 "algorithmic_bytes_per_sim": 536, "achieved_GBps": 536.0 * nb / t_tree / 1e9 if t_tree else None}
+        launches = a.steps * n_parts
+        rows_win = nn_by_rank[0] / launches
         if which == "fused":
-            roofline = conv_roofline(mode, leg.evaluators[0].CONV_FLOPS_PER_BOARD, nb, t_conv)
+            # the dominant kernel over the timed window of THIS rank: algorithmic flops of every row it evaluated / window seconds
+            tf = conv_flops * nn_by_rank[0] / dt_by_rank[0] / 1e12
+            traffic, source = pmc_traffic(mode, max(1, int(round(rows_win))))
+            roofline = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS["fp16"], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS["fp16"],
+                        "traffic": traffic, "traffic_source": source,
+                        "basis": "timed window, rank 0: nn_evals x flops_per_unit / window seconds -- every conv-stack launch of the window, "
+                                 "with whatever the step does not hide behind it counted as the kernel's time (a lower bound of the kernel's rate)",
+                        "flops_per_unit": conv_flops, "units_per_launch": rows_win, "rows_per_launch_in_window": rows_win,
+                        "launches_in_window": launches, "ms_per_launch": dt_by_rank[0] / launches * 1e3,
+                        "ms_per_launch_note": "window seconds / launches: the launches of the two half-batch streams overlap, each one's wall share",
+                        "nn_evals_per_s": nn_by_rank[0] / dt_by_rank[0], "cache_served_per_s": (exp_by_rank[0] - nn_by_rank[0]) / dt_by_rank[0]}
+            alone_tf = conv_flops * rows_alone / t_conv / 1e12 if t_conv else None
+            roofline["kernel_alone"] = {"rows_per_launch": rows_alone, "ms_per_launch": t_conv * 1e3, "achieved": alone_tf,
+                                        "frac": alone_tf / MFMA_PEAK_TFLOPS["fp16"] if alone_tf else None, "launches": a.profile_steps,
+                                        "how": "HIP events on the launch stream around each conv-stack launch of %d eager steps of the first engine right "
+                                               "after the window (nothing else on the chip): the figure rocprofv3 --kernel-trace reports for an "
+                                               "un-overlapped launch of that many rows" % a.profile_steps}
+            if mode == "fp32":
+                roofline["kernel"] = ("k_conv_stack_x3 (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, activations LDS-resident; "
+                                      "split-fp16 operands: float32-grade results, 3 fp16 MFMAs per multiply-add; one launch per step and "
+                                      "half-batch over the rows that hold leaves)")
+                roofline["bound_note"] = ("the matrix pipe at the clock the chip grants: on self-play operands sclk drops to ~1.85 GHz (2.38 GHz "
+                                          "on all-zero planes, same binary: 0.80-0.83 executed) -- profiles/r02_power_probe.jsonl")
+                roofline.update({"executed_tflops": 3.0 * tf, "executed_frac": 3.0 * tf / MFMA_PEAK_TFLOPS["fp16"],
+                                 "vs_fp32_matrix_peak": tf / MFMA_PEAK_TFLOPS["fp32"]})
+            else:
+                roofline["kernel"] = ("k_conv_stack (8 fused conv3x3+bias+ReLU+BN layers + both 1x1 head convs, 8 boards per workgroup "
+                                      "LDS-resident through all layers; one launch per step)")
         else:
             roofline = {"bound": "mfma", "kernel": "network forward via PyTorch/MIOpen (conv3x3 x8 + heads), launch group per step",
                         "achieved": nn_tflops, "peak": peak, "unit": "TFLOP/s",
                         "frac": (nn_tflops / peak) if nn_tflops else None, "traffic": None,
                         "ms_per_launch": t_nn * 1e3, "flops_per_unit": FLOPS_PER_EVAL, "units_per_launch": nb}
-        roofline.update({"network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL},
+        roofline.update({"network_forward": {"ms": t_nn * 1e3, "achieved": nn_tflops, "flops_per_unit": FLOPS_PER_EVAL, "rows": rows_alone or nb},
                          "tree_kernel": tree})
         value = exp_total / dt
         if whole is not None:
             whole["efficiency_vs_steady_state"] = whole["expansions_per_s"] / value
         extra = {"movegen_k1": movegen_probe(dev)}
         if world == 1 and a.extra_steps > 0:
+            if cache_log2:
+                off = throughput_leg(a, dev, mode, cache_log2=0)
+                off["note"] = ("the same workload, mode and window with the leaf cache off (every expansion is a network row): what `value` "
+                               "would be without memoising Checkers.predict")
+                extra["cache_off"] = off
             other = "bf16" if mode != "bf16" else "fp32"
             extra["bf16_throughput_mode" if other == "bf16" else "fp32_grade_mode"] = throughput_leg(a, dev, other)
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
@@ -713,26 +810,31 @@ def main():
                           "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": mode, "preroll_steps": pre,
                           "hip_graph": not a.no_graph, "evaluator": which,
                           "dense_rows": not a.no_dense_rows,
-                          "leaf_cache": ("2^%d records per engine: positions the network has already evaluated (Checkers.predict is a "
-                                         "pure function of planes 0-13; two trees per game) are expanded from cached priors / v; results "
-                                         "identical with and without" % a.leaf_cache_log2) if a.leaf_cache_log2 else "off",
-                          "streams": "2 half-batches of %d slots on 2 HIP streams" % nb if leg.split else "1",
+                          "leaf_cache": ("one table of 2^%d records per GPU, shared by the half-batch engines: positions the network has already "
+                                         "evaluated (Checkers.predict is a pure function of planes 0-13; two trees per game) are expanded from "
+                                         "cached priors / v; results identical with and without; value without it: extra.cache_off" % cache_log2)
+                                        if cache_log2 else "off",
+                          "leaf_cache_log2": cache_log2, "ranks_per_device": ckdist.ranks_per_device(),
+                          "streams": "2 half-batches of %d slots on 2 HIP streams" % nb if n_parts > 1 else "1",
                           "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
-               "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py); rules, search, tuples "
+               "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py; Keras's own arithmetic unpinned: TensorFlow "
+                         "is absent); rules, search, tuples "
                          "bit-exact vs the reference golden vectors (NumPy >= 2 promotion rules; the vectors regenerate bit-identically under NumPy 1.26 legacy rules)" if mode == "fp32" else
                          "throughput mode (not a parity claim)",
+               "ms_per_step_by_rank": [t / a.steps * 1e3 for t in dt_by_rank], "expansions_by_rank": exp_by_rank, "nn_evals_by_rank": nn_by_rank,
                "nn_evals": nn_total, "dup_leaves": dup_total, "duplicate_rate": dup_total / max(1.0, exp_total),
-               "nn_evals_per_s": nn_total / dt,
+               "nn_evals_per_s": nn_total / dt, "cache_served_per_s": dup_total / dt, "parked_slot_steps": parked_total,
                "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total, "games_finished_in_window": games_window,
                "active_slots_after_window": active_after_window,
                "sims_per_s": (exp_total + term_total) / dt,
                "games_per_hour": whole["games"] / whole["seconds"] * 3600.0 if whole else None,
                "games_per_hour_steady_state_est": (plies_total / dt) * 3600.0 / whole["mean_plies_per_game"] if whole and plies_total else None,
                "whole_run": whole, "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
-    leg.close()
     ckdist.barrier()
     if rank == 0:
         print(json.dumps(out))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

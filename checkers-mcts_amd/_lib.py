@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
-VERSION = 110                      # CKR_VERSION of include/ckr.h this binding was written against
+VERSION = 120                      # CKR_VERSION of include/ckr.h this binding was written against
 Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
@@ -25,7 +25,8 @@ class Config(C.Structure):
                 ("feature_dtype", C.c_int32), ("max_sims_per_step", C.c_int32),
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
                 ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
-                ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32), ("dense_rows", C.c_int32), ("reserved", C.c_int32)]
+                ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32), ("dense_rows", C.c_int32), ("n_workers", C.c_int32),
+                ("leaf_cache_park", C.c_int32), ("reserved", C.c_int32)]
 
 
 class NodeInfo(C.Structure):
@@ -49,11 +50,11 @@ class GameResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("expansions", "terminal_visits", "plies", "games", "reroot_misses",
                                           "nodes_created", "compactions", "pool_overflows", "steps",
-                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped")]
+                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped", "parked")]
 
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",
-           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_engine_create", "ckr_engine_compact_rows", "ckr_engine_set_row_range",
+           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_leaf_cache_create", "ckr_leaf_cache_destroy", "ckr_leaf_cache_flush", "ckr_engine_attach_cache", "ckr_engine_create", "ckr_engine_compact_rows", "ckr_engine_set_row_range",
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_end_ply", "ckr_engine_stats", "ckr_engine_mark", "ckr_engine_stats_at_mark", "ckr_engine_cache_flush", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
            "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_rollout_end_ply", "ckr_engine_set_ln_table",
@@ -94,6 +95,10 @@ def load():
     if hasattr(L, "ckr_engine_create"):
         L.ckr_engine_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
         L.ckr_engine_destroy.argtypes = [vp]
+        L.ckr_leaf_cache_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.ckr_leaf_cache_destroy.argtypes = [vp]
+        L.ckr_leaf_cache_flush.argtypes = [vp, vp]
+        L.ckr_engine_attach_cache.argtypes = [vp, vp, C.c_int32]
         L.ckr_engine_step.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ckr_engine_step_end_ply.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ckr_engine_compact_rows.argtypes = [vp, vp, vp, vp, vp, vp]

@@ -24,29 +24,41 @@ namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS,
-       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_N };
+       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_N };
 constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
 
 // ---- leaf cache: network outputs by position.  Checkers.predict is a pure function of planes 0-13 (Checkers.py:425-438),
 // i.e. of (p1, p2, kings, side to move, draw numerator k) and of the network that evaluates it; the reference nevertheless
 // evaluates a position once per tree node: both trees of a game (training_pipeline.py:353-386) expand the continuation of the
 // same game line, and transpositions repeat inside a tree.  The cache keeps what an expansion takes from the network -- the
-// masked, renormalised priors of the children in tree order and v -- in an open-addressing table in HBM shared by all slots
-// of the engine; a leaf found there is expanded on the spot as a network-free simulation.  Results do not depend on it: a
-// cached record holds exactly the floats the expansion would compute again from the same inputs.
+// masked, renormalised priors of the children in tree order and v -- in an open-addressing table in HBM; a leaf found there is
+// expanded on the spot as a network-free simulation.  Results do not depend on it: a cached record holds exactly the floats
+// the expansion would compute again from the same inputs.
 //
-// Concurrency without a single fence (the per-XCD L2s are not coherent with each other; what makes the plain stores of one
-// XCD visible to the plain loads of another is a kernel boundary).  E = number of the running k_step launch, the same in
-// every wave; generation = E >> gen_shift.
-//   claim[i]  : 0 = never used, else key hash (upper 40 bits, top bit set) | launch number of the writer (24 bits).  Changed
-//               only by a device-scope compare-and-swap (atomics act on memory, beyond the L2s).
-//   record[i] : written with plain stores by the wave whose compare-and-swap installed claim[i].
-//   FRESH     : a claim whose generation is the current or the previous one.  Readers accept only fresh claims written by an
-//               EARLIER launch (claim.launch != E): that record is complete and visible.  Writers take only slots that are
-//               unused or NOT fresh -- so a record a reader may accept in this launch is never overwritten in this launch,
-//               and a record being written in this launch (claim.launch == E) is never read.  All waves of a launch agree on
-//               what is fresh, because they share E.  A record therefore serves for one to two generations; one still in
-//               demand after that is evaluated and cached again.
+// One table per GPU (round 4): up to CACHE_MAX_ENGINES engines -- the half-batches of pipeline.SplitRunner, each stepping on
+// its own stream -- attach to one ckr_leaf_cache.  Concurrency without a fence inside the tree kernel (the per-XCD L2s are
+// not coherent with each other; what makes the plain stores of one kernel visible to the plain loads of another is a kernel
+// boundary):
+//   E         : number of a k_step launch, drawn from the cache's device clock by the launch's prologue (k_step_prologue, or
+//               the first thread of a single-workgroup engine): unique over all attached engines, increasing in time, 23 bits.
+//               The prologue of engine x also publishes published[x] = E -- every launch of x with a smaller number is
+//               complete -- and snapshots the other engines' published numbers (view[]).
+//   claim[i]  : 0 = never used, else tag (upper 38 bits of the key hash, top bit set) | PENDING | engine (2 bits) | launch E
+//               of the writer.  Changed only by device-scope compare-and-swap (atomics act on memory, beyond the L2s).
+//   record[i] : written with plain stores by the wave whose compare-and-swap installed the COMPLETE claim.
+//   generation: E >> gen_shift; d = signed distance between the reader's generation and the claim's.
+//   READABLE  : a complete claim with |d| <= 1 written by an EARLIER launch of the same engine (claim.E != E) or by a launch
+//               of another engine that had ended before this launch began (claim.E < view[engine]): that record is complete
+//               and visible, and the full key is compared.
+//   WRITABLE  : claim == 0 or |d| >= 3.  |d| == 2 is neither served nor overwritten: engines that share a table disagree on
+//               the current generation by at most one (the host keeps them within a few launches of each other), so a record
+//               one engine may still serve is never overwritten by another.
+//   PENDING   : a leaf that misses reserves its place at hand-out time (tag | PENDING | engine | E) and the expansion that
+//               consumes the network's answer, one launch later, turns the claim into a complete one and writes the record.
+//               A second requester of the same position -- the same step, the other half-batch's concurrent step, or the
+//               step in which the record is being written -- finds the pending / too-young claim and PARKS: its slot keeps
+//               the leaf, takes no row of the network batch, and probes again at its next step (at most CACHE_PARK_MAX
+//               times, then it goes to the network itself).  Every slot's sequence of simulations is unchanged.
 struct CacheRecord {
     uint32_t key[4];             // p1, p2, kings, side | k << 1 | network id << 8
     float    v;
@@ -56,7 +68,17 @@ struct CacheRecord {
 };
 static_assert(sizeof(CacheRecord) == 256, "two 128-byte lines per record");
 constexpr int CACHE_PROBES = 4;
-constexpr unsigned long long CACHE_LAUNCH_MASK = 0xFFFFFFull;
+constexpr int CACHE_MAX_ENGINES = 4;
+constexpr int CACHE_PARK_MAX = 4;
+constexpr unsigned long long CACHE_LAUNCH_MASK = 0x7FFFFFull;          // 23 bits
+constexpr int CACHE_ENGINE_SHIFT = 23;
+constexpr unsigned long long CACHE_PENDING = 1ull << 25;
+constexpr unsigned long long CACHE_TAG_MASK = ~((1ull << 26) - 1ull);
+struct CacheShared {             // device-resident control block of one table
+    unsigned long long clock;                          // launch numbers handed out so far
+    unsigned long long published[CACHE_MAX_ENGINES];   // per engine: number of its running (or last) launch
+};
+struct EpochState { uint32_t E; uint32_t view[CACHE_MAX_ENGINES]; };   // per engine, written by its prologue
 
 struct Dev {
     // configuration
@@ -75,7 +97,7 @@ struct Dev {
     int32_t* g_plen;             // its length (> 64: not recorded, the backup walks the parent links)
     int32_t* g_row;              // row of the slot in the network batch (x, p, v, net id); identity until
                                  // ckr_engine_compact_rows moves the active slots to the front
-    int32_t* g_gid;              // storage index of the slot's current game (results / tuple region)
+    int32_t* g_gid;              // storage index of the slot's current game (results / tuple region): worker * games_per_slot + game
     int32_t* next_game;          // dynamic queue: next unclaimed game index
     int32_t* n_finished;         // slots whose games are all played (the tail of a run: see tail_sims)
     // per tree (slot*2 + tree)
@@ -87,7 +109,13 @@ struct Dev {
     const double* uct_tab;       // rollout mode: pow(2 ln(N) / n, 0.5) for n <= N < uct_n, row N at N(N+1)/2
     // leaf cache (see CacheRecord); cache == nullptr: off
     unsigned long long* cache_claim; CacheRecord* cache; unsigned long long cache_mask; int cache_gen_shift;
-    uint32_t* g_epoch;           // [slot] number of k_step launches so far (every launch covers every slot: all equal)
+    CacheShared* cshared; EpochState* estate; int cache_engine; int cache_park;
+    int32_t* g_cslot;            // [slot] table index reserved for the pending leaf's record (-1: none)
+    unsigned long long* g_cword; // [slot] the PENDING claim word installed there
+    int32_t* g_parked;           // [slot] > 0: the pending leaf waits for another requester's evaluation (number of probes so far)
+    // virtual workers: slot -> the worker (local id in [0, n_workers)) it hosts; a slot whose worker has played its games
+    // takes the next unplayed worker.  RNG streams, tau and the tuple / result regions are keyed by worker, not by slot.
+    int n_workers; int32_t* g_worker; int32_t* next_worker;
     // dense rows (ckr_config.dense_rows): a slot that hands out a leaf takes the next free row of the network batch
     int dense_rows; int32_t* row_count;          // DEVICE counter = d_range[1] of ckr_engine_set_row_range, zeroed before every step
 };
@@ -106,6 +134,9 @@ template <typename WT> struct WaveT {
     using wtype = WT;
     const Dev& D; WaveLds& L; int slot, lane;
     uint32_t epoch = 0u;         // launch number (leaf cache)
+    uint32_t view[CACHE_MAX_ENGINES] = {0u, 0u, 0u, 0u};   // the other engines' published launch numbers at this launch's start
+    int wk = 0;                  // the worker this slot hosts (local id; global id = D.first_worker + wk)
+    __device__ uint32_t worker() const { return (uint32_t)(D.first_worker + wk); }
     __device__ WT* nW() const { return static_cast<WT*>(D.n_W); }
     __device__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
     __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
@@ -392,19 +423,40 @@ __device__ __forceinline__ unsigned long long cache_hash(const uint4 k) {
     a *= 0x165667B19E3779F9ull; a ^= a >> 32;
     return a;
 }
-// claim word of a key written in launch E; its table index comes from the low hash bits, its tag from the upper 40
-__device__ __forceinline__ unsigned long long cache_claim_word(unsigned long long h, uint32_t E) {
-    return ((h | 0x8000000000000000ull) & ~CACHE_LAUNCH_MASK) | ((unsigned long long)E & CACHE_LAUNCH_MASK);
+// tag of a key: its table index comes from the low hash bits, its tag from the upper 38 (top bit set: a claim is never 0)
+__device__ __forceinline__ unsigned long long cache_tag(unsigned long long h) { return (h | 0x8000000000000000ull) & CACHE_TAG_MASK; }
+// signed distance (in generations) between launch E and the launch a claim was written in
+__device__ __forceinline__ int cache_gen_dist(const Dev& D, unsigned long long claim, uint32_t E) {
+    const int gens = (int)(CACHE_LAUNCH_MASK >> D.cache_gen_shift) + 1;                              // the generation counter wraps with the launch number
+    const int raw = (int)(((E & (uint32_t)CACHE_LAUNCH_MASK) >> D.cache_gen_shift) - ((uint32_t)(claim & CACHE_LAUNCH_MASK) >> D.cache_gen_shift)) & (gens - 1);
+    return raw < gens / 2 ? raw : raw - gens;
 }
-__device__ __forceinline__ bool cache_fresh(const Dev& D, unsigned long long claim, uint32_t E) {
-    const uint32_t gens = (uint32_t)(CACHE_LAUNCH_MASK >> D.cache_gen_shift);                       // generation counter wraps with the 24-bit launch number
-    const uint32_t g = (uint32_t)(claim & CACHE_LAUNCH_MASK) >> D.cache_gen_shift, G = (E & (uint32_t)CACHE_LAUNCH_MASK) >> D.cache_gen_shift;
-    return claim != 0ull && ((G - g) & gens) <= 1u;
+__device__ __forceinline__ bool cache_writable(const Dev& D, unsigned long long claim, uint32_t E) {
+    if (claim == 0ull) return true;
+    const int d = cache_gen_dist(D, claim, E);
+    return d >= 3 || d <= -3;
 }
-// All lanes pass the same key.  On a hit: lane l < n gets the prior of child l, every lane v and n.
-template <class Wave> __device__ __forceinline__ bool cache_lookup(const Wave& w, const uint4 key, float& prior, float& v, int& n) {
+// complete, visible and not about to be overwritten (the key is still to be compared)
+template <class Wave> __device__ __forceinline__ bool cache_readable(const Wave& w, unsigned long long claim) {
+    if (claim == 0ull || (claim & CACHE_PENDING)) return false;
+    const int d = cache_gen_dist(w.D, claim, w.epoch);
+    if (d > 1 || d < -1) return false;
+    const uint32_t e = (uint32_t)(claim & CACHE_LAUNCH_MASK), x = (uint32_t)(claim >> CACHE_ENGINE_SHIFT) & 3u;
+    if ((int)x == w.D.cache_engine) return e != w.epoch;                                              // an earlier launch of this engine
+    uint32_t vx = w.view[0];
+    vx = x == 1u ? w.view[1] : vx; vx = x == 2u ? w.view[2] : vx; vx = x == 3u ? w.view[3] : vx;
+    return vx != 0u && ((vx - e - 1u) & (uint32_t)CACHE_LAUNCH_MASK) < (uint32_t)(CACHE_LAUNCH_MASK >> 1);   // e < view[x]: that launch had ended
+}
+enum { CACHE_HIT = 0, CACHE_MISS = 1, CACHE_PARK = 2 };
+// All lanes pass the same key.  CACHE_HIT: lane l < n gets the prior of child l, every lane v and n.  CACHE_MISS: the leaf
+// goes to the network; cslot >= 0: a place for its record is reserved (cword = the pending claim installed there).
+// CACHE_PARK (only if may_park): another requester's evaluation of this position is under way.
+template <class Wave> __device__ __forceinline__ int cache_probe(Wave& w, const uint4 key, bool may_park, float& prior, float& v, int& n,
+                                                                 int& cslot, unsigned long long& cword) {
     const Dev& D = w.D;
-    const unsigned long long h = cache_hash(key), mine = cache_claim_word(h, 0u);
+    const unsigned long long h = cache_hash(key), tag = cache_tag(h);
+    cslot = -1; cword = 0ull;
+    long long cand = -1; unsigned long long cand_val = 0ull;
     for (int i = 0; i < CACHE_PROBES; ++i) {
         const size_t at = (size_t)((h + (unsigned long long)i) & D.cache_mask);
         const unsigned long long claim = D.cache_claim[at];          // same round of loads as the record
@@ -413,42 +465,50 @@ template <class Wave> __device__ __forceinline__ bool cache_lookup(const Wave& w
         const float rv = r->v;
         const uint32_t rn = r->n;
         const float pr = r->prior[w.lane < CKR_MAX_CHILDREN ? w.lane : 0];
-        if (claim == 0ull) return false;
-        if ((claim & ~CACHE_LAUNCH_MASK) != mine) continue;
-        if (!cache_fresh(D, claim, w.epoch) || (claim & CACHE_LAUNCH_MASK) == ((unsigned long long)w.epoch & CACHE_LAUNCH_MASK)) return false;
-        if (k.x != key.x || k.y != key.y || k.z != key.z || k.w != key.w) return false;   // 40-bit tag collision: not this position
-        prior = pr; v = rv; n = (int)rn;
-        return true;
-    }
-    return false;
-}
-// priors of the n children (lane l < n: child l) and v of the position `key`, just computed from the network's output
-template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, const uint4 key, int n, float prior, float v) {
-    const Dev& D = w.D;
-    const unsigned long long h = cache_hash(key), mine = cache_claim_word(h, w.epoch);
-    for (int i = 0; i < CACHE_PROBES; ++i) {
-        const size_t at = (size_t)((h + (unsigned long long)i) & D.cache_mask);
-        unsigned long long cur = D.cache_claim[at];
-        if (!cache_fresh(D, cur, w.epoch)) {                        // unused, or too old for any reader: take it
-            unsigned long long old = 0ull;
-            if (w.lane == 0) old = atomicCAS(&D.cache_claim[at], cur, mine);
-            old = ((unsigned long long)(uint32_t)bcast_i32((int)(uint32_t)(old >> 32), 0) << 32) | (uint32_t)bcast_i32((int)(uint32_t)old, 0);
-            if (old == cur) {                                       // ours: write the record
-                CacheRecord* r = D.cache + at;
-                if (w.lane < n) r->prior[w.lane] = prior;
-                if (w.lane == 0) {
-                    *reinterpret_cast<uint4*>(r->key) = key;
-                    r->v = v; r->n = (uint32_t)n;
-                }
-                w.count(CNT_CINS);
-                return;
+        if (claim == 0ull) { if (cand < 0) { cand = (long long)at; cand_val = 0ull; } break; }   // never used: the key is not further along
+        const bool writable = cache_writable(D, claim, w.epoch);
+        if ((claim & CACHE_TAG_MASK) == tag) {
+            if (cache_readable(w, claim)) {
+                if (k.x != key.x || k.y != key.y || k.z != key.z || k.w != key.w) return CACHE_MISS;   // 38-bit tag collision: evaluated, not cached
+                prior = pr; v = rv; n = (int)rn;
+                return CACHE_HIT;
             }
-            cur = old;                                              // another wave was faster (or the plain load was stale)
-            if (!cache_fresh(D, cur, w.epoch)) continue;            // (only a stale load can bring us here: next slot)
+            if (!writable) {
+                const int d = cache_gen_dist(D, claim, w.epoch);
+                if (d >= -1 && d <= 1) return may_park ? CACHE_PARK : CACHE_MISS;     // pending, or written too recently to be read
+                continue;                                                           // |d| == 2: left alone, cached again elsewhere
+            }
         }
-        if ((cur & ~CACHE_LAUNCH_MASK) == (mine & ~CACHE_LAUNCH_MASK)) return;   // present, or being written by another wave
+        if (writable && cand < 0) { cand = (long long)at; cand_val = claim; }
     }
-    w.count(CNT_CDROP);                                             // neighbourhood full of fresh records: not cached
+    if (cand < 0) { w.count(CNT_CDROP); return CACHE_MISS; }          // neighbourhood full of live records: evaluated, not cached
+    const unsigned long long mine = tag | CACHE_PENDING | ((unsigned long long)D.cache_engine << CACHE_ENGINE_SHIFT) | (unsigned long long)(w.epoch & (uint32_t)CACHE_LAUNCH_MASK);
+    unsigned long long old = 0ull;
+    if (w.lane == 0) old = atomicCAS(&D.cache_claim[cand], cand_val, mine);
+    old = ((unsigned long long)(uint32_t)bcast_i32((int)(uint32_t)(old >> 32), 0) << 32) | (uint32_t)bcast_i32((int)(uint32_t)old, 0);
+    if (old == cand_val) { cslot = (int)cand; cword = mine; return CACHE_MISS; }
+    // another wave was faster (or the plain load was stale): the same position -> its evaluation is under way
+    if ((old & CACHE_TAG_MASK) == tag && !cache_writable(D, old, w.epoch) && may_park) return CACHE_PARK;
+    w.count(CNT_CDROP);
+    return CACHE_MISS;
+}
+// The expansion that consumes the network's answer for a leaf with a reserved place: the pending claim becomes a complete one
+// of this launch (nobody reads it before a later launch) and the record is written.  priors of the n children (lane l < n:
+// child l) and v as just computed from the network's output.
+template <class Wave> __device__ __forceinline__ void cache_complete(Wave& w, int cslot, unsigned long long cword, const uint4 key, int n, float prior, float v) {
+    const Dev& D = w.D;
+    const unsigned long long done = (cword & CACHE_TAG_MASK) | ((unsigned long long)D.cache_engine << CACHE_ENGINE_SHIFT) | (unsigned long long)(w.epoch & (uint32_t)CACHE_LAUNCH_MASK);
+    unsigned long long old = 0ull;
+    if (w.lane == 0) old = atomicCAS(&D.cache_claim[cslot], cword, done);
+    old = ((unsigned long long)(uint32_t)bcast_i32((int)(uint32_t)(old >> 32), 0) << 32) | (uint32_t)bcast_i32((int)(uint32_t)old, 0);
+    if (old != cword) { w.count(CNT_CDROP); return; }               // flushed in between
+    CacheRecord* r = D.cache + cslot;
+    if (w.lane < n) r->prior[w.lane] = prior;
+    if (w.lane == 0) {
+        *reinterpret_cast<uint4*>(r->key) = key;
+        r->v = v; r->n = (uint32_t)n;
+    }
+    w.count(CNT_CINS);
 }
 
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
@@ -459,9 +519,9 @@ template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, cons
 struct ExpandPre { int half, used, plen; uint32_t entry; };
 
 // CACHED: the priors come from the leaf cache (cached_prior: child `lane`), prow is not read.  net: the network that
-// evaluated the leaf (key of the cache record written when !CACHED).
+// evaluated the leaf (key of the cache record written when !CACHED and a place was reserved for it: cslot >= 0).
 template <bool CACHED, class Wave> __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
-                                                           float cached_prior, int cached_n, int net) {
+                                                           float cached_prior, int cached_n, int net, int cslot = -1, unsigned long long cword = 0ull) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const size_t tb = w.tbase(t, pre.half);
@@ -502,7 +562,7 @@ template <bool CACHED, class Wave> __device__ bool expand(Wave& w, int t, int le
         if (!CACHED) prior = w.L.u.p[meta_action(c.meta)] / total;
         write_node(w, tb + used + w.lane, c, leaf, prior, cst | ((b.meta & 1u) << 4));
     }
-    if (!CACHED && D.cache) cache_insert(w, cache_key(b, st, net), n, prior, v);
+    if (!CACHED && cslot >= 0) cache_complete(w, cslot, cword, cache_key(b, st, net), n, prior, v);
     if (w.lane == 0) {
         D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
         D.n_status[tb + leaf] = leaf_status | ST_EXPANDED;
@@ -559,7 +619,7 @@ template <class Wave> __device__ int descend(Wave& w, int t, int& plen_out, uint
         const uint32_t cst = D.n_status[ci], ckids = D.n_kids[ci];
         double dir = 0.0;
         if (D.epsilon != 0.0) {
-            dir = dirichlet_lane(D, act, (uint32_t)(D.first_worker + w.slot), ctr, w.lane);
+            dir = dirichlet_lane(D, act, w.worker(), ctr, w.lane);
             ++ctr;
         }
         const double sqrt_n = np < D.sqrt_n ? D.sqrt_tab[np] : sqrt((double)np);
@@ -654,7 +714,7 @@ template <int GAME, class Wave> __device__ uint32_t playout(Wave& w, ckr_board b
         const uint32_t n = st_nlegal(st);
         uint32_t k = 0u;
         if (!D.rollout_first) {                              // np.random.randint(0, len(legal_next_states))
-            const u32x4 r = philox(D.seed_lo, D.seed_hi, (uint32_t)(D.first_worker + w.slot), ctr, ply, 0x52u);
+            const u32x4 r = philox(D.seed_lo, D.seed_hi, w.worker(), ctr, ply, 0x52u);
             k = (uint32_t)(((unsigned long long)r.x * n) >> 32);
         }
         b = rules_child<GAME>(b, m, (int)k);
@@ -754,7 +814,7 @@ template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t o
             ckr_tuple* T = &D.tuples[tuple_index(w, moves)];
             if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
             if (w.lane == 0) {
-                T->board = gb; T->status = st; T->worker = D.first_worker + w.slot; T->game = game; T->ply = moves;
+                T->board = gb; T->status = st; T->worker = (int32_t)w.worker(); T->game = game; T->ply = moves;
                 T->n_children = 0; T->q = outcome == 3u ? 0.0f : -1.0f; T->q_kind = CKR_Q_INT; T->root_n = 0;
                 T->root_w = 0.0; T->chosen = -1;
             }
@@ -771,16 +831,18 @@ template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t o
     }
     if (w.lane == 0) {
         ckr_game_result* R = &D.results[D.g_gid[w.slot]];
-        R->worker = D.first_worker + w.slot; R->game = game; R->outcome = (int)outcome; R->move_count = moves;
+        R->worker = (int32_t)w.worker(); R->game = game; R->outcome = (int)outcome; R->move_count = moves;
         R->adjudicated = adjudicated; R->p1_net = D.tournament ? p1_net_of(D, w.slot) : 0;
         R->n_tuples = n_tuples; R->failed = failed;
         D.g_game[w.slot] = game + 1;
-        D.g_pending[w.slot] = -1;
+        D.g_pending[w.slot] = -1; D.g_parked[w.slot] = 0; D.g_cslot[w.slot] = -1;
     }
     w.count(CNT_GAMES);
     wave_mem_fence();
-    // next game of this worker: the fixed per-worker count of the reference (training_pipeline.py:349),
-    // or -- dynamic queue -- the next unclaimed game of the whole engine (no idle tail)
+    // next game of this worker: the fixed per-worker count of the reference (training_pipeline.py:349); after its last game the
+    // slot takes the next unplayed WORKER of the engine (virtual workers, n_workers > n_slots: that worker's Philox stream,
+    // tau and game counter start afresh, so results depend on worker ids only, never on which slot hosted a worker), or --
+    // dynamic queue -- the next unclaimed game of the whole engine (streams keyed by slot: not reproducible game by game)
     int gid = -1;
     if (D.dynamic) {
         int claimed = 0;
@@ -788,7 +850,15 @@ template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t o
         claimed = bcast_i32(claimed, 0);
         if (claimed < D.total_games) gid = claimed;
     } else if (game + 1 < D.games_per_slot) {
-        gid = w.slot * D.games_per_slot + game + 1;
+        gid = w.wk * D.games_per_slot + game + 1;
+    } else if (D.n_workers > D.n_slots) {
+        int nw = 0;
+        if (w.lane == 0) nw = atomicAdd(D.next_worker, 1);
+        nw = bcast_i32(nw, 0);
+        if (nw < D.n_workers) {
+            w.wk = nw; gid = nw * D.games_per_slot;
+            if (w.lane == 0) { D.g_worker[w.slot] = nw; D.g_game[w.slot] = 0; D.g_rng[w.slot] = 0u; D.g_tau[w.slot] = D.tau0; }
+        }
     }
     if (gid >= 0) {
         if (w.lane == 0) D.g_gid[w.slot] = gid;
@@ -821,7 +891,7 @@ template <int GAME = 0, class Wave> __device__ void finish_ply(Wave& w) {
         pick = first_lane(__ballot(act && cn == mx));
     } else {
         const uint32_t ctr = D.g_rng[w.slot];
-        pick = temperature_pick(D, w.L.u.ev, cn, act, n, tau, (uint32_t)(D.first_worker + w.slot), ctr, w.lane);
+        pick = temperature_pick(D, w.L.u.ev, cn, act, n, tau, w.worker(), ctr, w.lane);
         if (w.lane == 0) {
             D.g_rng[w.slot] = ctr + 1u;
             const double nt = decayed_tau(D, tau, moves);          // the pick used tau BEFORE the decay (:240-245)
@@ -849,7 +919,7 @@ template <int GAME = 0, class Wave> __device__ void finish_ply(Wave& w) {
             const WT rw = w.nW()[tb + root];
             const WT q = rn ? rw / (WT)rn : (WT)0;
             const bool neg = meta_mover(rb.meta) != (rb.meta & 1u);     // qval = -root.q / root.q, :365-368
-            T->board = rb; T->status = st; T->worker = D.first_worker + w.slot; T->game = D.g_game[w.slot];
+            T->board = rb; T->status = st; T->worker = (int32_t)w.worker(); T->game = D.g_game[w.slot];
             T->ply = moves; T->n_children = n;
             T->q = (float)(neg ? -q : q);
             T->q_kind = sizeof(WT) == 8 ? (neg ? CKR_Q_F64_NEG : CKR_Q_F64) : CKR_Q_F32;
@@ -945,11 +1015,12 @@ template <int GAME, typename WT> __global__ __launch_bounds__(256) void k_init(c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     WaveT<WT> w{D, lds[wave], slot, lane_id()};
+    w.wk = slot;
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     const int gid0 = D.dynamic ? slot : slot * D.games_per_slot;
     if (w.lane == 0) {
         D.g_game[slot] = 0; D.g_pending[slot] = -1; D.g_rng[slot] = 0u; D.g_tau[slot] = D.tau0; D.g_gid[slot] = gid0;
-        D.g_row[slot] = slot;
+        D.g_row[slot] = slot; D.g_worker[slot] = slot; D.g_parked[slot] = 0; D.g_cslot[slot] = -1;
         D.g_phase[slot] = gid0 < D.total_games ? PH_PLAYING : PH_FINISHED;
         if (gid0 >= D.total_games) atomicAdd(D.n_finished, 1);
     }
@@ -959,16 +1030,24 @@ template <int GAME, typename WT> __global__ __launch_bounds__(256) void k_init(c
     flush_counters(w);
 }
 
-__global__ void k_epoch_advance(uint32_t* __restrict__ epoch, int n, uint32_t by) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) epoch[i] += by;
+// The launch number of the k_step launch that follows (one thread): drawn from the table's clock, published for the other
+// engines that share the table, and their published numbers snapshot (see the leaf cache's protocol above).
+__device__ __forceinline__ void epoch_advance(const Dev& D, EpochState* out) {
+    const uint32_t E = (uint32_t)((atomicAdd(&D.cshared->clock, 1ull) + 1ull) & CACHE_LAUNCH_MASK);
+    __hip_atomic_store(&D.cshared->published[D.cache_engine], (unsigned long long)E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out->E = E;
+#pragma unroll
+    for (int x = 0; x < CACHE_MAX_ENGINES; ++x)
+        out->view[x] = (uint32_t)__hip_atomic_load(&D.cshared->published[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// dense rows: before every step the row counter {0, 0} and (arena) every row's network id -1 = no leaf in this row
-__global__ __launch_bounds__(256) void k_step_prologue(int32_t* __restrict__ range, int32_t* __restrict__ net, int n) {
+// Before every step.  Dense rows: the row counter {0, 0} and (arena) every row's network id -1 = no leaf in this row.
+// Leaf cache: the launch number.
+__global__ __launch_bounds__(256) void k_step_prologue(const Dev* __restrict__ Dp, int32_t* __restrict__ range, int32_t* __restrict__ net, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < 2) range[i] = 0;
-    if (net && i < n) net[i] = -1;
+    if (range && i < 2) range[i] = 0;
+    if (range && net && i < n) net[i] = -1;
+    if (i == 0 && Dp->cache) epoch_advance(*Dp, Dp->estate);
 }
 
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
@@ -978,10 +1057,17 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
                                               const float* __restrict__ v, void* x, int32_t* net_out, int flags) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
+    __shared__ EpochState s_epoch;
     int end_ply = flags & 1;
-    if (flags & 2) {                                           // dense rows, one workgroup (<= 4 slots): k_step_prologue's work, here
-        if (threadIdx.x < 2) (D.row_count - 1)[threadIdx.x] = 0;
-        if (net_out && (int)threadIdx.x < D.n_slots) net_out[threadIdx.x] = -1;
+    if (flags & 2) {                                           // one workgroup (<= 4 slots): k_step_prologue's work, here
+        if (D.dense_rows) {
+            if (threadIdx.x < 2) (D.row_count - 1)[threadIdx.x] = 0;
+            if (net_out && (int)threadIdx.x < D.n_slots) net_out[threadIdx.x] = -1;
+        }
+        if (D.cache && threadIdx.x == 0) { epoch_advance(D, &s_epoch); *D.estate = s_epoch; }
+        __syncthreads();
+    } else if (D.cache) {                                      // written by the prologue kernel in front of this launch
+        if (threadIdx.x < 1 + CACHE_MAX_ENGINES) (&s_epoch.E)[threadIdx.x] = (&D.estate->E)[threadIdx.x];
         __syncthreads();
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
@@ -989,30 +1075,59 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
     WaveT<WT> w{D, lds[wave], slot, lane_id()};
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (slot == 0) w.count(CNT_STEPS);
-    if (D.cache) {                                             // launch number, kept per slot: no cross-wave word needed
-        w.epoch = D.g_epoch[slot];
-        if (w.lane == 0) D.g_epoch[slot] = w.epoch + 1u;
+    if (D.cache) {
+        w.epoch = s_epoch.E;
+#pragma unroll
+        for (int i = 0; i < CACHE_MAX_ENGINES; ++i) w.view[i] = s_epoch.view[i];
     }
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
     const int row = D.g_row[slot];
     const int phase0 = D.g_phase[slot];
     const int t0 = (int)(D.g_board[slot].w & 1u);
+    const int parked0 = D.g_parked[slot];
+    const int cslot0 = D.g_cslot[slot];
+    const unsigned long long cword0 = D.g_cword[slot];
+    w.wk = D.g_worker[slot];
     ExpandPre pre;                                             // same round of loads (unused if nothing is pending)
     pre.half = D.t_half[slot * 2 + t0]; pre.used = D.t_used[slot * 2 + t0]; pre.plen = D.g_plen[slot];
     pre.entry = D.g_path[(size_t)slot * 64 + w.lane];
     asm volatile("" :: "v"(pre.half), "v"(pre.used), "v"(pre.plen), "v"(pre.entry));   // keep the loads up here
-    if (pending >= 0 && phase0 == PH_PLAYING) {
+    int leaf = -1, net = -1, free_sims = 0;
+    bool parked = false;                                       // the slot ends this step waiting for another requester's evaluation
+    int cslot = -1; unsigned long long cword = 0ull;           // place reserved in the leaf cache for the leaf handed out in this step
+    ckr_board lb{0u, 0u, 0u, 0u};
+    if (pending >= 0 && phase0 == PH_PLAYING && parked0 > 0) {
+        // the leaf waited for an evaluation of its position that another requester had under way: look again
+        const int t = t0;
+        net = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
+        lb = ld_board(&D.n_board[w.tbase(t, pre.half) + pending]);
+        uint32_t lm[8], lst;
+        movegen(lb, lm, lst);
+        float cprior = 0.0f, cv = 0.0f; int cn = 0;
+        const int res = cache_probe(w, cache_key(lb, lst, net), parked0 < CACHE_PARK_MAX && !end_ply, cprior, cv, cn, cslot, cword);
+        bool done = false;
+        if (res == CACHE_HIT && expand<true>(w, t, pending, nullptr, cv, pre, cprior, cn, net)) {
+            w.count(CNT_HIT);
+            if (w.lane == 0) { D.g_sims[slot] += 1; D.g_pending[slot] = -1; D.g_parked[slot] = 0; }
+            wave_mem_fence();
+            done = true;
+        }
+        if (!done) {
+            if (res == CACHE_PARK) { parked = true; w.count(CNT_PARK); if (w.lane == 0) D.g_parked[slot] = parked0 + 1; }
+            else { leaf = pending; w.count(CNT_NN); if (w.lane == 0) D.g_parked[slot] = 0; }      // (a hit whose expansion does not fit goes to the network path, which compacts)
+        }
+    } else if (pending >= 0 && phase0 == PH_PLAYING) {
         const int t = t0;
         const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
-        bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet);
+        bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
         if (!ok) {
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
             // to 48 children): drop the garbage now and retry; the recorded path is stale after the move, so the
             // backup walks the parent links (plen > 64)
             const int moved = compact(w, t, pending);
             ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
-            ok = moved >= 0 && expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet);
+            ok = moved >= 0 && expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet, cslot0, cword0);
         }
         if (ok) {
             if (w.lane == 0) D.g_sims[slot] += 1;
@@ -1024,47 +1139,50 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
         wave_mem_fence();
     }
     // B. advance until a leaf needs the network
-    int leaf = -1, net = -1, free_sims = 0;
-    ckr_board lb{0u, 0u, 0u, 0u};
     // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
     // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
     const int max_sims = D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
-    while (D.g_phase[slot] == PH_PLAYING) {
+    while (leaf < 0 && !parked && D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
         const int sims_done = D.g_sims[slot];
         const bool out_of_time = end_ply != 0 && sims_done >= 2;         // a root with visited children exists
-        end_ply = out_of_time ? 0 : end_ply;                             // one ply per time window
         if (sims_done >= D.budget || out_of_time) {                      // MCTS.computational_budget, :189-201
+            end_ply = out_of_time ? 0 : end_ply;                         // one ply per time window
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
             finish_ply(w); continue;
         }
         if (free_sims >= max_sims) break;
         const int t = (int)(D.g_board[slot].w & 1u);
         int plen = 0; uint32_t pentry = 0u;
-        leaf = descend(w, t, plen, pentry);
-        if (leaf < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
-        lb = ld_board(&D.n_board[w.tb(t) + leaf]);
+        const int found = descend(w, t, plen, pentry);
+        if (found < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
+        lb = ld_board(&D.n_board[w.tb(t) + found]);
         if (D.tournament) {
             const int p1_net = p1_net_of(D, slot);
             net = t == 0 ? p1_net : 1 - p1_net;                          // training_pipeline.py:523-529,536,546
         } else net = 0;
-        if (D.cache) {                                                   // evaluated before (by any slot, either tree)?
+        if (D.cache) {                                                   // evaluated before (by any slot, either tree, any engine of this GPU)?
             uint32_t lm[8], lst;
             movegen(lb, lm, lst);
             float cprior = 0.0f, cv = 0.0f; int cn = 0;
-            if (cache_lookup(w, cache_key(lb, lst, net), cprior, cv, cn)) {
+            const int res = cache_probe(w, cache_key(lb, lst, net), D.cache_park != 0 && (flags & 1) == 0, cprior, cv, cn, cslot, cword);
+            if (res == CACHE_HIT) {
                 const ExpandPre now{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], plen, pentry};
-                if (expand<true>(w, t, leaf, nullptr, cv, now, cprior, cn, net)) {
+                if (expand<true>(w, t, found, nullptr, cv, now, cprior, cn, net)) {
                     w.count(CNT_HIT);
                     if (w.lane == 0) D.g_sims[slot] += 1;
                     wave_mem_fence();
-                    leaf = -1; ++free_sims;
+                    ++free_sims;
                     continue;
                 }                                                        // pool full: let the network path compact and retry
+            } else if (res == CACHE_PARK) {
+                parked = true; w.count(CNT_PARK);
+                if (w.lane == 0) { D.g_pending[slot] = found; D.g_parked[slot] = 1; }
+                break;
             }
         }
+        leaf = found;
         w.count(CNT_NN);
-        break;
     }
     int out_row = row;
     if (D.dense_rows && leaf >= 0) {                          // rows [0, number of leaves) of this step's batch, in arrival order
@@ -1073,8 +1191,9 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
         out_row = bcast_i32(r, 0);
     }
     if (w.lane == 0) {
-        D.g_pending[slot] = leaf;
-        D.leaves[slot] = make_uint4(lb.p1, lb.p2, lb.kings, lb.meta);
+        if (!parked) D.g_pending[slot] = leaf;
+        if (leaf >= 0) { D.g_cslot[slot] = cslot; D.g_cword[slot] = cword; }
+        D.leaves[slot] = leaf >= 0 ? make_uint4(lb.p1, lb.p2, lb.kings, lb.meta) : make_uint4(0u, 0u, 0u, 0u);
         if (net_out && (leaf >= 0 || !D.dense_rows)) net_out[out_row] = leaf >= 0 ? net : -1;   // dense: idle rows preset to -1
     }
     if (leaf >= 0) write_features(w, lb, x, out_row);
@@ -1089,6 +1208,7 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     WaveT<float> w{D, lds[wave], slot, lane_id()};   // W is a python int in this mode: exact in float
+    w.wk = D.g_worker[slot];
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (slot == 0) w.count(CNT_STEPS);
     // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198): the wall-clock budget of the running searches is used up -- a slot
@@ -1145,7 +1265,7 @@ template <class Wave> __device__ int apply_action(Wave& w, int action) {
         st_board(&D.g_board[w.slot], cb);
         D.g_status[w.slot] = cst;
         D.g_moves[w.slot] += 1;
-        D.g_pending[w.slot] = -1;
+        D.g_pending[w.slot] = -1; D.g_parked[w.slot] = 0;
         D.g_phase[w.slot] = PH_IDLE;
     }
     w.count(CNT_PLIES);
@@ -1160,6 +1280,7 @@ template <typename WT> __global__ __launch_bounds__(256) void k_command(const De
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     WaveT<WT> w{D, lds[wave], slot, lane_id()};
+    w.wk = D.g_worker[slot];
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     const int c = cmd[slot];
     int e = 0;
@@ -1167,12 +1288,12 @@ template <typename WT> __global__ __launch_bounds__(256) void k_command(const De
         if (st_outcome(D.g_status[slot]) != 0u) e = 2;      // game over: nothing to search
         else {
             start_search(w);
-            if (w.lane == 0) { D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; }
+            if (w.lane == 0) { D.g_phase[slot] = PH_PLAYING; D.g_pending[slot] = -1; D.g_parked[slot] = 0; }
         }
     } else if (c == CKR_CMD_PLAY) {
         e = apply_action(w, arg[slot]);
     } else if (c == CKR_CMD_RESET) {
-        if (w.lane == 0) { D.g_game[slot] = 0; D.g_pending[slot] = -1; }
+        if (w.lane == 0) { D.g_game[slot] = 0; D.g_pending[slot] = -1; D.g_parked[slot] = 0; }
         wave_mem_fence();
         new_game(w);
         if (w.lane == 0) D.g_phase[slot] = PH_IDLE;
@@ -1283,9 +1404,19 @@ static void note_stream(hipStream_t* last, hipStream_t st) {
     if (cs == hipStreamCaptureStatusNone) *last = st;
 }
 
+// One leaf-cache table (see CacheRecord): owned by the caller (ckr_leaf_cache_create, shared by the engines attached to it) or
+// by one engine (ckr_config.leaf_cache_log2 > 0).
+struct ckr_leaf_cache {
+    int device = 0, log2 = 0, gen_shift = 0;
+    unsigned long long* claim = nullptr; CacheRecord* records = nullptr; CacheShared* shared = nullptr;
+    size_t capacity = 0;
+    unsigned attached = 0;             // bit x: engine index x is in use
+};
+
 struct ckr_engine {
     ckr_config cfg;
     Dev dev;
+    ckr_leaf_cache* cache = nullptr; bool owns_cache = false; int cache_index = -1;
     std::vector<void*> allocs;
     hipStream_t last_stream = nullptr;
     int64_t n_games_total = 0;
@@ -1310,11 +1441,72 @@ template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool
 }
 
 static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
-static_assert(sizeof(ckr_config) == 144, "ckr_config layout is mirrored by _lib.Config (ctypes)");
+static_assert(sizeof(ckr_config) == 152, "ckr_config layout is mirrored by _lib.Config (ctypes)");
 
 extern "C" {
 
 int ckr_engine_set_ln_table(ckr_engine* e, const double* ln, int32_t n);
+
+int ckr_leaf_cache_create(int32_t device, int32_t log2_records, int32_t gen_log2, ckr_leaf_cache** out) {
+    if (!out) return fail(CKR_ERR_INVALID, "ckr_leaf_cache_create: null argument");
+    if (int rc = require_device()) return rc;
+    if (log2_records < 10 || log2_records > 30) return fail(CKR_ERR_INVALID, "leaf cache: log2 of the records must be in [10, 30]");
+    if (gen_log2 < 0 || gen_log2 > 20) return fail(CKR_ERR_INVALID, "leaf cache: log2 of the generation length must be in [0, 20]");
+    CKR_HIP(hipSetDevice(device));
+    ckr_leaf_cache* lc = new ckr_leaf_cache();
+    lc->device = device; lc->log2 = log2_records; lc->capacity = (size_t)1 << log2_records;
+    lc->gen_shift = gen_log2 > 0 ? gen_log2 : (log2_records - 14 > 11 ? log2_records - 14 : 11);
+    // only the claims need zeroing: a record is read after its claim has been found complete
+    hipError_t err = hipMalloc((void**)&lc->claim, (lc->capacity + CACHE_PROBES) * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMalloc((void**)&lc->records, (lc->capacity + CACHE_PROBES) * sizeof(CacheRecord));
+    if (err == hipSuccess) err = hipMalloc((void**)&lc->shared, sizeof(CacheShared));
+    if (err == hipSuccess) err = hipMemset(lc->claim, 0, (lc->capacity + CACHE_PROBES) * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMemset(lc->shared, 0, sizeof(CacheShared));
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        (void)ckr_leaf_cache_destroy(lc);
+        return fail(err == hipErrorOutOfMemory ? CKR_ERR_OOM : CKR_ERR_HIP, "leaf cache of 2^%d records (%.1f GB): %s", (int)log2_records,
+                    (double)(((size_t)1 << log2_records) * 264.0 / 1e9), hipGetErrorString(err));
+    }
+    *out = lc;
+    return CKR_OK;
+}
+
+int ckr_leaf_cache_destroy(ckr_leaf_cache* lc) {
+    if (!lc) return CKR_OK;
+    if (lc->attached) return fail(CKR_ERR_STATE, "ckr_leaf_cache_destroy: engines are still attached (destroy them first)");
+    if (lc->claim) (void)hipFree(lc->claim);
+    if (lc->records) (void)hipFree(lc->records);
+    if (lc->shared) (void)hipFree(lc->shared);
+    delete lc;
+    return CKR_OK;
+}
+
+int ckr_leaf_cache_flush(ckr_leaf_cache* lc, void* stream) {
+    if (!lc) return fail(CKR_ERR_INVALID, "ckr_leaf_cache_flush: null cache");
+    // every claim back to "never used": nothing written so far can be served again, whatever the launch numbers do later
+    CKR_HIP(hipMemsetAsync(lc->claim, 0, (lc->capacity + CACHE_PROBES) * sizeof(unsigned long long), (hipStream_t)stream));
+    return CKR_OK;
+}
+
+int ckr_engine_attach_cache(ckr_engine* e, ckr_leaf_cache* lc, int32_t index) {
+    if (!e || !lc) return fail(CKR_ERR_INVALID, "ckr_engine_attach_cache: null argument");
+    if (index < 0 || index >= CACHE_MAX_ENGINES) return fail(CKR_ERR_INVALID, "ckr_engine_attach_cache: index must be in [0, %d)", CACHE_MAX_ENGINES);
+    if (e->cache) return fail(CKR_ERR_STATE, "ckr_engine_attach_cache: the engine already has a leaf cache");
+    if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_attach_cache: NEURAL_NET engines only");
+    if (e->steps > 0) return fail(CKR_ERR_STATE, "ckr_engine_attach_cache: attach before the first step");
+    if (lc->device != e->cfg.device) return fail(CKR_ERR_INVALID, "ckr_engine_attach_cache: cache and engine live on different devices");
+    if (lc->attached & (1u << index)) return fail(CKR_ERR_STATE, "ckr_engine_attach_cache: index %d is taken", (int)index);
+    Dev& D = e->dev;
+    lc->attached |= 1u << index;
+    e->cache = lc; e->owns_cache = false; e->cache_index = index;
+    D.cache_claim = lc->claim; D.cache = lc->records; D.cache_mask = (unsigned long long)(lc->capacity - 1);
+    D.cache_gen_shift = lc->gen_shift; D.cshared = lc->shared; D.cache_engine = index;
+    D.cache_park = (e->cfg.leaf_cache_park > 0 && !e->cfg.manual_play && e->cfg.budget < (1 << 30)) ? 1 : 0;
+    if (e->cfg.max_sims_per_step <= 0) D.max_sims = 2;           // cache hits are network-free simulations too
+    CKR_HIP(hipMemcpy(e->d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice));
+    return CKR_OK;
+}
 
 int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (!c || !out) return fail(CKR_ERR_INVALID, "ckr_engine_create: null argument");
@@ -1331,6 +1523,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (c->leaf_cache_log2 != 0 && (c->leaf_cache_log2 < 10 || c->leaf_cache_log2 > 30))
         return fail(CKR_ERR_INVALID, "leaf_cache_log2 must be 0 (off) or in [10, 30]");
     if (c->leaf_cache_gen_log2 < 0 || c->leaf_cache_gen_log2 > 20) return fail(CKR_ERR_INVALID, "leaf_cache_gen_log2 must be in [0, 20]");
+    if (c->n_workers != 0 && c->n_workers < c->n_slots) return fail(CKR_ERR_INVALID, "n_workers must be 0 (= n_slots) or >= n_slots");
+    if (c->n_workers > c->n_slots && (c->dynamic_queue || c->manual_play))
+        return fail(CKR_ERR_INVALID, "virtual workers (n_workers > n_slots) exclude dynamic_queue and manual_play");
     if (c->game == 1 && (c->neural_net || c->manual_play || c->tournament))
         return fail(CKR_ERR_INVALID, "Tic-Tac-Toe (game = 1) is offered in the random-rollout self-play mode only (neural_net = 0)");
     CKR_HIP(hipSetDevice(c->device));
@@ -1347,7 +1542,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.tail_shift = 1;                                             // tail = at most n_slots >> 1 slots still play
     if (const char* t = getenv("CKR_TAIL_SIMS")) D.tail_sims = D.tail_sims ? atoi(t) : 0;      // tuning experiments (profiles/r03_tail_sweep.txt)
     if (const char* t = getenv("CKR_TAIL_SHIFT")) D.tail_shift = atoi(t);
-    D.total_games = c->n_slots * c->games_per_slot;
+    D.n_workers = c->n_workers > 0 ? c->n_workers : c->n_slots;
+    D.total_games = D.n_workers * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
     D.w64 = (c->w_accum == 1 && c->neural_net) ? 1 : 0;
     const int cache_log2 = c->neural_net ? c->leaf_cache_log2 : 0;
@@ -1357,7 +1553,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
     D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32);
-    e->n_games_total = (int64_t)c->n_slots * c->games_per_slot;
+    e->n_games_total = (int64_t)D.n_workers * c->games_per_slot;
     const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C;
     int rc = CKR_OK;
 #define A(ptr, count, zero) if (rc == CKR_OK) rc = dalloc(e, &ptr, (count), (zero))
@@ -1368,6 +1564,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
     A(D.g_path, S * 64, true); A(D.g_plen, S, true); A(D.g_row, S, true); A(e->d_row_tmp, S, true);
     A(D.g_gid, S, true); A(D.next_game, (size_t)1, true); A(D.n_finished, (size_t)1, true);
+    A(D.g_worker, S, true); A(D.next_worker, (size_t)1, true); A(D.g_cslot, S, true); A(D.g_cword, S, true); A(D.g_parked, S, true);
+    A(D.estate, (size_t)1, true);
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
     A(D.tuples, NT ? NT : 1, true);
@@ -1375,16 +1573,6 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.results, (size_t)e->n_games_total, true);
     A(D.counters, (size_t)CNT_SHARDS * CNT_STRIDE, true); A(e->d_mark, (size_t)CNT_SHARDS * CNT_STRIDE, true);
     A(D.leaves, S, true);
-    A(D.g_epoch, S, true);
-    if (cache_log2 > 0) {
-        const size_t cap = (size_t)1 << cache_log2;
-        A(D.cache_claim, cap + CACHE_PROBES, true);
-        A(D.cache, cap + CACHE_PROBES, true);
-        D.cache_mask = (unsigned long long)(cap - 1);
-        // default: a generation = 2^(log2(records) - 14) launches, at least 2^11 (a launch of <= 4 096 slots writes <= 2^12 records:
-        // two live generations then fill at most half of the table)
-        D.cache_gen_shift = c->leaf_cache_gen_log2 > 0 ? c->leaf_cache_gen_log2 : (cache_log2 - 14 > 11 ? cache_log2 - 14 : 11);
-    }
     // node.n ** 0.5 is C pow() in the reference (python int ** float), which is
     // NOT always sqrt(): keep a host-computed table for the counts that occur.
     D.sqrt_n = 1 << 16;
@@ -1401,6 +1589,12 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
         }
         D.sqrt_tab = d_sqrt;
     }
+    {
+        const int32_t first_unhosted = c->n_slots;                 // workers [0, n_slots) start on the slots of their number
+        if (hipMemcpy(D.next_worker, &first_unhosted, sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            ckr_engine_destroy(e); return fail(CKR_ERR_HIP, "queue init failed");
+        }
+    }
     if (D.dynamic) {
         const int32_t first_unclaimed = c->n_slots < D.total_games ? c->n_slots : D.total_games;
         if (hipMemcpy(D.next_game, &first_unclaimed, sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1409,6 +1603,16 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     }
     if (!D.neural) {
         if (int rc2 = ckr_engine_set_ln_table(e, nullptr, 0)) { ckr_engine_destroy(e); return rc2; }
+    }
+    D.cache_park = (c->leaf_cache_park > 0 && cache_log2 > 0 && !c->manual_play && c->budget < (1 << 30)) ? 1 : 0;
+    if (cache_log2 > 0) {                                         // a table of its own (ckr_engine_attach_cache: a shared one)
+        ckr_leaf_cache* lc = nullptr;
+        // default: a generation = 2^(log2(records) - 14) launches, at least 2^11 (a launch of <= 4 096 slots writes <= 2^12 records:
+        // the generations a reader serves then fill at most half of the table)
+        if (int rc2 = ckr_leaf_cache_create(c->device, cache_log2, c->leaf_cache_gen_log2, &lc)) { ckr_engine_destroy(e); return rc2; }
+        e->cache = lc; e->owns_cache = true; e->cache_index = 0; lc->attached = 1u;
+        D.cache_claim = lc->claim; D.cache = lc->records; D.cache_mask = (unsigned long long)(lc->capacity - 1);
+        D.cache_gen_shift = lc->gen_shift; D.cshared = lc->shared; D.cache_engine = 0;
     }
     // results: mark all games unfinished
     if (hipMemset(D.results, 0xFF, (size_t)e->n_games_total * sizeof(ckr_game_result)) != hipSuccess) {
@@ -1434,6 +1638,11 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
 
 int ckr_engine_destroy(ckr_engine* e) {
     if (!e) return CKR_OK;
+    if (e->cache) {
+        if (e->owns_cache) { e->cache->attached = 0u; (void)ckr_leaf_cache_destroy(e->cache); }
+        else if (e->cache_index >= 0) e->cache->attached &= ~(1u << e->cache_index);
+        e->cache = nullptr;
+    }
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->d_pack) (void)hipFree(e->d_pack);
     if (e->d_off) (void)hipFree(e->d_off);
@@ -1491,15 +1700,16 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_step drives the NEURAL_NET search; use ckr_engine_rollout");
     if (e->steps > 0 && (!d_p || !d_v)) return fail(CKR_ERR_INVALID, "ckr_engine_step: network outputs required after the first step");
     note_stream(&e->last_stream, (hipStream_t)stream);
-    if (e->dev.dense_rows) {
-        if (!e->dev.row_count) return fail(CKR_ERR_STATE, "dense_rows: call ckr_engine_set_row_range before the first step");
-        // (a single-workgroup engine -- one interactive search -- resets them inside k_step: one launch less per simulation)
-        // One small kernel, not two hipMemsetAsync: captured into a HIP graph (ROCm 7.2) the 0xFF memset node left rows that look
-        // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
-        // past the rows in use); it is also one graph node instead of two.
-        if (e->cfg.n_slots > 4) hipLaunchKernelGGL(k_step_prologue, dim3((e->cfg.n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->d_range, d_net, (int)e->cfg.n_slots);
-    }
-    const int flags = (end_ply ? 1 : 0) | (e->dev.dense_rows && e->cfg.n_slots <= 4 ? 2 : 0);
+    if (e->dev.dense_rows && !e->dev.row_count) return fail(CKR_ERR_STATE, "dense_rows: call ckr_engine_set_row_range before the first step");
+    const bool prologue = e->dev.dense_rows || e->dev.cache;
+    // (a single-workgroup engine -- one interactive search -- does the prologue's work inside k_step: one launch less per simulation)
+    // One small kernel, not hipMemsetAsync calls: captured into a HIP graph (ROCm 7.2) a 0xFF memset node left rows that look
+    // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
+    // past the rows in use); it is also one graph node instead of two.
+    if (prologue && e->cfg.n_slots > 4)
+        hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (e->cfg.n_slots + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,
+                           e->dev.dense_rows ? e->d_range : (int32_t*)nullptr, d_net, (int)e->cfg.n_slots);
+    const int flags = (end_ply ? 1 : 0) | (prologue && e->cfg.n_slots <= 4 ? 2 : 0);
     if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     CKR_HIP(hipGetLastError());
@@ -1556,7 +1766,7 @@ int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS];
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK];
     return CKR_OK;
 }
 
@@ -1574,7 +1784,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS]; out->active_slots = active;
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK];
     return CKR_OK;
 }
 
@@ -1665,13 +1875,9 @@ int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t ca
 
 int ckr_engine_cache_flush(ckr_engine* e, void* stream) {
     if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_cache_flush: null engine");
-    if (!e->dev.cache) return CKR_OK;
+    if (!e->cache) return CKR_OK;
     note_stream(&e->last_stream, (hipStream_t)stream);
-    // two generations ahead: every record written so far is older than anything a reader accepts (cache_fresh)
-    hipLaunchKernelGGL(k_epoch_advance, dim3((e->cfg.n_slots + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->dev.g_epoch, (int)e->cfg.n_slots,
-                       2u << e->dev.cache_gen_shift);
-    CKR_HIP(hipGetLastError());
-    return CKR_OK;
+    return ckr_leaf_cache_flush(e->cache, stream);
 }
 
 int ckr_engine_command(ckr_engine* e, const int32_t* cmd, const int32_t* arg, int32_t* err) {

@@ -29,7 +29,9 @@ def init_from_env(backend=None):
     else $CKR_DIST_BACKEND, else RCCL ("nccl") when a GPU is present, gloo otherwise.  With gloo the
     gather payloads are staged through host memory (gather_rows)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # (CKR_FORCE_COLLECTIVE: a world of ONE rank still builds the process group, so that a 1-GPU box runs the job's collective
+    # through RCCL -- bench.py under `torchrun --nproc-per-node 1`)
+    if (world > 1 or (os.environ.get("CKR_FORCE_COLLECTIVE") and "RANK" in os.environ)) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("CKR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -88,6 +90,23 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(value, device):
+    """[value of rank 0, value of rank 1, ...] on every rank (one all_gather of a float64)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
+    out = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(x) for x in out.cpu().tolist()]
+
+
+def ranks_per_device():
+    """How many ranks of this job share one GPU (1 on a real multi-GPU node; > 1 when a gloo test job runs N ranks on a
+    1-GPU box): memory budgets (leaf caches) are divided by it."""
+    _, _, world = env_world()
+    return max(1, -(-world // max(1, torch.cuda.device_count())))
 
 
 def sum_over_ranks(value, device):

@@ -26,7 +26,8 @@ MCTS_KEYS = ("UCT_C", "CONSTRAINT", "BUDGET", "MULTIPROC", "NEURAL_NET", "VERBOS
 def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, tournament=False,
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=0, device=0,
-                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0, dense_rows=False):
+                       manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0, dense_rows=False,
+                       n_workers=None, leaf_cache_park=False):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -48,6 +49,11 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
 
     dense_rows: the network batch holds the step's leaves in rows [0, n) (arrival order) and Engine.row_range tells the
     evaluator n, so a step costs what its leaves cost (include/ckr.h, ckr_config.dense_rows).  Results do not depend on it.
+
+    n_workers: virtual workers (include/ckr.h, ckr_config.n_workers): the engine plays n_workers reference workers
+    (games_per_slot games each, global ids first_worker_id + [0, n_workers)) on n_slots concurrent slots; a slot whose worker is
+    done takes the next unplayed worker.  The output equals that of n_slots = n_workers bit for bit (streams, tau and tuple regions
+    are keyed by worker id).  None = n_slots.
 
     game: "checkers", or "tictactoe" -- the reference's second environment (GAME_ENV = TicTacToe(), play_TTT.py:47-60),
     random-rollout self-play only (NEURAL_NET False): the README's known-answer validation of the search core."""
@@ -90,7 +96,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
                        dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], w_accum=W_ACCUM[w_accum], seed=int(seed),
                        leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2),
-                       dense_rows=int(bool(dense_rows)))
+                       dense_rows=int(bool(dense_rows)), n_workers=int(n_workers or 0), leaf_cache_park=int(bool(leaf_cache_park)))
 
 
 def time_budget_of(mcts_kwargs):
@@ -98,14 +104,52 @@ def time_budget_of(mcts_kwargs):
     return float(mcts_kwargs["BUDGET"]) if mcts_kwargs["CONSTRAINT"] == "time" else None
 
 
+class LeafCache:
+    """One leaf-cache table on a GPU (include/ckr.h, ckr_leaf_cache_*), shared by the engines attached to it -- the half-batch
+    engines of pipeline.SplitRunner: a position evaluated for one half is served to the other.  2^log2 records of 264 bytes;
+    gen_log2: log2 of a generation in launches of all attached engines together (0 = the library's default)."""
+
+    def __init__(self, log2, device=0, gen_log2=0):
+        self._L = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CkrError("no HIP device: the leaf cache lives in device memory")
+        self.log2, self.device = int(log2), int(device.index if isinstance(device, torch.device) else device)
+        h = C.c_void_p()
+        _lib.check(self._L.ckr_leaf_cache_create(self.device, self.log2, int(gen_log2), C.byref(h)))
+        self._h = h
+        self._next_index = 0
+
+    def next_index(self):
+        i = self._next_index
+        self._next_index += 1
+        return i
+
+    def flush(self):
+        """Forget every record (the attached engines must be idle)."""
+        _lib.check(self._L.ckr_leaf_cache_flush(self._h, torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.check(self._L.ckr_leaf_cache_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One engine per GPU / process.  Calls are serialised by the caller."""
 
-    def __init__(self, cfg, feature_dtype=torch.float32):
+    def __init__(self, cfg, feature_dtype=torch.float32, cache=None):
+        """cache: a LeafCache to attach to (cfg.leaf_cache_log2 must be 0 then); the engine keeps it alive."""
         self._L = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.CkrError("no HIP device: the self-play engine has no CPU fallback")
         self.cfg = cfg
+        self.cache = None
         self.device = torch.device("cuda", cfg.device)
         h = C.c_void_p()
         _lib.check(self._L.ckr_engine_create(C.byref(cfg), C.byref(h)))
@@ -121,11 +165,19 @@ class Engine:
         if self.dense_rows:
             _lib.check(self._L.ckr_engine_set_row_range(self._h, self.row_range.data_ptr()))
         self._first = True
+        if cache is not None:
+            self.attach_cache(cache)
+
+    def attach_cache(self, cache, index=None):
+        """Share `cache` (a LeafCache) with the other engines attached to it; before the first step."""
+        _lib.check(self._L.ckr_engine_attach_cache(self._h, cache._h, cache.next_index() if index is None else int(index)))
+        self.cache = cache
 
     def close(self):
         if getattr(self, "_h", None):
             self._L.ckr_engine_destroy(self._h)
             self._h = None
+        self.cache = None
 
     def __del__(self):
         try:

@@ -172,6 +172,7 @@ class FusedEvaluator:
                                                  C.c_float, vp, vp, vp, vp]
         self.overflow = None
         self.row_cap = None                     # set_row_cap()
+        self.timing = None                      # a list: every forward appends (event before, event after) its conv-stack launch (bench.py)
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
         self._L.ckr_heads_tail.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]
@@ -287,7 +288,14 @@ class FusedEvaluator:
 
     def _forward(self, n, x, board_range=None):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        self._conv(n, x, stream, board_range)
+        if self.timing is not None:             # HIP events on the launch stream around the dominant kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._conv(n, x, stream, board_range)
+            e1.record()
+            self.timing.append((e0, e1))
+        else:
+            self._conv(n, x, stream, board_range)
         t = n["tail"]
         # Dense(512) + softmax and the value MLP: one launch
         _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), self._rows(n), t["fc_packed"].data_ptr(),

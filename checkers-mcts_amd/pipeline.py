@@ -19,6 +19,7 @@ Differences a user can observe (all documented in DESIGN.md):
     replaced by the alternative its own message suggests (a fresh root) and is
     counted in the run statistics.
 """
+import inspect
 import os
 import pickle
 import time
@@ -259,19 +260,28 @@ class SplitRunner:
     kernel and head kernels (latency-bound, a few % of the chip) run beside it instead of in front of it: the step's
     serial chain tree -> network -> tree is hidden behind the other half's network time.
 
-    make_engine(first_worker_offset, n_slots) -> Engine; make_evaluator(n_slots) -> evaluator."""
+    make_engine(first_worker_offset, n_workers, n_slots) -> Engine that plays workers [offset, offset + n_workers) of the job on
+    n_slots concurrent slots (virtual workers when n_workers > n_slots); make_evaluator(n_slots) -> evaluator.  The engines
+    normally share one engine.LeafCache (created by the caller and attached inside make_engine): a position evaluated for one
+    half is served to the other."""
 
-    def __init__(self, make_engine, make_evaluator, n_slots, use_graph=True, device=None, n_parts=None):
+    def __init__(self, make_engine, make_evaluator, n_workers, use_graph=True, device=None, n_parts=None, n_slots=None):
         n_parts = int(n_parts or os.environ.get("CKR_SPLIT_PARTS", 2))      # 2 measured best (3: -1.4 %, 4: -16 %; profiles/r03_split_parts.txt)
-        bounds = [n_slots * i // n_parts for i in range(n_parts + 1)]
+        n_slots = min(int(n_slots or n_workers), int(n_workers))
+        wb = [n_workers * i // n_parts for i in range(n_parts + 1)]
+        sb = [n_slots * i // n_parts for i in range(n_parts + 1)]
         self.parts = []
-        for first, cnt in ((bounds[i], bounds[i + 1] - bounds[i]) for i in range(n_parts)):
-            if cnt <= 0:
+        for i in range(n_parts):
+            first, workers, slots = wb[i], wb[i + 1] - wb[i], min(sb[i + 1] - sb[i], wb[i + 1] - wb[i])
+            if workers <= 0 or slots <= 0:
                 continue
-            eng = make_engine(first, cnt)
+            if workers == slots and len(inspect.signature(make_engine).parameters) == 2:
+                eng = make_engine(first, slots)                  # (offset, n_slots): one worker per slot
+            else:
+                eng = make_engine(first, workers, slots)
             stream = torch.cuda.Stream(device=eng.device)
             with torch.cuda.stream(stream):
-                runner = StepRunner(eng, make_evaluator(cnt), use_graph=use_graph)
+                runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
             self.parts.append((eng, runner, stream))
         self.device = self.parts[0][0].device
 
@@ -346,20 +356,34 @@ class SplitRunner:
             e.close()
 
 
-def default_leaf_cache_log2(n_slots, device=None):
-    """Size of an engine's leaf cache for n_slots concurrent games: 2^(log2(slots) + 16) records, at most 2^27 (264 B each:
-    35 GB for >= 2 048 slots) and never more than 1/8 of the device's memory.  A record serves for one to two generations of
-    2^(log2(records) - 14) steps -- 8 192 - 16 384 steps at 2^27, one to two games' length -- and about half of a step's slots
-    write one.  Measured on cfg3 (profiles/r03_leaf_cache_size_sweep.txt): 2^25 / 2^26 / 2^27 records serve 48.7 / 49.2 /
-    51.0 % of the leaves (51.0 % = every position seen since the start of the run), 6.74 / 6.96 / 7.09 M expansions/s."""
-    log2 = min(27, max(16, int(np.ceil(np.log2(max(1, int(n_slots))))) + 16))
+def default_leaf_cache_log2(n_slots, device=None, sharers=None):
+    """Size of a GPU's leaf cache for n_slots concurrent games: 2^(log2(slots) + 16) records (264 B each), at most 2^28 (70 GB for
+    >= 4 096 slots), never more than 1/4 of the device's memory and half of what is free right now, divided by `sharers` = the
+    number of such caches on the device (ranks of a job that share a GPU: dist.ranks_per_device(), the default).  A record
+    serves for one to two generations of 2^(log2(records) - 14) launches.  Measured on cfg3 with one cache per half-batch engine
+    (profiles/r03_leaf_cache_size_sweep.txt): 2^25 / 2^26 / 2^27 records per 2 048 slots serve 48.7 / 49.2 / 51.0 % of the
+    leaves (51.0 % = every position seen since the start of the run), 6.74 / 6.96 / 7.09 M expansions/s."""
+    log2 = min(28, max(16, int(np.ceil(np.log2(max(1, int(n_slots))))) + 16))
+    if sharers is None:
+        sharers = ckdist.ranks_per_device()
     try:
-        mem = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).total_memory
+        dev = device if device is not None else torch.cuda.current_device()
+        free, total = torch.cuda.mem_get_info(dev)
     except Exception:
         return log2
-    while log2 > 16 and (264 << log2) > mem // 8:
+    budget = min(total // 4, free // 2) // max(1, int(sharers))
+    while log2 > 16 and (264 << log2) > budget:
         log2 -= 1
     return log2
+
+
+def make_leaf_cache(log2, device, n_engines=1):
+    """The GPU's leaf cache for `n_engines` engines stepping side by side (None when log2 is 0): launch numbers advance
+    n_engines times per step, so a generation is as many launches longer."""
+    if not log2:
+        return None
+    gen = max(11, int(log2) - 14) + int(np.ceil(np.log2(max(1, int(n_engines)))))
+    return ckengine.LeafCache(int(log2), device, gen_log2=min(20, gen))
 
 
 def _warn_pool_overflows(stats, what):
@@ -424,6 +448,10 @@ class generate_Checkers_data:
         self.leaf_cache_log2 = selfplay_kwargs.get("LEAF_CACHE_LOG2")
         self.dense_rows = selfplay_kwargs.get("DENSE_ROWS", True)
         self.evaluator_kind = selfplay_kwargs.get("EVALUATOR")           # None = the hand-written kernels where they apply; "torch"
+        # virtual workers: at most SLOTS games run concurrently on a GPU (default 4 096, the batch that fills an MI355X); the
+        # NUM_CPUS workers of the job are hosted on them one after the other, each still playing NUM_SELFPLAY_GAMES games with
+        # its own noise / temperature streams -- the output is the same as with SLOTS = NUM_CPUS, bit for bit
+        self.slots = selfplay_kwargs.get("SLOTS", 4096)
         self.stats = None
         self.results = None
 
@@ -443,25 +471,29 @@ class generate_Checkers_data:
 
     def _play(self, dev, first, count, kind):
         """This rank's share of the job on its GPU: `count` workers from global id `first`; returns the packed tuples."""
-        def make_engine(offset, n):
+        neural = bool(self.mcts_kwargs["NEURAL_NET"])
+        timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
+        slots = count if (self.dynamic_queue or timed or not self.slots) else min(count, int(self.slots))
+        split = (neural and self.split_streams and slots >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue and not timed)
+        log2 = (default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)) if neural else 0
+        cache = make_leaf_cache(log2, dev, n_engines=2 if split else 1)
+
+        def make_engine(offset, workers, n):
             cfg = ckengine.config_from_kwargs(
-                self.mcts_kwargs, n_slots=n, games_per_slot=self.NUM_SELFPLAY_GAMES,
+                self.mcts_kwargs, n_slots=n, n_workers=workers, games_per_slot=self.NUM_SELFPLAY_GAMES,
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree,
                 feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue,
-                leaf_cache_log2=(default_leaf_cache_log2(n, dev) if self.leaf_cache_log2 is None else self.leaf_cache_log2)
-                if self.mcts_kwargs["NEURAL_NET"] else 0,
-                dense_rows=bool(self.dense_rows) and bool(self.mcts_kwargs["NEURAL_NET"]))
-            return ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
+                leaf_cache_log2=0, dense_rows=bool(self.dense_rows) and neural)
+            return ckengine.Engine(cfg, feature_dtype=self.nn_dtype, cache=cache)
 
-        if not self.mcts_kwargs["NEURAL_NET"]:     # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
-            eng = make_engine(0, count)
+        if not neural:                             # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
+            eng = make_engine(0, count, slots)
             eng.set_ln_table()
             eng.run_rollouts(time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             engines = [eng]
-        elif (self.split_streams and count >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue
-              and ckengine.time_budget_of(self.mcts_kwargs) is None):
+        elif split:
             runner = SplitRunner(make_engine, lambda n: make_evaluator(self.nn_fn, dev, self.nn_dtype, n, kind=kind, networks=self.networks),
-                                 count, use_graph=self.use_graph)
+                                 count, use_graph=self.use_graph, n_slots=slots)
             try:
                 runner.run_to_completion()
             except OverflowError:
@@ -469,8 +501,8 @@ class generate_Checkers_data:
                 raise
             engines = runner.engines
         else:
-            eng = make_engine(0, count)
-            runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, count, kind=kind, networks=self.networks),
+            eng = make_engine(0, count, slots)
+            runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, slots, kind=kind, networks=self.networks),
                                 use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             try:
                 runner.run_to_completion()
@@ -487,6 +519,8 @@ class generate_Checkers_data:
         raw_dev = torch.cat([e.pack_tuples_device() for e in engines], dim=0)
         for e in engines:
             e.close()
+        if cache is not None:
+            cache.close()
         return raw_dev
 
     def generate_data(self):
@@ -526,6 +560,7 @@ class tournament_Checkers:
         self.networks = tourney_kwargs.get("NETWORKS")                   # {file name: replacement spec / module}
         self.leaf_cache_log2 = tourney_kwargs.get("LEAF_CACHE_LOG2")     # as in generate_Checkers_data (the key carries the network id)
         self.dense_rows = tourney_kwargs.get("DENSE_ROWS", True)
+        self.slots = tourney_kwargs.get("SLOTS", 4096)                   # concurrent games per GPU (virtual workers, as in generate_Checkers_data)
         self.stats = None
 
     def start_tournament(self):
@@ -543,14 +578,15 @@ class tournament_Checkers:
         dev = ckdist.local_device(local_rank) if world > 1 else torch.device("cuda", torch.cuda.current_device())
         rows = torch.zeros((0, 8), dtype=torch.int32, device=dev)
         if count > 0:
+            timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
+            slots = count if (timed or not self.slots) else min(count, int(self.slots))
             cfg = ckengine.config_from_kwargs(
-                self.mcts_kwargs, n_slots=count, games_per_slot=self.NUM_GAMES, tournament=True,
+                self.mcts_kwargs, n_slots=slots, n_workers=count, games_per_slot=self.NUM_GAMES, tournament=True,
                 first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
-                seed=self.seed, device=dev.index,
-                leaf_cache_log2=default_leaf_cache_log2(count, dev) if self.leaf_cache_log2 is None else self.leaf_cache_log2,
-                dense_rows=bool(self.dense_rows))
-            eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype)
-            runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, count, spec_old=self.nn2_fn,
+                seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
+            cache = make_leaf_cache(default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2), dev)
+            eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype, cache=cache)
+            runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, slots, spec_old=self.nn2_fn,
                                                     networks=self.networks), use_graph=self.use_graph,
                                 time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             runner.run_to_completion()
@@ -558,6 +594,8 @@ class tournament_Checkers:
             _warn_pool_overflows(self.stats, "tournament")
             res = eng.results()
             eng.close()
+            if cache is not None:
+                cache.close()
             rows = torch.tensor([[r[k] for k in ("worker", "game", "outcome", "move_count", "adjudicated",
                                                  "p1_net", "n_tuples", "failed")] for r in res],
                                 dtype=torch.int32, device=dev).reshape(-1, 8)

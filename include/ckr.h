@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 110          /* 0.1.1: w_accum, leaf cache, ckr_tuple.q_kind / root_w double, ckr_hashnet_batch(inexact) */
+#define CKR_VERSION 120          /* 0.1.2: one leaf cache per GPU (ckr_leaf_cache_*, pending claims), virtual workers (n_workers) */
 
 typedef enum {
     CKR_OK = 0,
@@ -261,6 +261,20 @@ typedef struct {
                                     step costs what its leaves cost (slots that found no leaf within max_sims_per_step, finished
                                     games, cache-served expansions leave no hole).  Row order varies from run to run; results do
                                     not (the network kernels evaluate every row on its own: tests/test_leaf_cache_gpu.py) */
+    int32_t  n_workers;          /* virtual workers: 0 = n_slots (one worker per slot).  > n_slots: the engine plays n_workers reference
+                                    workers (global ids first_worker_id + [0, n_workers), games_per_slot games each) on n_slots
+                                    concurrent slots -- a slot whose worker has played its last game takes the next unplayed
+                                    worker.  Noise / temperature streams, tau carry-over (Q18: never reset within a worker) and the
+                                    tuple regions are keyed by WORKER id, so the output is the same, bit for bit, as with
+                                    n_slots = n_workers, whatever slot hosted a worker (training_pipeline.py:323-332: Pool.map
+                                    hands the workers of a job to NUM_CPUS processes in the same way) */
+    int32_t  leaf_cache_park;    /* 1: a leaf whose position another slot (or another engine attached to the same ckr_leaf_cache) is
+                                    having evaluated right now waits for that evaluation (a few steps at most) instead of taking a
+                                    row of the network batch itself.  0 = off, the default: measured on cfg3, 0.09 % of the
+                                    network's rows are such in-flight duplicates (0.002 % in steady state; the start of a run, when
+                                    every game requests the same openings, has nearly all of them:
+                                    profiles/r04_dup_probe.jsonl).  Ignored in manual_play and time-limited (budget = INT32_MAX)
+                                    engines.  Results do not depend on it */
     int32_t  reserved;
 } ckr_config;
 
@@ -304,12 +318,26 @@ typedef struct {
     uint64_t dup_leaves;         /* expansions served by the leaf cache: evaluations of a position the network had already seen */
     uint64_t cache_entries;      /* records written to the leaf cache */
     uint64_t cache_dropped;      /* records not cached because their probe neighbourhood was full */
+    uint64_t parked;             /* slot-steps spent waiting for another requester's evaluation of the same position (leaf_cache_park) */
 } ckr_stats;
 
 typedef struct ckr_engine ckr_engine;
 
 int ckr_engine_create(const ckr_config* cfg, ckr_engine** out);
 int ckr_engine_destroy(ckr_engine* e);
+
+/* One leaf-cache table per GPU, shared by the engines that play on it (pipeline.SplitRunner steps two half-batch engines on
+ * two HIP streams; the reference has no counterpart: every worker process evaluates every node, Checkers.py:425-438,
+ * MCTS.py:70-77).  Create the table (2^log2_records records of 264 bytes; gen_log2: log2 of a generation in k_step launches of
+ * ALL attached engines together, 0 = max(11, log2_records - 14)), create the engines with leaf_cache_log2 = 0 and attach each
+ * under its own index in [0, 4) before its first step.  A position evaluated for one engine is served to the others as soon as
+ * the launch that wrote it has ended.  Destroy the engines first.  ckr_leaf_cache_flush forgets every record (the network
+ * behind the evaluators has changed); the attached engines must be idle. */
+typedef struct ckr_leaf_cache ckr_leaf_cache;
+int ckr_leaf_cache_create(int32_t device, int32_t log2_records, int32_t gen_log2, ckr_leaf_cache** out);
+int ckr_leaf_cache_destroy(ckr_leaf_cache* c);
+int ckr_leaf_cache_flush(ckr_leaf_cache* c, void* stream);
+int ckr_engine_attach_cache(ckr_engine* e, ckr_leaf_cache* c, int32_t index);
 
 /* One lock-step simulation for every slot.  Consumes the network output for
  * the leaves handed out by the previous step (d_p[n_slots][512] softmax

@@ -81,6 +81,23 @@ def test_cfg3_full_size_selfplay_properties(E):
     assert checksum(np.concatenate([a, b])) == checksum(raw)
 
 
+def test_cfg3_virtual_workers_equal_the_static_run(E):
+    """NUM_CPUS = 16 384 workers of one game each (cfg3's kwargs) hosted on 4 096 slots -- a slot whose worker is done takes the
+    next unplayed worker -- give the tuples of the run in which all 16 384 workers play at once, byte for byte (streams and tau are
+    keyed by worker id: training_pipeline.py:323-349, MCTS.py:243-245), with the leaf cache and dense rows on in the hosted run."""
+    kw = mk(100, eps=0.25, tau=1.0)
+    static, res_s, st_s = play(E, kw, 16384, games_per_slot=1, terminate_cnt=200, seed=20260929)
+    hosted, res_h, st_h = play(E, kw, 4096, n_workers=16384, games_per_slot=1, terminate_cnt=200, seed=20260929, leaf_cache_log2=24,
+                               dense_rows=True)
+    assert len(res_s) == len(res_h) == 16384 and st_h["pool_overflows"] == 0
+    assert checksum(hosted) == checksum(static) and hosted.tobytes() == static.tobytes()
+    key = lambda r: (r["worker"], r["game"])
+    assert sorted(res_s, key=key) == sorted(res_h, key=key)
+    for k in ("expansions", "terminal_visits", "plies", "games"):
+        assert st_s[k] == st_h[k], k
+    assert st_h["steps"] > 2.5 * st_s["steps"]                               # four waves of workers on a quarter of the slots
+
+
 def test_cfg4_shape_400_sims_sharded(E):
     """cfg4's per-game shape (400 sims/move) on 512 games: two shards + concatenation (what the
     RCCL gather ships) equal the single-engine run; dynamic queue plays the same number of games."""
@@ -268,7 +285,7 @@ def test_cfg4_per_gpu_share_with_the_real_network(E):
 
 
 def test_cfg5_arena_share_with_two_real_networks(tmp_path, monkeypatch, capsys):
-    """BASELINE cfg5's shape on one GPU through the drop-in class: tournament_Checkers, 1 024 workers x 2 games, 800
+    """BASELINE cfg5's shape on one GPU through the drop-in class: tournament_Checkers, 2 048 workers x 2 games = the 4 096 games one GPU of the 8 plays, 800
     sims/move, two different random-init networks in the float32-grade kernels, every game to its natural end
     (training_pipeline.py:505-560); colours swap for each worker's second game; win / loss / draw bookkeeping adds up and
     the reference's result file is written."""
@@ -276,23 +293,23 @@ def test_cfg5_arena_share_with_two_real_networks(tmp_path, monkeypatch, capsys):
     from checkers_mcts_amd.pipeline import tournament_Checkers
     monkeypatch.chdir(tmp_path)
     kw = dict(mk(800, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
-    t = tournament_Checkers(dict(NEW_NN_FN="random:0", OLD_NN_FN="random:1", TOURNEY_GAMES=2, NUM_CPUS=1024, SEED=5), kw)
+    t = tournament_Checkers(dict(NEW_NN_FN="random:0", OLD_NN_FN="random:1", TOURNEY_GAMES=2, NUM_CPUS=2048, SEED=5), kw)
     out = t._start_tournament()
     st = t.stats
-    assert len(out) == 2048 and st["games"] == 2048 and st["pool_overflows"] == 0
+    assert len(out) == 4096 and st["games"] == 4096 and st["pool_overflows"] == 0
     assert all(r[3] in ("player1_wins", "player2_wins", "draw") for r in out)
-    assert [r[0] for r in out] == list(range(1, 2049))
-    assert all(out[i][1] == "random:0" and out[i + 1][1] == "random:1" for i in range(0, 2048, 2))      # :523-531
+    assert [r[0] for r in out] == list(range(1, 4097))
+    assert all(out[i][1] == "random:0" and out[i + 1][1] == "random:1" for i in range(0, 4096, 2))      # :523-531
     plies = sum(r[4] for r in out)
     assert st["plies"] == plies and st["expansions"] + st["terminal_visits"] == 800 * plies
     assert st["nn_evals"] + st["dup_leaves"] == st["expansions"]
     new = sum((r[3] == "player1_wins" and r[1] == "random:0") or (r[3] == "player2_wins" and r[2] == "random:0") for r in out)
     old = sum((r[3] == "player1_wins" and r[1] == "random:1") or (r[3] == "player2_wins" and r[2] == "random:1") for r in out)
     draws = sum(r[3] == "draw" for r in out)
-    assert new + old + draws == 2048
+    assert new + old + draws == 4096
     fn = t._save_tourney_results(out)
     assert t.summary == dict(new="random:0", old="random:1", new_wins=new, old_wins=old, draws=draws)
     assert "%d/%d/%d" % (new, old, draws) in open(fn, encoding="utf-8").read()
     with capsys.disabled():
-        print("\n[cfg5 share] 2 048 arena games, 800 sims/move: new %d, old %d, draws %d; %d plies (max %d); cache served %.1f %%"
+        print("\n[cfg5 share] 4 096 arena games, 800 sims/move: new %d, old %d, draws %d; %d plies (max %d); cache served %.1f %%"
               % (new, old, draws, plies, max(r[4] for r in out), 100.0 * st["dup_leaves"] / st["expansions"]))

@@ -190,3 +190,146 @@ def test_tiny_engines_reset_their_rows_inside_the_tree_kernel(E, n):
     assert len(a) == len(b) > 50 * n
     for f in ("board", "mask", "pi", "q", "z", "chosen", "root_n", "n_children"):
         assert (a[f] == b[f]).all(), f
+
+
+# ---- round 4: one table per GPU shared by several engines, pending claims, flushes ----------------------------------------
+
+def play_shared(E, kw, n_slots, salt, n_parts, log2, park, gen_log2=0, inexact=False, **cfg_kw):
+    """The job split into n_parts engines (contiguous worker blocks) that share ONE LeafCache and step alternately -- the layout
+    of pipeline.SplitRunner, without the streams.  Returns (sorted tuples, sorted results, summed stats)."""
+    cache = E.LeafCache(log2, 0, gen_log2=gen_log2) if log2 else None
+    bounds = [n_slots * i // n_parts for i in range(n_parts + 1)]
+    engines = [E.Engine(E.config_from_kwargs(kw, n_slots=bounds[i + 1] - bounds[i], first_worker_id=bounds[i], leaf_cache_park=park, **cfg_kw),
+                        cache=cache) for i in range(n_parts)]
+    ev = E.hashnet_evaluator(salt, inexact=inexact)
+    pv = [(None, None)] * n_parts
+    for step in range(200000):
+        for i, eng in enumerate(engines):
+            eng.step(*pv[i])
+            pv[i] = tuple(t.clone() for t in ev(eng))
+        if step % 64 == 63 and all(eng.stats()["active_slots"] == 0 for eng in engines):
+            break
+    raw = np.concatenate([eng.tuples_raw() for eng in engines])
+    raw = raw[np.lexsort((raw["ply"], raw["game"], raw["worker"]))]
+    res = sorted(tuple(sorted(r.items())) for eng in engines for r in eng.results())
+    st = {}
+    for eng in engines:
+        for k, v in eng.stats().items():
+            st[k] = st.get(k, 0) + v
+        eng.close()
+    if cache is not None:
+        cache.close()
+    return raw, res, st
+
+
+@pytest.mark.parametrize("n_parts,park,gen_log2", [(2, False, 0), (2, True, 0), (3, True, 0), (4, False, 5), (2, True, 5)])
+def test_shared_cache_on_off_identical(E, n_parts, park, gen_log2):
+    """Engines that share one table (ckr_leaf_cache_create + ckr_engine_attach_cache) give the tuples of the cache-less run byte
+    for byte, serve MORE leaves than private tables do (a position evaluated for one engine is served to the others), and --
+    with leaf_cache_park -- send fewer rows to the network still: every game starts from the same position, so the first steps
+    consist of in-flight duplicates.  gen_log2 = 5: generations of 32 launches, so records expire, sit out the dead
+    generation and are overwritten all the time."""
+    kw = mk(60, eps=0.25, tau=1.0)
+    common = dict(games_per_slot=2, terminate_cnt=80, seed=77, dense_rows=True)
+    off = play(E, kw, 96, E.hashnet_evaluator(9), **common)
+    on = play_shared(E, kw, 96, 9, n_parts, 14, park, gen_log2=gen_log2, **common)
+    assert off[0].tobytes() == on[0].tobytes() and off[1] == on[1]
+    for k in SEARCH_COUNTERS:
+        assert off[2][k] == on[2][k], k
+    assert on[2]["nn_evals"] + on[2]["dup_leaves"] == on[2]["expansions"]
+    assert on[2]["dup_leaves"] > 0.05 * on[2]["expansions"]
+    assert (on[2]["parked"] > 0) == park
+    if gen_log2 == 0:
+        private = [play(E, kw, 96 // n_parts, E.hashnet_evaluator(9), leaf_cache_log2=14, first_worker_id=i * (96 // n_parts), **common)[2]
+                   for i in range(n_parts)]
+        assert on[2]["dup_leaves"] > sum(p["dup_leaves"] for p in private)
+        if park:
+            unparked = play_shared(E, kw, 96, 9, n_parts, 14, False, **common)[2]
+            assert on[2]["nn_evals"] < unparked["nn_evals"]
+
+
+@pytest.mark.parametrize("w_accum", ["float32", "float64"])
+def test_shared_cache_with_parking_inexact_net_equals_plain_run(E, w_accum):
+    """The inexact net (outputs that do not sum exactly: every W bit depends on the order of the backups) through two engines, a
+    shared table and parked leaves: tuples, root W and q equal the cache-less single engine's."""
+    kw = mk(24)
+    common = dict(games_per_slot=2, terminate_cnt=40, seed=3, w_accum=w_accum)
+    plain = play(E, kw, 16, E.hashnet_evaluator(31, inexact=True), **common)
+    shared = play_shared(E, kw, 16, 31, 2, 12, True, inexact=True, **common)
+    assert plain[0].tobytes() == shared[0].tobytes() and plain[1] == shared[1]
+    assert shared[2]["dup_leaves"] > 0 and shared[2]["parked"] > 0
+
+
+def test_shared_cache_arena_and_tiny_engines(E):
+    """Arena (the key carries the network id) on two engines with one table; and single-workgroup engines (<= 4 slots: the launch
+    number is drawn inside k_step) beside a larger one."""
+    kw = dict(mk(80, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    runs = []
+    for log2 in (0, 13):
+        cache = E.LeafCache(log2, 0) if log2 else None
+        engines = [E.Engine(E.config_from_kwargs(kw, n_slots=n, first_worker_id=f, games_per_slot=2, tournament=True, seed=5, dense_rows=True,
+                                                 leaf_cache_park=True), cache=cache) for f, n in ((0, 3), (3, 61))]
+        ev = E.hashnet_evaluator(3, 4)
+        pv = [(None, None), (None, None)]
+        for step in range(200000):
+            for i, eng in enumerate(engines):
+                eng.step(*pv[i])
+                pv[i] = tuple(t.clone() for t in ev(eng))
+            if step % 64 == 63 and all(eng.stats()["active_slots"] == 0 for eng in engines):
+                break
+        runs.append((sorted(tuple(sorted(r.items())) for eng in engines for r in eng.results()),
+                     {k: sum(eng.stats()[k] for eng in engines) for k in SEARCH_COUNTERS + ("dup_leaves",)}))
+        for eng in engines:
+            eng.close()
+        if cache:
+            cache.close()
+    assert runs[0][0] == runs[1][0] and len(runs[0][0]) == 128
+    for k in SEARCH_COUNTERS:
+        assert runs[0][1][k] == runs[1][1][k], k
+    assert runs[1][1]["dup_leaves"] > 0 and runs[0][1]["dup_leaves"] == 0
+
+
+def test_attach_rules_and_flush_forgets_everything(E):
+    """API rules of the shared table; ckr_leaf_cache_flush / ckr_engine_cache_flush return every claim to 'never used', so no
+    number of flushes and no wrap of the launch counter can make an old network's record look fresh again (round 3 advanced the
+    generation counter instead, which wrapped after 512 flushes)."""
+    import torch
+    from checkers_mcts_amd import _lib
+    kw = mk(30, eps=0.0, tau=0.0)
+    cache = E.LeafCache(12, 0)
+    eng = E.Engine(E.config_from_kwargs(kw, n_slots=8, games_per_slot=50, terminate_cnt=60, seed=1, dense_rows=True), cache=cache)
+    with pytest.raises(_lib.CkrError):
+        eng.attach_cache(cache)                                              # already attached
+    other = E.Engine(E.config_from_kwargs(kw, n_slots=8, games_per_slot=1, terminate_cnt=60, seed=1, leaf_cache_log2=12))
+    with pytest.raises(_lib.CkrError):
+        other.attach_cache(cache)                                            # has a table of its own
+    other.close()
+    with pytest.raises(_lib.CkrError):
+        cache.close()                                                        # engines still attached
+    # play with network A, flush, play on with network B: B's evaluations only.  The reference run: no cache at all.
+    def run(use_cache, flushes):
+        c = E.LeafCache(12, 0) if use_cache else None
+        e = E.Engine(E.config_from_kwargs(kw, n_slots=8, games_per_slot=2, terminate_cnt=60, seed=1, dense_rows=True), cache=c)
+        p = v = None
+        from checkers_mcts_amd import rules
+        for step in range(100000):
+            salt = 5 if step < 300 else 6                                    # the network changes after 300 steps
+            if step == 300 and c is not None:
+                torch.cuda.synchronize()
+                for _ in range(flushes):
+                    e.cache_flush()
+            e.step(p, v)
+            p, v = rules.hashnet(e.x, salt)
+            if step % 64 == 63 and e.stats()["active_slots"] == 0:
+                break
+        raw, st = sorted_tuples(e), e.stats()
+        e.close()
+        if c is not None:
+            c.close()
+        return raw, st
+    plain, _ = run(False, 0)
+    for flushes in (1, 1030):                                                # 1 030 > the 512 generations the old scheme could tell apart
+        got, st = run(True, flushes)
+        assert got.tobytes() == plain.tobytes() and st["dup_leaves"] > 0
+    eng.close()
+    cache.close()
