@@ -134,11 +134,12 @@ template <typename WT> struct WaveT {
     using wtype = WT;
     const Dev& D; WaveLds& L; int slot, lane;
     uint32_t epoch = 0u;         // launch number (leaf cache)
-    uint32_t view[CACHE_MAX_ENGINES] = {0u, 0u, 0u, 0u};   // the other engines' published launch numbers at this launch's start
+    const uint32_t* view = nullptr;   // LDS: the engines' published launch numbers at this launch's start (indexed by engine: kept out of
+                                      // the handle itself -- a dynamically indexed member would pin the whole handle to scratch memory)
     int wk = 0;                  // the worker this slot hosts (local id; global id = D.first_worker + wk)
     __device__ uint32_t worker() const { return (uint32_t)(D.first_worker + wk); }
     __device__ WT* nW() const { return static_cast<WT*>(D.n_W); }
-    __device__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
+    __device__ __forceinline__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
     __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
     __device__ size_t tb(int t) const { return tbase(t, D.t_half[slot * 2 + t]); }
 };
@@ -153,10 +154,14 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// double-precision pow() is ~100 registers of OCML code: kept out of line so that its pressure (and the spills around it)
-// stays on the rare paths that need it -- gamma variates with alpha != 1, one temperature pick per ply -- instead of
-// shaping the register allocation of every descent
-__device__ __attribute__((noinline)) double pow_cold(double x, double y) { return pow(x, y); }
+// x ** y for the sampling paths (temperature pick, gamma variates): float32 hardware log2 / exp2.  These paths are pinned
+// distributionally, not bit for bit (the reference draws from NumPy's MT19937), and a relative error of 1e-6 in a sampling weight
+// is far below what any test of the distribution resolves; the OCML double-precision pow() / log() / cos() they used until round 3
+// cost ~100 VGPRs each and -- as callees -- set the register allocation of the whole tree kernel, which is what keeps it from
+// sharing a SIMD with the network kernel's waves ("Step pipeline").
+__device__ __forceinline__ float pow_fast(float x, float y) { return x <= 0.0f ? 0.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ float ln_fast(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float u01f(uint32_t r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-08f; }   // (0, 1), 24 bits
 
 // ---- gamma / Dirichlet noise (MCTS.py:107-108); distribution-level parity only
 __device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint32_t seed_hi, double a, uint32_t c0, uint32_t c1, uint32_t c2);
@@ -170,29 +175,28 @@ __device__ __forceinline__ double gamma_sample(const Dev& D, double a, uint32_t 
     return gamma_general(D.seed_lo, D.seed_hi, a, c0, c1, c2);
 }
 
-// alpha != 1: Marsaglia-Tsang (alpha < 1 through the alpha + 1 variate and a uniform power)
-__device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint32_t seed_hi, double a, uint32_t c0, uint32_t c1, uint32_t c2) {
-    struct { uint32_t seed_lo, seed_hi; } D{seed_lo, seed_hi};
+// alpha != 1: Marsaglia-Tsang (alpha < 1 through the alpha + 1 variate and a uniform power), float32 throughout
+__device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint32_t seed_hi, double a_in, uint32_t c0, uint32_t c1, uint32_t c2) {
     uint32_t it = 0;
-    double boost = 1.0;
-    if (a < 1.0) {
-        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0x80000000u);
-        boost = pow(u01(r.x, r.y), 1.0 / a); a += 1.0;
+    float a = (float)a_in, boost = 1.0f;
+    if (a < 1.0f) {
+        const u32x4 r = philox(seed_lo, seed_hi, c0, c1, c2, 0x80000000u);
+        boost = pow_fast(u01f(r.x), 1.0f / a); a += 1.0f;
     }
-    if (a == 1.0) {
-        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0u);
-        const float uf = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;
-        return (double)(-logf(uf)) * boost;
+    if (a == 1.0f) {
+        const u32x4 r = philox(seed_lo, seed_hi, c0, c1, c2, 0u);
+        return (double)(-ln_fast(u01f(r.x)) * boost);
     }
-    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    const float d = a - 1.0f / 3.0f, c = 1.0f / __builtin_sqrtf(9.0f * d);
     for (;; ++it) {
-        const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, it);
-        const u32x4 q = philox(D.seed_lo, D.seed_hi, c0, c1, c2, it | 0x40000000u);
-        const double nrm = sqrt(-2.0 * log(u01(r.x, r.y))) * cos(6.283185307179586 * u01(r.z, r.w));
-        double vv = 1.0 + c * nrm;
-        if (vv <= 0.0) continue;
+        const u32x4 r = philox(seed_lo, seed_hi, c0, c1, c2, it);
+        const u32x4 q = philox(seed_lo, seed_hi, c0, c1, c2, it | 0x40000000u);
+        // Box-Muller; v_cos_f32 takes its argument in revolutions
+        const float nrm = __builtin_sqrtf(-2.0f * ln_fast(u01f(r.x))) * __builtin_amdgcn_cosf(u01f(r.z));
+        float vv = 1.0f + c * nrm;
+        if (vv <= 0.0f) continue;
         vv = vv * vv * vv;
-        if (log(u01(q.x, q.y)) < 0.5 * nrm * nrm + d - d * vv + d * log(vv) || it > 64u) return d * vv * boost;
+        if (ln_fast(u01f(q.x)) < 0.5f * nrm * nrm + d - d * vv + d * ln_fast(vv) || it > 64u) return (double)(d * vv * boost);
     }
 }
 
@@ -207,7 +211,7 @@ __device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_
 // as an inverse-CDF pick over the children in tree order; `ev` = 64 doubles of LDS.  All lanes return the pick.
 __device__ __forceinline__ int temperature_pick(const Dev& D, double* ev, int cn, bool act, int n, double tau,
                                                 uint32_t worker, uint32_t ctr, int lane) {
-    ev[lane] = act ? pow_cold((double)cn, 1.0 / tau) : 0.0;
+    ev[lane] = act ? (double)pow_fast((float)cn, (float)(1.0 / tau)) : 0.0;
     __builtin_amdgcn_wave_barrier();
     double cum = 0.0;
     for (int j = 0; j <= lane && j < n; ++j) cum += ev[j];
@@ -306,7 +310,7 @@ template <int GAME> __device__ __forceinline__ uint4 rules_initial_board() {
 template <int GAME> __device__ __forceinline__ uint32_t rules_initial_status() { return GAME == 0 ? (7u << 8) : (9u << 8); }
 
 // ---- tree bookkeeping
-template <class Wave> __device__ void write_node(const Wave& w, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
+template <class Wave> __device__ __forceinline__ void write_node(const Wave& w, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
     const Dev& D = w.D;
     st_board(&D.n_board[idx], b);
     D.n_parent[idx] = parent; D.n_kids[idx] = 0u; D.n_N[idx] = 0; w.nW()[idx] = 0; D.n_P[idx] = prior;
@@ -443,8 +447,7 @@ template <class Wave> __device__ __forceinline__ bool cache_readable(const Wave&
     if (d > 1 || d < -1) return false;
     const uint32_t e = (uint32_t)(claim & CACHE_LAUNCH_MASK), x = (uint32_t)(claim >> CACHE_ENGINE_SHIFT) & 3u;
     if ((int)x == w.D.cache_engine) return e != w.epoch;                                              // an earlier launch of this engine
-    uint32_t vx = w.view[0];
-    vx = x == 1u ? w.view[1] : vx; vx = x == 2u ? w.view[2] : vx; vx = x == 3u ? w.view[3] : vx;
+    const uint32_t vx = w.view[x];
     return vx != 0u && ((vx - e - 1u) & (uint32_t)CACHE_LAUNCH_MASK) < (uint32_t)(CACHE_LAUNCH_MASK >> 1);   // e < view[x]: that launch had ended
 }
 enum { CACHE_HIT = 0, CACHE_MISS = 1, CACHE_PARK = 2 };
@@ -453,6 +456,8 @@ enum { CACHE_HIT = 0, CACHE_MISS = 1, CACHE_PARK = 2 };
 // CACHE_PARK (only if may_park): another requester's evaluation of this position is under way.
 template <class Wave> __device__ __forceinline__ int cache_probe(Wave& w, const uint4 key, bool may_park, float& prior, float& v, int& n,
                                                                  int& cslot, unsigned long long& cword) {
+    // (without leaf_cache_park nothing is reserved at hand-out time: the expansion inserts its record with ONE compare-and-swap,
+    // cache_insert -- a reservation costs a second atomic round trip per miss)
     const Dev& D = w.D;
     const unsigned long long h = cache_hash(key), tag = cache_tag(h);
     cslot = -1; cword = 0ull;
@@ -481,6 +486,7 @@ template <class Wave> __device__ __forceinline__ int cache_probe(Wave& w, const 
         }
         if (writable && cand < 0) { cand = (long long)at; cand_val = claim; }
     }
+    if (!D.cache_park) return CACHE_MISS;
     if (cand < 0) { w.count(CNT_CDROP); return CACHE_MISS; }          // neighbourhood full of live records: evaluated, not cached
     const unsigned long long mine = tag | CACHE_PENDING | ((unsigned long long)D.cache_engine << CACHE_ENGINE_SHIFT) | (unsigned long long)(w.epoch & (uint32_t)CACHE_LAUNCH_MASK);
     unsigned long long old = 0ull;
@@ -511,6 +517,39 @@ template <class Wave> __device__ __forceinline__ void cache_complete(Wave& w, in
     w.count(CNT_CINS);
 }
 
+// Without reservations (leaf_cache_park off): the expansion looks for a place now and takes it with one compare-and-swap.
+template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, const uint4 key, int n, float prior, float v) {
+    const Dev& D = w.D;
+    const unsigned long long h = cache_hash(key), tag = cache_tag(h);
+    const unsigned long long done = tag | ((unsigned long long)D.cache_engine << CACHE_ENGINE_SHIFT) | (unsigned long long)(w.epoch & (uint32_t)CACHE_LAUNCH_MASK);
+    for (int i = 0; i < CACHE_PROBES; ++i) {
+        const size_t at = (size_t)((h + (unsigned long long)i) & D.cache_mask);
+        unsigned long long cur = D.cache_claim[at];
+        if (cache_writable(D, cur, w.epoch)) {                      // unused, or too old for any reader of any engine: take it
+            unsigned long long old = 0ull;
+            if (w.lane == 0) old = atomicCAS(&D.cache_claim[at], cur, done);
+            old = ((unsigned long long)(uint32_t)bcast_i32((int)(uint32_t)(old >> 32), 0) << 32) | (uint32_t)bcast_i32((int)(uint32_t)old, 0);
+            if (old == cur) {                                       // ours: write the record
+                CacheRecord* r = D.cache + at;
+                if (w.lane < n) r->prior[w.lane] = prior;
+                if (w.lane == 0) {
+                    *reinterpret_cast<uint4*>(r->key) = key;
+                    r->v = v; r->n = (uint32_t)n;
+                }
+                w.count(CNT_CINS);
+                return;
+            }
+            cur = old;                                              // another wave was faster (or the plain load was stale)
+            if (cache_writable(D, cur, w.epoch)) continue;          // (only a stale load can bring us here: next place)
+        }
+        if ((cur & CACHE_TAG_MASK) == tag) {
+            const int d = cache_gen_dist(D, cur, w.epoch);
+            if (d >= -1 && d <= 1) return;                          // present, or being written by another wave
+        }
+    }
+    w.count(CNT_CDROP);                                             // neighbourhood full of live records: not cached
+}
+
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
 // Checkers.predict's mask/renormalise (Checkers.py:435-437) and
 // set_prior_probs (:440-452).  Returns false on pool overflow.
@@ -520,7 +559,7 @@ struct ExpandPre { int half, used, plen; uint32_t entry; };
 
 // CACHED: the priors come from the leaf cache (cached_prior: child `lane`), prow is not read.  net: the network that
 // evaluated the leaf (key of the cache record written when !CACHED and a place was reserved for it: cslot >= 0).
-template <bool CACHED, class Wave> __device__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
+template <bool CACHED, class Wave> __device__ __forceinline__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
                                                            float cached_prior, int cached_n, int net, int cslot = -1, unsigned long long cword = 0ull) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
@@ -562,7 +601,10 @@ template <bool CACHED, class Wave> __device__ bool expand(Wave& w, int t, int le
         if (!CACHED) prior = w.L.u.p[meta_action(c.meta)] / total;
         write_node(w, tb + used + w.lane, c, leaf, prior, cst | ((b.meta & 1u) << 4));
     }
-    if (!CACHED && cslot >= 0) cache_complete(w, cslot, cword, cache_key(b, st, net), n, prior, v);
+    if (!CACHED && D.cache) {
+        if (cslot >= 0) cache_complete(w, cslot, cword, cache_key(b, st, net), n, prior, v);
+        else if (!D.cache_park) cache_insert(w, cache_key(b, st, net), n, prior, v);
+    }
     if (w.lane == 0) {
         D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
         D.n_status[tb + leaf] = leaf_status | ST_EXPANDED;
@@ -588,7 +630,7 @@ template <bool CACHED, class Wave> __device__ bool expand(Wave& w, int t, int le
 // child (:93-94).  Scores are float64 exactly as NumPy evaluates them:
 //   q32 + ((c * P') * N_parent**0.5) / (1 + N_child),
 //   P' = float32((1-eps) * P) + eps * dirichlet.
-template <class Wave> __device__ int descend(Wave& w, int t, int& plen_out, uint32_t& entry_out) {
+template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int& plen_out, uint32_t& entry_out) {
     const Dev& D = w.D;
     const size_t tb = w.tb(t);
     int node = D.t_cursor[w.slot * 2 + t];
@@ -801,7 +843,7 @@ template <class Wave> __device__ size_t tuple_index(const Wave& w, int ply) {
     return (size_t)w.D.g_gid[w.slot] * (size_t)w.D.tuples_per_game + (size_t)ply;
 }
 
-template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
+template <int GAME = 0, class Wave> __device__ __attribute__((noinline)) void end_game(Wave& w, uint32_t outcome, int adjudicated, int failed) {
     const Dev& D = w.D;
     const int game = D.g_game[w.slot], moves = D.g_moves[w.slot];
     int n_tuples = 0;
@@ -873,7 +915,7 @@ template <int GAME = 0, class Wave> __device__ void end_game(Wave& w, uint32_t o
 // ---- end of a ply: MCTS.best_child (MCTS.py:227-248), Checkers.step
 // (Checkers.py:62-75), tuple emission, TERMINATE_CNT adjudication
 // (training_pipeline.py:387-405), cursor updates for both trees.
-template <int GAME = 0, class Wave> __device__ void finish_ply(Wave& w) {
+template <int GAME = 0, class Wave> __device__ __attribute__((noinline)) void finish_ply(Wave& w) {
     const Dev& D = w.D;
     const ckr_board gb = ld_board(&D.g_board[w.slot]);
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
@@ -966,7 +1008,7 @@ template <int GAME = 0, class Wave> __device__ void finish_ply(Wave& w) {
     else start_search<GAME>(w);
 }
 
-template <class Wave> __device__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
+template <class Wave> __device__ __forceinline__ void write_features(Wave& w, const ckr_board b, void* x, int row) {
     const Dev& D = w.D;
     uint32_t m[8], st;
     movegen(b, m, st);
@@ -1053,7 +1095,13 @@ __global__ __launch_bounds__(256) void k_step_prologue(const Dev* __restrict__ D
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
-template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
+// 127 VGPRs, nothing spilled, 4 waves per SIMD: every slot of a 4 096-slot engine is resident at once.  (Round 3's build needed
+// 168: the OCML double-precision pow() of the sampling paths, a callee, set the allocation.  At 96 VGPRs -- which would let a
+// wave share a SIMD with the two 208-VGPR waves of the float32-grade conv stack -- 48 values spill, and an A/B on one box
+// showed no gain from the co-residency: profiles/r04_kstep_launch_bounds.txt.)  The wave's handle `w` must never have its address
+// taken on the hot path (real calls get a copy) nor be indexed dynamically: either pins it to scratch memory, ~300 scratch
+// loads in this kernel.
+template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
                                               const float* __restrict__ v, void* x, int32_t* net_out, int flags) {
     const Dev& D = *Dp;
     __shared__ WaveLds lds[4];
@@ -1077,8 +1125,7 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
     if (slot == 0) w.count(CNT_STEPS);
     if (D.cache) {
         w.epoch = s_epoch.E;
-#pragma unroll
-        for (int i = 0; i < CACHE_MAX_ENGINES; ++i) w.view[i] = s_epoch.view[i];
+        w.view = s_epoch.view;
     }
     // A. consume the network output for the leaf handed out by the previous step
     const int pending = D.g_pending[slot];
@@ -1097,27 +1144,11 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
     bool parked = false;                                       // the slot ends this step waiting for another requester's evaluation
     int cslot = -1; unsigned long long cword = 0ull;           // place reserved in the leaf cache for the leaf handed out in this step
     ckr_board lb{0u, 0u, 0u, 0u};
-    if (pending >= 0 && phase0 == PH_PLAYING && parked0 > 0) {
-        // the leaf waited for an evaluation of its position that another requester had under way: look again
-        const int t = t0;
-        net = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
-        lb = ld_board(&D.n_board[w.tbase(t, pre.half) + pending]);
-        uint32_t lm[8], lst;
-        movegen(lb, lm, lst);
-        float cprior = 0.0f, cv = 0.0f; int cn = 0;
-        const int res = cache_probe(w, cache_key(lb, lst, net), parked0 < CACHE_PARK_MAX && !end_ply, cprior, cv, cn, cslot, cword);
-        bool done = false;
-        if (res == CACHE_HIT && expand<true>(w, t, pending, nullptr, cv, pre, cprior, cn, net)) {
-            w.count(CNT_HIT);
-            if (w.lane == 0) { D.g_sims[slot] += 1; D.g_pending[slot] = -1; D.g_parked[slot] = 0; }
-            wave_mem_fence();
-            done = true;
-        }
-        if (!done) {
-            if (res == CACHE_PARK) { parked = true; w.count(CNT_PARK); if (w.lane == 0) D.g_parked[slot] = parked0 + 1; }
-            else { leaf = pending; w.count(CNT_NN); if (w.lane == 0) D.g_parked[slot] = 0; }      // (a hit whose expansion does not fit goes to the network path, which compacts)
-        }
-    } else if (pending >= 0 && phase0 == PH_PLAYING) {
+    // a leaf that waited for an evaluation of its position another requester had under way (leaf_cache_park): the loop below
+    // looks it up again instead of descending
+    int resume = (pending >= 0 && phase0 == PH_PLAYING && parked0 > 0) ? pending : -1;
+    int park_count = resume >= 0 ? parked0 : 0;
+    if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
         const int t = t0;
         const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
         bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
@@ -1133,7 +1164,9 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
             if (w.lane == 0) D.g_sims[slot] += 1;
         } else {                                                          // the live subtree itself does not fit: give up on this game
             w.count(CNT_OVERFLOW);
-            end_game(w, 0u, 0, 1);
+            WaveT<WT> wc = w;                                                 // (a copy: see finish_ply below)
+            end_game(wc, 0u, 0, 1);
+            w.wk = wc.wk;
         }
         if (w.lane == 0 && D.g_pending[slot] == pending) D.g_pending[slot] = -1;
         wave_mem_fence();
@@ -1142,19 +1175,26 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
     // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
     // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
     const int max_sims = D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
-    while (leaf < 0 && !parked && D.g_phase[slot] == PH_PLAYING) {
+    while (D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
         const int sims_done = D.g_sims[slot];
         const bool out_of_time = end_ply != 0 && sims_done >= 2;         // a root with visited children exists
-        if (sims_done >= D.budget || out_of_time) {                      // MCTS.computational_budget, :189-201
-            end_ply = out_of_time ? 0 : end_ply;                         // one ply per time window
+        end_ply = out_of_time ? 0 : end_ply;                             // one ply per time window
+        if (resume < 0 && (sims_done >= D.budget || out_of_time)) {      // MCTS.computational_budget, :189-201
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
-            finish_ply(w); continue;
+            // (the end of a ply is a real call, once per BUDGET simulations: it gets a COPY of the wave's handle, so that the
+            // handle the hot path uses never has its address taken and stays in registers instead of scratch memory)
+            WaveT<WT> wc = w;
+            finish_ply(wc);
+            w.wk = wc.wk;
+            continue;
         }
         if (free_sims >= max_sims) break;
         const int t = (int)(D.g_board[slot].w & 1u);
-        int plen = 0; uint32_t pentry = 0u;
-        const int found = descend(w, t, plen, pentry);
+        int plen = pre.plen; uint32_t pentry = pre.entry;
+        int found = resume;
+        if (resume < 0) { found = descend(w, t, plen, pentry); park_count = 0; }
+        resume = -1;
         if (found < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
         lb = ld_board(&D.n_board[w.tb(t) + found]);
         if (D.tournament) {
@@ -1165,24 +1205,26 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
             uint32_t lm[8], lst;
             movegen(lb, lm, lst);
             float cprior = 0.0f, cv = 0.0f; int cn = 0;
-            const int res = cache_probe(w, cache_key(lb, lst, net), D.cache_park != 0 && (flags & 1) == 0, cprior, cv, cn, cslot, cword);
+            const bool may_park = D.cache_park != 0 && (flags & 1) == 0 && park_count < CACHE_PARK_MAX;
+            const int res = cache_probe(w, cache_key(lb, lst, net), may_park, cprior, cv, cn, cslot, cword);
             if (res == CACHE_HIT) {
                 const ExpandPre now{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], plen, pentry};
                 if (expand<true>(w, t, found, nullptr, cv, now, cprior, cn, net)) {
                     w.count(CNT_HIT);
-                    if (w.lane == 0) D.g_sims[slot] += 1;
+                    if (w.lane == 0) { D.g_sims[slot] += 1; if (D.cache_park) { D.g_pending[slot] = -1; D.g_parked[slot] = 0; } }
                     wave_mem_fence();
                     ++free_sims;
                     continue;
                 }                                                        // pool full: let the network path compact and retry
             } else if (res == CACHE_PARK) {
                 parked = true; w.count(CNT_PARK);
-                if (w.lane == 0) { D.g_pending[slot] = found; D.g_parked[slot] = 1; }
+                if (w.lane == 0) { D.g_pending[slot] = found; D.g_parked[slot] = park_count + 1; }
                 break;
             }
         }
         leaf = found;
         w.count(CNT_NN);
+        break;
     }
     int out_row = row;
     if (D.dense_rows && leaf >= 0) {                          // rows [0, number of leaves) of this step's batch, in arrival order
@@ -1192,7 +1234,7 @@ template <typename WT> __global__ __launch_bounds__(256, 3) void k_step(const De
     }
     if (w.lane == 0) {
         if (!parked) D.g_pending[slot] = leaf;
-        if (leaf >= 0) { D.g_cslot[slot] = cslot; D.g_cword[slot] = cword; }
+        if (leaf >= 0 && D.cache) { D.g_cslot[slot] = cslot; D.g_cword[slot] = cword; if (D.cache_park) D.g_parked[slot] = 0; }
         D.leaves[slot] = leaf >= 0 ? make_uint4(lb.p1, lb.p2, lb.kings, lb.meta) : make_uint4(0u, 0u, 0u, 0u);
         if (net_out && (leaf >= 0 || !D.dense_rows)) net_out[out_row] = leaf >= 0 ? net : -1;   // dense: idle rows preset to -1
     }

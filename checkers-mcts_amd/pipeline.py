@@ -279,7 +279,8 @@ class SplitRunner:
                 eng = make_engine(first, slots)                  # (offset, n_slots): one worker per slot
             else:
                 eng = make_engine(first, workers, slots)
-            stream = torch.cuda.Stream(device=eng.device)
+            prio = [int(x) for x in os.environ.get("CKR_STREAM_PRIORITIES", "").split(",") if x.strip()]      # tuning experiments
+            stream = torch.cuda.Stream(device=eng.device, priority=prio[i] if i < len(prio) else 0)
             with torch.cuda.stream(stream):
                 runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
             self.parts.append((eng, runner, stream))

@@ -232,7 +232,11 @@ def test_shared_cache_on_off_identical(E, n_parts, park, gen_log2):
     kw = mk(60, eps=0.25, tau=1.0)
     common = dict(games_per_slot=2, terminate_cnt=80, seed=77, dense_rows=True)
     off = play(E, kw, 96, E.hashnet_evaluator(9), **common)
-    on = play_shared(E, kw, 96, 9, n_parts, 14, park, gen_log2=gen_log2, **common)
+    # (launch numbers advance n_parts times per step: a generation of the default length in STEPS is as many launches longer --
+    # pipeline.make_leaf_cache does the same)
+    # ... and the shared table has the capacity of the n_parts private ones it replaces (the run writes ~25 records per place)
+    bits = (n_parts - 1).bit_length()
+    on = play_shared(E, kw, 96, 9, n_parts, 14 + bits, park, gen_log2=gen_log2 or 11 + bits, **common)
     assert off[0].tobytes() == on[0].tobytes() and off[1] == on[1]
     for k in SEARCH_COUNTERS:
         assert off[2][k] == on[2][k], k
@@ -244,7 +248,7 @@ def test_shared_cache_on_off_identical(E, n_parts, park, gen_log2):
                    for i in range(n_parts)]
         assert on[2]["dup_leaves"] > sum(p["dup_leaves"] for p in private)
         if park:
-            unparked = play_shared(E, kw, 96, 9, n_parts, 14, False, **common)[2]
+            unparked = play_shared(E, kw, 96, 9, n_parts, 14 + bits, False, gen_log2=11 + bits, **common)[2]
             assert on[2]["nn_evals"] < unparked["nn_evals"]
 
 
@@ -306,30 +310,25 @@ def test_attach_rules_and_flush_forgets_everything(E):
     other.close()
     with pytest.raises(_lib.CkrError):
         cache.close()                                                        # engines still attached
-    # play with network A, flush, play on with network B: B's evaluations only.  The reference run: no cache at all.
-    def run(use_cache, flushes):
-        c = E.LeafCache(12, 0) if use_cache else None
-        e = E.Engine(E.config_from_kwargs(kw, n_slots=8, games_per_slot=2, terminate_cnt=60, seed=1, dense_rows=True), cache=c)
-        p = v = None
-        from checkers_mcts_amd import rules
-        for step in range(100000):
-            salt = 5 if step < 300 else 6                                    # the network changes after 300 steps
-            if step == 300 and c is not None:
-                torch.cuda.synchronize()
-                for _ in range(flushes):
-                    e.cache_flush()
-            e.step(p, v)
-            p, v = rules.hashnet(e.x, salt)
-            if step % 64 == 63 and e.stats()["active_slots"] == 0:
-                break
+    # a job played with network A fills a table; after the flush a second job -- the same games, network B -- attached to the SAME
+    # table must see B's evaluations only: its tuples equal those of the cache-less run.  Negative control: without the flush it is
+    # served A's records and plays differently.
+    def job(salt, c):
+        e = E.Engine(E.config_from_kwargs(kw, n_slots=8, games_per_slot=2, terminate_cnt=60, seed=1, dense_rows=c is not None), cache=c)
+        e.run(E.hashnet_evaluator(salt))
         raw, st = sorted_tuples(e), e.stats()
         e.close()
-        if c is not None:
-            c.close()
         return raw, st
-    plain, _ = run(False, 0)
-    for flushes in (1, 1030):                                                # 1 030 > the 512 generations the old scheme could tell apart
-        got, st = run(True, flushes)
-        assert got.tobytes() == plain.tobytes() and st["dup_leaves"] > 0
+    plain_b, _ = job(6, None)
+    for flushes in (0, 1, 1030):                                             # 1 030 > the 512 generations the old scheme could tell apart
+        c = E.LeafCache(12, 0)
+        job(5, c)
+        torch.cuda.synchronize()
+        for _ in range(flushes):
+            c.flush()
+        got, st = job(6, c)
+        c.close()
+        assert st["dup_leaves"] > 0
+        assert (got.tobytes() == plain_b.tobytes()) == (flushes > 0), flushes
     eng.close()
     cache.close()
