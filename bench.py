@@ -60,8 +60,9 @@ HBM_PEAK_GBS = 8000.0
 # per-dispatch means; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), keyed by boards per launch: see
 # profiles/README.md.  Not re-measured by this script; launches of another size are scaled from the nearest entry.
 PMC_TRAFFIC = {
-    "fp32": {4096: (2 * 92311.8 + 9216.0) * 1024.0, 2048: (2 * 41613.4 + 4608.0) * 1024.0,
-             "source": "profiles/r03_pmc_conv_4096_boards.csv / r03_pmc_conv_2048_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
+    "fp32": {4096: (2 * 56562.1 + 9216.0) * 1024.0, 2048: (2 * 30849.8 + 4608.0) * 1024.0,
+             "source": "profiles/r04_pmc_conv_4096_boards.csv / r04_pmc_conv_2048_boards.csv (2 x FETCH_SIZE + WRITE_SIZE; leaves fed as "
+                       "16-byte board records)"},
     "bf16": {4096: (2 * 15114.1 + 9216.0) * 1024.0,
              "source": "profiles/r02_pmc_conv_4096_boards.csv (2 x FETCH_SIZE + WRITE_SIZE)"},
 }
@@ -93,6 +94,9 @@ def parse():
                          "slot: slots run dry at the end of the run) instead of the default: NUM_CPUS = slots x games-per-slot workers of "
                          "one game each, hosted on the slots one after the other (virtual workers: same per-worker semantics, "
                          "training_pipeline.py:323-349, results keyed by worker id, no idle tail until the queue is empty)")
+    ap.add_argument("--planes", action="store_true",
+                    help="float32-grade mode: the tree kernel writes the 14 float32 input planes of every leaf (3 584 B) for the conv stack to "
+                         "read back, as until round 3, instead of the leaf's 16-byte board record from which the conv stack builds them in LDS")
     ap.add_argument("--park", action="store_true",
                     help="leaf_cache_park: a leaf whose position is being evaluated for another slot right now waits for that evaluation")
     ap.add_argument("--no-complete", action="store_true", help="skip leg 3 (play the run to its end; M2)")
@@ -296,23 +300,25 @@ class Leg:
     def __init__(self, a, dev, mode, first_worker, n_workers, games_per_worker, split, cache_log2=None):
         from checkers_mcts_amd import engine as ckengine
         from checkers_mcts_amd.net import NetEvaluator, make_net
-        from checkers_mcts_amd.pipeline import SplitRunner, StepRunner, make_leaf_cache
+        from checkers_mcts_amd.pipeline import SplitRunner, StepRunner, make_leaf_cache, split_parts
         dtype = DTYPES[mode]
         kw = dict(MCTS_KWARGS, BUDGET=a.budget)
         self.which = a.evaluator or ("fused" if mode in ("bf16", "fp32") else "torch")
         if self.which == "fused" and mode not in ("bf16", "fp32"):
             raise SystemExit("--evaluator fused needs --nn-dtype bf16 or fp32")
         self.cache_log2 = cache_log2_of(a, dev) if cache_log2 is None else cache_log2
-        self.cache = make_leaf_cache(self.cache_log2, dev, n_engines=2 if split else 1)
+        self.cache = make_leaf_cache(self.cache_log2, dev, n_engines=max(2, split_parts(a.slots)) if split else 1)
+        # float32-grade kernels: the engines hand out 16-byte board records, the conv stack builds the planes in LDS
+        fdt = ckengine.BOARDS if (self.which == "fused" and mode == "fp32" and not a.planes) else dtype
 
         def make_engine(offset, workers, n):
             cfg = ckengine.config_from_kwargs(kw, n_slots=n, n_workers=workers, games_per_slot=games_per_worker, terminate_cnt=TERMINATE_CNT,
-                                              first_worker_id=first_worker + offset, feature_dtype=dtype, seed=20260929,
+                                              first_worker_id=first_worker + offset, feature_dtype=fdt, seed=20260929,
                                               device=dev.index, nodes_per_tree=a.nodes_per_tree or None,
                                               leaf_cache_log2=0, dense_rows=not a.no_dense_rows,
                                               dynamic_queue=a.dynamic_queue, leaf_cache_park=a.park,
                                               **({"max_sims_per_step": a.max_sims_per_step} if a.max_sims_per_step else {}))
-            return ckengine.Engine(cfg, feature_dtype=dtype, cache=self.cache)
+            return ckengine.Engine(cfg, cache=self.cache)
 
         def make_evaluator(n):
             if self.which == "fused":
@@ -323,7 +329,7 @@ class Leg:
 
         self.dev, self.split = dev, bool(split)
         if split:
-            self.runner = SplitRunner(make_engine, make_evaluator, n_workers, use_graph=not a.no_graph, n_slots=a.slots)
+            self.runner = SplitRunner(make_engine, make_evaluator, n_workers, use_graph=not a.no_graph, n_slots=a.slots, n_parts=max(2, split_parts(a.slots)))
             self.engines = self.runner.engines
             self.evaluators = [r.evaluator for _, r, _ in self.runner.parts]
         else:
@@ -447,11 +453,11 @@ def arena_leg(a, dev):
     from checkers_mcts_amd.net import make_net
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=torch.float32,
+    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=ckengine.BOARDS,
                                       seed=20260929, device=dev.index, dynamic_queue=True,
                                       leaf_cache_log2=cache_log2_of(a, dev),
                                       dense_rows=not a.no_dense_rows)
-    eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
+    eng = ckengine.Engine(cfg)
     ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
                         net_old=make_net(128, seed=1, device=dev, dtype=torch.float32), mode="f16x3")
     runner = StepRunner(eng, ev, use_graph=not a.no_graph)
@@ -479,9 +485,9 @@ def single_game_leg(a, dev):
     from checkers_mcts_amd.net import make_net
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(MCTS_KWARGS, BUDGET=400, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=1, games_per_slot=64, terminate_cnt=TERMINATE_CNT, feature_dtype=torch.float32,
+    cfg = ckengine.config_from_kwargs(kw, n_slots=1, games_per_slot=64, terminate_cnt=TERMINATE_CNT, feature_dtype=ckengine.BOARDS,
                                       seed=20260929, device=dev.index, leaf_cache_log2=20, dense_rows=True)
-    eng = ckengine.Engine(cfg, feature_dtype=torch.float32)
+    eng = ckengine.Engine(cfg)
     runner = StepRunner(eng, FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), 1, mode="f16x3"), use_graph=not a.no_graph)
     runner.warmup(3)
     runner.step(500)
@@ -815,7 +821,7 @@ def main():
                                          "cached priors / v; results identical with and without; value without it: extra.cache_off" % cache_log2)
                                         if cache_log2 else "off",
                           "leaf_cache_log2": cache_log2, "ranks_per_device": ckdist.ranks_per_device(),
-                          "streams": "2 half-batches of %d slots on 2 HIP streams" % nb if n_parts > 1 else "1",
+                          "streams": "%d part-batches of %d slots on %d HIP streams" % (n_parts, nb, n_parts) if n_parts > 1 else "1",
                           "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
                "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py; Keras's own arithmetic unpinned: TensorFlow "
                          "is absent); rules, search, tuples "

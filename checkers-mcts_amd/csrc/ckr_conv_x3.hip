@@ -30,6 +30,7 @@
 // buffer_load ... lds and one s_barrier per k-chunk; the barrier + DMA issue cost 9 % of the
 // kernel, its epilogues another 7 % with the matrix pipe idle.)
 #include "ckr_host.h"
+#include "ckr_device.hip.h"
 #include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -68,6 +69,7 @@ struct LayerDev {
     float* out;                // optional [B,8,8,128] float32 (activation * XS)
 };
 struct Args {
+    const uint4* xb;           // [B] 16-byte board records (ckr_board): the 14 input planes are built in LDS from them; or NULL and
     const float* x;            // [B,8,8,14] float32 NHWC
     const uint4* w;            // the whole network's weight stream: layer 0 = 9 slots (one per tap, 14 planes in one
                                // 16-channel slice), then 72 per layer (tap * 8 + slice), + RING - 1 slots of padding
@@ -305,14 +307,38 @@ __device__ __forceinline__ void conv_stack_body(const Args& A, char* smem) {
     const long long brd = board0 + (tid >> 6);
     const bool in_range = !A.range || (brd >= A.range[0] && brd < A.range[1]);
     if (tid < rows_valid && in_range) {                           // 14 float32 planes per position -> hi / lo, k-slots 0 and 1
-        const float2* src = reinterpret_cast<const float2*>(A.x + (board0 * 64 + tid) * 14);
         _Float16 h[16], lo[16];
         float amax = 0.0f;
+        if (A.xb) {
+            // the leaf arrives as its 16-byte board record; planes 0-13 (Checkers.py:431-432: men / kings of both players, side to
+            // move, draw counter k / 80, the eight legal-action masks) are what ckr_wave_ops.hip.h's wave_features writes for the
+            // same record -- the same float32 values, so the same hi / lo terms -- computed here per position instead of being
+            // written to HBM by the tree kernel and read back (3 584 B per leaf each way)
+            const uint4 q = A.xb[brd];
+            const ckr_board b{q.x, q.y, q.z, q.w};
+            uint32_t m[8], st;
+            ckr::movegen(b, m, st);
+            const int cell = tid & 63, cx = cell >> 3, cy = cell & 7;
+            const uint32_t bit = ((cx ^ cy) & 1) ? (1u << (cell >> 1)) : 0u;
+            float pl[14];
+            pl[0] = (b.p1 & ~b.kings & bit) ? 1.0f : 0.0f;
+            pl[1] = (b.p1 & b.kings & bit) ? 1.0f : 0.0f;
+            pl[2] = (b.p2 & ~b.kings & bit) ? 1.0f : 0.0f;
+            pl[3] = (b.p2 & b.kings & bit) ? 1.0f : 0.0f;
+            pl[4] = (float)(b.meta & 1u);
+            pl[5] = (float)((double)ckr::st_drawk(st) / 80.0);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const float2 v = src[j];
-            split1(v.x * A.xs, h[2 * j], lo[2 * j], amax);
-            split1(v.y * A.xs, h[2 * j + 1], lo[2 * j + 1], amax);
+            for (int d = 0; d < 8; ++d) pl[6 + d] = (m[d] & bit) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 14; ++j) split1(pl[j] * A.xs, h[j], lo[j], amax);
+        } else {
+            const float2* src = reinterpret_cast<const float2*>(A.x + (board0 * 64 + tid) * 14);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float2 v = src[j];
+                split1(v.x * A.xs, h[2 * j], lo[2 * j], amax);
+                split1(v.y * A.xs, h[2 * j + 1], lo[2 * j + 1], amax);
+            }
         }
         h[14] = h[15] = lo[14] = lo[15] = (_Float16)0.0f;
         f16x8 v0, v1, w0, w1;
@@ -360,17 +386,33 @@ __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_small(const Args A) {
 
 using namespace ckrx;
 
+static int conv_stack_f16x3(const float* d_x, const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
+                            const ckr_conv_heads* heads, float x_scale, const float* act_scales,
+                            const int32_t* d_board_range, int32_t* d_overflow, void* stream);
+
 extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
                                     const ckr_conv_heads* heads, float x_scale, const float* act_scales,
                                     const int32_t* d_board_range, int32_t* d_overflow, void* stream) {
+    return conv_stack_f16x3(d_x, nullptr, n_boards, layers, n_layers, heads, x_scale, act_scales, d_board_range, d_overflow, stream);
+}
+
+extern "C" int ckr_conv_stack_f16x3_boards(const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
+                                           const ckr_conv_heads* heads, float x_scale, const float* act_scales,
+                                           const int32_t* d_board_range, int32_t* d_overflow, void* stream) {
+    return conv_stack_f16x3(nullptr, d_boards, n_boards, layers, n_layers, heads, x_scale, act_scales, d_board_range, d_overflow, stream);
+}
+
+static int conv_stack_f16x3(const float* d_x, const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
+                            const ckr_conv_heads* heads, float x_scale, const float* act_scales,
+                            const int32_t* d_board_range, int32_t* d_overflow, void* stream) {
     if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: bad n_boards / n_layers");
     if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: x_scale must be positive");
     if (int rc = ckr::require_device()) return rc;
     if (n_boards == 0) return CKR_OK;
-    if (!d_x) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
+    if (!d_x && !d_boards) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
     Args A;
-    A.x = d_x; A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale;
+    A.x = d_x; A.xb = reinterpret_cast<const uint4*>(d_boards); A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale;
     // the scale of each layer's stored output (folded into its bias / scale / shift by the host) matters to the kernel only
     // where float32 values leave the stack: the two 1x1 head convolutions
     for (int i = 0; act_scales && i < n_layers; ++i)
@@ -406,15 +448,21 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
     A.w = (const uint4*)layers[0].weights;
     A.w_bytes = (long long)(expect - (const char*)layers[0].weights) + (long long)(RING - 1) * SLOT_BYTES;
     // n_boards <= SMALL_BOARDS: the single-board kernel (callers that know only few rows of a larger batch are in use -- the
-    // tail of a run -- pass that bound as n_boards).  CKR_X3_SMALL=0 keeps everything on the two-board kernel.
+    // tail of a run -- pass that bound as n_boards).  (-DCKR_EXPERIMENTS builds: CKR_X3_SMALL=0 keeps everything on the two-board kernel.)
     // (Launching both and letting the device range decide which computes was measured: the idle launch costs 7 us per step.)
+#ifdef CKR_EXPERIMENTS
     static const bool small_ok = !(getenv("CKR_X3_SMALL") && getenv("CKR_X3_SMALL")[0] == '0');
     static const bool small_all = getenv("CKR_X3_SMALL") && !strcmp(getenv("CKR_X3_SMALL"), "all");      // experiment: every launch on the single-board kernel
+#else
+    constexpr bool small_ok = true, small_all = false;
+#endif
     const bool small_only = small_ok && (n_boards <= SMALL_BOARDS || small_all);
     const int grid = (int)((n_boards + 1) / 2);
     // Kernel experiments (tools/slp_probe.py): CKR_X3_CODE_OBJECT names a gfx950 code object whose k_conv_stack_x3 -- the same
     // source built with other compiler flags, or its assembly with instructions inserted -- is launched instead of the
-    // linked kernel.  Unset in production.
+    // linked kernel.  Compiled in only with -DCKR_EXPERIMENTS (tools/slp_probe.py builds its own library): release builds read no
+    // code from the environment.
+#ifdef CKR_EXPERIMENTS
     static hipFunction_t alt = nullptr;
     static bool alt_tried = false;
     if (!alt_tried) {
@@ -431,6 +479,7 @@ extern "C" int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ck
         CKR_HIP(hipModuleLaunchKernel(alt, (unsigned)grid, 1, 1, NT, 1, 1, 0, (hipStream_t)stream, nullptr, cfg));
         return CKR_OK;
     }
+#endif
     if (small_only) hipLaunchKernelGGL(k_conv_stack_x3_small, dim3((unsigned)n_boards), dim3(NT), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     CKR_HIP(hipGetLastError());

@@ -1238,7 +1238,10 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
         D.leaves[slot] = leaf >= 0 ? make_uint4(lb.p1, lb.p2, lb.kings, lb.meta) : make_uint4(0u, 0u, 0u, 0u);
         if (net_out && (leaf >= 0 || !D.dense_rows)) net_out[out_row] = leaf >= 0 ? net : -1;   // dense: idle rows preset to -1
     }
-    if (leaf >= 0) write_features(w, lb, x, out_row);
+    if (leaf >= 0) {
+        if (D.feature_dtype == 3) { if (w.lane == 0) reinterpret_cast<uint4*>(x)[out_row] = make_uint4(lb.p1, lb.p2, lb.kings, lb.meta); }   // the consumer builds the planes
+        else write_features(w, lb, x, out_row);
+    }
     flush_counters(w);
 }
 
@@ -1558,7 +1561,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
                                                     "'time' pass INT32_MAX and end the plies with ckr_engine_step_end_ply");
     if (!c->tournament && !c->manual_play && c->terminate_cnt <= 0) return fail(CKR_ERR_INVALID, "self-play needs TERMINATE_CNT > 0");
     if (c->nodes_per_tree < 256 || c->nodes_per_tree >= (1 << 24)) return fail(CKR_ERR_INVALID, "nodes_per_tree must be in [256, 2^24)");
-    if (c->feature_dtype < 0 || c->feature_dtype > 2) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1 or 2");
+    if (c->feature_dtype < 0 || c->feature_dtype > 3) return fail(CKR_ERR_INVALID, "feature_dtype must be 0, 1, 2 (planes) or 3 (board records)");
     if (c->alpha <= 0.0 && c->epsilon != 0.0) return fail(CKR_ERR_INVALID, "DIRICHLET_ALPHA must be > 0");
     if (c->game != 0 && c->game != 1) return fail(CKR_ERR_INVALID, "game must be 0 (Checkers) or 1 (Tic-Tac-Toe)");
     if (c->w_accum != 0 && c->w_accum != 1) return fail(CKR_ERR_INVALID, "w_accum must be 0 (float32) or 1 (float64)");
@@ -1582,8 +1585,10 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.record_root = c->record_root_stats; D.manual = c->manual_play; D.dynamic = c->dynamic_queue;
     D.tail_sims = c->max_sims_per_step > 0 || !c->neural_net ? 0 : 4;
     D.tail_shift = 1;                                             // tail = at most n_slots >> 1 slots still play
-    if (const char* t = getenv("CKR_TAIL_SIMS")) D.tail_sims = D.tail_sims ? atoi(t) : 0;      // tuning experiments (profiles/r03_tail_sweep.txt)
+#ifdef CKR_EXPERIMENTS                                             // tuning knobs of profiles/r03_tail_sweep.txt: not in release builds
+    if (const char* t = getenv("CKR_TAIL_SIMS")) D.tail_sims = D.tail_sims ? atoi(t) : 0;
     if (const char* t = getenv("CKR_TAIL_SHIFT")) D.tail_shift = atoi(t);
+#endif
     D.n_workers = c->n_workers > 0 ? c->n_workers : c->n_slots;
     D.total_games = D.n_workers * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;

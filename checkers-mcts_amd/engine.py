@@ -13,7 +13,8 @@ import torch
 
 from . import _lib
 
-FEATURE_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+BOARDS = "boards"                  # feature "dtype" of an engine that hands its leaves out as 16-byte board records (ckr_config.feature_dtype = 3)
+FEATURE_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, BOARDS: 3}
 
 GAMES = {"checkers": 0, "tictactoe": 1}
 W_ACCUM = {"float32": 0, "float64": 1}
@@ -156,8 +157,12 @@ class Engine:
         self._h = h
         S = cfg.n_slots
         self.feature_dtype = feature_dtype
-        # NHWC network input written by the engine; channels-last view for torch
-        self.x = torch.zeros((S, 8, 8, 14), dtype=feature_dtype, device=self.device)
+        # what the engine writes per leaf: the NHWC network input (channels-last view for torch), or -- feature_dtype BOARDS -- the
+        # leaf's 16-byte board record, from which fused.FusedEvaluator's float32-grade conv stack builds the planes in LDS
+        feature_dtype = {v: k for k, v in FEATURE_DTYPES.items()}[cfg.feature_dtype]
+        self.leaf_records = feature_dtype == BOARDS
+        self.x = (torch.zeros((S, 4), dtype=torch.int32, device=self.device) if self.leaf_records else
+                  torch.zeros((S, 8, 8, 14), dtype=feature_dtype, device=self.device))
         self.net_id = torch.full((S,), -1, dtype=torch.int32, device=self.device)
         # board range of the network batch: [0, S) until compact_rows() moves the active slots to the front
         self.row_range = torch.tensor([0, S], dtype=torch.int32, device=self.device)
@@ -188,6 +193,8 @@ class Engine:
     @property
     def x_nchw(self):
         """Zero-copy [S,14,8,8] view with channels-last strides."""
+        if self.leaf_records:
+            raise ValueError("this engine hands out board records (feature_dtype BOARDS): there are no planes to view")
         return self.x.permute(0, 3, 1, 2)
 
     def step(self, p=None, v=None, end_ply=False):
@@ -382,7 +389,7 @@ def hashnet_evaluator(salt_new=0, salt_old=None, inexact=False):
     from . import rules
 
     def ev(engine):
-        x = engine.x if engine.x.dtype == torch.float32 else engine.x.float()
+        x = rules.features(engine.x) if engine.leaf_records else (engine.x if engine.x.dtype == torch.float32 else engine.x.float())
         p, v = rules.hashnet(x, salt_new, inexact)
         if salt_old is not None:
             p2, v2 = rules.hashnet(x, salt_old, inexact)

@@ -170,6 +170,7 @@ class FusedEvaluator:
         self._L.ckr_conv_stack_bf16.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads), vp, vp]
         self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
                                                  C.c_float, vp, vp, vp, vp]
+        self._L.ckr_conv_stack_f16x3_boards.argtypes = self._L.ckr_conv_stack_f16x3.argtypes
         self.overflow = None
         self.row_cap = None                     # set_row_cap()
         self.timing = None                      # a list: every forward appends (event before, event after) its conv-stack launch (bench.py)
@@ -281,8 +282,10 @@ class FusedEvaluator:
     def _conv(self, n, x, stream, board_range=None):
         rng = board_range.data_ptr() if board_range is not None else None
         if self.mode == "f16x3":
-            _lib.check(self._L.ckr_conv_stack_f16x3(x.data_ptr(), self._rows(n), n["layers"], n["n"], C.byref(n["heads"]), XS, n["xs_arr"], rng,
-                                                    self._overflow_ptr(x.device), stream))
+            # x: float32 planes [S,8,8,14], or the leaves' 16-byte board records int32 [S,4] (the kernel builds the planes in LDS)
+            fn = self._L.ckr_conv_stack_f16x3_boards if x.dtype == torch.int32 else self._L.ckr_conv_stack_f16x3
+            _lib.check(fn(x.data_ptr(), self._rows(n), n["layers"], n["n"], C.byref(n["heads"]), XS, n["xs_arr"], rng,
+                          self._overflow_ptr(x.device), stream))
         else:
             _lib.check(self._L.ckr_conv_stack_bf16(x.data_ptr(), self._rows(n), n["layers"], n["n"], C.byref(n["heads"]), rng, stream))
 
@@ -307,9 +310,10 @@ class FusedEvaluator:
     @torch.no_grad()
     def __call__(self, engine):
         x = engine.x
-        if x.dtype != (torch.bfloat16 if self.mode == "bf16" else torch.float32):
+        if not ((self.mode == "f16x3" and getattr(engine, "leaf_records", False)) or
+                x.dtype == (torch.bfloat16 if self.mode == "bf16" else torch.float32)):
             raise ValueError("FusedEvaluator(%s) needs the engine's features in %s" %
-                             (self.mode, "float32" if self.mode == "f16x3" else "bfloat16"))
+                             (self.mode, "float32 planes or as board records" if self.mode == "f16x3" else "bfloat16"))
         if len(self.nets) == 1:                      # engine.row_range: active rows after Engine.compact_rows()
             return self._forward(self.nets[0], x, engine.row_range)
         # Arena: every leaf belongs to exactly one of the two networks.  Sort the batch by network id
@@ -343,6 +347,12 @@ class FusedEvaluator:
                                 "last check are invalid" % (self.nets[0]["act_scales"],))
 
     CONV_FLOPS_PER_BOARD = 2 * (64 * 9 * 14 * 128 + 7 * 64 * 9 * 128 * 128)      # the 8 convs of the stack
+
+    @property
+    def feature_dtype(self):
+        """What an engine driven by this evaluator should hand out per leaf (engine.config_from_kwargs(feature_dtype=...))."""
+        from .engine import BOARDS
+        return BOARDS if self.mode == "f16x3" else torch.bfloat16
 
     def conv_only(self, x_bf16):
         """Launch just the conv-stack kernel (bench.py times it with HIP events)."""

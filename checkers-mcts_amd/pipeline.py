@@ -84,30 +84,45 @@ def load_network(spec, device="cuda", dtype=torch.float32, num_kernels=128, netw
     raise ValueError("unsupported network specification: %r" % (spec,))
 
 
+class EvaluatorPlan:
+    """The networks of a job, loaded once, and the evaluator kind that will run them: `.feature_dtype` is what the job's engines
+    hand out per leaf (engine.config_from_kwargs(feature_dtype=...): board records for the float32-grade kernels, which build the
+    planes themselves; planes of the network's dtype otherwise), `.build(n_slots)` makes the evaluator of one engine.
+
+    The hand-written MFMA conv stack (fused.FusedEvaluator, weights taken from the float32 network) serves bfloat16 (throughput
+    mode, bf16 operands) and float32 (split-fp16 operands with float32 accumulation: float32-grade results, the parity mode);
+    float16, or kind="torch", runs the PyTorch module instead."""
+
+    def __init__(self, spec, device, dtype, spec_old=None, kind=None, networks=None):
+        if kind not in (None, "fused", "torch"):
+            raise ValueError("evaluator kind must be 'fused' or 'torch'")
+        if networks:
+            spec = networks.get(spec, spec) if isinstance(spec, str) else spec
+            spec_old = networks.get(spec_old, spec_old) if isinstance(spec_old, str) else spec_old
+        # every file is read once: the networks are loaded in float32 and their width is looked up on the loaded modules
+        want_fused = kind != "torch" and dtype in (torch.bfloat16, torch.float32)
+        first = torch.float32 if want_fused else dtype
+        self.new = load_network(spec, device=device, dtype=first)
+        self.old = load_network(spec_old, device=device, dtype=first) if spec_old is not None else None
+        self.fused = want_fused and _is_128_wide(self.new, self.old)
+        self.mode = "bf16" if dtype == torch.bfloat16 else "f16x3"
+        if kind == "fused" and not self.fused:
+            raise ValueError("the fused conv stack needs NN_DTYPE bfloat16 or float32 and a 128-kernel network")
+        if not self.fused and first != dtype:
+            self.new = load_network(self.new, device=device, dtype=dtype)
+            self.old = load_network(self.old, device=device, dtype=dtype) if self.old is not None else None
+        self.feature_dtype = (ckengine.BOARDS if self.mode == "f16x3" else torch.bfloat16) if self.fused else dtype
+
+    def build(self, n_slots):
+        if self.fused:
+            from .fused import FusedEvaluator
+            return FusedEvaluator(self.new, n_slots, net_old=self.old, mode=self.mode)
+        return NetEvaluator(self.new, self.old)
+
+
 def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None, networks=None):
-    """Evaluator for the engine.  The hand-written MFMA conv stack (fused.FusedEvaluator,
-    weights taken from the float32 network) serves bfloat16 (throughput mode, bf16 operands)
-    and float32 (split-fp16 operands with float32 accumulation: float32-grade results, the
-    parity mode); float16, or kind="torch", runs the PyTorch module instead."""
-    if kind not in (None, "fused", "torch"):
-        raise ValueError("evaluator kind must be 'fused' or 'torch'")
-    if networks:
-        spec = networks.get(spec, spec) if isinstance(spec, str) else spec
-        spec_old = networks.get(spec_old, spec_old) if isinstance(spec_old, str) else spec_old
-    # every file is read once: the networks are loaded in float32 and their width is looked up on the loaded modules
-    want_fused = kind != "torch" and dtype in (torch.bfloat16, torch.float32)
-    first = torch.float32 if want_fused else dtype
-    new = load_network(spec, device=device, dtype=first)
-    old = load_network(spec_old, device=device, dtype=first) if spec_old is not None else None
-    if want_fused and _is_128_wide(new, old):
-        from .fused import FusedEvaluator
-        return FusedEvaluator(new, n_slots, net_old=old, mode="bf16" if dtype == torch.bfloat16 else "f16x3")
-    if kind == "fused":
-        raise ValueError("the fused conv stack needs NN_DTYPE bfloat16 or float32 and a 128-kernel network")
-    if first != dtype:
-        new = load_network(new, device=device, dtype=dtype)
-        old = load_network(old, device=device, dtype=dtype) if old is not None else None
-    return NetEvaluator(new, old)
+    """Evaluator for one engine of n_slots (see EvaluatorPlan); accepts planes or board records from the engine."""
+    return EvaluatorPlan(spec, device, dtype, spec_old=spec_old, kind=kind, networks=networks).build(n_slots)
 
 
 def _is_128_wide(*specs):
@@ -250,13 +265,24 @@ class StepRunner:
                 rows = self.eng.compact_rows(self.p, self.v)
 
 
-SPLIT_MIN_SLOTS = 1024          # a half-batch below 1 024 leaves (2 per CU-resident conv workgroup) no longer fills 256 CUs
+SPLIT_MIN_SLOTS = 1024          # a part below 1 024 slots (2 per CU-resident conv workgroup) no longer fills 256 CUs
+
+
+def split_parts(n_slots):
+    """Into how many engines / HIP streams SplitRunner divides n_slots concurrent games: 1 below 2 048 slots, 2, and 3 from 3 072
+    slots on.  Measured on cfg3 (4 096 slots) with ONE leaf cache shared by the parts: 2 parts 6.51-6.81 M expansions/s, 3 parts
+    6.75-7.00 M (+3 %), 4 parts 5.87 M (profiles/r04_split_parts.txt; round 3, with a private cache per part: 3 parts -1.4 %).
+    CKR_SPLIT_PARTS overrides."""
+    forced = os.environ.get("CKR_SPLIT_PARTS")
+    if forced:
+        return max(1, int(forced))
+    return max(1, min(3, int(n_slots) // SPLIT_MIN_SLOTS))
 
 
 class SplitRunner:
-    """Two half-batches on two HIP streams: the slots of a job are divided between two engines (contiguous worker-id
-    blocks -- results do not depend on the division, see dist.py) that step independently, each with its own HIP
-    graph on its own stream.  While one half's leaves are in the conv stack (matrix pipe), the other half's tree
+    """Part-batches on their own HIP streams: the slots of a job are divided between two or three engines (split_parts;
+    contiguous worker-id blocks -- results do not depend on the division, see dist.py) that step independently, each with its own
+    HIP graph on its own stream.  While one half's leaves are in the conv stack (matrix pipe), the other half's tree
     kernel and head kernels (latency-bound, a few % of the chip) run beside it instead of in front of it: the step's
     serial chain tree -> network -> tree is hidden behind the other half's network time.
 
@@ -266,8 +292,8 @@ class SplitRunner:
     half is served to the other."""
 
     def __init__(self, make_engine, make_evaluator, n_workers, use_graph=True, device=None, n_parts=None, n_slots=None):
-        n_parts = int(n_parts or os.environ.get("CKR_SPLIT_PARTS", 2))      # 2 measured best (3: -1.4 %, 4: -16 %; profiles/r03_split_parts.txt)
         n_slots = min(int(n_slots or n_workers), int(n_workers))
+        n_parts = int(n_parts or split_parts(n_slots))
         wb = [n_workers * i // n_parts for i in range(n_parts + 1)]
         sb = [n_slots * i // n_parts for i in range(n_parts + 1)]
         self.parts = []
@@ -475,17 +501,19 @@ class generate_Checkers_data:
         neural = bool(self.mcts_kwargs["NEURAL_NET"])
         timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
         slots = count if (self.dynamic_queue or timed or not self.slots) else min(count, int(self.slots))
-        split = (neural and self.split_streams and slots >= 2 * SPLIT_MIN_SLOTS and not self.dynamic_queue and not timed)
+        split = (neural and self.split_streams and split_parts(slots) >= 2 and not self.dynamic_queue and not timed)
         log2 = (default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)) if neural else 0
-        cache = make_leaf_cache(log2, dev, n_engines=2 if split else 1)
+        cache = make_leaf_cache(log2, dev, n_engines=split_parts(slots) if split else 1)
+        plan = EvaluatorPlan(self.nn_fn, dev, self.nn_dtype, kind=kind, networks=self.networks) if neural else None
+        fdt = plan.feature_dtype if neural else self.nn_dtype
 
         def make_engine(offset, workers, n):
             cfg = ckengine.config_from_kwargs(
                 self.mcts_kwargs, n_slots=n, n_workers=workers, games_per_slot=self.NUM_SELFPLAY_GAMES,
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree,
-                feature_dtype=self.nn_dtype, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue,
+                feature_dtype=fdt, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue,
                 leaf_cache_log2=0, dense_rows=bool(self.dense_rows) and neural)
-            return ckengine.Engine(cfg, feature_dtype=self.nn_dtype, cache=cache)
+            return ckengine.Engine(cfg, cache=cache)
 
         if not neural:                             # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
             eng = make_engine(0, count, slots)
@@ -493,8 +521,7 @@ class generate_Checkers_data:
             eng.run_rollouts(time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             engines = [eng]
         elif split:
-            runner = SplitRunner(make_engine, lambda n: make_evaluator(self.nn_fn, dev, self.nn_dtype, n, kind=kind, networks=self.networks),
-                                 count, use_graph=self.use_graph, n_slots=slots)
+            runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots)
             try:
                 runner.run_to_completion()
             except OverflowError:
@@ -503,8 +530,7 @@ class generate_Checkers_data:
             engines = runner.engines
         else:
             eng = make_engine(0, count, slots)
-            runner = StepRunner(eng, make_evaluator(self.nn_fn, dev, self.nn_dtype, slots, kind=kind, networks=self.networks),
-                                use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
+            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             try:
                 runner.run_to_completion()
             except OverflowError:
@@ -581,15 +607,14 @@ class tournament_Checkers:
         if count > 0:
             timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
             slots = count if (timed or not self.slots) else min(count, int(self.slots))
+            plan = EvaluatorPlan(self.nn1_fn, dev, self.nn_dtype, spec_old=self.nn2_fn, networks=self.networks)
             cfg = ckengine.config_from_kwargs(
                 self.mcts_kwargs, n_slots=slots, n_workers=count, games_per_slot=self.NUM_GAMES, tournament=True,
-                first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=self.nn_dtype,
+                first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=plan.feature_dtype,
                 seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
             cache = make_leaf_cache(default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2), dev)
-            eng = ckengine.Engine(cfg, feature_dtype=self.nn_dtype, cache=cache)
-            runner = StepRunner(eng, make_evaluator(self.nn1_fn, dev, self.nn_dtype, slots, spec_old=self.nn2_fn,
-                                                    networks=self.networks), use_graph=self.use_graph,
-                                time_budget=ckengine.time_budget_of(self.mcts_kwargs))
+            eng = ckengine.Engine(cfg, cache=cache)
+            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
             runner.run_to_completion()
             self.stats = eng.stats()
             _warn_pool_overflows(self.stats, "tournament")

@@ -166,6 +166,12 @@ int ckr_conv_stack_bf16(const void* d_x, int64_t n_boards, const ckr_conv_layer*
 int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_layer* layers,
                          int32_t n_layers, const ckr_conv_heads* heads, float x_scale, const float* act_scales,
                          const int32_t* d_board_range, int32_t* d_overflow, void* stream);
+/* The same, fed with the leaves' 16-byte board records instead of their 14 float32 planes (ckr_config.feature_dtype = 3: the tree
+ * kernel then writes 16 B per leaf and this kernel builds planes 0-13 in LDS -- Checkers.predict's input construction,
+ * Checkers.py:431-432, fused into the first convolution; identical results). */
+int ckr_conv_stack_f16x3_boards(const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers,
+                         int32_t n_layers, const ckr_conv_heads* heads, float x_scale, const float* act_scales,
+                         const int32_t* d_board_range, int32_t* d_overflow, void* stream);
 
 /* Arena batches (tournament_Checkers swaps game_env.neural_net per side, training_pipeline.py:
  * 529,536,546): every leaf belongs to one of two networks.  ckr_arena_partition sorts the batch
@@ -221,7 +227,8 @@ typedef struct {
     double   tau, tau_decay;     /* TEMPERATURE_TAU, TEMPERATURE_DECAY */
     int32_t  reset_tau_each_game;/* 0 = reference behaviour: tau is per worker, never reset (Q18) */
     int32_t  nodes_per_tree;     /* semispace capacity of one search tree */
-    int32_t  feature_dtype;      /* 0 float32, 1 float16, 2 bfloat16 */
+    int32_t  feature_dtype;      /* what ckr_engine_step writes per leaf into d_x: 0 float32, 1 float16, 2 bfloat16 planes [8][8][14];
+                                    3: the 16-byte board record (ckr_board), for ckr_conv_stack_f16x3_boards */
     int32_t  max_sims_per_step;  /* cap on NN-free simulations (terminal visits) a slot runs back to back in one step before it
                                     hands out a leaf; results do not depend on it (<= 0: the measured throughput optimum -- 4, or 2 with the
                                     leaf cache, whose hits are network-free simulations too -- and 4 once half of the slots have played

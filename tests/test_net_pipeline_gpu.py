@@ -411,3 +411,38 @@ def test_dense_rows_network_ids_match_leaf_count_in_graph_mode():
             counts.append(count)
     assert max(counts) == S and min(counts[5:]) < S                       # full batches, then slots running dry
     eng.close()
+
+
+def test_conv_stack_fed_with_board_records_gives_the_planes_bits():
+    """Round 4: an engine driven by the float32-grade kernels hands out its leaves as 16-byte board records (feature_dtype BOARDS)
+    and the conv stack builds planes 0-13 in LDS (Checkers.predict's input construction, Checkers.py:431-432, fused into the first
+    convolution) -- the same float32 plane values as ckr_features_batch writes, so pi and v are the SAME BITS as with planes: on
+    synthetic positions incl. every draw-counter value (plane 5 = k / 80 is the one plane that is not 0 / 1), ragged launch sizes
+    incl. the single-board kernel, and two full self-play jobs, one per leaf format, whose tuples are byte-identical."""
+    import torch
+    from checkers_mcts_amd import engine as E, net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import StepRunner
+    from test_engine_gpu import mk, sorted_tuples
+    m = N.PolicyValueNet(128).keras_init(3).perturb_bn(7).eval().cuda()
+    boards = _positions(3000, 41)
+    boards[:160, 3] = (boards[:160, 3] & 0x7FFFF & ~np.uint32(0x7F << 12)) | (np.arange(160, dtype=np.uint32) % 80 << 12) | np.uint32(200 << 19)   # r = 0..79, long history
+    b = rules.boards_to_device(boards)
+    x = rules.features(b).contiguous()
+    assert len(torch.unique(x[:160, 0, 0, 5])) == 80
+    for n in (3000, 257, 256, 37, 1):
+        ev = FusedEvaluator(m, n, mode="f16x3")
+        p0, v0 = (t.clone() for t in ev.forward_features(x[:n].contiguous()))
+        p1, v1 = ev.forward_features(b[:n].contiguous().view(torch.int32))
+        torch.cuda.synchronize()
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), n
+    kw = mk(40, eps=0.25, tau=1.0)
+    outs = []
+    for fdt in (torch.float32, E.BOARDS):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=96, games_per_slot=1, terminate_cnt=60, seed=9, feature_dtype=fdt, leaf_cache_log2=14,
+                                            dense_rows=True))
+        assert eng.leaf_records == (fdt == E.BOARDS) and eng.x.shape == ((96, 4) if eng.leaf_records else (96, 8, 8, 14))
+        StepRunner(eng, FusedEvaluator(m, 96, mode="f16x3")).run_to_completion()
+        outs.append((sorted_tuples(eng), eng.stats()))
+        eng.close()
+    assert outs[0][0].tobytes() == outs[1][0].tobytes() and outs[0][1]["expansions"] == outs[1][1]["expansions"] > 96 * 40

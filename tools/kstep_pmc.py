@@ -14,8 +14,9 @@ kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=100, MULTIPROC=Fa
           TRAINING=True, DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25, TEMPERATURE_TAU=1.0, TEMPERATURE_DECAY=0.1, TEMP_DECAY_DELAY=10)
 CACHE = int(os.environ.get("KSTEP_CACHE_LOG2", "0"))          # round 3: leaf cache (records = 2^CACHE) and dense rows
 DENSE = os.environ.get("KSTEP_DENSE", "0") == "1"
+BOARDS = os.environ.get("KSTEP_BOARDS", "0") == "1"              # round 4: leaves handed out as 16-byte board records
 eng = E.Engine(E.config_from_kwargs(kw, n_slots=S, games_per_slot=8, terminate_cnt=200, seed=20260929, leaf_cache_log2=CACHE,
-                                    dense_rows=DENSE))
+                                    dense_rows=DENSE, feature_dtype=E.BOARDS if BOARDS else torch.float32))
 runner = StepRunner(eng, make_evaluator("random:0", eng.device, torch.float32, S), use_graph=False)
 runner.step(STEPS)
 torch.cuda.synchronize()

@@ -17,6 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "build", "slp")
+sys.path.insert(0, ROOT)
 SRC = os.path.join(ROOT, "checkers-mcts_amd", "csrc", "ckr_conv_x3.hip")
 LLVM = "/opt/rocm/lib/llvm/bin"
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
@@ -70,6 +71,9 @@ def edit(lines, where, before=None, after=None, match=PK):
 
 def build():
     os.makedirs(OUT, exist_ok=True)
+    # the CKR_X3_CODE_OBJECT hook is compiled out of release builds of libckr.so: this probe runs against its own library
+    from checkers_mcts_amd import build as ckbuild
+    subprocess.check_call([ckbuild.HIPCC] + ckbuild.FLAGS + ["-DCKR_EXPERIMENTS"] + ckbuild.sources() + ["-o", os.path.join(OUT, "libckr_experiments.so")])
     slp = compile_asm("slp", [])
     compile_asm("noslp", ["-fno-slp-vectorize"])
     compile_asm("slp_waitcnt_forcezero", ["-mllvm", "-amdgpu-waitcnt-forcezero"])
@@ -147,7 +151,7 @@ print(json.dumps(out))
 def run():
     names = ["linked"] + sorted(f[:-3] for f in os.listdir(OUT) if f.endswith(".co"))
     for name in names:
-        env = dict(os.environ)
+        env = dict(os.environ, CKR_LIB_PATH=os.path.join(OUT, "libckr_experiments.so"))
         env.pop("CKR_X3_CODE_OBJECT", None)
         if name != "linked":
             env["CKR_X3_CODE_OBJECT"] = os.path.join(OUT, name + ".co")
