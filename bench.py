@@ -373,9 +373,13 @@ class Leg:
         return out
 
     def check_range(self):
-        for ev in self.evaluators:
-            if hasattr(ev, "check_range"):
-                ev.check_range()
+        """StepRunner.check_evaluator on every part (the float32-grade kernels' range flag: re-calibration instead of an abort)."""
+        if self.split:
+            for _, runner, stream in self.runner.parts:
+                with torch.cuda.stream(stream):
+                    runner.check_evaluator()
+        else:
+            self.runner.check_evaluator()
 
     def run_to_completion(self, trace):
         if self.split:
@@ -419,7 +423,7 @@ def timed_window(leg, dev, steps, barrier=lambda: None):
     s1 = leg.stats()
     if marked:
         s0 = leg.stats_at_mark()
-    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves", "parked")}
+    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves", "parked", "stalled_steps")}
 
 
 def throughput_leg(a, dev, mode, cache_log2=None):
@@ -830,6 +834,7 @@ def main():
                "ms_per_step_by_rank": [t / a.steps * 1e3 for t in dt_by_rank], "expansions_by_rank": exp_by_rank, "nn_evals_by_rank": nn_by_rank,
                "nn_evals": nn_total, "dup_leaves": dup_total, "duplicate_rate": dup_total / max(1.0, exp_total),
                "nn_evals_per_s": nn_total / dt, "cache_served_per_s": dup_total / dt, "parked_slot_steps": parked_total,
+               "stalled_steps_in_window": d["stalled_steps"],
                "expansions": exp_total, "terminal_visits": term_total, "plies": plies_total, "games_finished_in_window": games_window,
                "active_slots_after_window": active_after_window,
                "sims_per_s": (exp_total + term_total) / dt,

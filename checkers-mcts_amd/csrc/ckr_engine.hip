@@ -24,7 +24,7 @@ namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS,
-       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_N };
+       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_STALL, CNT_N };
 constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
 
 // ---- leaf cache: network outputs by position.  Checkers.predict is a pure function of planes 0-13 (Checkers.py:425-438),
@@ -113,6 +113,10 @@ struct Dev {
     int32_t* g_cslot;            // [slot] table index reserved for the pending leaf's record (-1: none)
     unsigned long long* g_cword; // [slot] the PENDING claim word installed there
     int32_t* g_parked;           // [slot] > 0: the pending leaf waits for another requester's evaluation (number of probes so far)
+    // evaluation flag (ckr_engine_set_eval_flag): DEVICE int32 the network kernels raise when the batch they just evaluated must not
+    // be used (an activation left the range of the float32-grade kernels' operand scales).  While it is set, a step expands
+    // nothing: every slot hands out its pending leaf again.
+    const int32_t* eval_flag;
     // virtual workers: slot -> the worker (local id in [0, n_workers)) it hosts; a slot whose worker has played its games
     // takes the next unplayed worker.  RNG streams, tau and the tuple / result regions are keyed by worker, not by slot.
     int n_workers; int32_t* g_worker; int32_t* next_worker;
@@ -1148,7 +1152,17 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     // looks it up again instead of descending
     int resume = (pending >= 0 && phase0 == PH_PLAYING && parked0 > 0) ? pending : -1;
     int park_count = resume >= 0 ? parked0 : 0;
-    if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
+    // the network's answer to the last batch is void (see Dev.eval_flag): nothing is expanded, nothing descends; a slot with a
+    // leaf at the network hands the same leaf out again (same reservation in the leaf cache), the others idle for this step
+    const bool stalled = D.eval_flag != nullptr && *D.eval_flag != 0;
+    if (stalled) {
+        if (slot == 0) w.count(CNT_STALL);
+        if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
+            leaf = pending; cslot = cslot0; cword = cword0;
+            lb = ld_board(&D.n_board[w.tbase(t0, pre.half) + pending]);
+            net = D.tournament ? (t0 == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
+        } else if (resume >= 0) parked = true;                             // still waiting: keeps its leaf
+    } else if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
         const int t = t0;
         const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
         bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
@@ -1175,7 +1189,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
     // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
     const int max_sims = D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
-    while (D.g_phase[slot] == PH_PLAYING) {
+    while (!stalled && D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
         const int sims_done = D.g_sims[slot];
         const bool out_of_time = end_ply != 0 && sims_done >= 2;         // a root with visited children exists
@@ -1764,6 +1778,15 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     return CKR_OK;
 }
 
+int ckr_engine_set_eval_flag(ckr_engine* e, const int32_t* d_flag) {
+    if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_set_eval_flag: null engine");
+    if (!e->dev.neural) return fail(CKR_ERR_STATE, "ckr_engine_set_eval_flag: NEURAL_NET engines only");
+    CKR_HIP(hipDeviceSynchronize());
+    e->dev.eval_flag = d_flag;
+    CKR_HIP(hipMemcpy(e->d_dev, &e->dev, sizeof(Dev), hipMemcpyHostToDevice));
+    return CKR_OK;
+}
+
 int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range) {
     if (!e || !d_range) return fail(CKR_ERR_INVALID, "ckr_engine_set_row_range: null argument");
     if (!e->dev.dense_rows) return fail(CKR_ERR_STATE, "ckr_engine_set_row_range needs an engine created with dense_rows = 1");
@@ -1813,7 +1836,7 @@ int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS];
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL];
     return CKR_OK;
 }
 
@@ -1831,7 +1854,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS]; out->active_slots = active;
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL];
     return CKR_OK;
 }
 

@@ -212,6 +212,12 @@ class Engine:
         _lib.check(fn(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
 
+    def set_eval_flag(self, flag):
+        """flag: DEVICE int32 tensor of one element (None: none) that the evaluator raises when its last batch must not be used; while
+        it is set, steps expand nothing and hand the same leaves out again (include/ckr.h, ckr_engine_set_eval_flag)."""
+        self._eval_flag = flag                              # keep the tensor alive
+        _lib.check(self._L.ckr_engine_set_eval_flag(self._h, flag.data_ptr() if flag is not None else None))
+
     def compact_rows(self, p, v):
         """Move the slots that are still playing to the front of the network batch (tail of a run):
         p / v (the pending network outputs) are permuted in place, `self.row_range` (device int32

@@ -67,7 +67,8 @@ def pow2_scale(amax, target=HI_TARGET):
 def calibration_boards(n, device, seed=1234):
     """n synthetic positions as 16-byte board records (uint32[n, 4]) for the one-pass range calibration of the split-fp16
     path: per side 1-12 pieces on distinct squares, men never on their promotion row, a random share of kings, random side
-    to move.  Not games: only the MAGNITUDE of the activations they cause is used, with a fourfold margin."""
+    to move, every other one late in a game with a running draw counter.  Not games: only the MAGNITUDE of the activations
+    they cause is used, with a fourfold margin; positions of real play that exceed it are handled by FusedEvaluator.recover."""
     import numpy as np
     rng = np.random.RandomState(seed)
     out = np.zeros((n, 4), np.uint32)
@@ -87,7 +88,10 @@ def calibration_boards(n, device, seed=1234):
             if king:
                 kings |= 1 << int(s_)
         stm = int(rng.randint(0, 2))
-        out[i] = (p1, p2, kings, stm | ((1 - stm) << 1) | (1 << 19))          # side, mover = the other player, history length 1
+        # half of the positions carry a long history and a draw counter r in [0, 80): plane 5 = (r + 1) / 80 over the whole board,
+        # up to 1.0 -- the one input plane that is not 0 / 1, a direction real games push and positions without history never do
+        hist, r = (1, 0) if i % 2 == 0 else (200, int(rng.randint(0, 79)))
+        out[i] = (p1, p2, kings, stm | ((1 - stm) << 1) | (r << 12) | (hist << 19))   # side, mover = the other player, r, history length
     return torch.from_numpy(out.view(np.int32)).to(device)
 
 
@@ -159,7 +163,7 @@ class FusedEvaluator:
     the device; `debug_outputs` additionally keeps the bf16 body / policy-conv
     activations in HBM (tests)."""
 
-    def __init__(self, net, n_slots, net_old=None, debug_outputs=False, mode="bf16"):
+    def __init__(self, net, n_slots, net_old=None, debug_outputs=False, mode="bf16", calib_target=None):
         """mode "bf16": ckr_conv_stack_bf16 (throughput mode, bf16 operands);
         mode "f16x3": ckr_conv_stack_f16x3 (float32-grade: split-fp16 operands, float32 features)."""
         if mode not in ("bf16", "f16x3"):
@@ -179,13 +183,17 @@ class FusedEvaluator:
         self._L.ckr_heads_tail.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp]
         self.S = n_slots
         self.debug = debug_outputs
-        self.nets = [self._prepare(net)]
-        if net_old is not None:
-            self.nets.append(self._prepare(net_old))
+        self.calib_target = float(calib_target or HI_TARGET)     # (tests pass a target beyond the fp16 range to provoke recover())
+        self.sources = [net] + ([net_old] if net_old is not None else [])
+        self.recoveries = 0                     # recover() calls that widened the operand scales
+        self.nets = [self._prepare(m) for m in self.sources]
         self.static_outputs = True              # p / v are always the same device buffers: no copies in the runner
         self.supports_row_range = net_old is None   # single network: honours Engine.compact_rows() (tail of a run)
 
-    def _prepare(self, net):
+    def _prepare(self, net, extra=None, target=None):
+        """extra: float32 planes [n,8,8,14] of positions to calibrate on besides the synthetic set (recover(): the batch that left
+        the range); target: where the largest magnitude seen is put (HI_TARGET = four times below the largest fp16)."""
+        target = target or self.calib_target
         if self.mode == "f16x3":
             # one-pass range calibration at weight-pack time: the network runs once, in these same kernels, on synthetic
             # positions with deliberately small activation scales (room for magnitudes up to 4e6; up to 1e16 after the
@@ -195,6 +203,8 @@ class FusedEvaluator:
             boards = calibration_boards(256, dev)
             from . import rules
             xcal = rules.features(boards.view(torch.int32)).contiguous()
+            if extra is not None and extra.shape[0]:
+                xcal = torch.cat([xcal, extra.to(xcal.dtype)], dim=0).contiguous()
             act = None
             for attempt in range(4):
                 trial = [2.0 ** (-6 - 10 * attempt)] * (len(net.body) + 1)
@@ -208,7 +218,7 @@ class FusedEvaluator:
                 self.overflow.zero_()
             if act is None:
                 raise OverflowError("split-fp16 kernels: the network's activations exceed 1e16 (or are not finite) on the calibration positions")
-            return self._build(net, self.S, [pow2_scale(a) for a in act], pow2_scale(feat), debug_all=False)
+            return self._build(net, self.S, [pow2_scale(a, target) for a in act], pow2_scale(feat, target), debug_all=False)
         return self._build(net, self.S, None, None, debug_all=False)
 
     def _build(self, net, S, act_scales, feat_scale, debug_all):
@@ -336,6 +346,40 @@ class FusedEvaluator:
         _lib.check(self._L.ckr_arena_merge(p.data_ptr(), v.data_ptr(), p2.data_ptr(), v2.data_ptr(), self._dest.data_ptr(),
                                            self._ranges.data_ptr(), S, self._p.data_ptr(), self._v.data_ptr(), stream))
         return self._p, self._v
+
+    def flag(self):
+        """The DEVICE int32 the kernels raise when an activation leaves the calibrated range (None in the bf16 mode): hand it to
+        Engine.set_eval_flag and the engine consumes nothing from a flagged batch."""
+        if self.mode != "f16x3":
+            return None
+        dev = next(self.sources[0].parameters()).device
+        self._overflow_ptr(dev)
+        return self.overflow
+
+    def recover(self, engine):
+        """If the range flag is up: re-calibrate every network's per-layer scales on the synthetic set PLUS the batch that tripped
+        (with twice the usual headroom), rebuild the kernels' constants, and evaluate the engine's current batch again -- the
+        engine (Engine.set_eval_flag) has consumed nothing since the flag went up and has handed the same leaves out again, so
+        after this call p / v hold valid answers for them and the searches continue as if the scales had been right from the
+        start.  Returns True if it had to act (the caller then drops its captured graph: scale-dependent constants are baked into
+        the launches, and p / v are new buffers).  Raises OverflowError only if the network's activations cannot be represented at
+        any scale (not finite)."""
+        if self.overflow is None or not int(self.overflow.item()):
+            return False
+        from . import rules
+        x = engine.x
+        n = int(engine.row_range[1].item()) if getattr(engine, "dense_rows", False) else x.shape[0]
+        rows = x[:max(1, n)]
+        planes = rules.features(rows.contiguous()) if getattr(engine, "leaf_records", False) else rows.float()
+        self.overflow.zero_()
+        self.nets = [self._prepare(m, extra=planes, target=HI_TARGET / 2.0) for m in self.sources]
+        self.recoveries += 1
+        self(engine)
+        torch.cuda.synchronize(x.device)
+        if int(self.overflow.item()):
+            raise OverflowError("split-fp16 kernels: activations out of range even after re-calibration on the batch (layer scales %s)"
+                                % (self.nets[0]["act_scales"],))
+        return True
 
     def check_range(self):
         """Assertion on the float32-grade kernels' operand range: raises if an activation exceeded the fp16 range of its hi

@@ -275,10 +275,9 @@ class MCTS:
             chunk = 1 if timed else 32                       # steps issued per look at the slot (steps after the search has
             while True:                                      # parked are no-ops in the tree kernel)
                 runner.step(chunk)
+                runner.check_evaluator()                     # float32-grade kernels: widen the operand scales if a position needs it
                 if not cls._engine.game(0)[3] or out_of_time():
                     break
-            if hasattr(runner.evaluator, "check_range"):
-                runner.evaluator.check_range()
         n_before = int(getattr(root_node, "_number_of_visits", 0) or 0)
         root_node._load()
         cls.rollout_count = max(0, int(root_node.n) - n_before) if timed else cls.budget

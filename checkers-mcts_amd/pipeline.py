@@ -169,6 +169,38 @@ class StepRunner:
         self.v = torch.zeros((S,), dtype=torch.float32, device=eng.device)
         self.graph = None
         self.steps = 0
+        self.recoveries = 0
+        # float32-grade kernels: the engine consumes nothing from a batch on which the evaluator raised its range flag
+        flag = evaluator.flag() if hasattr(evaluator, "flag") else None
+        if flag is not None:
+            eng.set_eval_flag(flag)
+
+    def check_evaluator(self):
+        """Between steps: if the evaluator's range flag is up (an activation beyond the calibrated operand scales of the float32-grade
+        kernels), widen the scales and re-evaluate the batch (FusedEvaluator.recover), forget the leaf cache's records (computed
+        at the old scales) and drop the captured graph.  No search has used the flagged batch: the engine stalls while the flag is
+        up.  The reference's float32 predict has no range limit (Checkers.py:433); neither has this path any more."""
+        ev = self.evaluator
+        if not hasattr(ev, "recover"):
+            if hasattr(ev, "check_range"):
+                ev.check_range()
+            return False
+        torch.cuda.synchronize(self.eng.device)
+        if not ev.recover(self.eng):
+            return False
+        self.recoveries += 1
+        if getattr(ev, "static_outputs", False):
+            self.p, self.v = ev.nets[0]["p"], ev.nets[0]["v"]
+            if len(ev.nets) > 1:
+                self.p, self.v = ev._p, ev._v
+        if self.eng.cache is not None or self.eng.cfg.leaf_cache_log2:
+            self.eng.cache_flush()
+        import warnings
+        warnings.warn("float32-grade kernels: activations left the calibrated range; operand scales re-calibrated on the batch (no search "
+                      "used the flagged evaluations)", RuntimeWarning)
+        if self.graph is not None:
+            self.graph = None
+        return True
 
     def _eval_into_buffers(self):
         p, v = self.evaluator(self.eng)
@@ -254,8 +286,7 @@ class StepRunner:
             active = self.eng.stats()["active_slots"]
             if trace is not None:
                 trace.append((self.steps, active, time.perf_counter()))
-            if hasattr(self.evaluator, "check_range"):
-                self.evaluator.check_range()
+            self.check_evaluator()
             if active == 0:
                 self.set_row_cap(None)
                 return self.steps
@@ -355,8 +386,7 @@ class SplitRunner:
                 eng, runner, stream = part
                 with torch.cuda.stream(stream):
                     active = eng.stats()["active_slots"]
-                    if hasattr(runner.evaluator, "check_range"):
-                        runner.evaluator.check_range()
+                    runner.check_evaluator()
                     S = eng.cfg.n_slots
                     if active == 0:
                         runner.set_row_cap(None)

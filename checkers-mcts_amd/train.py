@@ -367,7 +367,9 @@ def train_nn(training_data, neural_network, **kwargs):
                 if dev.type != "cuda":
                     for grp in opt.param_groups:
                         grp["lr"] = float(lr)
-                if use_graph and int(sel.shape[0]) == BATCH_SIZE and captured.get("warm", 0) >= 3:
+                # (the padded ragged batch runs eagerly: the captured step has n_rows = BATCH_SIZE baked in, and this batch must enter
+                # the epoch's loss sums with the weight of its n_real rows -- as rows_seen counts it)
+                if use_graph and int(sel.shape[0]) == BATCH_SIZE and n_real == BATCH_SIZE and captured.get("warm", 0) >= 3:
                     if "graph" not in captured:
                         captured["graph"], captured["static"] = capture_train_step(acc)
                         data.batch(sel, out=captured["static"])

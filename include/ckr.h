@@ -326,6 +326,7 @@ typedef struct {
     uint64_t cache_entries;      /* records written to the leaf cache */
     uint64_t cache_dropped;      /* records not cached because their probe neighbourhood was full */
     uint64_t parked;             /* slot-steps spent waiting for another requester's evaluation of the same position (leaf_cache_park) */
+    uint64_t stalled_steps;      /* steps in which nothing was expanded because the evaluation flag was raised (ckr_engine_set_eval_flag) */
 } ckr_stats;
 
 typedef struct ckr_engine ckr_engine;
@@ -391,6 +392,13 @@ int ckr_engine_compact_rows(ckr_engine* e, float* d_p, float* d_v, int32_t* d_ne
 /* dense_rows engines: d_range = DEVICE int32[2]; every ckr_engine_step first zeroes it (and presets d_net to -1) on the
  * step's stream, the tree kernel then counts the leaves it hands out in d_range[1].  Call once before the first step. */
 int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range);
+/* Evaluation flag: d_flag = DEVICE int32 (NULL: none) that the network kernels raise when the batch they have just evaluated must
+ * not be used -- ckr_conv_stack_f16x3's / ckr_heads_tail's d_overflow: an activation left the range of the split-fp16 operand
+ * scales.  The reference's float32 predict has no such limit (Checkers.py:433), so nothing computed from a flagged batch may
+ * reach a tree: while *d_flag != 0 every ckr_engine_step expands nothing and every slot hands the SAME leaf out again (counted in
+ * ckr_stats.stalled_steps).  The caller notices the flag at its next look, widens the scales, evaluates the batch again, clears
+ * the flag -- and the searches go on as if nothing had happened (fused.FusedEvaluator.recover, pipeline.StepRunner). */
+int ckr_engine_set_eval_flag(ckr_engine* e, const int32_t* d_flag);
 
 /* Counters (synchronises the stream the last step ran on). */
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out);

@@ -35,7 +35,7 @@ def test_struct_sizes_match_header():
     from checkers_mcts_amd import _lib
     assert C.sizeof(_lib.Tuple) == 288
     assert C.sizeof(_lib.GameResult) == 32
-    assert C.sizeof(_lib.Stats) == 120
+    assert C.sizeof(_lib.Stats) == 128
     assert C.sizeof(_lib.Config) == 152
     assert C.sizeof(_lib.NodeInfo) == 40
 

@@ -446,3 +446,48 @@ def test_conv_stack_fed_with_board_records_gives_the_planes_bits():
         outs.append((sorted_tuples(eng), eng.stats()))
         eng.close()
     assert outs[0][0].tobytes() == outs[1][0].tobytes() and outs[0][1]["expansions"] == outs[1][1]["expansions"] > 96 * 40
+
+
+def test_range_flag_stalls_the_engine_and_recovery_recalibrates(oracle):
+    """The reference evaluates its network in float32 without any range limit (Checkers.py:433).  The float32-grade kernels'
+    per-layer operand scales are calibrated when the weights are packed; if play meets an activation beyond them the kernels raise
+    a device flag.  Round 4: nothing computed from a flagged batch reaches a tree -- while the flag is up ckr_engine_step expands
+    nothing and hands the same leaves out again (ckr_engine_set_eval_flag) -- and the runner's next look re-calibrates on the
+    batch, evaluates it again and carries on (FusedEvaluator.recover, StepRunner.check_evaluator): the job neither aborts nor
+    uses a saturated value.  Provoked here with a calibration target beyond the fp16 range (every real batch trips at once); the
+    recovered run's tuples equal the run that was calibrated properly from the start (power-of-two scales move no significand),
+    and the recovered evaluator is within 1e-5 of float64."""
+    import warnings
+    import torch
+    import net_ref
+    from checkers_mcts_amd import engine as E, net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import StepRunner
+    from test_engine_gpu import mk, sorted_tuples
+    from test_fullsize_gpu import check_tuples
+    m = N.PolicyValueNet(128).keras_init(3).perturb_bn(7).eval().cuda()
+    kw = mk(30, eps=0.25, tau=1.0)
+    runs = []
+    for target in (None, 2.0 ** 19):
+        eng = E.Engine(E.config_from_kwargs(kw, n_slots=64, games_per_slot=1, terminate_cnt=40, seed=4, feature_dtype=E.BOARDS, leaf_cache_log2=14,
+                                            dense_rows=True))
+        ev = FusedEvaluator(m, 64, mode="f16x3", calib_target=target)
+        runner = StepRunner(eng, ev)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            runner.run_to_completion(check_every=16)
+        st = eng.stats()
+        runs.append((sorted_tuples(eng), st, runner.recoveries, ev.recoveries, len([w for w in caught if "re-calibrated" in str(w.message)])))
+        if target:                                          # the evaluator as recovery left it, on a batch of the job's own leaves
+            raw = runs[-1][0]
+            x = __import__("checkers_mcts_amd.rules", fromlist=["x"]).features(torch.from_numpy(raw["board"][::7][:64].view(np.int32).copy()).cuda())
+            p, v = ev.forward_features(x.contiguous())
+            rp, rv = net_ref.forward({k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}, x.cpu().numpy())
+            assert np.abs(p.cpu().numpy() - rp).max() < 1e-5 and np.abs(v.cpu().numpy() - rv.reshape(-1)).max() < 1e-5
+        eng.close()
+    (raw0, st0, r0, e0, w0), (raw1, st1, r1, e1, w1) = runs
+    assert (r0, e0, w0, st0["stalled_steps"]) == (0, 0, 0, 0)
+    assert r1 == e1 == w1 == 1 and 1 <= st1["stalled_steps"] <= 16          # flagged at the first batch, noticed at the first look
+    assert st1["games"] == st0["games"] == 64 and st1["expansions"] == st0["expansions"]
+    check_tuples(E, raw1, 30)
+    assert raw1.tobytes() == raw0.tobytes()

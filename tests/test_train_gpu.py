@@ -74,6 +74,23 @@ def test_selfplay_train_arena_loop_without_pickles(tmp_path, monkeypatch):
     t = tournament_Checkers(dict(NEW_NN_FN=fn, OLD_NN_FN="random:0", TOURNEY_GAMES=2, NUM_CPUS=4, SEED=3), mk_)
     out = t._start_tournament()
     assert len(out) == 8 and all(r[3] in ("player1_wins", "player2_wins", "draw") for r in out)
+    # second iteration (train_Checkers.py:104-179 run twice): the TRAINED model file plays the self-play games through the
+    # float32-grade kernels -- board-record leaves, per-layer scales calibrated for this network, the range flag wired into the
+    # engine --, its tuples train the next network, and that one in turn is within 1e-5 of float64 on its predecessor's games
+    sk2 = dict(sk, TRAINING_ITERATION=1, NN_FN=fn, SEED=6)
+    gen2 = generate_Checkers_data(sk2, kw)
+    tuples2 = gen2.generate_tuples()
+    assert gen2.stats["stalled_steps"] == 0 and gen2.stats["games"] == 64 and tuples2.shape[0] >= 64 * 30
+    tk2 = dict(tk, TRAINING_ITERATION=1)
+    hist2, fn2 = T.train_nn(tuples2, load_network(fn, device="cuda").train(), **tk2)
+    assert os.path.exists(fn2) and fn2 != fn
+    trained2 = load_network(fn2, device="cuda")
+    xs2, _, _ = T.TrainingData(tuples=tuples2).batch(torch.arange(0, 192, device="cuda") * 5)
+    ev2 = FusedEvaluator(trained2, xs2.shape[0], mode="f16x3")
+    pf2, vf2 = ev2.forward_features(xs2.contiguous())
+    rp2, rv2 = net_ref.forward({k: t_.detach().cpu().numpy() for k, t_ in trained2.state_dict().items()}, xs2.cpu().numpy())
+    assert np.abs(pf2.cpu().numpy() - rp2).max() < 1e-5 and np.abs(vf2.cpu().numpy() - rv2).max() < 1e-5
+    ev2.check_range()
 
 
 def test_training_set_smaller_than_one_batch_still_trains(tmp_path, monkeypatch):
