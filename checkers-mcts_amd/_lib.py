@@ -26,7 +26,7 @@ class Config(C.Structure):
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
                 ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
                 ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32), ("dense_rows", C.c_int32), ("n_workers", C.c_int32),
-                ("leaf_cache_park", C.c_int32), ("reserved", C.c_int32)]
+                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32)]
 
 
 class NodeInfo(C.Structure):
@@ -55,7 +55,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",
            "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_conv_stack_f16x3_boards", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_leaf_cache_create", "ckr_leaf_cache_destroy", "ckr_leaf_cache_flush", "ckr_engine_attach_cache", "ckr_engine_create", "ckr_engine_compact_rows", "ckr_engine_set_row_range", "ckr_engine_set_eval_flag",
-           "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_end_ply", "ckr_engine_stats", "ckr_engine_mark", "ckr_engine_stats_at_mark", "ckr_engine_cache_flush", "ckr_engine_results",
+           "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_single", "ckr_engine_step_end_ply", "ckr_engine_subtree", "ckr_engine_stats", "ckr_engine_mark", "ckr_engine_stats_at_mark", "ckr_engine_cache_flush", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
            "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_rollout_end_ply", "ckr_engine_set_ln_table",
            "ckr_probe_dirichlet", "ckr_probe_temperature", "ckr_probe_tau_schedule",
@@ -101,6 +101,8 @@ def load():
         L.ckr_engine_attach_cache.argtypes = [vp, vp, C.c_int32]
         L.ckr_engine_step.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ckr_engine_step_end_ply.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.ckr_engine_step_single.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.ckr_engine_subtree.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, i64, C.POINTER(i64)]
         L.ckr_engine_compact_rows.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ckr_engine_set_row_range.argtypes = [vp, vp]
         L.ckr_engine_set_eval_flag.argtypes = [vp, vp]

@@ -18,6 +18,7 @@
 #include <hip/hip_fp16.h>
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace ckr {
@@ -117,6 +118,10 @@ struct Dev {
     // be used (an activation left the range of the float32-grade kernels' operand scales).  While it is set, a step expands
     // nothing: every slot hands out its pending leaf again.
     const int32_t* eval_flag;
+    // CONSTRAINT == 'time' with a clock per search (ckr_config.time_budget_us): a search that has run for time_ticks ticks of the
+    // 100 MHz device wall clock since it began (g_start, set by start_search) ends its ply -- MCTS.computational_budget,
+    // MCTS.py:196-198, with MCTS.start_time per slot instead of one host clock for all games of an engine
+    long long time_ticks; unsigned long long* g_start;
     // virtual workers: slot -> the worker (local id in [0, n_workers)) it hosts; a slot whose worker has played its games
     // takes the next unplayed worker.  RNG streams, tau and the tuple / result regions are keyed by worker, not by slot.
     int n_workers; int32_t* g_worker; int32_t* next_worker;
@@ -397,7 +402,7 @@ template <int GAME = 0, class Wave> __device__ void start_search(Wave& w) {
     } else if (D.C - D.t_used[ti] < D.margin) {
         compact(w, t);
     }
-    if (w.lane == 0) { D.t_searched[ti] = 1; D.g_sims[w.slot] = 0; }
+    if (w.lane == 0) { D.t_searched[ti] = 1; D.g_sims[w.slot] = 0; if (D.time_ticks) D.g_start[w.slot] = wall_clock64(); }
     wave_mem_fence();
 }
 
@@ -1188,11 +1193,13 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     // B. advance until a leaf needs the network
     // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
     // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
-    const int max_sims = D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
-    while (!stalled && D.g_phase[slot] == PH_PLAYING) {
+    const int max_sims = (flags & 4) ? 1 : D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
+    bool did_sim = (flags & 4) != 0 && pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0 && !stalled;   // single-simulation step: the expansion above completed one
+    while (!stalled && !did_sim && D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
         const int sims_done = D.g_sims[slot];
-        const bool out_of_time = end_ply != 0 && sims_done >= 2;         // a root with visited children exists
+        const bool clock_up = end_ply != 0 || (D.time_ticks != 0 && (long long)(wall_clock64() - D.g_start[slot]) >= D.time_ticks);
+        const bool out_of_time = clock_up && sims_done >= 2;             // a root with visited children exists
         end_ply = out_of_time ? 0 : end_ply;                             // one ply per time window
         if (resume < 0 && (sims_done >= D.budget || out_of_time)) {      // MCTS.computational_budget, :189-201
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
@@ -1273,7 +1280,8 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
     // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198): the wall-clock budget of the running searches is used up -- a slot
     // whose root has visited children ends its ply first, then goes on with the next search
     for (int it = 0; it < sims && D.g_phase[slot] == PH_PLAYING;) {
-        const bool out_of_time = end_ply != 0 && D.g_sims[slot] >= 2;
+        const bool clock_up = end_ply != 0 || (D.time_ticks != 0 && (long long)(wall_clock64() - D.g_start[slot]) >= D.time_ticks);
+        const bool out_of_time = clock_up && D.g_sims[slot] >= 2;
         end_ply = out_of_time ? 0 : end_ply;
         if (D.g_sims[slot] >= D.budget || out_of_time) {
             if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
@@ -1603,6 +1611,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (const char* t = getenv("CKR_TAIL_SIMS")) D.tail_sims = D.tail_sims ? atoi(t) : 0;
     if (const char* t = getenv("CKR_TAIL_SHIFT")) D.tail_shift = atoi(t);
 #endif
+    if (c->time_budget_us < 0) return fail(CKR_ERR_INVALID, "time_budget_us must be >= 0");
+    D.time_ticks = (long long)c->time_budget_us * 100ll;          // wall_clock64(): 100 MHz
     D.n_workers = c->n_workers > 0 ? c->n_workers : c->n_slots;
     D.total_games = D.n_workers * c->games_per_slot;
     D.neural = c->neural_net ? 1 : 0; D.rollout_first = c->rollout_first;
@@ -1626,7 +1636,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.g_path, S * 64, true); A(D.g_plen, S, true); A(D.g_row, S, true); A(e->d_row_tmp, S, true);
     A(D.g_gid, S, true); A(D.next_game, (size_t)1, true); A(D.n_finished, (size_t)1, true);
     A(D.g_worker, S, true); A(D.next_worker, (size_t)1, true); A(D.g_cslot, S, true); A(D.g_cword, S, true); A(D.g_parked, S, true);
-    A(D.estate, (size_t)1, true);
+    A(D.estate, (size_t)1, true); A(D.g_start, S, true);
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
     A(D.tuples, NT ? NT : 1, true);
@@ -1748,6 +1758,10 @@ int ckr_engine_rollout_end_ply(ckr_engine* e, int32_t sims, void* stream) { retu
 
 static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream, int end_ply);
 
+int ckr_engine_step_single(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
+    return engine_step(e, d_p, d_v, d_x, d_net, stream, 4);
+}
+
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
     return engine_step(e, d_p, d_v, d_x, d_net, stream, 0);
 }
@@ -1770,7 +1784,7 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     if (prologue && e->cfg.n_slots > 4)
         hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (e->cfg.n_slots + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,
                            e->dev.dense_rows ? e->d_range : (int32_t*)nullptr, d_net, (int)e->cfg.n_slots);
-    const int flags = (end_ply ? 1 : 0) | (prologue && e->cfg.n_slots <= 4 ? 2 : 0);
+    const int flags = (end_ply == 1 ? 1 : 0) | (end_ply == 4 ? 4 : 0) | (prologue && e->cfg.n_slots <= 4 ? 2 : 0);
     if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     CKR_HIP(hipGetLastError());
@@ -2011,6 +2025,54 @@ int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* ro
     for (int i = 0; i < n; ++i)
         if (int rc = read_node(e, base + (size_t)i, &children[i])) return rc;
     *n_children = n;
+    return CKR_OK;
+}
+
+int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_depth, ckr_node_info* out, int32_t* depth, int64_t cap, int64_t* n) {
+    if (!e || slot < 0 || slot >= e->cfg.n_slots || tree < 0 || tree > 1 || max_depth < 0 || !n)
+        return fail(CKR_ERR_INVALID, "ckr_engine_subtree: bad argument");
+    CKR_HIP(hipDeviceSynchronize());
+    const int ti = slot * 2 + tree;
+    int32_t cursor = -1, half = 0, used = 0;
+    CKR_HIP(hipMemcpy(&cursor, e->dev.t_cursor + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&half, e->dev.t_half + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(&used, e->dev.t_used + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *n = 0;
+    if (cursor < 0 || used <= 0) return CKR_OK;
+    const size_t tb = ((size_t)(ti * 2 + half)) * (size_t)e->dev.C, U = (size_t)used;
+    std::vector<ckr_board> board(U); std::vector<uint32_t> kids(U), status(U); std::vector<int32_t> cnt(U); std::vector<float> prior(U);
+    std::vector<double> wd(U); std::vector<float> wf(e->dev.w64 ? 0 : U);
+    CKR_HIP(hipMemcpy(board.data(), e->dev.n_board + tb, U * sizeof(ckr_board), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(kids.data(), e->dev.n_kids + tb, U * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(status.data(), e->dev.n_status + tb, U * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(cnt.data(), e->dev.n_N + tb, U * sizeof(int32_t), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemcpy(prior.data(), e->dev.n_P + tb, U * sizeof(float), hipMemcpyDeviceToHost));
+    if (e->dev.w64) CKR_HIP(hipMemcpy(wd.data(), static_cast<const double*>(e->dev.n_W) + tb, U * sizeof(double), hipMemcpyDeviceToHost));
+    else {
+        CKR_HIP(hipMemcpy(wf.data(), static_cast<const float*>(e->dev.n_W) + tb, U * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < U; ++i) wd[i] = (double)wf[i];
+    }
+    // depth first, the LAST child of a node first: the order in which MCTS.traverse_tree prints (MCTS.py:336-341)
+    std::vector<std::pair<int32_t, int32_t>> stack{{cursor, 0}};
+    int64_t k = 0;
+    while (!stack.empty()) {
+        const auto [node, d] = stack.back();
+        stack.pop_back();
+        if (out && depth && k < cap) {
+            ckr_node_info& o = out[k];
+            o.board = board[(size_t)node]; o.status = status[(size_t)node] & ~(ST_EXPANDED | ST_MOVER); o.n = cnt[(size_t)node];
+            o.w = wd[(size_t)node]; o.p = prior[(size_t)node]; o.reserved = 0;
+            depth[k] = d;
+        }
+        ++k;
+        if ((status[(size_t)node] & ST_EXPANDED) && d < max_depth) {
+            const int nk = (int)(kids[(size_t)node] >> 24), base = (int)(kids[(size_t)node] & 0xFFFFFFu);
+            for (int c = 0; c < nk; ++c)
+                if ((size_t)(base + c) < U) stack.push_back({base + c, d + 1});          // popped last-to-first
+        }
+    }
+    *n = k;
+    if (out && k > cap) return fail(CKR_ERR_INVALID, "ckr_engine_subtree: buffer too small (%lld > %lld)", (long long)k, (long long)cap);
     return CKR_OK;
 }
 

@@ -28,7 +28,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=0, device=0,
                        manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0, dense_rows=False,
-                       n_workers=None, leaf_cache_park=False):
+                       n_workers=None, leaf_cache_park=False, device_clock=True):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -64,10 +64,14 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
             raise KeyError(key)                       # MCTS.__init__ indexes kwargs directly
     if k["CONSTRAINT"] not in ("rollout", "time"):
         raise ValueError("Invalid MCTS computational constraint!")        # MCTS.py:200
+    time_budget_us = 0
     if k["CONSTRAINT"] == "time":
-        # BUDGET is seconds of wall-clock search per ply (MCTS.py:196-198): no rollout limit in the engine; the runner
-        # owns the clock and ends the plies with Engine.step(..., end_ply=True)  (time_budget_of(kwargs))
+        # BUDGET is seconds of wall-clock search per ply (MCTS.py:196-198): no rollout limit in the engine; every slot times its
+        # own searches on the device's wall clock (ckr_config.time_budget_us) -- MCTS.start_time per search, as in the reference.
+        # device_clock=False: the caller owns ONE clock for all slots and ends the plies with Engine.step(..., end_ply=True)
         budget = 2 ** 31 - 1
+        if device_clock:
+            time_budget_us = max(1, min(2 ** 31 - 1, int(round(float(k["BUDGET"]) * 1e6))))
         if nodes_per_tree is None:
             # unbounded searches: as large a pool as a quarter of the device memory allows (44 B per node, 4 semispaces per
             # slot), at most 2^18 nodes; a search whose live subtree outgrows it abandons the game (counted as failed)
@@ -97,12 +101,19 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        device=int(device), neural_net=int(bool(k["NEURAL_NET"])), rollout_first=int(bool(rollout_first)),
                        dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], w_accum=W_ACCUM[w_accum], seed=int(seed),
                        leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2),
-                       dense_rows=int(bool(dense_rows)), n_workers=int(n_workers or 0), leaf_cache_park=int(bool(leaf_cache_park)))
+                       dense_rows=int(bool(dense_rows)), n_workers=int(n_workers or 0), leaf_cache_park=int(bool(leaf_cache_park)),
+                       time_budget_us=int(time_budget_us))
 
 
 def time_budget_of(mcts_kwargs):
     """Seconds of search per ply when CONSTRAINT == 'time' (MCTS.py:196-198), else None."""
     return float(mcts_kwargs["BUDGET"]) if mcts_kwargs["CONSTRAINT"] == "time" else None
+
+
+def host_clock_budget(cfg, mcts_kwargs):
+    """The time budget a RUNNER has to enforce itself (one host clock for all slots, Engine.step(end_ply=True)): only for engines
+    created with device_clock=False; engines with ckr_config.time_budget_us time every search on the device."""
+    return time_budget_of(mcts_kwargs) if (mcts_kwargs["CONSTRAINT"] == "time" and not cfg.time_budget_us) else None
 
 
 class LeafCache:
@@ -197,10 +208,11 @@ class Engine:
             raise ValueError("this engine hands out board records (feature_dtype BOARDS): there are no planes to view")
         return self.x.permute(0, 3, 1, 2)
 
-    def step(self, p=None, v=None, end_ply=False):
+    def step(self, p=None, v=None, end_ply=False, single=False):
         """One lock-step simulation.  p [S,512] float32 softmax output and
         v [S] float32 for the leaves of the previous step (None on the first).
-        end_ply (CONSTRAINT == 'time'): the wall-clock budget is used up -- every searching slot ends its ply in this step."""
+        end_ply (CONSTRAINT == 'time', host clock): the wall-clock budget is used up -- every searching slot ends its ply in this step.
+        single: every slot runs at most ONE simulation in this step (MCTS_Node.selection(), MCTS.py:405-409)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if p is not None:
             if not (p.dtype == torch.float32 and p.is_contiguous() and v.dtype == torch.float32 and v.is_contiguous()):
@@ -208,7 +220,7 @@ class Engine:
             pp, vp = p.data_ptr(), v.data_ptr()
         else:
             pp = vp = None
-        fn = self._L.ckr_engine_step_end_ply if end_ply else self._L.ckr_engine_step
+        fn = self._L.ckr_engine_step_end_ply if end_ply else self._L.ckr_engine_step_single if single else self._L.ckr_engine_step
         _lib.check(fn(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
 
@@ -344,6 +356,19 @@ class Engine:
         conv = lambda k: dict(board=np.array(k.board[:], np.uint32), status=int(k.status), n=int(k.n),
                               w=(np.float64(k.w) if self.cfg.w_accum else np.float32(k.w)), p=np.float32(k.p))
         return conv(root), [conv(kids[i]) for i in range(n.value)]
+
+    def subtree(self, slot, tree, max_depth):
+        """[(node info, level below the root)] of one tree in MCTS.print_tree's order (depth first, last child first), or []."""
+        n = C.c_int64(0)
+        _lib.check(self._L.ckr_engine_subtree(self._h, slot, tree, int(max_depth), None, None, 0, C.byref(n)))
+        if n.value == 0:
+            return []
+        nodes = (_lib.NodeInfo * n.value)()
+        depth = np.zeros(n.value, np.int32)
+        _lib.check(self._L.ckr_engine_subtree(self._h, slot, tree, int(max_depth), nodes, depth.ctypes.data, n.value, C.byref(n)))
+        wt = np.float64 if self.cfg.w_accum else np.float32
+        return [(dict(board=np.array(nodes[i].board[:], np.uint32), status=int(nodes[i].status), n=int(nodes[i].n), w=wt(nodes[i].w),
+                      p=np.float32(nodes[i].p)), int(depth[i])) for i in range(n.value)]
 
     def leaves(self):
         out = np.zeros((self.cfg.n_slots, 4), np.uint32)

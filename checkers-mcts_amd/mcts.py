@@ -119,6 +119,20 @@ class Checkers:
         out = int(codec.status_outcome(status))
         return out != 0, codec.OUTCOME_NAMES[out]
 
+    def print_board(self):
+        """Console picture of the live state and whose turn it is (Checkers.py:366-395)."""
+        from tabulate import tabulate
+        player = int(self.state[4, 0, 0])
+        player_mark = self.player1_man if player == 0 else self.player2_man
+        pieces = (self.state[0] - self.state[2]) + 2 * (self.state[1] - self.state[3])
+        marks = {1: self.player1_man, -1: self.player2_man, 2: self.player1_king, -2: self.player2_king}
+        table = [[marks[int(sq)] if int(sq) else ("." if r % 2 == c % 2 else "") for c, sq in enumerate(row)] for r, row in enumerate(pieces)]
+        print(tabulate(table, tablefmt="fancy_grid"))
+        if not self.done:
+            print("Move #{}: It's now Player {}'s turn ({})".format(self.move_count + 1, player + 1, player_mark))
+        else:
+            print("Game over after {} moves! The outcome is: {}".format(self.move_count + 1, self.outcome))
+
     def current_player(self, state):
         return "player1" if int(state[4, 0, 0]) == 0 else "player2"            # Checkers.py:397-403
 
@@ -262,9 +276,9 @@ class MCTS:
         cls._sync()
         if cls._engine.command(CMD_SEARCH)[0]:
             raise ValueError("begin_tree_search on a finished game")
-        timed = cls.constraint == "time"                     # BUDGET seconds of wall clock instead of BUDGET rollouts (:196-198)
-        cls.start_time = time.time()
-        out_of_time = (lambda: time.time() - cls.start_time >= cls.budget) if timed else (lambda: False)
+        timed = cls.constraint == "time"                     # BUDGET seconds of wall clock instead of BUDGET rollouts (:196-198):
+        cls.start_time = time.time()                         # the engine times the search on the device (time_budget_us)
+        out_of_time = lambda: False
         if not cls.neural_net:                               # random playouts (MCTS.py:78-89,132-143), all in-kernel
             while True:
                 cls._engine.rollout(8 if timed else cls.budget)
@@ -330,9 +344,16 @@ class MCTS:
 
     @classmethod
     def print_tree(cls, root_node, max_tree_depth=10):
-        print("|- ({}/{}) ({:.1f}%)".format(root_node.w, root_node.n, root_node.pwin))
-        for c in root_node.children:
-            print("\t|- ({}/{}) ({:.1f}%)".format(c.w, c.n, c.pwin))
+        """Tree diagram of the search tree under the root, (W/N) (win %) per node, depth first with the last child of every node
+        first and max_tree_depth levels deep -- what the reference's print_tree / traverse_tree print (MCTS.py:312-342).  The
+        nodes come from the engine in that order (ckr_engine_subtree); root_node must be the root of the live position's tree."""
+        cls._sync()
+        tree = int(cls.game_env.state[4, 0, 0])
+        for info, level in cls._engine.subtree(0, tree, max_tree_depth):
+            w, n = info["w"], info["n"]
+            q = (w / n) if n else 0
+            w_str = "{0}".format(str(round(w, 1) if w % 1 else int(w)))
+            print("\t" * level + "|- ({}/{}) ({:.1f}%)".format(w_str, n, np.round((q + 1) / 2 * 100, 1)))
 
 
 class MCTS_Node:
@@ -397,4 +418,27 @@ class MCTS_Node:
         return np.round((self.q + 1) / 2 * 100, 1)
 
     def selection(self):
-        raise NotImplementedError("single simulations run inside the GPU engine; use MCTS.begin_tree_search")
+        """ONE simulation of the tree policy from the root of the live position (MCTS.py:405-409: MCTS.tree_policy(self)): the
+        engine runs single-simulation steps (ckr_engine_step_single) until this root has one visit more; the node's statistics and
+        children are then reloaded.  Only roots can be stepped (the reference's recursion below the root happens inside the call)."""
+        if self.parent is not None:
+            raise ValueError("MCTS_Node.selection: simulations start at the root of the live position (MCTS.begin_tree_search)")
+        MCTS._sync()
+        eng = MCTS._engine
+        if not eng.game(0)[3] and eng.command(CMD_SEARCH)[0]:
+            raise ValueError("selection on a finished game")
+        root, _ = eng.root(0, int(MCTS.game_env.state[4, 0, 0]))
+        n0 = root["n"] if root is not None else 0
+        if not MCTS.neural_net:
+            eng.rollout(1)
+        else:
+            runner = MCTS._search_runner()
+            for _ in range(4):                               # hand-out, evaluation, expansion: at most three steps
+                eng.step(runner.p, runner.v, single=True)
+                runner._eval_into_buffers()
+                runner.check_evaluator()
+                root, _ = eng.root(0, int(MCTS.game_env.state[4, 0, 0]))
+                if root is not None and root["n"] > n0:
+                    break
+        self._load()
+        MCTS.rollout_count += 1

@@ -161,8 +161,9 @@ class StepRunner:
     replayed, so the host only issues one graph launch per simulation step."""
 
     def __init__(self, eng, evaluator, use_graph=True, time_budget=None):
-        """time_budget (seconds; CONSTRAINT == 'time', MCTS.py:196-198): run_to_completion searches every ply for that
-        long and then ends the plies of all slots in one step (Engine.step(end_ply=True))."""
+        """time_budget (seconds; CONSTRAINT == 'time', MCTS.py:196-198, for engines created with device_clock=False: ONE host
+        clock for all slots): run_to_completion searches every ply for that long and then ends the plies of all slots in one step
+        (Engine.step(end_ply=True)).  Engines with ckr_config.time_budget_us time every search themselves: time_budget None."""
         self.eng, self.evaluator, self.use_graph, self.time_budget = eng, evaluator, use_graph, time_budget
         S = eng.cfg.n_slots
         self.p = torch.zeros((S, 512), dtype=torch.float32, device=eng.device)
@@ -509,6 +510,9 @@ class generate_Checkers_data:
         # NUM_CPUS workers of the job are hosted on them one after the other, each still playing NUM_SELFPLAY_GAMES games with
         # its own noise / temperature streams -- the output is the same as with SLOTS = NUM_CPUS, bit for bit
         self.slots = selfplay_kwargs.get("SLOTS", 4096)
+        # True: generate_data() writes one pickle per WORKER and returns their NUM_CPUS names, like the reference's Pool.map over
+        # _generate_data (training_pipeline.py:323-332); default: one pickle for the job (merge_data takes either)
+        self.file_per_worker = selfplay_kwargs.get("FILE_PER_WORKER", False)
         self.stats = None
         self.results = None
 
@@ -548,7 +552,7 @@ class generate_Checkers_data:
         if not neural:                             # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
             eng = make_engine(0, count, slots)
             eng.set_ln_table()
-            eng.run_rollouts(time_budget=ckengine.time_budget_of(self.mcts_kwargs))
+            eng.run_rollouts(sims_per_launch=64 if timed else None)      # 'time': every search is timed on the device (time_budget_us)
             engines = [eng]
         elif split:
             runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots)
@@ -560,7 +564,7 @@ class generate_Checkers_data:
             engines = runner.engines
         else:
             eng = make_engine(0, count, slots)
-            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
+            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
             try:
                 runner.run_to_completion()
             except OverflowError:
@@ -582,13 +586,19 @@ class generate_Checkers_data:
 
     def generate_data(self):
         """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
-        name (a str for one worker, a one-element list otherwise, mirroring
-        training_pipeline.py:325-332); None on ranks other than 0."""
+        name (a str for one worker, a list otherwise, mirroring training_pipeline.py:325-332: one element, or -- FILE_PER_WORKER --
+        NUM_CPUS of them); None on ranks other than 0."""
         gathered = self.generate_tuples()
         if gathered is None:
             return None
         raw = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=ckengine.TUPLE_DTYPE)
-        memory = tuples_to_memory(raw, neural_net=bool(self.mcts_kwargs["NEURAL_NET"]))
+        neural = bool(self.mcts_kwargs["NEURAL_NET"])
+        if self.file_per_worker and self.num_cpus > 1:                  # NUM_CPUS files, process number = worker id (:332,457-463)
+            stamp = _timestamp()
+            workers = np.unique(raw["worker"])
+            return [self._save_memory(tuples_to_memory(raw[raw["worker"] == w], neural_net=neural), self.TRAINING_ITERATION, stamp, int(w))
+                    for w in workers]
+        memory = tuples_to_memory(raw, neural_net=neural)
         filename = self._save_memory(memory, self.TRAINING_ITERATION, _timestamp(), 0)
         return [filename] if self.num_cpus > 1 else filename
 
@@ -644,7 +654,7 @@ class tournament_Checkers:
                 seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
             cache = make_leaf_cache(default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2), dev)
             eng = ckengine.Engine(cfg, cache=cache)
-            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.time_budget_of(self.mcts_kwargs))
+            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
             runner.run_to_completion()
             self.stats = eng.stats()
             _warn_pool_overflows(self.stats, "tournament")

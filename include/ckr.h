@@ -282,7 +282,13 @@ typedef struct {
                                     every game requests the same openings, has nearly all of them:
                                     profiles/r04_dup_probe.jsonl).  Ignored in manual_play and time-limited (budget = INT32_MAX)
                                     engines.  Results do not depend on it */
-    int32_t  reserved;
+    int32_t  time_budget_us;     /* CONSTRAINT == 'time' (MCTS.computational_budget, MCTS.py:189-201: a search lasts BUDGET seconds of
+                                    wall-clock time) with a clock per SEARCH, as in the reference (MCTS.start_time is set by
+                                    begin_tree_search, :216): > 0 = microseconds; budget = INT32_MAX.  Every slot notes the device's
+                                    100 MHz wall clock when its search starts and ends its ply in the first step after that many
+                                    microseconds (and two simulations) have passed -- no host clock, plain ckr_engine_step /
+                                    ckr_engine_rollout calls.  0: none (rollout budgets; or the host ends the plies of ALL slots
+                                    at once with ckr_engine_step_end_ply) */
 } ckr_config;
 
 /* One training tuple, compact form (training_pipeline.py:364-369,406-410,
@@ -360,7 +366,13 @@ int ckr_engine_attach_cache(ckr_engine* e, ckr_leaf_cache* c, int32_t index);
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x,
                     int32_t* d_net, void* stream);
 
-/* CONSTRAINT == 'time' (MCTS.computational_budget, MCTS.py:196-198: a search lasts BUDGET seconds of wall-clock time
+/* The same step in which every slot runs AT MOST ONE simulation, network-free ones included (MCTS_Node.selection(),
+ * MCTS.py:405-409: one call of the tree policy): a slot whose pending leaf is expanded in this step has completed its simulation
+ * and hands out no new leaf. */
+int ckr_engine_step_single(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream);
+
+/* CONSTRAINT == 'time' with ONE clock, kept by the host, for all games of an engine (ckr_config.time_budget_us gives every search
+ * its own clock on the device and needs none of this) (MCTS.computational_budget, MCTS.py:196-198: a search lasts BUDGET seconds of wall-clock time
  * instead of BUDGET rollouts): create the engine with budget = INT32_MAX, drive ckr_engine_step for the wall-clock
  * budget, then call this variant once -- the same step, in which every searching slot completes its simulation in
  * flight and then ends its ply (move choice, tuple, re-root, next search) exactly as if its rollout budget had been
@@ -433,6 +445,11 @@ int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t
 /* Per-ply root child statistics (record_root_stats = 1): W and P for tuple i
  * at out[i][CKR_MAX_CHILDREN]. */
 int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t cap);
+/* The subtree under the root of tree `tree` of a slot, down to max_depth levels below the root, depth first with the LAST child of
+ * every node first -- the order in which MCTS.print_tree / traverse_tree walk it (MCTS.py:312-342): out[i] = node, depth[i] = its
+ * level (root 0).  HOST arrays of `cap` entries (NULL: count only); *n = number of nodes. */
+int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_depth, ckr_node_info* out, int32_t* depth, int64_t cap,
+                       int64_t* n);
 /* Leaf boards handed out by the last step (parity tests): HOST out[n_slots]. */
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out);
 

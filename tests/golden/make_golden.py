@@ -17,6 +17,8 @@ Fixture families:
   tournament_v1.npz  tournament_Checkers._start_tournament outcomes
   rollout_v1.npz     NEURAL_NET=False (random-rollout MCTS) self-play tuples with np.random.randint pinned to 0
   ttt_v1.npz         the README's Tic-Tac-Toe validation: MCTS vs MCTS with random rollouts (randint pinned), root statistics per ply
+  console_v1.json    what the reference prints to the console: Checkers.print_board, MCTS.print_tree; root statistics after single
+                     MCTS_Node.selection() calls
   text_v1.json       the text files the pipeline classes write: tournament_Checkers.start_tournament's two tables,
                      record_params' dumps, final_evaluation's score table (and the score matrix behind it)
 The fixtures are data (inputs + the reference's outputs); no reference source
@@ -550,6 +552,58 @@ def gen_text():
     with open(os.path.join(OUT, "text_v1.json"), "w", encoding="utf-8") as f:
         json.dump(out, f, indent=1, ensure_ascii=False, sort_keys=True)
     print("text: tournament %d chars, final evaluation table %s" % (len(out["tournament"]["text"]), out["final_evaluation"]["table"]))
+
+
+def gen_console(budget=30, salt=0, plies=4, depth=2, n_selections=12):
+    """What the reference prints: Checkers.print_board (Checkers.py:366-395) of the live game and MCTS.print_tree (MCTS.py:312-342)
+    of the root after each of the first searches of search_v1's case 0 (HashNet, no noise, no temperature); and the root statistics
+    after each of n_selections single MCTS_Node.selection() calls (MCTS.py:405-409) from the initial position."""
+    import contextlib
+    import io
+    import json
+    out = dict(cfg=dict(budget=budget, salt=salt, plies=plies, depth=depth), boards=[], trees=[], selections=[])
+    env = rt.new_env()
+    env.neural_net = ref_shim.HashNet(salt)
+    MCTS(**mcts_kwargs(budget, training=False, env=env))
+    initial = env.state
+    root1 = MCTS_Node(initial, parent=None)
+    best1 = best2 = root2 = None
+    for _ in range(plies):
+        if env.current_player(env.state) == "player1":
+            if env.move_count != 0:
+                root1 = MCTS.new_root_node(best1)
+            root = root1
+        else:
+            root2 = MCTS_Node(env.state, parent=None, initial_state=initial) if env.move_count == 1 else MCTS.new_root_node(best2)
+            root = root2
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            env.print_board()
+        out["boards"].append(buf.getvalue())
+        with contextlib.redirect_stdout(io.StringIO()):
+            MCTS.begin_tree_search(root)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            MCTS.print_tree(root, max_tree_depth=depth)
+        out["trees"].append(buf.getvalue())
+        best = MCTS.best_child(root)
+        if root is root1:
+            best1 = best
+        else:
+            best2 = best
+        env.step(best.state)
+    env = rt.new_env()
+    env.neural_net = ref_shim.HashNet(salt)
+    MCTS(**mcts_kwargs(budget, training=False, env=env))
+    root = MCTS_Node(env.state, parent=None)
+    for _ in range(n_selections):
+        root.selection()
+        out["selections"].append(dict(n=int(root.n), w=float(root.w), child_n=[int(c.n) for c in root.children],
+                                      child_action=[_action_of(c.state) for c in root.children]))
+    with open(os.path.join(OUT, "console_v1.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False, sort_keys=True)
+    print("console: %d boards, %d trees (%d lines in the first), %d selections" % (len(out["boards"]), len(out["trees"]),
+                                                                                  out["trees"][0].count("\n"), len(out["selections"])))
 
 
 if __name__ == "__main__":

@@ -476,10 +476,14 @@ def test_time_constrained_search(E, fast):
     import torch
     from checkers_mcts_amd.pipeline import StepRunner
     kw = dict(mk(1, eps=0.25, tau=1.0), CONSTRAINT="time", BUDGET=0.02)
-    cfg = E.config_from_kwargs(kw, n_slots=64, games_per_slot=1, terminate_cnt=12, seed=3,       # fast: leaf cache + dense rows too
-                               leaf_cache_log2=14 if fast else 0, dense_rows=fast)
+    # fast: leaf cache + dense rows, and a clock per search on the device (ckr_config.time_budget_us: MCTS.start_time per search, as
+    # in the reference); otherwise ONE host clock for all slots (Engine.step(end_ply=True))
+    cfg = E.config_from_kwargs(kw, n_slots=64, games_per_slot=1, terminate_cnt=12, seed=3,
+                               leaf_cache_log2=14 if fast else 0, dense_rows=fast, device_clock=fast)
+    assert (cfg.time_budget_us == 20000) == fast
     eng = E.Engine(cfg)
-    runner = StepRunner(eng, E.hashnet_evaluator(4), use_graph=False, time_budget=E.time_budget_of(kw))
+    runner = StepRunner(eng, E.hashnet_evaluator(4), use_graph=False, time_budget=E.host_clock_budget(cfg, kw))
+    assert (runner.time_budget is None) == fast
     t0 = time.perf_counter()
     runner.run_to_completion()
     dt = time.perf_counter() - t0
@@ -499,10 +503,11 @@ def test_time_constrained_rollout_search(E):
     """CONSTRAINT == 'time' (MCTS.py:189-201) in the random-rollout mode: every ply is searched for BUDGET seconds of wall clock,
     then all games move; the number of rollouts per search is whatever fitted, the accounting stays exact."""
     kw = dict(mk(0.02), CONSTRAINT="time", NEURAL_NET=False)
-    for game, terminate in (("checkers", 12), ("tictactoe", 16)):
-        eng = E.Engine(E.config_from_kwargs(kw, n_slots=32, games_per_slot=1, terminate_cnt=terminate, seed=3, game=game))
+    for game, terminate, device_clock in (("checkers", 12, False), ("tictactoe", 16, False), ("checkers", 12, True)):
+        cfg = E.config_from_kwargs(kw, n_slots=32, games_per_slot=1, terminate_cnt=terminate, seed=3, game=game, device_clock=device_clock)
+        eng = E.Engine(cfg)
         eng.set_ln_table()
-        st = eng.run_rollouts(time_budget=E.time_budget_of(kw))
+        st = eng.run_rollouts(sims_per_launch=64, time_budget=E.host_clock_budget(cfg, kw))
         assert st["games"] == 32 and st["pool_overflows"] == 0 and st["active_slots"] == 0
         t = sorted_tuples(eng)
         searched = t[t["chosen"] >= 0]

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel launch statistics from a rocprofv3 --kernel-trace output directory (CSV or rocpd database):
+"""Per-kernel launch statistics from a rocprofv3 --kernel-trace [--stats] output directory (kernel-trace CSV, or the rocpd
+sqlite database rocprofv3 writes by default -- its per-dispatch table, so min / max are available too; this replaces the
+former tools/rocprof_summary.py, which read the database's top_kernels view):
     python tools/kernel_stats.py gpurun_out/prof_r02 > profiles/r02_kernel_stats.csv"""
 import csv
 import glob
