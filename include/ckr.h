@@ -445,11 +445,6 @@ int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t
 /* Per-ply root child statistics (record_root_stats = 1): W and P for tuple i
  * at out[i][CKR_MAX_CHILDREN]. */
 int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t cap);
-/* The subtree under the root of tree `tree` of a slot, down to max_depth levels below the root, depth first with the LAST child of
- * every node first -- the order in which MCTS.print_tree / traverse_tree walk it (MCTS.py:312-342): out[i] = node, depth[i] = its
- * level (root 0).  HOST arrays of `cap` entries (NULL: count only); *n = number of nodes. */
-int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_depth, ckr_node_info* out, int32_t* depth, int64_t cap,
-                       int64_t* n);
 /* Leaf boards handed out by the last step (parity tests): HOST out[n_slots]. */
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out);
 
@@ -479,6 +474,11 @@ int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* sta
  * tree order; *n_children = -1 when the tree has no node for the live state. */
 int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* root,
                     ckr_node_info* children, int32_t* n_children);
+/* The subtree under the root of tree `tree` of a slot, down to max_depth levels below the root, depth first with the LAST child of
+ * every node first -- the order in which MCTS.print_tree / traverse_tree walk it (MCTS.py:312-342): out[i] = node, depth[i] = its
+ * level (root 0).  HOST arrays of `cap` entries (NULL: count only); *n = number of nodes. */
+int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_depth, ckr_node_info* out, int32_t* depth, int64_t cap,
+                       int64_t* n);
 
 /* ---- training step: the device side of train_nn (training_pipeline.py:123-179) ------------------- *
  * One optimisation step of create_nn's model (:59-114) on a batch of B boards is a sequence of these calls, issued by
