@@ -95,7 +95,7 @@ def test_cfg3_virtual_workers_equal_the_static_run(E):
     assert sorted(res_s, key=key) == sorted(res_h, key=key)
     for k in ("expansions", "terminal_visits", "plies", "games"):
         assert st_s[k] == st_h[k], k
-    assert st_h["steps"] > 2.5 * st_s["steps"]                               # four waves of workers on a quarter of the slots
+    assert st_h["steps"] > 1.5 * st_s["steps"]                               # four waves of workers on a quarter of the slots (their cache hits save steps)
 
 
 def test_cfg4_shape_400_sims_sharded(E):
