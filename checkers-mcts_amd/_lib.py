@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
-VERSION = 120                      # CKR_VERSION of include/ckr.h this binding was written against
+VERSION = 121                      # CKR_VERSION of include/ckr.h this binding was written against
 Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
@@ -59,7 +59,7 @@ EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_bat
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
            "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_rollout_end_ply", "ckr_engine_set_ln_table",
            "ckr_probe_dirichlet", "ckr_probe_temperature", "ckr_probe_tau_schedule",
-           "ckr_gemm_nt", "ckr_conv_gemm", "ckr_conv_wgrad", "ckr_conv_wflip", "ckr_conv_bias_relu_bn", "ckr_conv_bn_relu_backward", "ckr_conv_bias_grad",
+           "ckr_gemm_nt", "ckr_conv_gemm", "ckr_conv_gemm_pieces", "ckr_split_pieces", "ckr_conv_wsplit", "ckr_conv_wgrad", "ckr_conv_wflip", "ckr_conv_bias_relu_bn", "ckr_conv_bn_relu_backward", "ckr_conv_bias_grad",
            "ckr_gemm_small", "ckr_gemm_tall", "ckr_im2col", "ckr_bn_forward", "ckr_bn_backward",
            "ckr_policy_loss", "ckr_value_loss", "ckr_loss_sums", "ckr_adam_step", "ckr_sum_rows", "ckr_value_head_step", "ckr_policy_head_step"]
 

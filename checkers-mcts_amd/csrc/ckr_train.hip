@@ -244,20 +244,44 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef CKR_NT6_STAGE
 }
 
-// k_gemm_nt6 with the operand splitting UNDER the MFMAs (round 3).  In k_gemm_nt6 a chunk is split and staged between two
-// barriers while the matrix pipe idles (PMC: busy 46-50 %).  Here LDS holds two chunk buffers: while the 48 MFMAs of chunk c
-// run out of one, the registers holding chunk c + 1 (fetched an iteration ago) are split and stored into the other, piece by
-// piece between the MFMAs, and each register is refilled with its part of chunk c + 2 as soon as it has been staged -- every
-// global load has a whole iteration to arrive.  One barrier per chunk.  106 KB of LDS: one workgroup per CU, as before.
+// ---- the same GEMMs on operands split ONCE where they are produced (round 4).  k_gemm_nt6 splits every float32 operand into
+// its three bfloat16 pieces while it stages a chunk -- the weights 64 times per GEMM (once per row tile), an activation nine times
+// (once per tap) and again in the weight gradient -- and that VALU work, between two barriers with the matrix pipe idle, is half of
+// the kernel's time (PMC: matrix pipe busy 46-50 %).  Here the PRODUCER of a tensor (k_bn_apply128, k_bn_bwd_apply128, k_wsplit)
+// also stores its pieces, in the order a GEMM stages them: a row of C floats becomes C / 32 blocks of 192 bytes,
+//     [chunk of 32 columns][piece 1 | piece 2 | piece 3][32 bf16]        (768 B per 128-float row, 6 912 B per 1 152-float row)
+// so that the LDS image of a row's K chunk ([b1 x 32 | b2 x 32 | b3 x 32], as in k_gemm_nt6) is ONE contiguous 192-byte block of
+// global memory and staging is twelve 16-byte copies per thread and chunk: no conversion, no select (a tap that leaves the board
+// reads row `zero_row`, an all-zero row behind the tensor).  Same pieces, same products, same order: bit-identical to k_gemm_nt6.
+__device__ __forceinline__ void store_pieces4(void* __restrict__ base, size_t row, int row_bytes, int c, const float4 v) {
+    const Split4 sp = split3(v);
+    char* dst = reinterpret_cast<char*>(base) + row * (size_t)row_bytes + (c >> 5) * 192 + (c & 31) * 2;
+    *reinterpret_cast<uint2*>(dst) = sp.p1;
+    *reinterpret_cast<uint2*>(dst + 64) = sp.p2;
+    *reinterpret_cast<uint2*>(dst + 128) = sp.p3;
+}
+// x[rows][cols] float32 -> pieces (cols % 32 == 0); one thread per float4
+__global__ __launch_bounds__(256) void k_split_rows(const float* __restrict__ x, long long rows, int cols, void* __restrict__ out3) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, n4 = rows * (cols / 4);
+    if (t >= n4) return;
+    const long long r = t / (cols / 4);
+    const int c = (int)(t % (cols / 4)) * 4;
+    store_pieces4(out3, (size_t)r, cols / 32 * 192, c, *reinterpret_cast<const float4*>(x + r * cols + c));
+}
+
+constexpr int P4 = 13;                                             // LDS row pitch in 16-byte units: 192 B + 16 B (as P6)
 template <int GATHER>
-__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_gemm_nt6p(const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb,
-                                                 float* __restrict__ C, int ldc, int M, int K) {
-    extern __shared__ __attribute__((aligned(16))) uint2 lds6[];  // [2][As | Bs]
-    constexpr int BUF = (BM + BN) * P6;
+__global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_p6(const uint4* __restrict__ A3, const uint4* __restrict__ B3,
+                                                float* __restrict__ C, int ldc, int M, int K, int zero_row) {
+    __shared__ __attribute__((aligned(16))) uint4 As4[BM * P4];
+    __shared__ __attribute__((aligned(16))) uint4 Bs4[BN * P4];
+    const uint2* As = reinterpret_cast<const uint2*>(As4);
+    const uint2* Bs = reinterpret_cast<const uint2*>(Bs4);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kper = K / gridDim.z, kbeg = blockIdx.z * kper, kend = kbeg + kper;
+    const int kper = K / gridDim.z, kbeg = blockIdx.z * kper;
+    const int row_units = K / 32 * 12;                            // 16-byte units per operand row (GATHER: 48 per activation row)
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -265,87 +289,65 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;                // named scalars: see k_gemm_nt
-    const int frow = tid >> 3, fc4 = tid & 7;
-    unsigned on_board = 0xf;
-    auto load_a = [&](int k0, int i) -> float4 {
-        const int row = frow + 32 * i;
-        if (GATHER == 0) return *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * lda + k0 + 4 * fc4);
-        const int tap = k0 >> 7, dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int p = m0 + row, y = ((p >> 3) & 7) + GATHER * dy, x = (p & 7) + GATHER * dx;
-        const bool in = (unsigned)y < 8u && (unsigned)x < 8u;
-        on_board = (on_board & ~(1u << i)) | ((unsigned)in << i);
-        return *reinterpret_cast<const float4*>(A + (size_t)(p + (in ? GATHER * (8 * dy + dx) : 0)) * 128 + (k0 & 127) + 4 * fc4);
-    };
-    auto load_b = [&](int k0, int i) -> float4 {
-        return *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + frow + 32 * i) * ldb + k0 + 4 * fc4);
-    };
-#define CKR_P6_STAGE(buf, r, i, keep)                                                                 \
-    { const bool in = keep;                                                                           \
-      const Split4 sp = split3(make_float4(in ? r.x : 0.f, in ? r.y : 0.f, in ? r.z : 0.f, in ? r.w : 0.f)); \
-      uint2* dst = buf + (frow + 32 * i) * P6 + fc4;                                                  \
-      dst[0] = sp.p1; dst[8] = sp.p2; dst[16] = sp.p3; }
-#define CKR_P6_STAGE_A(buf, r, i) CKR_P6_STAGE(buf, r, i, GATHER == 0 || (on_board & (1u << i)))
-    // prologue: chunk 0 staged into buffer 0, chunk 1 in the registers
-    ra0 = load_a(kbeg, 0); ra1 = load_a(kbeg, 1); ra2 = load_a(kbeg, 2); ra3 = load_a(kbeg, 3);
-    rb0 = load_b(kbeg, 0); rb1 = load_b(kbeg, 1); rb2 = load_b(kbeg, 2); rb3 = load_b(kbeg, 3);
-    {
-        uint2* As = lds6; uint2* Bs = lds6 + BM * P6;
-        const int k1 = min(kbeg + BK, kend - BK);
-        CKR_P6_STAGE_A(As, ra0, 0) ra0 = load_a(k1, 0); CKR_P6_STAGE_A(As, ra1, 1) ra1 = load_a(k1, 1);
-        CKR_P6_STAGE_A(As, ra2, 2) ra2 = load_a(k1, 2); CKR_P6_STAGE_A(As, ra3, 3) ra3 = load_a(k1, 3);
-        CKR_P6_STAGE(Bs, rb0, 0, true) rb0 = load_b(k1, 0); CKR_P6_STAGE(Bs, rb1, 1, true) rb1 = load_b(k1, 1);
-        CKR_P6_STAGE(Bs, rb2, 2, true) rb2 = load_b(k1, 2); CKR_P6_STAGE(Bs, rb3, 3, true) rb3 = load_b(k1, 3);
+    // unit u = tid + 256 i (i < 6) of a tile's chunk: row u / 12, 16-byte unit u % 12 of the row's 192-byte block -- twelve
+    // consecutive lanes read one contiguous block
+    int srow[6], sj[6];
+    unsigned taps_ok[6];                                          // GATHER: bit tap = that tap of the staged row lies on the board
+    unsigned boff[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + 256 * i;
+        srow[i] = u / 12; sj[i] = u - 12 * srow[i];
+        boff[i] = (unsigned)((n0 + srow[i]) * row_units + sj[i]);
+        taps_ok[i] = 0u;
+        if (GATHER != 0) {
+            const int p = m0 + srow[i], y = (p >> 3) & 7, x = p & 7;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + GATHER * (tap / 3 - 1), xx = x + GATHER * (tap % 3 - 1);
+                taps_ok[i] |= (unsigned)((unsigned)yy < 8u && (unsigned)xx < 8u) << tap;
+            }
+        }
     }
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK, cur ^= 1) {
-        const uint2* As = lds6 + cur * BUF; const uint2* Bs = As + BM * P6;
-        uint2* An = lds6 + (cur ^ 1) * BUF; uint2* Bn = An + BM * P6;
-        // (the last iteration stages the clamped re-fetch of the last chunk into the idle buffer: no branch in the loop body,
-        // so that the splitting can be scheduled between the MFMAs)
-        const int k2 = min(k0 + 2 * BK, kend - BK);
-        bf16x8 fa[2][3], fb[2][3], ga[2][3], gb[2][3];
-#define CKR_P6_FRAGS(fa, fb, kk)                                                                      \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                 \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                               \
-            fa[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half); \
-            fb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half); }
-        // the six products of the four accumulators, product-major: consecutive MFMAs are independent
-#define CKR_P6_MFMAS(fa, fb)                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                               \
-            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};                    \
-            _Pragma("unroll") for (int a = 0; a < 2; ++a)                                             \
-            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                             \
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[b][QB[q]], acc[a][b], 0, 0, 0); }
-        CKR_P6_FRAGS(fa, fb, 0)
-        __builtin_amdgcn_sched_barrier(0);
-        // Eight sub-blocks of 6 MFMAs (one accumulator pair's three products each) with one staged piece of the next chunk, its
-        // refill and -- in the first half -- three of the second half's fragment reads between them; fenced, so that each keeps
-        // its share of the VALU work under its own MFMAs.
-#define CKR_P6_SUB(fa, fb, a, qlo, WORK)                                                              \
-        { WORK                                                                                        \
-          _Pragma("unroll") for (int q = qlo; q < qlo + 3; ++q) {                                     \
-              constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};                  \
-              acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[0][QB[q]], acc[a][0], 0, 0, 0); \
-              acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[1][QB[q]], acc[a][1], 0, 0, 0); } \
-          _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                             \
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
-              __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);                                      \
-              __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                                      \
-              if (i == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }                        \
-          __builtin_amdgcn_sched_barrier(0); }
-#define CKR_P6_GREAD(t, q) ga[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 + 2 * half); \
-                           gb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 + 2 * half);
-        CKR_P6_SUB(fa, fb, 0, 0, CKR_P6_GREAD(0, 0) CKR_P6_GREAD(0, 1) CKR_P6_STAGE_A(An, ra0, 0) ra0 = load_a(k2, 0);)
-        CKR_P6_SUB(fa, fb, 0, 3, CKR_P6_GREAD(0, 2) CKR_P6_STAGE_A(An, ra1, 1) ra1 = load_a(k2, 1);)
-        CKR_P6_SUB(fa, fb, 1, 0, CKR_P6_GREAD(1, 0) CKR_P6_GREAD(1, 1) CKR_P6_STAGE_A(An, ra2, 2) ra2 = load_a(k2, 2);)
-        CKR_P6_SUB(fa, fb, 1, 3, CKR_P6_GREAD(1, 2) CKR_P6_STAGE_A(An, ra3, 3) ra3 = load_a(k2, 3);)
-        CKR_P6_SUB(ga, gb, 0, 0, CKR_P6_STAGE(Bn, rb0, 0, true) rb0 = load_b(k2, 0);)
-        CKR_P6_SUB(ga, gb, 0, 3, CKR_P6_STAGE(Bn, rb1, 1, true) rb1 = load_b(k2, 1);)
-        CKR_P6_SUB(ga, gb, 1, 0, CKR_P6_STAGE(Bn, rb2, 2, true) rb2 = load_b(k2, 2);)
-        CKR_P6_SUB(ga, gb, 1, 3, CKR_P6_STAGE(Bn, rb3, 3, true) rb3 = load_b(k2, 3);)
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5;   // named scalars: see k_gemm_nt
+    auto load_a = [&](int k0, int i) -> uint4 {
+        if (GATHER == 0) return A3[(size_t)(m0 + srow[i]) * row_units + (k0 >> 5) * 12 + sj[i]];
+        const int tap = k0 >> 7, shift = GATHER * (8 * (tap / 3 - 1) + (tap % 3 - 1));
+        const int on = -(int)((taps_ok[i] >> tap) & 1u);         // all ones / zero: arithmetic, so that the loads stay branch-free
+        const int p = zero_row + ((m0 + srow[i] + shift - zero_row) & on);
+        return A3[(unsigned)(p * 48 + ((k0 & 127) >> 5) * 12 + sj[i])];
+    };
+    auto load_b = [&](int k0, int i) -> uint4 { return B3[boff[i] + (k0 >> 5) * 12]; };
+#define CKR_P6_FETCH(k0)                                                                              \
+    ra0 = load_a(k0, 0); ra1 = load_a(k0, 1); ra2 = load_a(k0, 2); ra3 = load_a(k0, 3); ra4 = load_a(k0, 4); ra5 = load_a(k0, 5); \
+    rb0 = load_b(k0, 0); rb1 = load_b(k0, 1); rb2 = load_b(k0, 2); rb3 = load_b(k0, 3); rb4 = load_b(k0, 4); rb5 = load_b(k0, 5);
+#define CKR_P6_PUT(buf, r, i) buf[srow[i] * P4 + sj[i]] = r;
+    CKR_P6_FETCH(kbeg)
+    for (int k0 = kbeg; k0 < kbeg + kper; k0 += BK) {
         __syncthreads();
+        CKR_P6_PUT(As4, ra0, 0) CKR_P6_PUT(As4, ra1, 1) CKR_P6_PUT(As4, ra2, 2) CKR_P6_PUT(As4, ra3, 3) CKR_P6_PUT(As4, ra4, 4) CKR_P6_PUT(As4, ra5, 5)
+        CKR_P6_PUT(Bs4, rb0, 0) CKR_P6_PUT(Bs4, rb1, 1) CKR_P6_PUT(Bs4, rb2, 2) CKR_P6_PUT(Bs4, rb3, 3) CKR_P6_PUT(Bs4, rb4, 4) CKR_P6_PUT(Bs4, rb5, 5)
+        __syncthreads();
+        {
+            const int kn = min(k0 + BK, kbeg + kper - BK);        // next chunk in flight under the MFMAs (the last one re-reads itself)
+            CKR_P6_FETCH(kn)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {                           // lanes 0-31 own k = 16 kk + 0..7, lanes 32-63 16 kk + 8..15
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    fa[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half);
+                    fb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) { CKR_MFMA6(acc[a][b], fa[a], fb[b]) }
+        }
     }
     float* Cz = C + (size_t)blockIdx.z * (size_t)M * ldc;
 #pragma unroll
@@ -359,14 +361,159 @@ __global__ __launch_bounds__(GT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     const int row = m0 + 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
                     Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
                 }
-#undef CKR_P6_STAGE
-#undef CKR_P6_STAGE_A
-#undef CKR_P6_FRAGS
-#undef CKR_P6_MFMAS
-#undef CKR_P6_SUB
-#undef CKR_P6_GREAD
+#undef CKR_P6_FETCH
+#undef CKR_P6_PUT
 }
-constexpr int GEMM6P_LDS = 2 * (BM + BN) * P6 * 8;
+
+// k_gemm_p6 with TWO chunk buffers in LDS and one barrier per chunk: while the 48 MFMAs of chunk c run out of one buffer, the
+// registers holding chunk c + 1 (fetched an iteration ago) are stored into the other and refilled with chunk c + 2 -- every global
+// load has a whole iteration to arrive and no wave waits at a barrier with the matrix pipe idle.  WM = 2: 128 x 128 tile, 4 waves,
+// 106 KB of LDS (one workgroup per CU, one wave per SIMD); WM = 4: 256 x 128 tile, 8 waves, 160 KB (two waves per SIMD).
+template <int GATHER, int WM>
+__global__ __launch_bounds__(128 * WM) void k_gemm_p6d(const uint4* __restrict__ A3, const uint4* __restrict__ B3,
+                                                        float* __restrict__ C, int ldc, int M, int K, int zero_row) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];  // [2][A rows | B rows] x P4
+    constexpr int TM = 64 * WM, NT = 128 * WM, NB = 128 * 12 / NT, BUF = (TM + BN) * P4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * BN;
+    const int kper = K / gridDim.z, kbeg = blockIdx.z * kper, kend = kbeg + kper;
+    const int row_units = K / 32 * 12;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    int alds[6], blds[NB];                                        // LDS unit of staged unit i (same in both buffers)
+    unsigned aoff[6], taps_ok[6], boff[NB];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int u = tid + NT * i, r = u / 12, j = u - 12 * r;
+        alds[i] = r * P4 + j;
+        taps_ok[i] = 0u;
+        if (GATHER != 0) {
+            const int p = m0 + r, y = (p >> 3) & 7, x = p & 7;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + GATHER * (tap / 3 - 1), xx = x + GATHER * (tap % 3 - 1);
+                taps_ok[i] |= (unsigned)((unsigned)yy < 8u && (unsigned)xx < 8u) << tap;
+            }
+            aoff[i] = (unsigned)((m0 + r) * 48 + j);
+        } else aoff[i] = (unsigned)((m0 + r) * row_units + j);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int u = tid + NT * i, r = u / 12, j = u - 12 * r;
+        blds[i] = TM * P4 + r * P4 + j;
+        boff[i] = (unsigned)((n0 + r) * row_units + j);
+    }
+    // staging registers: named scalars (arrays filled through a lambda end up in scratch memory here: every global load would be
+    // followed by a scratch store, and every LDS store by a scratch load and a wait)
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5;
+    rb3 = rb4 = rb5 = make_uint4(0u, 0u, 0u, 0u);
+    auto load_a = [&](int k0, int i) -> uint4 {
+        if (GATHER == 0) return A3[aoff[i] + (k0 >> 5) * 12];
+        const int tap = k0 >> 7, shift = GATHER * (8 * (tap / 3 - 1) + (tap % 3 - 1)) * 48, cu = ((k0 & 127) >> 5) * 12;
+        const int on = -(int)((taps_ok[i] >> tap) & 1u);
+        const int z = zero_row * 48 + (int)(aoff[i] % 48u);
+        return A3[(unsigned)(z + (((int)aoff[i] + shift - z) & on) + cu)];
+    };
+    auto load_b = [&](int k0, int i) -> uint4 { return B3[boff[i] + (k0 >> 5) * 12]; };
+#define CKR_P6D_FETCH(k0)                                                                             \
+    ra0 = load_a(k0, 0); ra1 = load_a(k0, 1); ra2 = load_a(k0, 2); ra3 = load_a(k0, 3); ra4 = load_a(k0, 4); ra5 = load_a(k0, 5); \
+    rb0 = load_b(k0, 0); rb1 = load_b(k0, 1); rb2 = load_b(k0, 2);                                    \
+    if constexpr (NB > 3) { rb3 = load_b(k0, 3); rb4 = load_b(k0, 4); rb5 = load_b(k0, 5); }
+#define CKR_P6D_PUT(buf)                                                                              \
+    (buf)[alds[0]] = ra0; (buf)[alds[1]] = ra1; (buf)[alds[2]] = ra2; (buf)[alds[3]] = ra3; (buf)[alds[4]] = ra4; (buf)[alds[5]] = ra5; \
+    (buf)[blds[0]] = rb0; (buf)[blds[1]] = rb1; (buf)[blds[2]] = rb2;                                  \
+    if constexpr (NB > 3) { (buf)[blds[3]] = rb3; (buf)[blds[4]] = rb4; (buf)[blds[5]] = rb5; }
+    CKR_P6D_FETCH(kbeg)
+    CKR_P6D_PUT(lds4)
+    { const int k1 = min(kbeg + BK, kend - BK); CKR_P6D_FETCH(k1) }
+    __syncthreads();
+    // Per chunk: the first half runs the 24 MFMAs of k = 0..15 while the fragments of k = 16..31 are read and the staged chunk
+    // c + 1 is stored into the other buffer; ONE barrier (LDS traffic only: the global loads in flight are not waited for); the
+    // second half runs the other 24 MFMAs while chunk c + 2 is requested from memory and the k = 0..15 fragments of chunk c + 1
+    // are read from the buffer the barrier has just completed -- the next iteration starts on its MFMAs at once.
+    bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
+#define CKR_P6D_FRAGS(fa, fb, As, Bs, kk)                                                             \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
+    _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                   \
+        fa[t][q] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half); \
+        fb[t][q] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 32 * t + l31) * P6 + 8 * q + 4 * kk + 2 * half); }
+    // product-major: consecutive MFMAs are independent; per accumulator the order of CKR_MFMA6
+#define CKR_P6D_MFMAS(fa, fb)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                                   \
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};                        \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                 \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                 \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][QA[q]], fb[b][QB[q]], acc[a][b], 0, 0, 0); }
+    {
+        const uint2* As = reinterpret_cast<const uint2*>(lds4);
+        const uint2* Bs = As + TM * P6;
+        CKR_P6D_FRAGS(f0a, f0b, As, Bs, 0)
+    }
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, cur ^= 1) {
+        const uint2* As = reinterpret_cast<const uint2*>(lds4 + cur * BUF);
+        const uint2* Bs = As + TM * P6;
+        uint4* nxt = lds4 + (cur ^ 1) * BUF;
+        const uint2* An = reinterpret_cast<const uint2*>(nxt);
+        const uint2* Bn = An + TM * P6;
+        __builtin_amdgcn_sched_barrier(0);
+        CKR_P6D_FRAGS(f1a, f1b, As, Bs, 1)
+        CKR_P6D_PUT(nxt)                                           // (the last iteration stores a clamped re-fetch: no branch in the body)
+        CKR_P6D_MFMAS(f0a, f0b)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6 + NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24 - 12 - 6 - NB, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        { const int k2 = min(k0 + 2 * BK, kend - BK); CKR_P6D_FETCH(k2) }
+        CKR_P6D_FRAGS(f0a, f0b, An, Bn, 0)
+        CKR_P6D_MFMAS(f1a, f1b)
+#pragma unroll
+        for (int i = 0; i < 6 + NB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CKR_P6D_FRAGS
+#undef CKR_P6D_MFMAS
+    float* Cz = C + (size_t)blockIdx.z * (size_t)M * ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + 64 * wm + 32 * a + 8 * g + 4 * half + i, col = n0 + 64 * wn + 32 * b + l31;
+                    Cz[(size_t)row * ldc + col] = acc[a][b][4 * g + i];
+                }
+}
+#undef CKR_P6D_FETCH
+#undef CKR_P6D_PUT
+template <int WM> constexpr int gemm_p6d_lds() { return 2 * (64 * WM + BN) * P4 * 16; }
 
 // Weight gradient of a 3x3 convolution with 128 kernels: C[z][o][n0 + c] = sum_{p in slice z} dZ[p][o] * X[p + off(tap)][c]
 // (0 outside the board); gridDim = (taps, 1, slices), n0 = 128 * blockIdx.x, tap = tap0 + blockIdx.x (tap0 = 4 and one
@@ -561,6 +708,23 @@ __global__ void k_wflip(const float* __restrict__ w, LayerOffsets offs, float* _
     const int t = blockIdx.x * blockDim.x + threadIdx.x;          // t = (c * 9 + tap) * 128 + o
     const int o = t & 127, tap = (t >> 7) % 9, c = t / 1152;
     wt[(size_t)blockIdx.y * 147456 + t] = w[offs.off[blockIdx.y] + (size_t)o * 1152 + tap * 128 + c];
+}
+
+// The pieces (see k_gemm_p6) of the seven 128 -> 128 kernels, as the forward GEMM reads them (w3[l][o][k], k = tap * 128 + c) and
+// flipped for the data-gradient GEMM (wt3[l][c][tap * 128 + o] = W[l][o][tap * 128 + c]).  gridDim = (144, layers, 2); either
+// output may be NULL.
+__global__ __launch_bounds__(256) void k_wsplit(const float* __restrict__ w, LayerOffsets offs, void* __restrict__ w3, void* __restrict__ wt3) {
+    const int t = blockIdx.x * 256 + threadIdx.x;                 // float4 index within [128][1152]
+    const int row = t / 288, k = (t - row * 288) * 4;
+    const float* W = w + offs.off[blockIdx.y];
+    if (blockIdx.z == 0) {
+        if (w3) store_pieces4(reinterpret_cast<char*>(w3) + (size_t)blockIdx.y * 128 * 6912, (size_t)row, 6912, k, *reinterpret_cast<const float4*>(W + (size_t)row * 1152 + k));
+    } else if (wt3) {
+        const int tap = k >> 7, o = k & 127, c = row;
+        const float4 v = make_float4(W[(size_t)o * 1152 + tap * 128 + c], W[(size_t)(o + 1) * 1152 + tap * 128 + c],
+                                     W[(size_t)(o + 2) * 1152 + tap * 128 + c], W[(size_t)(o + 3) * 1152 + tap * 128 + c]);
+        store_pieces4(reinterpret_cast<char*>(wt3) + (size_t)blockIdx.y * 128 * 6912, (size_t)row, 6912, k, v);
+    }
 }
 
 // out[i] = sum_z part[z][i] (+ add[i]); float4 granularity.  Block = 64 columns x 4 slice groups (group g adds slices
@@ -850,7 +1014,7 @@ __global__ __launch_bounds__(1024) void k_fwd_reduce128(const float* __restrict_
 __global__ __launch_bounds__(1024) void k_bn_apply128(const float* __restrict__ a, const float* __restrict__ part, int npart, int P, int rpb,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                                      float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ stats,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, void* __restrict__ out3) {
     __shared__ double red[1024];
     __shared__ __attribute__((aligned(16))) float sc[128], sh[128];          // out = a * sc + sh
     sum_partials(part, npart, 256, red);
@@ -879,6 +1043,7 @@ __global__ __launch_bounds__(1024) void k_bn_apply128(const float* __restrict__ 
         o.x = g.x * ((v.x - mean.x) * inv.x) + bt.x; o.y = g.y * ((v.y - mean.y) * inv.y) + bt.y;
         o.z = g.z * ((v.z - mean.z) * inv.z) + bt.z; o.w = g.w * ((v.w - mean.w) * inv.w) + bt.w;
         *reinterpret_cast<float4*>(out + i) = o;
+        if (out3) store_pieces4(out3, (size_t)r, 768, 4 * c4, o);       // the operand of the next block's GEMM, split once (k_gemm_p6)
     }
 }
 
@@ -918,7 +1083,7 @@ __global__ __launch_bounds__(1024) void k_bwd_reduce128(const float* __restrict_
 // written over dout; partial sums of dz per channel (the conv bias gradient): part2[blk][128]
 __global__ __launch_bounds__(1024) void k_bn_bwd_apply128(float* __restrict__ dout, const float* __restrict__ a, const float* __restrict__ stats,
                                                          const float* __restrict__ part, int npart, const float* __restrict__ gamma, int P, int rpb,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part2) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part2, void* __restrict__ dz3) {
     __shared__ double red[1024];
     __shared__ __attribute__((aligned(16))) float sdb[128], sdg[128];
     __shared__ __attribute__((aligned(16))) float r2[32][128];
@@ -946,6 +1111,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_apply128(float* __restrict__ do
         o.z = av.z > 0.f ? g.z * (d.z - db.z - ((av.z - mean.z) * inv.z) * dg.z) : 0.f;
         o.w = av.w > 0.f ? g.w * (d.w - db.w - ((av.w - mean.w) * inv.w) * dg.w) : 0.f;
         *reinterpret_cast<float4*>(dout + i) = o;
+        if (dz3) store_pieces4(dz3, (size_t)r, 768, 4 * c4, o);         // the operand of the data-gradient GEMM, split once
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
     *reinterpret_cast<float4*>(&r2[rl][4 * c4]) = s;
@@ -1617,28 +1783,74 @@ int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction
         if (direction > 0) hipLaunchKernelGGL(k_gemm_nt<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
         else hipLaunchKernelGGL(k_gemm_nt<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
     } else {
-        // CKR_TRAIN_GEMM6=staged: round 2's kernel (operands split between two barriers) instead of the pipelined one
-        // k_gemm_nt6p (operand splitting under the MFMAs, 106 KB of LDS, one workgroup per CU) is an EXPERIMENT kept selectable
-        // (CKR_TRAIN_GEMM6=pipelined): alone it wins where the grid puts one workgroup on a CU anyway (batch 128: 18.2 against
-        // 21.2 us) and loses where two staged workgroups per CU overlap each other (batch 1 024: 127 against 110 us); inside the
-        // training step, where the weight-gradient GEMM of the side stream shares the CUs, it gains nothing (0.733-0.745 ms
-        // either way, three runs each) -- profiles/r03_train_gemm_pipelined.txt.
-        static const char* force = getenv("CKR_TRAIN_GEMM6");
-        const bool pipelined = force && !strcmp(force, "pipelined");
-        static bool lds_set = false;
-        if (pipelined && !lds_set) {
-            CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt6p<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM6P_LDS));
-            CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt6p<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM6P_LDS));
-            lds_set = true;
-        }
-        if (pipelined) {
-            if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6p<1>, grid, dim3(GT), GEMM6P_LDS, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
-            else hipLaunchKernelGGL(k_gemm_nt6p<-1>, grid, dim3(GT), GEMM6P_LDS, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
-        } else {
-            if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
-            else hipLaunchKernelGGL(k_gemm_nt6<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
-        }
+        if (direction > 0) hipLaunchKernelGGL(k_gemm_nt6<1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
+        else hipLaunchKernelGGL(k_gemm_nt6<-1>, grid, dim3(GT), 0, (hipStream_t)stream, act, 128, w, 1152, workspace, 128, (int)P, 1152);
     }
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// ckr_conv_gemm on operands that were split into their three bfloat16 pieces where they were produced (k_gemm_p6): act3 = the
+// pieces of an activation [P + 1][128] whose row P is all zero (768 bytes per row; written by ckr_conv_bias_relu_bn /
+// ckr_conv_bn_relu_backward, or ckr_split_pieces), w3 = the pieces of the kernel rows [128][1152] (ckr_conv_wsplit).
+int ckr_conv_gemm_pieces(const void* act3, const void* w3, int32_t P, int32_t direction, int32_t slices, float* workspace, void* stream) {
+    if (!act3 || !w3 || !workspace || P <= 0 || P % 128 || (direction != 1 && direction != -1) || slices < 1 || 1152 % (BK * slices))
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_gemm_pieces: P must be a multiple of 128, direction +1 or -1, slices a divisor of 36");
+    if (int rc = ckr::require_device()) return rc;
+    // Kernel by batch size (profiles/r04_train_gemm_presplit.txt): the double-buffered kernels win where their grid is one full
+    // round of workgroups -- 128 x 128 tiles (one workgroup of four waves per CU) for batches up to 256 boards with split-K,
+    // 256 x 128 tiles of eight waves from 1 024 boards on; in between the single-buffered kernel keeps two workgroups per CU.
+    // (-DCKR_EXPERIMENTS builds: CKR_P6_VARIANT = 0 | 2 | 4 forces one.)
+    int variant = P <= 16384 ? 2 : (P >= 65536 && P % 256 == 0) ? 4 : 0;
+#ifdef CKR_EXPERIMENTS
+    if (const char* v = getenv("CKR_P6_VARIANT")) variant = atoi(v);
+    if (variant == 4 && P % 256) variant = 2;
+#endif
+    static bool lds_set = false;
+    if (!lds_set) {
+        CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_p6d<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_p6d_lds<2>()));
+        CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_p6d<-1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_p6d_lds<2>()));
+        CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_p6d<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_p6d_lds<4>()));
+        CKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_p6d<-1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_p6d_lds<4>()));
+        lds_set = true;
+    }
+    const uint4* a3 = (const uint4*)act3;
+    const uint4* b3 = (const uint4*)w3;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 2) {
+        const dim3 grid(1, P / 128, slices);
+        if (direction > 0) hipLaunchKernelGGL((k_gemm_p6d<1, 2>), grid, dim3(256), gemm_p6d_lds<2>(), st, a3, b3, workspace, 128, (int)P, 1152, (int)P);
+        else hipLaunchKernelGGL((k_gemm_p6d<-1, 2>), grid, dim3(256), gemm_p6d_lds<2>(), st, a3, b3, workspace, 128, (int)P, 1152, (int)P);
+    } else if (variant == 4) {
+        const dim3 grid(1, P / 256, slices);
+        if (direction > 0) hipLaunchKernelGGL((k_gemm_p6d<1, 4>), grid, dim3(512), gemm_p6d_lds<4>(), st, a3, b3, workspace, 128, (int)P, 1152, (int)P);
+        else hipLaunchKernelGGL((k_gemm_p6d<-1, 4>), grid, dim3(512), gemm_p6d_lds<4>(), st, a3, b3, workspace, 128, (int)P, 1152, (int)P);
+    } else {
+        const dim3 grid(1, P / BM, slices);
+        if (direction > 0) hipLaunchKernelGGL(k_gemm_p6<1>, grid, dim3(GT), 0, st, a3, b3, workspace, 128, (int)P, 1152, (int)P);
+        else hipLaunchKernelGGL(k_gemm_p6<-1>, grid, dim3(GT), 0, st, a3, b3, workspace, 128, (int)P, 1152, (int)P);
+    }
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// The pieces of x[rows][cols] float32 (cols a multiple of 32): out3[rows][cols / 32][3][32] bfloat16.
+int ckr_split_pieces(const float* x, int64_t rows, int32_t cols, void* out3, void* stream) {
+    if (!x || !out3 || rows <= 0 || cols <= 0 || cols % 32) return ckr::fail(CKR_ERR_INVALID, "ckr_split_pieces: cols must be a multiple of 32");
+    if (int rc = ckr::require_device()) return rc;
+    LAUNCH1D(k_split_rows, rows * (cols / 4), stream, x, (long long)rows, (int)cols, out3);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// w3[l] = the pieces of the kernel of layer l ([128][1152] float32 at w + offsets[l]), wt3[l] = the pieces of its flipped copy
+// (ckr_conv_wflip's layout); either may be NULL.  l < layers <= 8.
+int ckr_conv_wsplit(const float* w, const int64_t* offsets, int32_t layers, void* w3, void* wt3, void* stream) {
+    if (!w || !offsets || (!w3 && !wt3) || layers < 1 || layers > 8) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_wsplit: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    LayerOffsets lo;
+    for (int l = 0; l < 8; ++l) lo.off[l] = l < layers ? offsets[l] : 0;
+    hipLaunchKernelGGL(k_wsplit, dim3(144, layers, 2), dim3(256), 0, (hipStream_t)stream, w, lo, w3, wt3);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
@@ -1675,14 +1887,15 @@ int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float
 // batch statistics -> stats[2][128] (mean, 1 / sqrt(var + eps)), moving statistics updated, out = BatchNorm(a).
 // part: workspace of 256 * ceil(P / 128) + 128 floats.  The slices may alias a (slices == 1, workspace == a).
 int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* bias, int32_t P, const float* gamma, const float* beta, float eps,
-                          float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part, void* stream) {
+                          float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part, void* out_pieces,
+                          void* stream) {
     if (!workspace || slices < 1 || !bias || !gamma || !beta || !run_mean || !run_var || !stats || !a || !out || !part || P <= 0)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bias_relu_bn: bad argument");
     if (int rc = ckr::require_device()) return rc;
     const int rpb = rows_per_block(P), nblk = (P + rpb - 1) / rpb;
     hipLaunchKernelGGL(k_fwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, bias, (int)P, rpb, a, part, (const float*)run_mean);
     hipLaunchKernelGGL(k_bn_apply128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, (const float*)a, (const float*)part, nblk, (int)P, rpb, gamma, beta,
-                       eps, momentum, run_mean, run_var, stats, out);
+                       eps, momentum, run_mean, run_var, stats, out, out_pieces);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }
@@ -1691,7 +1904,7 @@ int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* b
 // above; slices == 0: dout is given) + add (optional: a second consumer's gradient); then dz = d loss / d (conv output) written
 // over dout, dgamma, dbeta, dbias.  a, stats: the block's kept activation and statistics.  part: 384 * ceil(P / 128) floats.
 int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const float* add, float* dout, const float* a, const float* stats,
-                              const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* stream) {
+                              const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* dz_pieces, void* stream) {
     if ((slices > 0 && !workspace) || slices < 0 || !dout || !a || !stats || !gamma || !dgamma || !dbeta || !part || P <= 0)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_bn_relu_backward: bad argument");
     if (int rc = ckr::require_device()) return rc;
@@ -1699,7 +1912,7 @@ int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const floa
     float* part2 = part + (size_t)256 * nblk;
     hipLaunchKernelGGL(k_bwd_reduce128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, workspace, (int)slices, add, a, stats, (int)P, rpb, dout, part);
     hipLaunchKernelGGL(k_bn_bwd_apply128, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, dout, a, stats, (const float*)part, nblk, gamma, (int)P, rpb,
-                       dgamma, dbeta, part2);
+                       dgamma, dbeta, part2, dz_pieces);
     if (dbias) hipLaunchKernelGGL(k_sum_rows, dim3(2), dim3(256), 0, (hipStream_t)stream, (const float*)part2, nblk, 128, dbias);
     CKR_HIP(hipGetLastError());
     return CKR_OK;

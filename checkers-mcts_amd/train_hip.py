@@ -57,10 +57,12 @@ class HipTrainStep:
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         L.ckr_gemm_nt.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
         L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        L.ckr_conv_gemm_pieces.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.ckr_conv_wsplit.argtypes = [vp, C.POINTER(i64), i32, vp, vp, vp]
         L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
         L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
-        L.ckr_conv_bias_relu_bn.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp]
-        L.ckr_conv_bn_relu_backward.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.ckr_conv_bias_relu_bn.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.ckr_conv_bn_relu_backward.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.ckr_conv_bias_grad.argtypes = [vp, i32, vp, vp]
         L.ckr_gemm_small.argtypes = [vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp]
         L.ckr_gemm_tall.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
@@ -76,8 +78,13 @@ class HipTrainStep:
         L.ckr_policy_head_step.argtypes = [C.POINTER(PolicyHeadArgs), i32, vp]
         self.net = net
         # matrix pipe of the conv GEMMs: "f32" = float32 MFMA, "bf16x6" = float32 operands as three bfloat16 pieces, six products
-        # per multiply-add on the bf16 MFMA (float32-grade results, 2.65 x the rate); see include/ckr.h
-        self.pipe = {"f32": 0, "bf16x6": 1}[pipe or os.environ.get("CKR_TRAIN_PIPE", "bf16x6")]
+        # per multiply-add on the bf16 MFMA (float32-grade results, 2.65 x the rate; the default); "bf16x6p" = the same arithmetic,
+        # bit for bit, with every operand of the forward / data-gradient GEMMs split ONCE by the kernel that produces it (the
+        # BatchNorm kernels, ckr_conv_wsplit) instead of in every GEMM that reads it: the GEMMs alone are 18-22 % faster, the step
+        # is not (the pieces are 1.5 x the bytes of the float32 tensors the weight gradient still reads) -- DESIGN.md section 3
+        self.pipe_name = pipe or os.environ.get("CKR_TRAIN_PIPE", "bf16x6")
+        self.pieces = self.pipe_name == "bf16x6p"
+        self.pipe = {"f32": 0, "bf16x6": 1, "bf16x6p": 1}[self.pipe_name]
         P = 64 * int(batch_size)
         # split-K until ~256 workgroups exist (one per CU): forward / data gradient over the 36 chunks of K = 1152,
         # the weight gradient (9 tap tiles) over the positions, never fewer than 4 chunks of 32 per slice on average
@@ -135,6 +142,13 @@ class HipTrainStep:
         self.ws_w = z(self.wgrad_slices * 128 * 1152)                                # ... and weight gradient (side stream)
         self.side = torch.cuda.Stream(device=dev)
         self.wt = z(7, 128, 1152)                          # flipped kernels of layers 1..7 for the data-gradient GEMMs
+        if self.pieces:
+            # bfloat16 pieces of what the forward / data-gradient GEMMs read: block outputs, dz of every block (P + 1 rows of 768
+            # bytes, the last one zero: a tap outside the board reads it), the kernels and their flipped copies (layers 1..7)
+            zb = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device=dev)
+            self.out3 = [zb(P + 1, 768) for _ in range(7)]            # out[0..6]
+            self.dz3 = [None] + [zb(P + 1, 768) for _ in range(7)]    # dz[1..7]
+            self.w3, self.wt3 = zb(7, 128, 6912), zb(7, 128, 6912)
         self.d_act, self.d_act2 = z(P, 128), z(P, 128)
         # dz of every conv block in its own buffer: reusing two would make each block's first backward kernel wait for the weight
         # gradient two blocks up -- a node with two parents in the captured graph, ~6 us on the critical path each
@@ -183,6 +197,8 @@ class HipTrainStep:
         self.w("vbn.g").copy_(net.val_bn.weight.detach().float()); self.w("vbn.beta").copy_(net.val_bn.bias.detach().float())
         self.run["vbn"][0].copy_(net.val_bn.running_mean); self.run["vbn"][1].copy_(net.val_bn.running_var)
         self.w("f2.w").copy_(net.val_fc2.weight.detach().float().reshape(-1)); self.w("f2.b").copy_(net.val_fc2.bias.detach().float())
+        if self.pieces:
+            _lib.check(self._L.ckr_conv_wsplit(self.W.data_ptr(), self.w_offsets, 7, self.w3.data_ptr(), None, self._s()))
 
     @torch.no_grad()
     def store_to_module(self):
@@ -228,7 +244,8 @@ class HipTrainStep:
         rm, rv = self.run[key]
         _lib.check(self._L.ckr_conv_bias_relu_bn(ws.data_ptr(), slices, self.w(key + ".b").data_ptr(), self.P, self.w(key + ".g").data_ptr(),
                                                  self.w(key + ".beta").data_ptr(), self.bn_eps, self.bn_mom, rm.data_ptr(), rv.data_ptr(),
-                                                 self.stats[key].data_ptr(), self.a[l].data_ptr(), self.out[l].data_ptr(), self.part.data_ptr(), self._s()))
+                                                 self.stats[key].data_ptr(), self.a[l].data_ptr(), self.out[l].data_ptr(), self.part.data_ptr(),
+                                                 self.out3[l].data_ptr() if self.pieces and l < 7 else None, self._s()))
 
     def _join(self, main):
         """The main stream continues when the side stream's work so far is done."""
@@ -344,7 +361,10 @@ class HipTrainStep:
             if l == 7:                                            # the value head hangs off the body's output, beside the policy conv block
                 body_done = torch.cuda.Event()
                 body_done.record(main)
-            _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.pipe, self.ws.data_ptr(), s))
+            if self.pieces:
+                _lib.check(L.ckr_conv_gemm_pieces(self.out3[6 if l == 7 else l - 1].data_ptr(), self.w3[l - 1].data_ptr(), P, 1, self.slices, self.ws.data_ptr(), s))
+            else:
+                _lib.check(L.ckr_conv_gemm(inp.data_ptr(), self.w("c%d.w" % l).data_ptr(), P, 1, self.slices, self.pipe, self.ws.data_ptr(), s))
             if l == 7:
                 # A side branch is issued AFTER the main chain's next kernel: the graph keeps a node's first-captured child in
                 # the parent's hardware queue and hands the others to another queue behind a signal (measured: ~10 us for every
@@ -354,7 +374,10 @@ class HipTrainStep:
                     ss = self.side.cuda_stream
                     # re-laid copies of kernels that are fixed during the step, off the critical path: the flipped conv kernels
                     # of the data-gradient GEMMs, the transposed Dense(512) kernel
-                    _lib.check(L.ckr_conv_wflip(self.W.data_ptr(), self.w_offsets, 7, self.wt.data_ptr(), ss))
+                    if self.pieces:
+                        _lib.check(L.ckr_conv_wsplit(self.W.data_ptr(), self.w_offsets, 7, None, self.wt3.data_ptr(), ss))
+                    else:
+                        _lib.check(L.ckr_conv_wflip(self.W.data_ptr(), self.w_offsets, 7, self.wt.data_ptr(), ss))
                     if self.fused_policy:
                         self._policy_head_fused(pi, 3)
                     prep_done = torch.cuda.Event()
@@ -381,10 +404,12 @@ class HipTrainStep:
             _lib.check(L.ckr_conv_bn_relu_backward(self.ws.data_ptr(), nslices, add.data_ptr() if add is not None else None, d.data_ptr(),
                                                    self.a[l].data_ptr(), self.stats[key].data_ptr(), self.w(key + ".g").data_ptr(), P,
                                                    self.g(key + ".g").data_ptr(), self.g(key + ".beta").data_ptr(), None,
-                                                   part.data_ptr(), s))                                   # d := dz
+                                                   part.data_ptr(), self.dz3[l].data_ptr() if self.pieces and l > 0 else None, s))   # d := dz
             dz_done = torch.cuda.Event()
             dz_done.record(main)
-            if l > 0:                                             # the critical path first (see the forward pass): gradient w.r.t. the block's input
+            if l > 0 and self.pieces:                             # the critical path first (see the forward pass): gradient w.r.t. the block's input
+                _lib.check(L.ckr_conv_gemm_pieces(self.dz3[l].data_ptr(), self.wt3[l - 1].data_ptr(), P, -1, self.slices, self.ws.data_ptr(), s))
+            elif l > 0:
                 _lib.check(L.ckr_conv_gemm(d.data_ptr(), self.wt[l - 1].data_ptr(), P, -1, self.slices, self.pipe, self.ws.data_ptr(), s))
             # the side branch is issued AFTER the main chain's next kernel: in the captured graph the node that continues the
             # critical path then follows its predecessor directly (a node with two children otherwise delays both by ~10 us)
@@ -410,3 +435,5 @@ class HipTrainStep:
         _lib.check(L.ckr_adam_step(self.W.data_ptr(), self.G.data_ptr(), self.M.data_ptr(), self.V.data_ptr(), self.reg.data_ptr(), self.n,
                                    lr_t.data_ptr(), self.betas[0], self.betas[1], self.eps, self.step_t.data_ptr(),
                                    self.penalty.data_ptr() if acc is not None else None, losses, s))
+        if self.pieces:                                           # the next step's forward GEMMs read the updated kernels' pieces
+            _lib.check(L.ckr_conv_wsplit(self.W.data_ptr(), self.w_offsets, 7, self.w3.data_ptr(), None, s))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 120          /* 0.1.2: one leaf cache per GPU (ckr_leaf_cache_*, pending claims), virtual workers (n_workers) */
+#define CKR_VERSION 121          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces) */
 
 typedef enum {
     CKR_OK = 0,
@@ -503,6 +503,16 @@ int ckr_conv_gemm(const float* act, const float* w, int32_t P, int32_t direction
 /* dw[o][tap * 128 + c] = sum_p dz[p][o] x[p + off(tap)][c] (taps = 9), or dw[o][c] = sum_p dz[p][o] x[p][c] (taps = 1: the
  * first layer on its im2col matrix); the P / 32 chunks of positions split over `slices` <= P / 32, workspace[slices][128][128 taps]. */
 int ckr_conv_wgrad(const float* dz, const float* x, int32_t P, int32_t taps, int32_t slices, int32_t pipe, float* workspace, float* dw, void* stream);
+/* ckr_conv_gemm (pipe 1 arithmetic, bit for bit) on operands split into their three bfloat16 pieces ONCE, by the kernel that
+ * produced them, instead of in every GEMM that reads them (round 4): act3 = pieces of an activation of P + 1 positions whose last
+ * row is zero (a tap outside the board reads it), w3 = pieces of the kernel rows [128][1152] (ckr_conv_wsplit; direction -1: its
+ * flipped copy).  A row of C floats is stored as C / 32 blocks of [3 pieces][32] bfloat16 (192 bytes per K chunk of a GEMM). */
+int ckr_conv_gemm_pieces(const void* act3, const void* w3, int32_t P, int32_t direction, int32_t slices, float* workspace, void* stream);
+/* out3 = the pieces of x[rows][cols] (cols % 32 == 0). */
+int ckr_split_pieces(const float* x, int64_t rows, int32_t cols, void* out3, void* stream);
+/* w3[l] / wt3[l] ([128][1152] rows of pieces each; either may be NULL) = the pieces of the kernel at w + offsets[l] and of its
+ * flipped copy (ckr_conv_wflip's layout) for l < layers <= 8. */
+int ckr_conv_wsplit(const float* w, const int64_t* offsets, int32_t layers, void* w3, void* wt3, void* stream);
 /* wt[l][c][tap * 128 + o] = w[offsets[l] + o * 1152 + tap * 128 + c] for l < layers <= 8; offsets: HOST array, in floats. */
 int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float* wt, void* stream);
 /* Forward of a conv block after its GEMM: a = ReLU(sum of `slices` workspace slices + bias) (kept for the backward pass),
@@ -510,12 +520,16 @@ int ckr_conv_wflip(const float* w, const int64_t* offsets, int32_t layers, float
  * unbiased variance), out = gamma * (a - mean) * inv_std + beta.  part: >= 256 ceil(P / 128) + 128 floats of workspace. */
 int ckr_conv_bias_relu_bn(const float* workspace, int32_t slices, const float* bias, int32_t P, const float* gamma, const float* beta,
                           float eps, float momentum, float* run_mean, float* run_var, float* stats, float* a, float* out, float* part,
-                          void* stream);
+                          void* out_pieces, void* stream);
+/* out_pieces (may be NULL): `out` again as the three bfloat16 pieces of every float, in the order ckr_conv_gemm_pieces stages them
+ * ([P + 1][4 chunks of 32 planes][3 pieces][32] bfloat16 = 768 bytes per position; row P is never written and must be zero). */
 /* Backward of a conv block before its GEMMs: dout = sum of the workspace slices (slices == 0: dout as given) + add (may be
  * NULL); dz = gradient w.r.t. the convolution's output written over dout; dgamma, dbeta, dbias (may be NULL, see
  * ckr_conv_bias_grad).  part: >= 384 ceil(P / 128). */
 int ckr_conv_bn_relu_backward(const float* workspace, int32_t slices, const float* add, float* dout, const float* a, const float* stats,
-                              const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* stream);
+                              const float* gamma, int32_t P, float* dgamma, float* dbeta, float* dbias, float* part, void* dz_pieces,
+                              void* stream);
+/* dz_pieces (may be NULL): dz again as bfloat16 pieces, as out_pieces above. */
 /* dbias from the partial sums a ckr_conv_bn_relu_backward call with dbias == NULL left in `part` (so that it can run on another
  * stream, off the backward chain's critical path). */
 int ckr_conv_bias_grad(const float* part, int32_t P, float* dbias, void* stream);

@@ -102,6 +102,75 @@ def test_implicit_conv_gemms_match_float64_conv(pipe):
         _lib.check(L.ckr_conv_gemm(x.data_ptr(), wk.data_ptr(), P, 1, 5, pipe, ws.data_ptr(), st))
 
 
+def test_conv_gemms_on_presplit_operands_equal_the_splitting_kernels():
+    """ckr_conv_gemm_pieces (operands split into their three bfloat16 pieces by the producer: ckr_split_pieces here, the BatchNorm
+    kernels in the step) computes the same products in the same order as ckr_conv_gemm with pipe 1: identical bits, forward and
+    data gradient, every split-K factor, in each of its three kernels (double-buffered 128 x 128 tiles up to 256 boards, the
+    single-buffered kernel in between, 256 x 128 tiles of eight waves from 1 024 boards on); and the pieces themselves add up to the
+    float32 values."""
+    from checkers_mcts_amd import _lib
+    L = _lib.load()
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    L.ckr_conv_gemm_pieces.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.ckr_split_pieces.argtypes = [vp, i64, i32, vp, vp]
+    L.ckr_conv_wsplit.argtypes = [vp, C.POINTER(i64), i32, vp, vp, vp]
+    L.ckr_conv_wflip.argtypes = [vp, C.POINTER(i64), i32, vp, vp]
+    g = torch.Generator().manual_seed(8)
+    st = torch.cuda.current_stream().cuda_stream
+    for B, slice_list in ((2, (1, 2, 4, 9)), (6, (1, 2, 4, 9)), (34, (1, 4)), (320, (1, 2)), (1024, (1, 3))):
+        P = 64 * B
+        x = (torch.randn(P, 128, generator=g) * torch.exp(3 * torch.randn(P, 1, generator=g))).cuda()      # rows of very different magnitude
+        wk = (torch.randn(2, 128, 1152, generator=g) * 0.05).cuda()                                          # two layers
+        x3 = torch.zeros(P + 1, 768, dtype=torch.uint8, device="cuda")
+        _lib.check(L.ckr_split_pieces(x.data_ptr(), P, 128, x3.data_ptr(), st))
+        pieces = x3[:P].view(torch.bfloat16).reshape(P, 4, 3, 32).double()
+        assert torch.equal(pieces.sum(2).reshape(P, 128), x.double())      # b1 + b2 + b3 == x exactly (each residual is exact in float32)
+        assert not bool(x3[P].any())
+        w3 = torch.zeros(2, 128, 6912, dtype=torch.uint8, device="cuda")
+        wt3 = torch.zeros_like(w3)
+        offs = (i64 * 2)(0, 128 * 1152)
+        _lib.check(L.ckr_conv_wsplit(wk.data_ptr(), offs, 2, w3.data_ptr(), wt3.data_ptr(), st))
+        wt = torch.zeros(2, 128, 1152, device="cuda")
+        _lib.check(L.ckr_conv_wflip(wk.data_ptr(), offs, 2, wt.data_ptr(), st))
+        assert torch.equal(w3.view(torch.bfloat16).reshape(2, 128, 36, 3, 32).double().sum(3).reshape(2, 128, 1152), wk.double())
+        assert torch.equal(wt3.view(torch.bfloat16).reshape(2, 128, 36, 3, 32).double().sum(3).reshape(2, 128, 1152), wt.double())
+        for slices in slice_list:
+            for direction, w_plain, w_pieces in ((1, wk[1], w3[1]), (-1, wt[1], wt3[1])):
+                ws1 = torch.zeros(slices, P, 128, device="cuda")
+                ws2 = torch.full((slices, P, 128), 7.0, device="cuda")
+                _lib.check(L.ckr_conv_gemm(x.data_ptr(), w_plain.data_ptr(), P, direction, slices, 1, ws1.data_ptr(), st))
+                _lib.check(L.ckr_conv_gemm_pieces(x3.data_ptr(), w_pieces.data_ptr(), P, direction, slices, ws2.data_ptr(), st))
+                assert torch.equal(ws1, ws2), (B, slices, direction)
+    with pytest.raises(ValueError):
+        _lib.check(L.ckr_conv_gemm_pieces(x3.data_ptr(), w3.data_ptr(), P, 1, 5, ws2.data_ptr(), st))
+    with pytest.raises(ValueError):
+        _lib.check(L.ckr_split_pieces(x.data_ptr(), P, 100, x3.data_ptr(), st))
+
+
+def test_presplit_step_equals_the_splitting_step_bit_for_bit():
+    """HipTrainStep with pipe "bf16x6p" and "bf16x6" (the default): the same arithmetic in the same order, so three Adam steps
+    leave identical parameters, moments, moving statistics and loss sums."""
+    import copy
+    from checkers_mcts_amd.train_hip import HipTrainStep
+    B = 128
+    runs = []
+    for pipe in ("bf16x6", "bf16x6p"):
+        net = make_net(4)
+        hs = HipTrainStep(net, B, 1e-3, 1e-3, pipe=pipe)
+        lr = torch.tensor(1e-3, device="cuda")
+        acc = torch.zeros(3, dtype=torch.float64, device="cuda")
+        for i in range(3):
+            x, pi, tv = make_batch(B, 40 + i)
+            hs.step(x, pi, tv, lr, acc, B)
+        torch.cuda.synchronize()
+        runs.append((hs.W.clone(), hs.M.clone(), hs.V.clone(), acc.clone(), [hs.run["c%d" % l][1].clone() for l in range(8)]))
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert torch.equal(a, b)
+    for a, b in zip(runs[0][4], runs[1][4]):
+        assert torch.equal(a, b)
+
+
 def relu_decisions(hs):
     """The ReLU decisions the HIP step took (its kept post-ReLU activations > 0), in the float64 graph's shapes."""
     B = hs.B
@@ -150,7 +219,7 @@ def float64_loss(net, x, pi, tv, decisions, flip_tol=1e-5):
 
 
 @pytest.mark.parametrize("B", [32, 128, 320])         # 320: 256-row reduction blocks, split-K 2, uneven weight-gradient slices
-@pytest.mark.parametrize("pipe", ["f32", "bf16x6"])
+@pytest.mark.parametrize("pipe", ["f32", "bf16x6", "bf16x6p"])
 def test_one_step_gradients_match_autograd(B, pipe):
     import copy
     from checkers_mcts_amd.train_hip import HipTrainStep

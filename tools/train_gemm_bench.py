@@ -13,6 +13,8 @@ L = _lib.load()
 vp, i32 = C.c_void_p, C.c_int32
 L.ckr_conv_gemm.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
 L.ckr_conv_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+L.ckr_conv_gemm_pieces.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+L.ckr_split_pieces.argtypes = [vp, C.c_int64, i32, vp, vp]
 PIPE = {"f32": 0, "bf16x6": 1}[os.environ.get("CKR_TRAIN_PIPE", "bf16x6")]
 P = 64 * B
 x = torch.randn(P, 128, device="cuda")
@@ -42,6 +44,19 @@ for s in (1, 2, 3, 4, 6, 9):
     out["forward"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
     us = timed(lambda: _lib.check(L.ckr_conv_gemm(dz.data_ptr(), w.data_ptr(), P, -1, s, PIPE, ws.data_ptr(), st)))
     out["dgrad"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
+# the same two GEMMs on operands split once by their producers (ckr_conv_gemm_pieces; the step's default, pipe "bf16x6p")
+x3 = torch.zeros(P + 1, 768, dtype=torch.uint8, device="cuda")
+dz3 = torch.zeros(P + 1, 768, dtype=torch.uint8, device="cuda")
+w3 = torch.zeros(128, 6912, dtype=torch.uint8, device="cuda")
+_lib.check(L.ckr_split_pieces(x.data_ptr(), P, 128, x3.data_ptr(), st))
+_lib.check(L.ckr_split_pieces(dz.data_ptr(), P, 128, dz3.data_ptr(), st))
+_lib.check(L.ckr_split_pieces(w.data_ptr(), 128, 1152, w3.data_ptr(), st))
+out["forward_presplit"], out["dgrad_presplit"] = {}, {}
+for s in (1, 2, 3, 4, 6, 9):
+    us = timed(lambda: _lib.check(L.ckr_conv_gemm_pieces(x3.data_ptr(), w3.data_ptr(), P, 1, s, ws.data_ptr(), st)))
+    out["forward_presplit"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
+    us = timed(lambda: _lib.check(L.ckr_conv_gemm_pieces(dz3.data_ptr(), w3.data_ptr(), P, -1, s, ws.data_ptr(), st)))
+    out["dgrad_presplit"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
 for s in (14, 16, 28, 32, 56, 64):
     us = timed(lambda: _lib.check(L.ckr_conv_wgrad(dz.data_ptr(), x.data_ptr(), P, 9, s, PIPE, ws.data_ptr(), dw.data_ptr(), st)))
     out["wgrad"][s] = [round(us, 1), round(flops / us / 1e6, 1)]
