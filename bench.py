@@ -810,11 +810,11 @@ def main():
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
             cpu = cpu_baseline(a.budget, a.cpu_seconds)
-        out = {"metric": "MCTS node-expansions/sec (whole node) at 100 sims/move", "value": value,
+        out = {"metric": "MCTS node-expansions/sec (whole node) at %d sims/move" % a.budget, "value": value,   # BASELINE's metric at the default --budget 100
                "unit": "node-expansions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": DTYPE_LABEL[mode], "data": "synthetic",
-               "config": {"workload": "cfg3: batched MCTS %d sims/move, %d concurrent self-play games per GPU, "
+               "config": {"workload": ("cfg3" if a.budget == 100 else "cfg4 (per-GPU share)" if a.budget == 400 else "cfg3 shape") + ": batched MCTS %d sims/move, %d concurrent self-play games per GPU, "
                                       "random-init policy/value net (Keras-default init), TERMINATE_CNT 200"
                                       % (a.budget, a.slots),
                           "slots_per_gpu": a.slots, "budget": a.budget, "nn_dtype": mode, "preroll_steps": pre,

@@ -36,7 +36,7 @@ def main():
     first, _ = ckdist.shard_range(a.slots * world, rank, world)
     cfg = E.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=a.games_per_slot,
                                terminate_cnt=0 if a.tournament else a.terminate, tournament=a.tournament,
-                               first_worker_id=first, feature_dtype=dt, seed=a.seed, device=local_rank,
+                               first_worker_id=first, feature_dtype=dt, seed=a.seed, device=dev.index,
                                dynamic_queue=a.dynamic,
                                leaf_cache_log2=0 if a.no_cache else default_leaf_cache_log2(a.slots, dev), dense_rows=not a.no_cache)
     eng = E.Engine(cfg, feature_dtype=dt)
@@ -61,13 +61,23 @@ def main():
     exp = ckdist.sum_over_ranks(st["expansions"], dev)
     games = ckdist.sum_over_ranks(st["games"], dev)
     terms = ckdist.sum_over_ranks(st["terminal_visits"], dev)           # collectives on every rank, not inside the rank-0 branch
+    oc = np.array([r["outcome"] for r in res] or [0])
+    p1 = np.array([r.get("p1_net", 0) for r in res] or [0])
+    # arena bookkeeping over all ranks: outcome 1 / 2 = player 1 / 2 won, 3 = draw; the new network plays player 1 in the games
+    # whose p1_net is 0 (training_pipeline.py:523-528: colours swapped for the second half)
+    new_wins = ckdist.sum_over_ranks(int((((oc == 1) & (p1 == 0)) | ((oc == 2) & (p1 == 1))).sum()), dev)
+    old_wins = ckdist.sum_over_ranks(int((((oc == 1) & (p1 == 1)) | ((oc == 2) & (p1 == 0))).sum()), dev)
+    draws = ckdist.sum_over_ranks(int((oc == 3).sum()), dev)
+    failed = ckdist.sum_over_ranks(int(sum(r["failed"] for r in res)), dev)
+    longest = ckdist.max_over_ranks(float(max([r["move_count"] for r in res] or [0])), dev)
     if rank == 0:
         moves = np.array([r["move_count"] for r in res] or [0])
         out = dict(n_gpus=world, slots_per_gpu=a.slots, games_per_slot=a.games_per_slot, dynamic_queue=a.dynamic, budget=a.budget, nn_dtype=a.nn_dtype, steps=steps,
                    seconds=t_all, play_seconds=t_play, gather_seconds=t_gather, games=games,
                    games_per_hour=games / t_all * 3600, expansions=exp, expansions_per_s=exp / t_all,
                    sims_per_s=(exp + terms) / t_all, ms_per_step=t_play / max(1, steps) * 1e3,
-                   tuples_gathered=int(gathered.shape[0]), rank0_stats=st,
+                   tuples_gathered=int(gathered.shape[0]), all_ranks=dict(new_net_wins=new_wins, old_net_wins=old_wins, draws=draws, failed=failed, longest_game_plies=longest),
+                   rank0_stats=st,
                    rank0_game_length=dict(mean=float(moves.mean()), min=int(moves.min()), max=int(moves.max())),
                    rank0_outcomes={str(k): int((np.array([r["outcome"] for r in res]) == k).sum()) for k in (1, 2, 3)},
                    rank0_adjudicated=int(sum(r["adjudicated"] for r in res)), rank0_failed=int(sum(r["failed"] for r in res)))
