@@ -141,8 +141,6 @@ class HipTrainStep:
         self.ws = z(max(self.slices * P * 128, 4 * B * 512))                         # split-K partial products: forward / data gradient
         self.ws_w = z(self.wgrad_slices * 128 * 1152)                                # ... and weight gradient (side stream)
         self.side = torch.cuda.Stream(device=dev)
-        self.schedule = int(os.environ.get("CKR_TRAIN_SCHEDULE", "0"))
-        self.ws_w0 = z(self.wgrad_slices0 * 128 * 128)             # the first layer's weight-gradient slices (schedule 1: on the main stream)
         self.wt = z(7, 128, 1152)                          # flipped kernels of layers 1..7 for the data-gradient GEMMs
         if self.pieces:
             # bfloat16 pieces of what the forward / data-gradient GEMMs read: block outputs, dz of every block (P + 1 rows of 768
@@ -418,25 +416,14 @@ class HipTrainStep:
             self.side.wait_event(dz_done)
             with torch.cuda.stream(self.side):
                 ss = self.side.cuda_stream
-                if self.schedule == 0:
-                    if l == 7 and self.fused_policy:
-                        self._policy_head_fused(pi, 2)
-                    if l == 0:                                    # the step's tail: one tap tile only, so many position slices
-                        _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices0, self.pipe, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
-                    _lib.check(L.ckr_conv_bias_grad(part.data_ptr(), P, self.g(key + ".b").data_ptr(), ss))
+                if l == 7 and self.fused_policy:
+                    self._policy_head_fused(pi, 2)
+                if l == 0:                                        # the step's tail: one tap tile only, so many position slices
+                    _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices0, self.pipe, self.ws_w.data_ptr(), self.g("c0.w").data_ptr(), ss))
+                _lib.check(L.ckr_conv_bias_grad(part.data_ptr(), P, self.g(key + ".b").data_ptr(), ss))
                 if l > 0:
                     inp = self.out[6] if l == 7 else self.out[l - 1]
                     _lib.check(L.ckr_conv_wgrad(d.data_ptr(), inp.data_ptr(), P, 9, self.wgrad_slices, self.pipe, self.ws_w.data_ptr(), self.g(key + ".w").data_ptr(), ss))
-                elif self.schedule == 1:
-                    # schedule 1: the side stream runs the weight-gradient GEMMs first, each as soon as its dz exists, and the small
-                    # reductions nothing waits for (policy head parameters, the eight bias gradients) behind the last of them; the
-                    # first layer's weight gradient runs on the main stream, which has nothing else left to do
-                    if self.fused_policy:
-                        self._policy_head_fused(pi, 2)
-                    for l2 in range(7, -1, -1):
-                        _lib.check(L.ckr_conv_bias_grad(self.parts_bwd[l2].data_ptr(), P, self.g("c%d.b" % l2).data_ptr(), ss))
-            if l == 0 and self.schedule == 1:
-                _lib.check(L.ckr_conv_wgrad(d.data_ptr(), self.col0.data_ptr(), P, 1, self.wgrad_slices0, self.pipe, self.ws_w0.data_ptr(), self.g("c0.w").data_ptr(), s))
             if l == 0:
                 break
             nslices = self.slices
