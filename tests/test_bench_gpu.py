@@ -67,3 +67,21 @@ def test_bench_under_torchrun_with_rccl_world_of_one(tmp_path):
     d = last_json(out)
     check_line(d, 1)
     assert "RCCL" in d["whole_run"]["gather"]["collective"]
+
+
+def test_arena_job_on_two_ranks_sharing_the_gpu(tmp_path):
+    """BASELINE cfg5's job shape through tools/selfplay_run.py (the command behind profiles/r04_cfg5_full_*): two ranks under
+    torch.distributed.run share the box's GPU, every rank plays its block of arena games to their natural end, the W / L / D
+    bookkeeping is summed over the ranks (training_pipeline.py:505-560: the tournament's outcome counts)."""
+    env = dict(os.environ, CKR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29633", os.path.join(ROOT, "tools", "selfplay_run.py"), "--tournament", "--slots", "64", "--budget", "20", "--nn-dtype", "fp32"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    d = last_json(out)
+    a = d["all_ranks"]
+    assert d["n_gpus"] == 2 and d["games"] == 128 and a["failed"] == 0
+    assert a["new_net_wins"] + a["old_net_wins"] + a["draws"] == 128
+    assert sum(d["rank0_outcomes"].values()) == 64 and d["rank0_adjudicated"] == 0          # natural ends only: no TERMINATE_CNT in the arena
+    assert d["expansions"] > 0 and a["longest_game_plies"] >= d["rank0_game_length"]["max"] >= d["rank0_game_length"]["min"] > 0
