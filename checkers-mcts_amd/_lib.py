@@ -54,7 +54,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",
-           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_conv_stack_f16x3_boards", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_leaf_cache_create", "ckr_leaf_cache_destroy", "ckr_leaf_cache_flush", "ckr_engine_attach_cache", "ckr_engine_create", "ckr_engine_compact_rows", "ckr_engine_set_row_range", "ckr_engine_set_eval_flag",
+           "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_conv_stack_f16x3_boards", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_leaf_cache_create", "ckr_leaf_cache_destroy", "ckr_leaf_cache_flush", "ckr_engine_attach_cache", "ckr_engine_create", "ckr_engine_compact_rows", "ckr_engine_set_row_range", "ckr_engine_set_eval_flag", "ckr_engine_set_prefetch",
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_single", "ckr_engine_step_end_ply", "ckr_engine_subtree", "ckr_engine_stats", "ckr_engine_mark", "ckr_engine_stats_at_mark", "ckr_engine_cache_flush", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
            "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_rollout_end_ply", "ckr_engine_set_ln_table",
@@ -106,6 +106,7 @@ def load():
         L.ckr_engine_compact_rows.argtypes = [vp, vp, vp, vp, vp, vp]
         L.ckr_engine_set_row_range.argtypes = [vp, vp]
         L.ckr_engine_set_eval_flag.argtypes = [vp, vp]
+        L.ckr_engine_set_prefetch.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.ckr_engine_stats.argtypes = [vp, C.POINTER(Stats)]
         L.ckr_engine_mark.argtypes = [vp, vp]
         L.ckr_engine_cache_flush.argtypes = [vp, vp]

@@ -127,7 +127,18 @@ struct Dev {
     int n_workers; int32_t* g_worker; int32_t* next_worker;
     // dense rows (ckr_config.dense_rows): a slot that hands out a leaf takes the next free row of the network batch
     int dense_rows; int32_t* row_count;          // DEVICE counter = d_range[1] of ckr_engine_set_row_range, zeroed before every step
+    // evaluation ahead of the search (ckr_engine_set_prefetch; see prefetch_children): while few slots still play, the rows of the
+    // network batch that no leaf needs evaluate the children of the nodes a step expands, and the next step turns the answers
+    // into leaf-cache records -- the leaf of a later simulation is then found in the cache and expanded without a network round trip
+    int pf_rows;                 // prefetched positions take rows [pf_base, pf_rows) of the batch (the leaves: [0, number of leaves), and no more
+    int pf_base;                 // slots play than pf_base); pf_rows == 0: off.  The evaluator computes rows [0, pf_rows) at every step
+    int pf_sims;                 // network-free simulations per slot and step while it is on
+    int32_t* pf_counter;         // DEVICE: prefetched positions handed out in this step (zeroed by the step's prologue)
+    int32_t* g_pf_n;             // [slot] positions handed out by the last step
+    int32_t* g_pf_row;           // [slot][PF_MAX] their rows | network id << 30 (-1: none)
+    uint4* g_pf_board;           // [slot][PF_MAX] their board records
 };
+constexpr int PF_MAX = 48;       // prefetched positions per slot and step
 
 struct WaveLds {
     union { float p[512]; float feat[896]; double ev[64]; } u;   // raw probabilities | features | sampling
@@ -557,6 +568,94 @@ template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, cons
         }
     }
     w.count(CNT_CDROP);                                             // neighbourhood full of live records: not cached
+}
+
+// ---- evaluation ahead of the search (the tail of a run, where a step lasts as long as one network launch whatever its few rows).
+// Checkers.predict is a pure function of the position (Checkers.py:425-438) and the leaf of every simulation is a child of an
+// expanded node, so the children of a node can be evaluated as soon as the node is expanded: prefetch_children hands their board
+// records out as extra rows of this step's batch (those not in the leaf cache yet), prefetch_consume -- first thing in the next
+// step -- builds from each answer exactly the record an expansion would write (the masked, renormalised priors of the position's
+// children in tree order and v) and inserts it.  The search itself is untouched: a later simulation that reaches one of these
+// children finds it in the cache (or not, and asks the network as before), so every slot's sequence of simulations and every
+// result is the same with and without -- only more of them are network-free, i.e. run inside one step.
+template <class Wave> __device__ __attribute__((noinline)) void prefetch_children(Wave w, int t, int node, int net, void* x, int32_t* net_out) {
+    const Dev& D = w.D;
+    const int pf_count = D.g_pf_n[w.slot];                                      // handed out by this step so far (kept in memory: nothing of
+    if (pf_count >= PF_MAX || D.pf_base + *D.pf_counter >= D.pf_rows) return;   // this lives in k_step's registers; the row counter: a plain read)
+    const size_t tb = w.tb(t);
+    const uint32_t kids = D.n_kids[tb + node];
+    const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
+    bool want = false;
+    ckr_board c{0u, 0u, 0u, 0u};
+    if (w.lane < n) {
+        c = ld_board(&D.n_board[tb + base + w.lane]);
+        const uint32_t cst = D.n_status[tb + base + w.lane];
+        if (st_outcome(cst) == 0u && !(cst & ST_EXPANDED)) {                    // terminal children never reach the network
+            const unsigned long long h = cache_hash(cache_key(c, cst, net)), tag = cache_tag(h);
+            bool present = false;
+#pragma unroll
+            for (int i = 0; i < CACHE_PROBES; ++i) {
+                const unsigned long long claim = D.cache_claim[(size_t)((h + (unsigned long long)i) & D.cache_mask)];
+                if (claim != 0ull && (claim & CACHE_TAG_MASK) == tag) {
+                    const int d = cache_gen_dist(D, claim, w.epoch);
+                    present = present || (d >= -1 && d <= 1);                   // served now, soon, or being written: not again
+                }
+            }
+            want = !present;
+        }
+    }
+    unsigned long long bal = __ballot(want);
+    const unsigned long long lt = (1ull << w.lane) - 1ull;
+    int rank = __popcll(bal & lt);
+    want = want && pf_count + rank < PF_MAX;
+    bal = __ballot(want);
+    const int cnt = __popcll(bal);
+    if (cnt == 0) return;
+    rank = __popcll(bal & lt);
+    int r0 = 0;
+    if (w.lane == 0) r0 = atomicAdd(D.pf_counter, cnt);
+    r0 = bcast_i32(r0, 0);
+    if (want) {
+        const int row = D.pf_base + r0 + rank, at = w.slot * PF_MAX + pf_count + rank;
+        const bool ok = row < D.pf_rows;                                        // (beyond the last row: not handed out)
+        D.g_pf_row[at] = ok ? (row | (net << 30)) : -1;
+        if (ok) {
+            const uint4 rec = make_uint4(c.p1, c.p2, c.kings, c.meta);
+            D.g_pf_board[at] = rec;
+            reinterpret_cast<uint4*>(x)[row] = rec;
+            if (net_out) net_out[row] = net;
+        }
+    }
+    if (w.lane == 0) D.g_pf_n[w.slot] = pf_count + cnt;
+    wave_mem_fence();
+}
+
+template <class Wave> __device__ __attribute__((noinline)) void prefetch_consume(Wave w, const float* __restrict__ p, const float* __restrict__ v, int count) {
+    const Dev& D = w.D;
+    for (int k = 0; k < count; ++k) {
+        const int rw = D.g_pf_row[w.slot * PF_MAX + k];
+        if (rw < 0) continue;
+        const int row = rw & 0x3FFFFFFF, net = (rw >> 30) & 1;
+        const ckr_board b = ld_board(&D.g_pf_board[w.slot * PF_MAX + k]);
+        const float4* src = reinterpret_cast<const float4*>(p + (size_t)row * 512);
+        const float4 p0 = src[w.lane], p1 = src[w.lane + 64];
+        const float val = v[row];
+        uint32_t m[8], st;
+        movegen(b, m, st);
+        // what expand() computes from the network's answer for this position (Checkers.predict's mask / renormalise,
+        // Checkers.py:435-437, and set_prior_probs, :440-452): the same floats, in the same order
+        if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
+        float4* dl = reinterpret_cast<float4*>(w.L.u.p);
+        dl[w.lane] = p0; dl[w.lane + 64] = p1;
+        __builtin_amdgcn_wave_barrier();
+        const float total = wave_masked_sum(w.L.u.p, w.L.mask);
+        const int n = wave_children(b, m, w.L.kids, true);
+        __builtin_amdgcn_wave_barrier();
+        float prior = 0.0f;
+        if (w.lane < n) prior = w.L.u.p[meta_action(w.L.kids[w.lane].meta)] / total;
+        cache_insert(w, cache_key(b, st, net), n, prior, val);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
@@ -1099,6 +1198,7 @@ __global__ __launch_bounds__(256) void k_step_prologue(const Dev* __restrict__ D
     if (range && i < 2) range[i] = 0;
     if (range && net && i < n) net[i] = -1;
     if (i == 0 && Dp->cache) epoch_advance(*Dp, Dp->estate);
+    if (i == 1 && Dp->pf_counter) *Dp->pf_counter = 0;
 }
 
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
@@ -1122,6 +1222,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             if (net_out && (int)threadIdx.x < D.n_slots) net_out[threadIdx.x] = -1;
         }
         if (D.cache && threadIdx.x == 0) { epoch_advance(D, &s_epoch); *D.estate = s_epoch; }
+        if (D.pf_counter && threadIdx.x == 1) *D.pf_counter = 0;
         __syncthreads();
     } else if (D.cache) {                                      // written by the prologue kernel in front of this launch
         if (threadIdx.x < 1 + CACHE_MAX_ENGINES) (&s_epoch.E)[threadIdx.x] = (&D.estate->E)[threadIdx.x];
@@ -1160,6 +1261,13 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     // the network's answer to the last batch is void (see Dev.eval_flag): nothing is expanded, nothing descends; a slot with a
     // leaf at the network hands the same leaf out again (same reservation in the leaf cache), the others idle for this step
     const bool stalled = D.eval_flag != nullptr && *D.eval_flag != 0;
+    // positions handed out ahead of the search by the previous step (prefetch_children): their answers become leaf-cache records
+    const int pf_prev = D.g_pf_n ? D.g_pf_n[slot] : 0;
+    if (pf_prev > 0) {
+        if (!stalled) prefetch_consume(w, p, v, pf_prev);                 // (by value: the handle of the hot path stays in registers)
+        if (w.lane == 0) D.g_pf_n[slot] = 0;
+        wave_mem_fence();
+    }
     if (stalled) {
         if (slot == 0) w.count(CNT_STALL);
         if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
@@ -1170,6 +1278,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     } else if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
         const int t = t0;
         const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
+        int expanded = pending;                                           // the leaf's index (it moves if the tree is compacted below)
         bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
         if (!ok) {
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
@@ -1178,9 +1287,11 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             const int moved = compact(w, t, pending);
             ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
             ok = moved >= 0 && expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet, cslot0, cword0);
+            expanded = moved;
         }
         if (ok) {
             if (w.lane == 0) D.g_sims[slot] += 1;
+            if (D.pf_rows > 0 && (flags & 5) == 0) { wave_mem_fence(); prefetch_children(w, t, expanded, pnet, x, net_out); }
         } else {                                                          // the live subtree itself does not fit: give up on this game
             w.count(CNT_OVERFLOW);
             WaveT<WT> wc = w;                                                 // (a copy: see finish_ply below)
@@ -1193,7 +1304,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     // B. advance until a leaf needs the network
     // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
     // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
-    const int max_sims = (flags & 4) ? 1 : D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
+    const int max_sims = (flags & 4) ? 1 : D.pf_rows > 0 && (flags & 1) == 0 ? D.pf_sims : D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
     bool did_sim = (flags & 4) != 0 && pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0 && !stalled;   // single-simulation step: the expansion above completed one
     while (!stalled && !did_sim && D.g_phase[slot] == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
@@ -1234,6 +1345,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
                     w.count(CNT_HIT);
                     if (w.lane == 0) { D.g_sims[slot] += 1; if (D.cache_park) { D.g_pending[slot] = -1; D.g_parked[slot] = 0; } }
                     wave_mem_fence();
+                    if (D.pf_rows > 0 && (flags & 5) == 0) prefetch_children(w, t, found, net, x, net_out);
                     ++free_sims;
                     continue;
                 }                                                        // pool full: let the network path compact and retry
@@ -1637,6 +1749,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.g_gid, S, true); A(D.next_game, (size_t)1, true); A(D.n_finished, (size_t)1, true);
     A(D.g_worker, S, true); A(D.next_worker, (size_t)1, true); A(D.g_cslot, S, true); A(D.g_cword, S, true); A(D.g_parked, S, true);
     A(D.estate, (size_t)1, true); A(D.g_start, S, true);
+    if (c->neural_net && c->dense_rows && !c->manual_play && c->feature_dtype == 3) {   // evaluation ahead of the search (ckr_engine_set_prefetch)
+        A(D.g_pf_n, S, true); A(D.g_pf_row, S * PF_MAX, true); A(D.g_pf_board, S * PF_MAX, true); A(D.pf_counter, (size_t)1, true);
+    }
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
     A(D.tuples, NT ? NT : 1, true);
@@ -1781,9 +1896,10 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     // One small kernel, not hipMemsetAsync calls: captured into a HIP graph (ROCm 7.2) a 0xFF memset node left rows that look
     // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
     // past the rows in use); it is also one graph node instead of two.
+    const int n_rows = e->dev.pf_rows > e->cfg.n_slots ? e->dev.pf_rows : e->cfg.n_slots;       // rows whose network id the prologue resets
     if (prologue && e->cfg.n_slots > 4)
-        hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (e->cfg.n_slots + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,
-                           e->dev.dense_rows ? e->d_range : (int32_t*)nullptr, d_net, (int)e->cfg.n_slots);
+        hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (n_rows + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,
+                           e->dev.dense_rows ? e->d_range : (int32_t*)nullptr, d_net, n_rows);
     const int flags = (end_ply == 1 ? 1 : 0) | (end_ply == 4 ? 4 : 0) | (prologue && e->cfg.n_slots <= 4 ? 2 : 0);
     if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
@@ -1808,6 +1924,22 @@ int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range) {
     e->d_range = d_range;
     e->dev.row_count = d_range + 1;
     CKR_HIP(hipMemcpy(e->d_dev, &e->dev, sizeof(Dev), hipMemcpyHostToDevice));
+    return CKR_OK;
+}
+
+int ckr_engine_set_prefetch(ckr_engine* e, int32_t first_row, int32_t rows, int32_t sims_per_step, int32_t row_capacity) {
+    if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_set_prefetch: null engine");
+    Dev& D = e->dev;
+    if (rows != 0) {
+        if (!D.g_pf_n) return fail(CKR_ERR_STATE, "ckr_engine_set_prefetch needs a dense_rows NEURAL_NET engine that hands out board records (feature_dtype 3)");
+        if (!D.cache) return fail(CKR_ERR_STATE, "ckr_engine_set_prefetch needs a leaf cache: the prefetched evaluations are served from it");
+        if (first_row < 0 || rows <= first_row || rows > row_capacity || row_capacity < e->cfg.n_slots || sims_per_step < 1)
+            return fail(CKR_ERR_INVALID, "ckr_engine_set_prefetch: 0 <= first_row < rows <= row_capacity (the rows of the caller's x / p / v / "
+                                         "network-id buffers, >= n_slots), sims_per_step >= 1");
+    }
+    CKR_HIP(hipDeviceSynchronize());
+    D.pf_base = rows ? first_row : 0; D.pf_rows = rows; D.pf_sims = rows ? sims_per_step : 0;
+    CKR_HIP(hipMemcpy(e->d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice));
     return CKR_OK;
 }
 

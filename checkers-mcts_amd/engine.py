@@ -155,8 +155,9 @@ class LeafCache:
 class Engine:
     """One engine per GPU / process.  Calls are serialised by the caller."""
 
-    def __init__(self, cfg, feature_dtype=torch.float32, cache=None):
-        """cache: a LeafCache to attach to (cfg.leaf_cache_log2 must be 0 then); the engine keeps it alive."""
+    def __init__(self, cfg, feature_dtype=torch.float32, cache=None, extra_rows=0):
+        """cache: a LeafCache to attach to (cfg.leaf_cache_log2 must be 0 then); the engine keeps it alive.
+        extra_rows: rows of the network batch beyond one per slot (set_prefetch can hand them out)."""
         self._L = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.CkrError("no HIP device: the self-play engine has no CPU fallback")
@@ -166,7 +167,7 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self._L.ckr_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h
-        S = cfg.n_slots
+        S = self.rows = cfg.n_slots + int(extra_rows)
         self.feature_dtype = feature_dtype
         # what the engine writes per leaf: the NHWC network input (channels-last view for torch), or -- feature_dtype BOARDS -- the
         # leaf's 16-byte board record, from which fused.FusedEvaluator's float32-grade conv stack builds the planes in LDS
@@ -176,7 +177,7 @@ class Engine:
                   torch.zeros((S, 8, 8, 14), dtype=feature_dtype, device=self.device))
         self.net_id = torch.full((S,), -1, dtype=torch.int32, device=self.device)
         # board range of the network batch: [0, S) until compact_rows() moves the active slots to the front
-        self.row_range = torch.tensor([0, S], dtype=torch.int32, device=self.device)
+        self.row_range = torch.tensor([0, cfg.n_slots], dtype=torch.int32, device=self.device)
         self.dense_rows = bool(cfg.dense_rows) and bool(cfg.neural_net) and not bool(cfg.manual_play)
         if self.dense_rows:
             _lib.check(self._L.ckr_engine_set_row_range(self._h, self.row_range.data_ptr()))
@@ -223,6 +224,26 @@ class Engine:
         fn = self._L.ckr_engine_step_end_ply if end_ply else self._L.ckr_engine_step_single if single else self._L.ckr_engine_step
         _lib.check(fn(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
+
+    @property
+    def can_prefetch(self):
+        """Evaluation ahead of the search (set_prefetch) needs dense rows, board-record leaves and a leaf cache."""
+        return bool(self.dense_rows and self.leaf_records and (self.cache is not None or self.cfg.leaf_cache_log2))
+
+    def set_prefetch(self, first_row=0, rows=0, sims_per_step=8):
+        """The tail of a run (include/ckr.h, ckr_engine_set_prefetch): rows [first_row, rows) of every step's batch evaluate the
+        children of the nodes the step expands, and the next step files the answers in the leaf cache.  The caller guarantees that
+        at most first_row slots still play; the evaluator must compute rows [0, rows) at every step (`eval_range`).  rows = 0: off.
+        Results do not depend on it."""
+        _lib.check(self._L.ckr_engine_set_prefetch(self._h, int(first_row), int(rows), int(sims_per_step), int(self.rows)))
+        self._prefetch_range = (torch.tensor([0, int(rows)], dtype=torch.int32, device=self.device) if rows else None)
+
+    @property
+    def eval_range(self):
+        """DEVICE int32 [lo, hi): the rows of the batch the evaluator has to compute at the next step -- the leaves' rows
+        (row_range), or [0, rows) while set_prefetch hands out rows beyond them."""
+        r = getattr(self, "_prefetch_range", None)
+        return r if r is not None else self.row_range
 
     def set_eval_flag(self, flag):
         """flag: DEVICE int32 tensor of one element (None: none) that the evaluator raises when its last batch must not be used; while

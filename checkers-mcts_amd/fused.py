@@ -325,7 +325,7 @@ class FusedEvaluator:
             raise ValueError("FusedEvaluator(%s) needs the engine's features in %s" %
                              (self.mode, "float32 planes or as board records" if self.mode == "f16x3" else "bfloat16"))
         if len(self.nets) == 1:                      # engine.row_range: active rows after Engine.compact_rows()
-            return self._forward(self.nets[0], x, engine.row_range)
+            return self._forward(self.nets[0], x, getattr(engine, "eval_range", engine.row_range))
         # Arena: every leaf belongs to exactly one of the two networks.  Sort the batch by network id
         # (static shapes: HIP-graph safe) so that each network owns one contiguous share, hand the split
         # point to the conv kernels ON THE DEVICE -- tiles of the other share exit at once -- and
@@ -368,7 +368,7 @@ class FusedEvaluator:
             return False
         from . import rules
         x = engine.x
-        n = int(engine.row_range[1].item()) if getattr(engine, "dense_rows", False) else x.shape[0]
+        n = int(getattr(engine, "eval_range", engine.row_range)[1].item()) if getattr(engine, "dense_rows", False) else x.shape[0]
         rows = x[:max(1, n)]
         planes = rules.features(rows.contiguous()) if getattr(engine, "leaf_records", False) else rows.float()
         self.overflow.zero_()

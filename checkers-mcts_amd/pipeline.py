@@ -217,6 +217,40 @@ class StepRunner:
         self.steps += 1
 
     TAIL_ROWS = 256                                       # the float32-grade conv stack's low-latency kernel takes <= 256 boards
+    # Evaluation ahead of the search (Engine.set_prefetch) once few slots still play: a launch of <= PREFETCH_ROWS boards costs the
+    # conv stack one round of workgroups whatever its rows, so the rows no leaf needs evaluate the children of the nodes a step
+    # expands (~6 positions per slot and expansion not in the cache yet); later leaves are then served by the cache inside the step.
+    PREFETCH_ROWS = 512
+    PREFETCH_SIMS = 8                                     # network-free simulations per slot and step while it is on
+    PREFETCH_SHARE = 6                                    # it starts when (slots still playing) x PREFETCH_SHARE fit into the rows
+
+    def tail_mode(self, active):
+        """The tail of a dense-rows run, decided from the number of slots that still play (it never grows once the work queue is
+        empty): <= TAIL_ROWS slots -> the evaluator launches for TAIL_ROWS boards (low-latency kernel); once PREFETCH_SHARE rows per
+        playing slot fit into a batch of PREFETCH_ROWS -> evaluation ahead of the search on such batches (on TAIL_ROWS rows again
+        for the last few slots).  Returns True if the launch configuration changed (the step's graph is captured again)."""
+        eng, S = self.eng, self.eng.cfg.n_slots
+        if not getattr(eng, "dense_rows", False) or self.time_budget is not None:
+            return False
+        big = min(S, self.PREFETCH_ROWS)
+        prefetch = (os.environ.get("CKR_PREFETCH", "1") != "0" and getattr(eng, "can_prefetch", False)
+                    and hasattr(self.evaluator, "set_row_cap") and 0 < active * self.PREFETCH_SHARE <= big)
+        if prefetch:
+            rows = self.TAIL_ROWS if active * self.PREFETCH_SHARE <= self.TAIL_ROWS < S else big
+            base = 1 << max(0, int(active - 1).bit_length())                 # rows [0, base) for the leaves: re-set when the playing slots halve
+            state = ("prefetch", rows, min(base, rows - 1))
+            if getattr(self, "_tail_state", None) == state:
+                return False
+            torch.cuda.synchronize(eng.device)
+            eng.set_prefetch(state[2], rows, self.PREFETCH_SIMS)
+            self.evaluator.row_cap = None                       # (so that set_row_cap sees a change and drops the graph)
+            self.set_row_cap(rows)                              # drops the step's graph and captures it again: new rows, new range pointer
+            self._tail_state = state
+            return True
+        if active <= self.TAIL_ROWS < S:
+            self._tail_state = ("cap", self.TAIL_ROWS)
+            return self.set_row_cap(self.TAIL_ROWS)
+        return False
 
     def set_row_cap(self, cap):
         """The tail of a run: at most `cap` rows of the batch can be in use from now on (dense rows: a step's leaves occupy rows
@@ -232,6 +266,15 @@ class StepRunner:
             if cap is not None:
                 self.warmup(0)
         return True
+
+    def end_tail(self):
+        """The run is over: whole batches again (a runner may be stepped further, e.g. by a test)."""
+        if getattr(self, "_tail_state", None) and self._tail_state[0] == "prefetch":
+            torch.cuda.synchronize(self.eng.device)
+            self.eng.set_prefetch(0, 0)
+            self.graph = None
+        self._tail_state = None
+        self.set_row_cap(None)
 
     def warmup(self, n=3):
         for _ in range(n):
@@ -289,10 +332,9 @@ class StepRunner:
                 trace.append((self.steps, active, time.perf_counter()))
             self.check_evaluator()
             if active == 0:
-                self.set_row_cap(None)
+                self.end_tail()
                 return self.steps
-            if getattr(self.eng, "dense_rows", False) and active <= self.TAIL_ROWS < S and self.time_budget is None:
-                self.set_row_cap(self.TAIL_ROWS)
+            self.tail_mode(active)
             if can_compact and active <= rows - max(6, S // 32):
                 rows = self.eng.compact_rows(self.p, self.v)
 
@@ -390,11 +432,10 @@ class SplitRunner:
                     runner.check_evaluator()
                     S = eng.cfg.n_slots
                     if active == 0:
-                        runner.set_row_cap(None)
+                        runner.end_tail()
                         live.remove(part)
                     elif getattr(eng, "dense_rows", False):
-                        if active <= runner.TAIL_ROWS < S:
-                            runner.set_row_cap(runner.TAIL_ROWS)
+                        runner.tail_mode(active)
                     elif (getattr(runner.evaluator, "supports_row_range", False) and not getattr(eng, "dense_rows", False)
                           and active <= rows[id(eng)] - max(6, S // 32)):
                         rows[id(eng)] = eng.compact_rows(runner.p, runner.v)

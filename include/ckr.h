@@ -411,6 +411,17 @@ int ckr_engine_set_row_range(ckr_engine* e, int32_t* d_range);
  * ckr_stats.stalled_steps).  The caller notices the flag at its next look, widens the scales, evaluates the batch again, clears
  * the flag -- and the searches go on as if nothing had happened (fused.FusedEvaluator.recover, pipeline.StepRunner). */
 int ckr_engine_set_eval_flag(ckr_engine* e, const int32_t* d_flag);
+/* Evaluation ahead of the search, for the tail of a run (few slots still play: a step then lasts as long as one network launch,
+ * whatever its few rows).  Checkers.predict is a pure function of the position (Checkers.py:425-438) and the leaf of every simulation
+ * is a child of an expanded node (MCTS.py:70-77); with rows > 0 every step also hands out the children of the nodes it expands --
+ * those the leaf cache does not hold yet -- as rows [first_row, rows) of its batch, and the next step turns the answers into the
+ * leaf-cache records an expansion would write.  Later simulations then find their leaf in the cache and run on inside the same
+ * step (up to sims_per_step network-free simulations per slot and step).  No result changes: the search is the same sequence of
+ * simulations, fewer of them wait for the network.  The CALLER guarantees that no more than first_row slots still play (their leaves
+ * take rows [0, number of leaves)) and that the evaluator computes rows [0, rows) of the batch at every step -- not only
+ * d_range's.  row_capacity = the rows of the caller's x / p / v / network-id buffers (>= n_slots; rows <= row_capacity).  Needs
+ * dense_rows, feature_dtype 3 and a leaf cache; rows = 0 switches it off.  Synchronises the device. */
+int ckr_engine_set_prefetch(ckr_engine* e, int32_t first_row, int32_t rows, int32_t sims_per_step, int32_t row_capacity);
 
 /* Counters (synchronises the stream the last step ran on). */
 int ckr_engine_stats(ckr_engine* e, ckr_stats* out);
