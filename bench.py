@@ -491,8 +491,13 @@ def single_game_leg(a, dev):
     kw = dict(MCTS_KWARGS, BUDGET=400, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
     cfg = ckengine.config_from_kwargs(kw, n_slots=1, games_per_slot=64, terminate_cnt=TERMINATE_CNT, feature_dtype=ckengine.BOARDS,
                                       seed=20260929, device=dev.index, leaf_cache_log2=20, dense_rows=True)
-    eng = ckengine.Engine(cfg)
-    runner = StepRunner(eng, FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), 1, mode="f16x3"), use_graph=not a.no_graph)
+    # 63 rows beside the slot's own: the children of every node the search expands are evaluated ahead of it (Engine.set_prefetch) and
+    # served from the leaf cache when a later simulation reaches them -- a launch of 64 boards costs the low-latency kernel what one costs
+    rows = 1 if os.environ.get("CKR_PREFETCH", "1") == "0" else 64
+    eng = ckengine.Engine(cfg, extra_rows=rows - 1)
+    runner = StepRunner(eng, FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), rows, mode="f16x3"), use_graph=not a.no_graph)
+    if rows > 1:
+        eng.set_prefetch(1, rows, 16)
     runner.warmup(3)
     runner.step(500)
 

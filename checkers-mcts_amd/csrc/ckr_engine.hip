@@ -134,11 +134,9 @@ struct Dev {
     int pf_base;                 // slots play than pf_base); pf_rows == 0: off.  The evaluator computes rows [0, pf_rows) at every step
     int pf_sims;                 // network-free simulations per slot and step while it is on
     int32_t* pf_counter;         // DEVICE: prefetched positions handed out in this step (zeroed by the step's prologue)
-    int32_t* g_pf_n;             // [slot] positions handed out by the last step
-    int32_t* g_pf_row;           // [slot][PF_MAX] their rows | network id << 30 (-1: none)
-    uint4* g_pf_board;           // [slot][PF_MAX] their board records
+    int32_t* g_pf_net;           // [row] network id of the position handed out in that row by the last step (-1: none)
+    uint4* g_pf_board;           // [row] its board record
 };
-constexpr int PF_MAX = 48;       // prefetched positions per slot and step
 
 struct WaveLds {
     union { float p[512]; float feat[896]; double ev[64]; } u;   // raw probabilities | features | sampling
@@ -573,15 +571,14 @@ template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, cons
 // ---- evaluation ahead of the search (the tail of a run, where a step lasts as long as one network launch whatever its few rows).
 // Checkers.predict is a pure function of the position (Checkers.py:425-438) and the leaf of every simulation is a child of an
 // expanded node, so the children of a node can be evaluated as soon as the node is expanded: prefetch_children hands their board
-// records out as extra rows of this step's batch (those not in the leaf cache yet), prefetch_consume -- first thing in the next
+// records out as extra rows of this step's batch (those not in the leaf cache yet), k_prefetch_consume -- first thing in the next
 // step -- builds from each answer exactly the record an expansion would write (the masked, renormalised priors of the position's
 // children in tree order and v) and inserts it.  The search itself is untouched: a later simulation that reaches one of these
 // children finds it in the cache (or not, and asks the network as before), so every slot's sequence of simulations and every
 // result is the same with and without -- only more of them are network-free, i.e. run inside one step.
 template <class Wave> __device__ __attribute__((noinline)) void prefetch_children(Wave w, int t, int node, int net, void* x, int32_t* net_out) {
     const Dev& D = w.D;
-    const int pf_count = D.g_pf_n[w.slot];                                      // handed out by this step so far (kept in memory: nothing of
-    if (pf_count >= PF_MAX || D.pf_base + *D.pf_counter >= D.pf_rows) return;   // this lives in k_step's registers; the row counter: a plain read)
+    if (D.pf_base + *D.pf_counter >= D.pf_rows) return;                         // (a plain read of the counter: no row left, most likely)
     const size_t tb = w.tb(t);
     const uint32_t kids = D.n_kids[tb + node];
     const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
@@ -604,57 +601,20 @@ template <class Wave> __device__ __attribute__((noinline)) void prefetch_childre
             want = !present;
         }
     }
-    unsigned long long bal = __ballot(want);
-    const unsigned long long lt = (1ull << w.lane) - 1ull;
-    int rank = __popcll(bal & lt);
-    want = want && pf_count + rank < PF_MAX;
-    bal = __ballot(want);
+    const unsigned long long bal = __ballot(want);
     const int cnt = __popcll(bal);
     if (cnt == 0) return;
-    rank = __popcll(bal & lt);
+    const int rank = __popcll(bal & ((1ull << w.lane) - 1ull));
     int r0 = 0;
     if (w.lane == 0) r0 = atomicAdd(D.pf_counter, cnt);
     r0 = bcast_i32(r0, 0);
-    if (want) {
-        const int row = D.pf_base + r0 + rank, at = w.slot * PF_MAX + pf_count + rank;
-        const bool ok = row < D.pf_rows;                                        // (beyond the last row: not handed out)
-        D.g_pf_row[at] = ok ? (row | (net << 30)) : -1;
-        if (ok) {
-            const uint4 rec = make_uint4(c.p1, c.p2, c.kings, c.meta);
-            D.g_pf_board[at] = rec;
-            reinterpret_cast<uint4*>(x)[row] = rec;
-            if (net_out) net_out[row] = net;
-        }
-    }
-    if (w.lane == 0) D.g_pf_n[w.slot] = pf_count + cnt;
-    wave_mem_fence();
-}
-
-template <class Wave> __device__ __attribute__((noinline)) void prefetch_consume(Wave w, const float* __restrict__ p, const float* __restrict__ v, int count) {
-    const Dev& D = w.D;
-    for (int k = 0; k < count; ++k) {
-        const int rw = D.g_pf_row[w.slot * PF_MAX + k];
-        if (rw < 0) continue;
-        const int row = rw & 0x3FFFFFFF, net = (rw >> 30) & 1;
-        const ckr_board b = ld_board(&D.g_pf_board[w.slot * PF_MAX + k]);
-        const float4* src = reinterpret_cast<const float4*>(p + (size_t)row * 512);
-        const float4 p0 = src[w.lane], p1 = src[w.lane + 64];
-        const float val = v[row];
-        uint32_t m[8], st;
-        movegen(b, m, st);
-        // what expand() computes from the network's answer for this position (Checkers.predict's mask / renormalise,
-        // Checkers.py:435-437, and set_prior_probs, :440-452): the same floats, in the same order
-        if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
-        float4* dl = reinterpret_cast<float4*>(w.L.u.p);
-        dl[w.lane] = p0; dl[w.lane + 64] = p1;
-        __builtin_amdgcn_wave_barrier();
-        const float total = wave_masked_sum(w.L.u.p, w.L.mask);
-        const int n = wave_children(b, m, w.L.kids, true);
-        __builtin_amdgcn_wave_barrier();
-        float prior = 0.0f;
-        if (w.lane < n) prior = w.L.u.p[meta_action(w.L.kids[w.lane].meta)] / total;
-        cache_insert(w, cache_key(b, st, net), n, prior, val);
-        __builtin_amdgcn_wave_barrier();
+    const int row = D.pf_base + r0 + rank;
+    if (want && row < D.pf_rows) {                                              // (beyond the last row: not handed out)
+        const uint4 rec = make_uint4(c.p1, c.p2, c.kings, c.meta);
+        D.g_pf_board[row] = rec;
+        D.g_pf_net[row] = net;
+        reinterpret_cast<uint4*>(x)[row] = rec;
+        if (net_out) net_out[row] = net;
     }
 }
 
@@ -1201,6 +1161,44 @@ __global__ __launch_bounds__(256) void k_step_prologue(const Dev* __restrict__ D
     if (i == 1 && Dp->pf_counter) *Dp->pf_counter = 0;
 }
 
+// The answers to the positions the previous step handed out ahead of the search (prefetch_children): one wave per row builds the
+// record an expansion of that position would write -- Checkers.predict's mask / renormalise (Checkers.py:435-437) and
+// set_prior_probs' priors in child order (:440-452), the same floats in the same order as expand() -- and inserts it.  Launched in
+// front of the step's prologue: the row counter still holds the previous step's count, and the records carry the previous launch's
+// number, so this engine's k_step -- a later launch -- may serve them at once, while the other engines of the table serve them only
+// after this engine's prologue has published the next number, i.e. after this kernel has ended (see the cache protocol above).
+__global__ __launch_bounds__(256) void k_prefetch_consume(const Dev* __restrict__ Dp, const float* __restrict__ p, const float* __restrict__ v) {
+    const Dev& D = *Dp;
+    __shared__ WaveLds lds[4];
+    if (D.eval_flag != nullptr && *D.eval_flag != 0) return;              // the batch is void: nothing is filed (the leaves are handed out again)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), idx = blockIdx.x * 4 + wave;
+    const int count = min(*D.pf_counter, D.pf_rows - D.pf_base);
+    if (idx >= count) return;
+    const int row = D.pf_base + idx, net = D.g_pf_net[row];
+    if (net < 0) return;
+    WaveT<float> w{D, lds[wave], 0, lane_id()};
+    w.epoch = D.estate->E;
+    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
+    const ckr_board b = ld_board(&D.g_pf_board[row]);
+    const float4* src = reinterpret_cast<const float4*>(p + (size_t)row * 512);
+    const float4 p0 = src[w.lane], p1 = src[w.lane + 64];
+    const float val = v[row];
+    uint32_t m[8], st;
+    movegen(b, m, st);
+    if (w.lane < 8) w.L.mask[w.lane] = sel8(m, w.lane);
+    float4* dl = reinterpret_cast<float4*>(w.L.u.p);
+    dl[w.lane] = p0; dl[w.lane + 64] = p1;
+    __builtin_amdgcn_wave_barrier();
+    const float total = wave_masked_sum(w.L.u.p, w.L.mask);
+    const int n = wave_children(b, m, w.L.kids, true);
+    __builtin_amdgcn_wave_barrier();
+    float prior = 0.0f;
+    if (w.lane < n) prior = w.L.u.p[meta_action(w.L.kids[w.lane].meta)] / total;
+    cache_insert(w, cache_key(b, st, net), n, prior, val);
+    if (w.lane == 0) D.g_pf_net[row] = -1;
+    flush_counters(w);
+}
+
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
@@ -1261,13 +1259,6 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     // the network's answer to the last batch is void (see Dev.eval_flag): nothing is expanded, nothing descends; a slot with a
     // leaf at the network hands the same leaf out again (same reservation in the leaf cache), the others idle for this step
     const bool stalled = D.eval_flag != nullptr && *D.eval_flag != 0;
-    // positions handed out ahead of the search by the previous step (prefetch_children): their answers become leaf-cache records
-    const int pf_prev = D.g_pf_n ? D.g_pf_n[slot] : 0;
-    if (pf_prev > 0) {
-        if (!stalled) prefetch_consume(w, p, v, pf_prev);                 // (by value: the handle of the hot path stays in registers)
-        if (w.lane == 0) D.g_pf_n[slot] = 0;
-        wave_mem_fence();
-    }
     if (stalled) {
         if (slot == 0) w.count(CNT_STALL);
         if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
@@ -1607,6 +1598,7 @@ struct ckr_engine {
     Dev* d_dev = nullptr;              // device copy of `dev` (owned by allocs)
     int32_t* d_range = nullptr;        // dense rows: the caller's DEVICE int32[2] = {0, leaves of the last step}
     unsigned long long* d_mark = nullptr;   // ckr_engine_mark: copy of the event counters taken in stream order
+    int32_t pf_capacity = 0;           // rows of the per-row prefetch arrays (ckr_engine_set_prefetch)
 };
 
 template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool zero = true) {
@@ -1749,8 +1741,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.g_gid, S, true); A(D.next_game, (size_t)1, true); A(D.n_finished, (size_t)1, true);
     A(D.g_worker, S, true); A(D.next_worker, (size_t)1, true); A(D.g_cslot, S, true); A(D.g_cword, S, true); A(D.g_parked, S, true);
     A(D.estate, (size_t)1, true); A(D.g_start, S, true);
-    if (c->neural_net && c->dense_rows && !c->manual_play && c->feature_dtype == 3) {   // evaluation ahead of the search (ckr_engine_set_prefetch)
-        A(D.g_pf_n, S, true); A(D.g_pf_row, S * PF_MAX, true); A(D.g_pf_board, S * PF_MAX, true); A(D.pf_counter, (size_t)1, true);
+    if (c->neural_net && (c->dense_rows || c->manual_play) && c->feature_dtype == 3) {  // evaluation ahead of the search (ckr_engine_set_prefetch)
+        A(D.pf_counter, (size_t)1, true);                             // (the per-row arrays: ckr_engine_set_prefetch, which knows the rows)
     }
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
@@ -1896,6 +1888,8 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     // One small kernel, not hipMemsetAsync calls: captured into a HIP graph (ROCm 7.2) a 0xFF memset node left rows that look
     // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
     // past the rows in use); it is also one graph node instead of two.
+    if (e->dev.pf_rows > 0 && d_p && d_v)                            // the answers to what the previous step handed out ahead of the search
+        hipLaunchKernelGGL(k_prefetch_consume, dim3((e->dev.pf_rows - e->dev.pf_base + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v);
     const int n_rows = e->dev.pf_rows > e->cfg.n_slots ? e->dev.pf_rows : e->cfg.n_slots;       // rows whose network id the prologue resets
     if (prologue && e->cfg.n_slots > 4)
         hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (n_rows + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,
@@ -1931,13 +1925,20 @@ int ckr_engine_set_prefetch(ckr_engine* e, int32_t first_row, int32_t rows, int3
     if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_set_prefetch: null engine");
     Dev& D = e->dev;
     if (rows != 0) {
-        if (!D.g_pf_n) return fail(CKR_ERR_STATE, "ckr_engine_set_prefetch needs a dense_rows NEURAL_NET engine that hands out board records (feature_dtype 3)");
+        if (!D.pf_counter) return fail(CKR_ERR_STATE, "ckr_engine_set_prefetch needs a dense_rows (or manual_play) NEURAL_NET engine that hands out board records (feature_dtype 3)");
         if (!D.cache) return fail(CKR_ERR_STATE, "ckr_engine_set_prefetch needs a leaf cache: the prefetched evaluations are served from it");
         if (first_row < 0 || rows <= first_row || rows > row_capacity || row_capacity < e->cfg.n_slots || sims_per_step < 1)
             return fail(CKR_ERR_INVALID, "ckr_engine_set_prefetch: 0 <= first_row < rows <= row_capacity (the rows of the caller's x / p / v / "
                                          "network-id buffers, >= n_slots), sims_per_step >= 1");
     }
     CKR_HIP(hipDeviceSynchronize());
+    if (rows != 0 && row_capacity > e->pf_capacity) {                 // per-row bookkeeping of the positions handed out ahead
+        if (int rc = dalloc(e, &D.g_pf_board, (size_t)row_capacity, true)) return rc;
+        if (int rc = dalloc(e, &D.g_pf_net, (size_t)row_capacity, false)) return rc;
+        e->pf_capacity = row_capacity;
+    }
+    if (D.g_pf_net) CKR_HIP(hipMemset(D.g_pf_net, 0xFF, (size_t)e->pf_capacity * sizeof(int32_t)));
+    CKR_HIP(hipMemset(D.pf_counter, 0, sizeof(int32_t)));
     D.pf_base = rows ? first_row : 0; D.pf_rows = rows; D.pf_sims = rows ? sims_per_step : 0;
     CKR_HIP(hipMemcpy(e->d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice));
     return CKR_OK;
@@ -2093,6 +2094,8 @@ int ckr_engine_cache_flush(ckr_engine* e, void* stream) {
     if (!e) return fail(CKR_ERR_INVALID, "ckr_engine_cache_flush: null engine");
     if (!e->cache) return CKR_OK;
     note_stream(&e->last_stream, (hipStream_t)stream);
+    // positions handed out ahead of the search whose answers are not filed yet were evaluated by the OLD network: dropped
+    if (e->dev.pf_counter) CKR_HIP(hipMemsetAsync(e->dev.pf_counter, 0, sizeof(int32_t), (hipStream_t)stream));
     return ckr_leaf_cache_flush(e->cache, stream);
 }
 

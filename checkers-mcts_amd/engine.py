@@ -227,8 +227,9 @@ class Engine:
 
     @property
     def can_prefetch(self):
-        """Evaluation ahead of the search (set_prefetch) needs dense rows, board-record leaves and a leaf cache."""
-        return bool(self.dense_rows and self.leaf_records and (self.cache is not None or self.cfg.leaf_cache_log2))
+        """Evaluation ahead of the search (set_prefetch) needs dense rows (or an interactive engine), board-record leaves and a leaf cache."""
+        return bool((self.dense_rows or self.cfg.manual_play) and self.cfg.neural_net and self.leaf_records
+                    and (self.cache is not None or self.cfg.leaf_cache_log2))
 
     def set_prefetch(self, first_row=0, rows=0, sims_per_step=8):
         """The tail of a run (include/ckr.h, ckr_engine_set_prefetch): rows [first_row, rows) of every step's batch evaluate the

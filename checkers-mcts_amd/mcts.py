@@ -18,6 +18,7 @@ only what the reference keeps in Python objects: the move choice rule
 (best_child, MCTS.py:227-248), the state planes handed to callers, and the
 history list.
 """
+import os
 import time
 
 import numpy as np
@@ -200,14 +201,21 @@ class MCTS:
         cls.tau_decay_delay = kwargs["TEMP_DECAY_DELAY"]
         if cls._engine is not None:
             cls._engine.close()
+        # The reference's own network class on the device is evaluated by the hand-written float32-grade kernels (_search_runner): the
+        # engine then hands its leaf out as a 16-byte board record, on a batch of LOOKAHEAD_ROWS rows whose other rows evaluate the
+        # children of every node the search expands ahead of it (Engine.set_prefetch) -- a launch of that many boards costs the
+        # low-latency kernel what one board costs, and the leaf of most later simulations is then served by the leaf cache.
+        cls._lookahead = bool(kwargs["NEURAL_NET"] and kwargs.get("EVALUATOR") != "torch" and cls._fusable(getattr(cls.game_env, "neural_net", None))
+                              and kwargs.get("LEAF_CACHE_LOG2", 18) and os.environ.get("CKR_PREFETCH", "1") != "0")
         cfg = ckengine.config_from_kwargs(kwargs, n_slots=1, games_per_slot=1, manual_play=True,
+                                          feature_dtype=ckengine.BOARDS if cls._lookahead else torch.float32,
                                           seed=int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))),
                                           max_sims_per_step=1 << 30, nodes_per_tree=kwargs.get("NODES_PER_TREE"),
                                           # both players' trees (and transpositions) ask for the same positions again: 2^18 records
                                           # (69 MB) served for 16 384 - 32 768 simulation steps; flushed when the network changes
                                           leaf_cache_log2=kwargs.get("LEAF_CACHE_LOG2", 18) if kwargs["NEURAL_NET"] else 0, leaf_cache_gen_log2=14,
                                           rollout_first=bool(kwargs.get("ROLLOUT_FIRST", False)))   # test hook
-        cls._engine = ckengine.Engine(cfg)
+        cls._engine = ckengine.Engine(cfg, extra_rows=cls.LOOKAHEAD_ROWS - 1 if cls._lookahead else 0)
         if not cls.neural_net:
             cls._engine.set_ln_table(kwargs.get("LN_TABLE"))     # np.log of this host for the UCT term (MCTS.py:114)
         cls._runner = cls._runner_key = None
@@ -232,11 +240,22 @@ class MCTS:
                 raise ValueError("Illegal next state (invalid move)!")
             cls._applied.append(np.array(rec, np.uint32))
 
+    LOOKAHEAD_ROWS = 64                                     # rows of the interactive engine's batch (see __init__)
+    LOOKAHEAD_SIMS = 16                                     # network-free simulations per step while children are evaluated ahead
+
+    @staticmethod
+    def _fusable(net):
+        from .net import PolicyValueNet
+        return (isinstance(net, PolicyValueNet) and net.num_kernels == 128 and not net.training
+                and next(net.parameters()).is_cuda)
+
     @classmethod
     def _evaluator(cls):
         net = cls.game_env.neural_net
         if callable(net) and not isinstance(net, torch.nn.Module) and not hasattr(net, "predict"):
             return net                                      # device evaluator: engine -> (p, v)
+        if cls._engine.leaf_records:                        # (an engine created for the fused kernels meets another network: planes from the records)
+            return lambda eng: _evaluate_features(net, rules.features(eng.x))
         return lambda eng: _evaluate_features(net, eng.x)
 
     @classmethod
@@ -247,11 +266,9 @@ class MCTS:
         kernel) and the step is replayed from a HIP graph: ~0.12 ms per simulation step.  EVALUATOR='torch' in the MCTS kwargs,
         any other module, a .predict object or a device evaluator: that evaluator, eagerly.  Rebuilt when the network object or
         (in-place) its weights change."""
-        from .net import PolicyValueNet
         from .pipeline import StepRunner
         net = cls.game_env.neural_net
-        fused = (isinstance(net, PolicyValueNet) and net.num_kernels == 128 and cls._evaluator_kind != "torch"
-                 and next(net.parameters()).is_cuda and not net.training)
+        fused = cls._fusable(net) and cls._evaluator_kind != "torch"
         version = (sum(int(t._version) for t in list(net.parameters()) + list(net.buffers())) if isinstance(net, torch.nn.Module) else 0)
         key = (id(net), fused, version, id(cls._engine))
         if cls._runner_key != key or not isinstance(net, torch.nn.Module):
@@ -259,9 +276,14 @@ class MCTS:
         if cls._runner is None or cls._runner_key != key:
             if fused:
                 from .fused import FusedEvaluator
-                ev = FusedEvaluator(net, 1, mode="f16x3")
+                ev = FusedEvaluator(net, cls._engine.rows, mode="f16x3")
             else:
                 ev = cls._evaluator()
+            if cls._engine.can_prefetch:                     # children of expanded nodes evaluated ahead of the search (fused kernels only)
+                if fused and cls._engine.rows > 1:
+                    cls._engine.set_prefetch(1, cls._engine.rows, cls.LOOKAHEAD_SIMS)
+                else:
+                    cls._engine.set_prefetch(0, 0)
             cls._runner = StepRunner(cls._engine, ev, use_graph=fused)
             cls._runner.steps = 1                           # the engine has stepped before: p / v are always passed
             cls._runner_key = key

@@ -165,7 +165,7 @@ class StepRunner:
         clock for all slots): run_to_completion searches every ply for that long and then ends the plies of all slots in one step
         (Engine.step(end_ply=True)).  Engines with ckr_config.time_budget_us time every search themselves: time_budget None."""
         self.eng, self.evaluator, self.use_graph, self.time_budget = eng, evaluator, use_graph, time_budget
-        S = eng.cfg.n_slots
+        S = getattr(eng, "rows", eng.cfg.n_slots)                  # rows of the network batch (>= one per slot)
         self.p = torch.zeros((S, 512), dtype=torch.float32, device=eng.device)
         self.v = torch.zeros((S,), dtype=torch.float32, device=eng.device)
         self.graph = None
@@ -220,9 +220,11 @@ class StepRunner:
     # Evaluation ahead of the search (Engine.set_prefetch) once few slots still play: a launch of <= PREFETCH_ROWS boards costs the
     # conv stack one round of workgroups whatever its rows, so the rows no leaf needs evaluate the children of the nodes a step
     # expands (~6 positions per slot and expansion not in the cache yet); later leaves are then served by the cache inside the step.
+    # (profiles/r04_prefetch_sweep.txt: rows 512 / 1 024, share 3 / 4 / 6, 5 / 8 / 16 simulations per step: 19.03-19.38 s for the
+    # bench's run of 16 384 games against 19.78 s without; CKR_PREFETCH=0 switches it off)
     PREFETCH_ROWS = 512
-    PREFETCH_SIMS = 8                                     # network-free simulations per slot and step while it is on
-    PREFETCH_SHARE = 6                                    # it starts when (slots still playing) x PREFETCH_SHARE fit into the rows
+    PREFETCH_SIMS = 16                                    # network-free simulations per slot and step while it is on
+    PREFETCH_SHARE = 4                                    # it starts when (slots still playing) x PREFETCH_SHARE fit into the rows
 
     def tail_mode(self, active):
         """The tail of a dense-rows run, decided from the number of slots that still play (it never grows once the work queue is

@@ -420,7 +420,8 @@ int ckr_engine_set_eval_flag(ckr_engine* e, const int32_t* d_flag);
  * simulations, fewer of them wait for the network.  The CALLER guarantees that no more than first_row slots still play (their leaves
  * take rows [0, number of leaves)) and that the evaluator computes rows [0, rows) of the batch at every step -- not only
  * d_range's.  row_capacity = the rows of the caller's x / p / v / network-id buffers (>= n_slots; rows <= row_capacity).  Needs
- * dense_rows, feature_dtype 3 and a leaf cache; rows = 0 switches it off.  Synchronises the device. */
+ * dense_rows (or a manual_play engine, whose leaf always takes row `slot`), feature_dtype 3 and a leaf cache; rows = 0 switches it
+ * off.  ckr_engine_cache_flush also drops the positions whose answers are not filed yet.  Synchronises the device. */
 int ckr_engine_set_prefetch(ckr_engine* e, int32_t first_row, int32_t rows, int32_t sims_per_step, int32_t row_capacity);
 
 /* Counters (synchronises the stream the last step ran on). */
