@@ -525,8 +525,10 @@ def single_game_leg(a, dev):
         t_api.append(time.perf_counter() - t1)
     return {"sims_per_s": sims / dt, "us_per_step": dt / steps * 1e6, "search_api_ms_per_400_simulations": float(np.median(t_api)) * 1e3, "us_per_simulation": dt / max(1, sims) * 1e6, "steps": steps, "budget": 400,
             "dtype": DTYPE_LABEL["fp32"],
-            "note": "one game, one tree search at a time: a step = tree kernel + the single-board conv kernel (k_conv_stack_x3_small) + heads, "
-                    "one graph replay; leaves already evaluated come from the leaf cache"}
+            "rows_per_step": rows,
+            "note": "one game, one tree search at a time: a step = tree kernel + the single-board conv kernel (k_conv_stack_x3_small) on %d rows + heads, "
+                    "one graph replay; the rows beside the leaf's evaluate the children of the nodes the step expands ahead of the search (Engine.set_prefetch), "
+                    "so most later leaves come from the leaf cache and a step runs up to 16 simulations (CKR_PREFETCH=0: one row, one leaf per step)" % rows}
 
 
 def rollout_leg(a, dev):
