@@ -224,6 +224,7 @@ class StepRunner:
     # bench's run of 16 384 games against 19.78 s without; CKR_PREFETCH=0 switches it off)
     PREFETCH_ROWS = 512
     PREFETCH_SIMS = 16                                    # network-free simulations per slot and step while it is on
+    PREFETCH_SIMS_SOLO = 10                               # ... for an un-split engine (small jobs: the tree kernel's time shows)
     PREFETCH_SHARE = 4                                    # it starts when (slots still playing) x PREFETCH_SHARE fit into the rows
 
     def tail_mode(self, active):
@@ -234,22 +235,25 @@ class StepRunner:
         eng, S = self.eng, self.eng.cfg.n_slots
         if not getattr(eng, "dense_rows", False) or self.time_budget is not None:
             return False
-        big = min(S, self.PREFETCH_ROWS)
+        solo = getattr(self, "solo", True)                   # the only engine on the chip: a launch of LOOKAHEAD_BATCH boards is one round
+        rows_have = getattr(eng, "rows", S)
+        big = min(rows_have, LOOKAHEAD_BATCH if solo else self.PREFETCH_ROWS)
+        share = 2 if solo else self.PREFETCH_SHARE
         prefetch = (os.environ.get("CKR_PREFETCH", "1") != "0" and getattr(eng, "can_prefetch", False)
-                    and hasattr(self.evaluator, "set_row_cap") and 0 < active * self.PREFETCH_SHARE <= big)
+                    and hasattr(self.evaluator, "set_row_cap") and 0 < active * share <= big)
         if prefetch:
-            rows = self.TAIL_ROWS if active * self.PREFETCH_SHARE <= self.TAIL_ROWS < S else big
+            rows = self.TAIL_ROWS if active * self.PREFETCH_SHARE <= self.TAIL_ROWS < rows_have else big
             base = 1 << max(0, int(active - 1).bit_length())                 # rows [0, base) for the leaves: re-set when the playing slots halve
             state = ("prefetch", rows, min(base, rows - 1))
             if getattr(self, "_tail_state", None) == state:
                 return False
             torch.cuda.synchronize(eng.device)
-            eng.set_prefetch(state[2], rows, self.PREFETCH_SIMS)
+            eng.set_prefetch(state[2], rows, self.PREFETCH_SIMS_SOLO if solo else self.PREFETCH_SIMS)
             self.evaluator.row_cap = None                       # (so that set_row_cap sees a change and drops the graph)
             self.set_row_cap(rows)                              # drops the step's graph and captures it again: new rows, new range pointer
             self._tail_state = state
             return True
-        if active <= self.TAIL_ROWS < S:
+        if active <= self.TAIL_ROWS < rows_have:
             self._tail_state = ("cap", self.TAIL_ROWS)
             return self.set_row_cap(self.TAIL_ROWS)
         return False
@@ -355,6 +359,22 @@ def split_parts(n_slots):
     return max(1, min(3, int(n_slots) // SPLIT_MIN_SLOTS))
 
 
+LOOKAHEAD_BATCH = 1024          # boards one conv launch of an un-split engine computes in ONE round of workgroups (2 per workgroup, 2 per CU)
+
+
+def lookahead_rows(n_slots, fused_boards=True, up_to=256):
+    """Rows of the network batch for an un-split engine of n_slots games.  A job of a few hundred games (the reference's tournaments:
+    10 ... 400 games) never fills the chip: every step is one latency-bound launch whatever its rows, so the batch gets rows beyond one
+    per slot, up to LOOKAHEAD_BATCH, and StepRunner.tail_mode uses them from the first step on to evaluate children of expanded nodes
+    ahead of the search (Engine.set_prefetch).  n_slots when that does not apply (CKR_PREFETCH=0, other evaluators, more than
+    `up_to` slots: measured with tools/small_jobs_probe.py, profiles/r04_small_jobs_lookahead.jsonl -- a self-play job of 512 games is
+    better off with its own 512 rows and the tail's lookahead, a tournament of 400 -- two conv launches per step, games played to
+    their natural end -- with 1 024)."""
+    if not fused_boards or os.environ.get("CKR_PREFETCH", "1") == "0" or n_slots > up_to:
+        return int(n_slots)
+    return int(min(LOOKAHEAD_BATCH, max(64, 8 * int(n_slots))))
+
+
 class SplitRunner:
     """Part-batches on their own HIP streams: the slots of a job are divided between two or three engines (split_parts;
     contiguous worker-id blocks -- results do not depend on the division, see dist.py) that step independently, each with its own
@@ -385,6 +405,7 @@ class SplitRunner:
             stream = torch.cuda.Stream(device=eng.device, priority=prio[i] if i < len(prio) else 0)
             with torch.cuda.stream(stream):
                 runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
+            runner.solo = False                              # the parts share the chip: smaller lookahead batches (tail_mode)
             self.parts.append((eng, runner, stream))
         self.device = self.parts[0][0].device
 
@@ -584,13 +605,17 @@ class generate_Checkers_data:
         plan = EvaluatorPlan(self.nn_fn, dev, self.nn_dtype, kind=kind, networks=self.networks) if neural else None
         fdt = plan.feature_dtype if neural else self.nn_dtype
 
+        # an un-split job of few games: rows beyond one per slot, for evaluation ahead of the search from the first step on
+        rows = (lookahead_rows(slots, neural and plan.fused and fdt == ckengine.BOARDS and bool(self.dense_rows) and cache is not None and not timed)
+                if not split else slots)
+
         def make_engine(offset, workers, n):
             cfg = ckengine.config_from_kwargs(
                 self.mcts_kwargs, n_slots=n, n_workers=workers, games_per_slot=self.NUM_SELFPLAY_GAMES,
                 terminate_cnt=self.TERMINATE_CNT, first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree,
                 feature_dtype=fdt, seed=self.seed, device=dev.index, dynamic_queue=self.dynamic_queue,
                 leaf_cache_log2=0, dense_rows=bool(self.dense_rows) and neural)
-            return ckengine.Engine(cfg, cache=cache)
+            return ckengine.Engine(cfg, cache=cache, extra_rows=max(0, rows - n) if not split else 0)
 
         if not neural:                             # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
             eng = make_engine(0, count, slots)
@@ -607,7 +632,7 @@ class generate_Checkers_data:
             engines = runner.engines
         else:
             eng = make_engine(0, count, slots)
-            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
+            runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
             try:
                 runner.run_to_completion()
             except OverflowError:
@@ -696,8 +721,10 @@ class tournament_Checkers:
                 first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=plan.feature_dtype,
                 seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
             cache = make_leaf_cache(default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2), dev)
-            eng = ckengine.Engine(cfg, cache=cache)
-            runner = StepRunner(eng, plan.build(slots), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
+            rows = lookahead_rows(slots, plan.fused and plan.feature_dtype == ckengine.BOARDS and bool(self.dense_rows) and cache is not None and not timed,
+                                  up_to=512)
+            eng = ckengine.Engine(cfg, cache=cache, extra_rows=max(0, rows - slots))
+            runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
             runner.run_to_completion()
             self.stats = eng.stats()
             _warn_pool_overflows(self.stats, "tournament")
