@@ -137,3 +137,30 @@ def test_pipeline_tail_with_the_real_network_prefetch_on_off(monkeypatch):
     for k in SEARCH_COUNTERS:
         assert outs[0][1][k] == outs[1][1][k], k
     assert outs[1][1]["dup_leaves"] > outs[0][1]["dup_leaves"] and outs[1][1]["steps"] < outs[0][1]["steps"]
+
+
+def test_small_jobs_look_ahead_from_the_first_step(monkeypatch):
+    """A tournament of 48 games and a self-play job of 96 (the reference's job sizes) never fill the chip: their engines get a batch
+    of rows beyond one per slot (pipeline.lookahead_rows) and evaluate ahead of the search from the first step on.  The tournament's
+    game list and the self-play tuples equal those with CKR_PREFETCH=0; both take fewer than half the steps."""
+    import torch
+    from checkers_mcts_amd import pipeline as P
+    kw = dict(mk(40, training=False, eps=0.25, tau=0.0), TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    tk = dict(TOURNEY_GAMES=2, NUM_CPUS=48, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=8)
+    sp = dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=100, NUM_CPUS=96, NN_FN="random:0", SEED=3)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CKR_PREFETCH", flag)
+        assert P.lookahead_rows(48, True, up_to=512) == (48 if flag == "0" else 384) and P.lookahead_rows(600, True) == 600
+        t = P.tournament_Checkers(dict(tk), dict(kw))
+        games = t._start_tournament()
+        g = P.generate_Checkers_data(dict(sp), dict(mk(40, eps=0.25, tau=1.0)))
+        tup = g.generate_tuples().cpu().numpy().view(np.uint8).reshape(-1, 288)
+        rows = np.ascontiguousarray(tup).view(np.dtype((np.void, 288))).ravel().copy()
+        rows.sort()
+        runs[flag] = (games, dict(t.stats), rows.tobytes(), dict(g.stats))
+    a, b = runs["0"], runs["1"]
+    assert a[0] == b[0] and len(a[0]) == 96 and a[2] == b[2] and len(a[2]) > 96 * 20 * 288
+    for k in SEARCH_COUNTERS:
+        assert a[1][k] == b[1][k] and a[3][k] == b[3][k], k
+    assert b[1]["steps"] < 0.5 * a[1]["steps"] and b[3]["steps"] < 0.5 * a[3]["steps"]
