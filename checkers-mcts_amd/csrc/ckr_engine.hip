@@ -141,6 +141,8 @@ struct Dev {
 struct WaveLds {
     union { float p[512]; float feat[896]; double ev[64]; } u;   // raw probabilities | features | sampling
     ckr_board kids[CKR_MAX_CHILDREN];
+    uint32_t kst[CKR_MAX_CHILDREN];                              // status words of kids[] as the last expansion wrote them (prefetch_children)
+    uint32_t kn;                                                 // ... and their number
     uint32_t mask[8];
     uint32_t cnt[CNT_N];                                         // per-wave event counters (lane 0), flushed once
 };
@@ -576,18 +578,17 @@ template <class Wave> __device__ __forceinline__ void cache_insert(Wave& w, cons
 // children in tree order and v) and inserts it.  The search itself is untouched: a later simulation that reaches one of these
 // children finds it in the cache (or not, and asks the network as before), so every slot's sequence of simulations and every
 // result is the same with and without -- only more of them are network-free, i.e. run inside one step.
-template <class Wave> __device__ __attribute__((noinline)) void prefetch_children(Wave w, int t, int node, int net, void* x, int32_t* net_out) {
+// Called right behind the expansion: the children and their status words are still in the wave's LDS (WaveLds.kids / kst).
+template <class Wave> __device__ __attribute__((noinline)) void prefetch_children(Wave w, int net, void* x, int32_t* net_out) {
     const Dev& D = w.D;
+    const int n = (int)w.L.kn;
     if (D.pf_base + *D.pf_counter >= D.pf_rows) return;                         // (a plain read of the counter: no row left, most likely)
-    const size_t tb = w.tb(t);
-    const uint32_t kids = D.n_kids[tb + node];
-    const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
     bool want = false;
     ckr_board c{0u, 0u, 0u, 0u};
     if (w.lane < n) {
-        c = ld_board(&D.n_board[tb + base + w.lane]);
-        const uint32_t cst = D.n_status[tb + base + w.lane];
-        if (st_outcome(cst) == 0u && !(cst & ST_EXPANDED)) {                    // terminal children never reach the network
+        c = w.L.kids[w.lane];
+        const uint32_t cst = w.L.kst[w.lane];
+        if (st_outcome(cst) == 0u) {                                            // terminal children never reach the network
             const unsigned long long h = cache_hash(cache_key(c, cst, net)), tag = cache_tag(h);
             bool present = false;
 #pragma unroll
@@ -668,12 +669,14 @@ template <bool CACHED, class Wave> __device__ __forceinline__ bool expand(Wave& 
         movegen(c, cm, cst);
         if (!CACHED) prior = w.L.u.p[meta_action(c.meta)] / total;
         write_node(w, tb + used + w.lane, c, leaf, prior, cst | ((b.meta & 1u) << 4));
+        w.L.kst[w.lane] = cst;
     }
     if (!CACHED && D.cache) {
         if (cslot >= 0) cache_complete(w, cslot, cword, cache_key(b, st, net), n, prior, v);
         else if (!D.cache_park) cache_insert(w, cache_key(b, st, net), n, prior, v);
     }
     if (w.lane == 0) {
+        w.L.kn = (uint32_t)n;
         D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
         D.n_status[tb + leaf] = leaf_status | ST_EXPANDED;
         D.t_used[ti] = used + n;
@@ -1269,7 +1272,6 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     } else if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
         const int t = t0;
         const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
-        int expanded = pending;                                           // the leaf's index (it moves if the tree is compacted below)
         bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
         if (!ok) {
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
@@ -1278,11 +1280,10 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             const int moved = compact(w, t, pending);
             ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
             ok = moved >= 0 && expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet, cslot0, cword0);
-            expanded = moved;
         }
         if (ok) {
             if (w.lane == 0) D.g_sims[slot] += 1;
-            if (D.pf_rows > 0 && (flags & 5) == 0) { wave_mem_fence(); prefetch_children(w, t, expanded, pnet, x, net_out); }
+            if (D.pf_rows > 0 && (flags & 5) == 0) { wave_mem_fence(); prefetch_children(w, pnet, x, net_out); }
         } else {                                                          // the live subtree itself does not fit: give up on this game
             w.count(CNT_OVERFLOW);
             WaveT<WT> wc = w;                                                 // (a copy: see finish_ply below)
@@ -1336,7 +1337,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
                     w.count(CNT_HIT);
                     if (w.lane == 0) { D.g_sims[slot] += 1; if (D.cache_park) { D.g_pending[slot] = -1; D.g_parked[slot] = 0; } }
                     wave_mem_fence();
-                    if (D.pf_rows > 0 && (flags & 5) == 0) prefetch_children(w, t, found, net, x, net_out);
+                    if (D.pf_rows > 0 && (flags & 5) == 0) prefetch_children(w, net, x, net_out);
                     ++free_sims;
                     continue;
                 }                                                        // pool full: let the network path compact and retry
