@@ -249,8 +249,7 @@ class StepRunner:
                 return False
             torch.cuda.synchronize(eng.device)
             eng.set_prefetch(state[2], rows, self.PREFETCH_SIMS_SOLO if solo else self.PREFETCH_SIMS)
-            self.evaluator.row_cap = None                       # (so that set_row_cap sees a change and drops the graph)
-            self.set_row_cap(rows)                              # drops the step's graph and captures it again: new rows, new range pointer
+            self.set_row_cap(rows, force=True)                  # drops the step's graph and captures it again: new rows, new range pointer
             self._tail_state = state
             return True
         if active <= self.TAIL_ROWS < rows_have:
@@ -258,12 +257,13 @@ class StepRunner:
             return self.set_row_cap(self.TAIL_ROWS)
         return False
 
-    def set_row_cap(self, cap):
+    def set_row_cap(self, cap, force=False):
         """The tail of a run: at most `cap` rows of the batch can be in use from now on (dense rows: a step's leaves occupy rows
         [0, number of leaves) and no more slots play than that).  The evaluator launches its kernels for that many boards and
-        the step's graph is captured again (None: the whole batch; the graph is captured again at the next step, if any)."""
+        the step's graph is captured again (None: the whole batch; the graph is captured again at the next step, if any).
+        force: capture again even if the cap is the same (something else baked into the graph has changed)."""
         ev = self.evaluator
-        if not hasattr(ev, "set_row_cap") or getattr(ev, "row_cap", None) == cap:
+        if not hasattr(ev, "set_row_cap") or (getattr(ev, "row_cap", None) == cap and not force):
             return False
         ev.set_row_cap(cap)
         if self.graph is not None:
