@@ -696,6 +696,7 @@ class tournament_Checkers:
         self.leaf_cache_log2 = tourney_kwargs.get("LEAF_CACHE_LOG2")     # as in generate_Checkers_data (the key carries the network id)
         self.dense_rows = tourney_kwargs.get("DENSE_ROWS", True)
         self.slots = tourney_kwargs.get("SLOTS", 4096)                   # concurrent games per GPU (virtual workers, as in generate_Checkers_data)
+        self.split_streams = tourney_kwargs.get("SPLIT_STREAMS", True)   # part-batches on their own HIP streams from 2 048 slots on
         self.stats = None
 
     def start_tournament(self):
@@ -716,20 +717,39 @@ class tournament_Checkers:
             timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
             slots = count if (timed or not self.slots) else min(count, int(self.slots))
             plan = EvaluatorPlan(self.nn1_fn, dev, self.nn_dtype, spec_old=self.nn2_fn, networks=self.networks)
-            cfg = ckengine.config_from_kwargs(
-                self.mcts_kwargs, n_slots=slots, n_workers=count, games_per_slot=self.NUM_GAMES, tournament=True,
-                first_worker_id=first, nodes_per_tree=self.nodes_per_tree, feature_dtype=plan.feature_dtype,
-                seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
-            cache = make_leaf_cache(default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2), dev)
-            rows = lookahead_rows(slots, plan.fused and plan.feature_dtype == ckengine.BOARDS and bool(self.dense_rows) and cache is not None and not timed,
-                                  up_to=512)
-            eng = ckengine.Engine(cfg, cache=cache, extra_rows=max(0, rows - slots))
-            runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
-            runner.run_to_completion()
-            self.stats = eng.stats()
+            split = bool(self.split_streams) and split_parts(slots) >= 2 and not timed
+            log2 = default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)
+            cache = make_leaf_cache(log2, dev, n_engines=split_parts(slots) if split else 1)
+            batch_rows = slots if split else lookahead_rows(slots, plan.fused and plan.feature_dtype == ckengine.BOARDS and bool(self.dense_rows)
+                                                            and cache is not None and not timed, up_to=512)
+
+            def make_engine(offset, workers, n):
+                cfg = ckengine.config_from_kwargs(
+                    self.mcts_kwargs, n_slots=n, n_workers=workers, games_per_slot=self.NUM_GAMES, tournament=True,
+                    first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree, feature_dtype=plan.feature_dtype,
+                    seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
+                return ckengine.Engine(cfg, cache=cache, extra_rows=0 if split else max(0, batch_rows - n))
+
+            if split:
+                # part-batches on their own HIP streams, as in generate_Checkers_data: while one part's leaves are in the two
+                # networks' conv stacks, the other parts' tree, partition and head kernels run beside them (results do not
+                # depend on the division: workers are sharded by contiguous id blocks, dist.py)
+                runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots)
+                runner.run_to_completion()
+                engines = runner.engines
+            else:
+                eng = make_engine(0, count, slots)
+                runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
+                runner.run_to_completion()
+                engines = [eng]
+            self.stats = {}
+            for e in engines:
+                for k, v in e.stats().items():
+                    self.stats[k] = self.stats.get(k, 0) + v
             _warn_pool_overflows(self.stats, "tournament")
-            res = eng.results()
-            eng.close()
+            res = [r for e in engines for r in e.results()]
+            for e in engines:
+                e.close()
             if cache is not None:
                 cache.close()
             rows = torch.tensor([[r[k] for k in ("worker", "game", "outcome", "move_count", "adjudicated",

@@ -496,3 +496,21 @@ def test_range_flag_stalls_the_engine_and_recovery_recalibrates(oracle):
     for f in ("board", "mask", "status", "worker", "game", "ply", "n_children", "chosen", "z", "root_n", "pi"):
         assert (raw1[f] == raw0[f]).all(), f
     assert np.abs(raw1["q"] - raw0["q"]).max() < 1e-5 and np.abs(raw1["root_w"] - raw0["root_w"]).max() < 1e-3
+
+
+def test_large_tournament_on_part_batches_equals_one_engine():
+    """tournament_Checkers from 2 048 concurrent games on divides them between engines that step on their own HIP streams (as
+    generate_Checkers_data does): the game list equals the one of a single engine -- workers are sharded by contiguous id blocks and every
+    worker keeps its own noise stream and colour schedule (training_pipeline.py:523-528)."""
+    from checkers_mcts_amd import pipeline as P
+    kw = dict(KW, BUDGET=16, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    tk = dict(TOURNEY_GAMES=2, NUM_CPUS=2100, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=4)
+    assert P.split_parts(2100) == 2
+    one = P.tournament_Checkers(dict(tk, SPLIT_STREAMS=False), dict(kw))
+    a = one._start_tournament()
+    parts = P.tournament_Checkers(dict(tk), dict(kw))
+    b = parts._start_tournament()
+    assert a == b and len(a) == 4200
+    for k in ("expansions", "terminal_visits", "plies", "games"):
+        assert one.stats[k] == parts.stats[k], k
+    assert len({g[3] for g in a}) == 3                              # wins of both colours and draws occur
