@@ -455,30 +455,53 @@ def arena_leg(a, dev):
     from checkers_mcts_amd import engine as ckengine
     from checkers_mcts_amd.fused import FusedEvaluator
     from checkers_mcts_amd.net import make_net
-    from checkers_mcts_amd.pipeline import StepRunner
+    from checkers_mcts_amd.pipeline import SplitRunner, StepRunner, make_leaf_cache, split_parts
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
-    cfg = ckengine.config_from_kwargs(kw, n_slots=a.slots, games_per_slot=2, tournament=True, feature_dtype=ckengine.BOARDS,
-                                      seed=20260929, device=dev.index, dynamic_queue=True,
-                                      leaf_cache_log2=cache_log2_of(a, dev),
-                                      dense_rows=not a.no_dense_rows)
-    eng = ckengine.Engine(cfg)
-    ev = FusedEvaluator(make_net(128, seed=0, device=dev, dtype=torch.float32), a.slots,
-                        net_old=make_net(128, seed=1, device=dev, dtype=torch.float32), mode="f16x3")
-    runner = StepRunner(eng, ev, use_graph=not a.no_graph)
+    parts = 1 if a.no_split else split_parts(a.slots)
+    cache = make_leaf_cache(cache_log2_of(a, dev), dev, n_engines=parts)
+    nets = (make_net(128, seed=0, device=dev, dtype=torch.float32), make_net(128, seed=1, device=dev, dtype=torch.float32))
+
+    def make_engine(offset, workers, n):
+        cfg = ckengine.config_from_kwargs(kw, n_slots=n, n_workers=workers, games_per_slot=2, tournament=True, feature_dtype=ckengine.BOARDS,
+                                          first_worker_id=offset, seed=20260929, device=dev.index, leaf_cache_log2=0,
+                                          dense_rows=not a.no_dense_rows)
+        return ckengine.Engine(cfg, cache=cache)
+
+    def make_evaluator(n):
+        return FusedEvaluator(nets[0], n, net_old=nets[1], mode="f16x3")
+    # part-batches on their own streams, as pipeline.tournament_Checkers plays a tournament of this size
+    if parts >= 2:
+        runner = SplitRunner(make_engine, make_evaluator, a.slots, use_graph=not a.no_graph, n_slots=a.slots, n_parts=parts)
+        engines = runner.engines
+    else:
+        eng = make_engine(0, a.slots, a.slots)
+        runner = StepRunner(eng, make_evaluator(a.slots), use_graph=not a.no_graph)
+        engines = [eng]
     runner.warmup(3)
     runner.step(1600)                                     # two plies into the games: the second tree of every game has started
 
-    class _One:                                           # single engine, single stream
+    class _Leg:
         step = staticmethod(runner.step)
-        stats = staticmethod(eng.stats)
-    dt, d = timed_window(_One, dev, a.extra_steps)
-    eng.close()
-    del ev, runner
+
+        @staticmethod
+        def stats():
+            out = {}
+            for e in engines:
+                for k, v in e.stats().items():
+                    out[k] = out.get(k, 0) + v
+            return out
+    dt, d = timed_window(_Leg, dev, a.extra_steps)
+    for e in engines:
+        e.close()
+    if cache is not None:
+        cache.close()
+    del runner, engines
     torch.cuda.empty_cache()
     return {"sims_per_s": (d["expansions"] + d["terminal_visits"]) / dt, "ms_per_step": dt / a.extra_steps * 1e3,
-            "steps": a.extra_steps, "budget": 800, "dtype": DTYPE_LABEL["fp32"],
+            "steps": a.extra_steps, "budget": 800, "dtype": DTYPE_LABEL["fp32"], "parts": parts,
             "note": "each leaf is evaluated by its own network only (batch partitioned by network id on the device); "
-                    "sample from the third ply of the games; leaf cache (keyed by position AND network) and dense rows as in the headline"}
+                    "sample from the third ply of the games; leaf cache (keyed by position AND network), dense rows and part-batches on "
+                    "their own streams as in the headline"}
 
 
 def single_game_leg(a, dev):
