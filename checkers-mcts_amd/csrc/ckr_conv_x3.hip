@@ -256,6 +256,30 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
         load_a(rsrc, voff, g0 + s + RING - 1, apf);               // beyond the layer: the next layer's first slots / the padding
         if (s + 1 < NSLOTS) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
+#ifdef CKR_X3_PROBE
+            // timing probe (tools/x3_lds_probe.py; results are WRONG): what the kernel would cost if the activation fragments of the
+            // taps with dx != 0 came from the dx = 0 fragments (1: for free -- an upper bound; 2: through one DPP wave shift and one
+            // mask per register, the price of deriving them in registers) instead of from LDS
+            const int ntap = c8 == CPT - 1 ? tap + 1 : tap;
+            if (CPT > 1 && ntap % 3 != 1) {
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+#if CKR_X3_PROBE == 1
+                    bn.h[pt] = bc.h[pt]; bn.l[pt] = bc.l[pt];
+#else
+                    const u32x4 sh = *reinterpret_cast<const u32x4*>(&bc.h[pt]), sl = *reinterpret_cast<const u32x4*>(&bc.l[pt]);
+                    u32x4 dh, dl;
+                    const unsigned keep = (lane & 7) == 7 ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        dh[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sh[j], 0x130, 0xF, 0xF, false) & keep;
+                        dl[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sl[j], 0x130, 0xF, 0xF, false) & keep;
+                    }
+                    bn.h[pt] = *reinterpret_cast<const f16x8*>(&dh); bn.l[pt] = *reinterpret_cast<const f16x8*>(&dl);
+#endif
+                }
+            } else
+#endif
             load_b(act, c8 == CPT - 1 ? 0 : c8 + 1, rowaddr, bn);
         }
         mfma_block<PT>(ac, bc, acc);

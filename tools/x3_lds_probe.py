@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Timing probe for k_conv_stack_x3 (results of the probe builds are WRONG by construction): how much of the kernel's time on real
+operands is the LDS traffic of the activation fragments?  Builds libckr with -DCKR_X3_PROBE=1 (the fragments of the six taps with
+dx != 0 are copies of the dx = 0 fragments: 2/3 of the ds_read_b128 gone, nothing in their place) and =2 (derived through a DPP wave
+shift + mask per register: the price of making them in registers), and times the float32-grade conv stack on 4 096 boards of random
+planes with each.
+
+    python tools/x3_lds_probe.py build     # here (hipcc cross-compiles)
+    python tools/x3_lds_probe.py run       # on the GPU: one JSON line per build"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "build", "x3probe")
+sys.path.insert(0, ROOT)
+
+
+def build():
+    from checkers_mcts_amd import build as ckbuild
+    os.makedirs(OUT, exist_ok=True)
+    for k in (0, 1, 2):
+        extra = ["-DCKR_X3_PROBE=%d" % k] if k else []
+        subprocess.check_call([ckbuild.HIPCC] + ckbuild.FLAGS + extra + ckbuild.sources() + ["-o", os.path.join(OUT, "libckr_probe%d.so" % k)])
+
+
+def run_one(k):
+    from checkers_mcts_amd import _lib
+    _lib.LIB_PATH = os.path.join(OUT, "libckr_probe%d.so" % k)
+    import torch
+    from checkers_mcts_amd import net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    S = 4096
+    m = N.PolicyValueNet(128).keras_init(0).eval().cuda()
+    fe = FusedEvaluator(m, S, mode="f16x3")
+    x = (torch.rand(S, 8, 8, 14, device="cuda") < 0.2).float().contiguous()
+    for _ in range(20):
+        fe.conv_only(x)
+    torch.cuda.synchronize()
+    out = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            fe.conv_only(x)
+        e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / 200 * 1e3)
+    print(json.dumps(dict(probe=k, us_per_launch=[round(v, 1) for v in out])), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    elif sys.argv[1] == "run":
+        for k in (0, 1, 2, 0):
+            subprocess.call([sys.executable, os.path.abspath(__file__), "one", str(k)])
+    else:
+        run_one(int(sys.argv[2]))
