@@ -253,10 +253,13 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
     load_b(act, 0, rowaddr, b0);
     __builtin_amdgcn_sched_barrier(0);
     auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BF<PT>& bc, BF<PT>& bn) {
+#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 3
+        if (s & 1) apf = ac; else                                  // probe 3: every other weight fragment pair is a register copy (half the L2 -> register stream)
+#endif
         load_a(rsrc, voff, g0 + s + RING - 1, apf);               // beyond the layer: the next layer's first slots / the padding
         if (s + 1 < NSLOTS) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
-#ifdef CKR_X3_PROBE
+#if defined(CKR_X3_PROBE) && CKR_X3_PROBE != 3
             // timing probe (tools/x3_lds_probe.py; results are WRONG): what the kernel would cost if the activation fragments of the
             // taps with dx != 0 came from the dx = 0 fragments (1: for free -- an upper bound; 2: through one DPP wave shift and one
             // mask per register, the price of deriving them in registers) instead of from LDS
