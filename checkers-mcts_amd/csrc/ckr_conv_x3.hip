@@ -110,6 +110,37 @@ template <int PT> __device__ __forceinline__ void load_b(const char* __restrict_
 }
 
 template <int PT> __device__ __forceinline__ void mfma_block(const AF& a, const BF<PT>& b, f32x16 (&acc)[PT]) {
+#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 4
+    // probe 4: the activation fragment stays in place for two consecutive MFMAs (wh xh, wl xh), then wh xl -- another operand order
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
+    return;
+#endif
+#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 6
+    // probe 6: hh, lh, hl by groups of PT (the activation hi fragments are used by two consecutive groups)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
+    return;
+#endif
+#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 5
+    // probe 5: per position tile all three products back to back (dependent accumulator chain of three)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
+    }
+    return;
+#endif
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
 #pragma unroll
