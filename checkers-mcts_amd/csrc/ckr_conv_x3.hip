@@ -121,6 +121,16 @@ template <int PT> __device__ __forceinline__ void mfma_block(const AF& a, const 
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
     return;
 #endif
+#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 7
+    // probe 7: the present order with the operands in each other's slots (the fragment that stays in place is the B operand)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[pt], a.h, acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[pt], a.h, acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[pt], a.l, acc[pt], 0, 0, 0);
+    return;
+#endif
 #if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 6
     // probe 6: hh, lh, hl by groups of PT (the activation hi fragments are used by two consecutive groups)
 #pragma unroll

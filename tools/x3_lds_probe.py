@@ -3,7 +3,7 @@
 operands is the LDS traffic of the activation fragments?  Builds libckr with -DCKR_X3_PROBE=1 (the fragments of the six taps with
 dx != 0 are copies of the dx = 0 fragments: 2/3 of the ds_read_b128 gone, nothing in their place) and =2 (derived through a DPP wave
 shift + mask per register: the price of making them in registers) and =3 (every other pair of weight fragments is a register copy: half
-the L2 -> register weight stream) and =4 / 5 / 6 (other orders of the three MFMAs per multiply-add), and times the float32-grade conv stack on 4 096 boards of random
+the L2 -> register weight stream) and =4 / 5 / 6 (other orders of the three MFMAs per multiply-add) and =7 (the operands in each other's MFMA slots), and times the float32-grade conv stack on 4 096 boards of random
 planes with each.
 
     python tools/x3_lds_probe.py build     # here (hipcc cross-compiles)
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 def build():
     from checkers_mcts_amd import build as ckbuild
     os.makedirs(OUT, exist_ok=True)
-    for k in (0, 1, 2, 3, 4, 5, 6):
+    for k in (0, 1, 2, 3, 4, 5, 6, 7):
         extra = ["-DCKR_X3_PROBE=%d" % k] if k else []
         subprocess.check_call([ckbuild.HIPCC] + ckbuild.FLAGS + extra + ckbuild.sources() + ["-o", os.path.join(OUT, "libckr_probe%d.so" % k)])
 
@@ -50,7 +50,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
     elif sys.argv[1] == "run":
-        for k in (0, 1, 2, 3, 4, 5, 6, 0):
+        for k in (0, 1, 2, 3, 4, 5, 6, 7, 0):
             subprocess.call([sys.executable, os.path.abspath(__file__), "one", str(k)])
     else:
         run_one(int(sys.argv[2]))
