@@ -745,7 +745,7 @@ def main():
         t_gather = ckdist.max_over_ranks(time.perf_counter() - g0, dev)
         bytes_by_rank = ckdist.all_ranks(payload.shape[0] * payload.shape[1], dev)
         tot = {k: ckdist.sum_over_ranks(st[k], dev) for k in ("expansions", "terminal_visits", "plies", "games", "pool_overflows", "nn_evals", "dup_leaves",
-                                                                  "cache_entries", "cache_dropped", "parked")}
+                                                                  "cache_entries", "cache_dropped", "parked", "evaluated_ahead")}
         if rank == 0:
             n_rows = int(gathered.shape[0])
             issued = torch.distributed.is_initialized() and (world > 1 or bool(os.environ.get("CKR_FORCE_COLLECTIVE")))
@@ -757,7 +757,10 @@ def main():
                      "pool_overflows": int(tot["pool_overflows"]),
                      "leaf_cache": {"nn_evals": tot["nn_evals"], "dup_leaves": tot["dup_leaves"],
                                     "duplicate_rate": tot["dup_leaves"] / max(1.0, tot["expansions"]),
-                                    "records_written": tot["cache_entries"], "records_dropped": tot["cache_dropped"], "parked_slot_steps": tot["parked"]},
+                                    "records_written": tot["cache_entries"], "records_dropped": tot["cache_dropped"], "parked_slot_steps": tot["parked"],
+                                    # the tail: positions evaluated ahead of the search on rows no leaf needed (Engine.set_prefetch): network
+                                    # rows beside nn_evals, spent while the chip was mostly idle
+                                    "rows_evaluated_ahead": tot["evaluated_ahead"]},
                      "gather": {"collective": "all_gather(sizes) + gather(padded rows) to rank 0 (%s)"
                                               % (("RCCL" if torch.distributed.get_backend() == "nccl" else torch.distributed.get_backend() + ", rows staged through host memory") if issued else "single rank: no collective issued"),
                                 "tuples": n_rows, "bytes": n_rows * 288, "bytes_by_rank": bytes_by_rank, "seconds": t_gather},

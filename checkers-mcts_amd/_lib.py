@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
-VERSION = 121                      # CKR_VERSION of include/ckr.h this binding was written against
+VERSION = 122                      # CKR_VERSION of include/ckr.h this binding was written against
 Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
@@ -50,7 +50,7 @@ class GameResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("expansions", "terminal_visits", "plies", "games", "reroot_misses",
                                           "nodes_created", "compactions", "pool_overflows", "steps",
-                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped", "parked", "stalled_steps")]
+                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped", "parked", "stalled_steps", "evaluated_ahead")]
 
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_movegen_batch", "ckr_children_batch",

@@ -25,7 +25,7 @@ namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS,
-       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_STALL, CNT_N };
+       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_STALL, CNT_AHEAD, CNT_N };
 constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
 
 // ---- leaf cache: network outputs by position.  Checkers.predict is a pure function of planes 0-13 (Checkers.py:425-438),
@@ -610,6 +610,7 @@ template <class Wave> __device__ __attribute__((noinline)) void prefetch_childre
     if (w.lane == 0) r0 = atomicAdd(D.pf_counter, cnt);
     r0 = bcast_i32(r0, 0);
     const int row = D.pf_base + r0 + rank;
+    { const int room = D.pf_rows - D.pf_base - r0; w.count(CNT_AHEAD, (uint32_t)(room <= 0 ? 0 : cnt < room ? cnt : room)); }
     if (want && row < D.pf_rows) {                                              // (beyond the last row: not handed out)
         const uint4 rec = make_uint4(c.p1, c.p2, c.kings, c.meta);
         D.g_pf_board[row] = rec;
@@ -1984,7 +1985,7 @@ int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS];
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL]; out->evaluated_ahead = c[CNT_AHEAD];
     return CKR_OK;
 }
 
@@ -2002,7 +2003,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS]; out->active_slots = active;
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL]; out->evaluated_ahead = c[CNT_AHEAD];
     return CKR_OK;
 }
 

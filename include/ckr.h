@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 121          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces) */
+#define CKR_VERSION 122          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces) */
 
 typedef enum {
     CKR_OK = 0,
@@ -333,6 +333,7 @@ typedef struct {
     uint64_t cache_dropped;      /* records not cached because their probe neighbourhood was full */
     uint64_t parked;             /* slot-steps spent waiting for another requester's evaluation of the same position (leaf_cache_park) */
     uint64_t stalled_steps;      /* steps in which nothing was expanded because the evaluation flag was raised (ckr_engine_set_eval_flag) */
+    uint64_t evaluated_ahead;    /* positions handed to the network ahead of the search (ckr_engine_set_prefetch): rows beside nn_evals */
 } ckr_stats;
 
 typedef struct ckr_engine ckr_engine;

@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.ckr_version() == 121
+    assert lib.ckr_version() == 122
     assert isinstance(lib.ckr_last_error(), bytes)
 
 
@@ -35,7 +35,7 @@ def test_struct_sizes_match_header():
     from checkers_mcts_amd import _lib
     assert C.sizeof(_lib.Tuple) == 288
     assert C.sizeof(_lib.GameResult) == 32
-    assert C.sizeof(_lib.Stats) == 128
+    assert C.sizeof(_lib.Stats) == 136
     assert C.sizeof(_lib.Config) == 152
     assert C.sizeof(_lib.NodeInfo) == 40
 

@@ -54,6 +54,7 @@ def test_prefetch_on_off_identical_hashnet_selfplay(E):
     assert on[2]["nn_evals"] + on[2]["dup_leaves"] == on[2]["expansions"]
     assert on[2]["dup_leaves"] > off[2]["dup_leaves"] and on[2]["nn_evals"] < off[2]["nn_evals"]      # more leaves served by the cache
     assert on[2]["cache_entries"] > off[2]["cache_entries"]                  # records filed from prefetched answers
+    assert off[2]["evaluated_ahead"] == 0 and on[2]["evaluated_ahead"] > 1000
     assert on[3] < off[3]                                                    # the same games in fewer steps
 
 
