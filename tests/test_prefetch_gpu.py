@@ -42,9 +42,11 @@ def play(E, kw, n_slots, evaluator, prefetch, share=3, **cfg_kw):
     return raw, res, st, steps, on_steps
 
 
-def test_prefetch_on_off_identical_hashnet_selfplay(E):
+@pytest.mark.parametrize("park", [False, True])
+def test_prefetch_on_off_identical_hashnet_selfplay(E, park):
+    """(park: with the leaf cache's pending claims -- a slot that finds its position being evaluated for another waits a step.)"""
     kw = mk(60, eps=0.25, tau=1.0)
-    common = dict(games_per_slot=1, terminate_cnt=120, seed=11, leaf_cache_log2=19)
+    common = dict(games_per_slot=1, terminate_cnt=120, seed=11, leaf_cache_log2=19, leaf_cache_park=park)
     off = play(E, kw, 128, E.hashnet_evaluator(9), False, **common)
     on = play(E, kw, 128, E.hashnet_evaluator(9), True, **common)
     assert off[0].tobytes() == on[0].tobytes() and off[1] == on[1] and len(off[0]) > 128 * 20
