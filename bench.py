@@ -858,6 +858,7 @@ def main():
                                          "cached priors / v; results identical with and without; value without it: extra.cache_off" % cache_log2)
                                         if cache_log2 else "off",
                           "leaf_cache_log2": cache_log2, "ranks_per_device": ckdist.ranks_per_device(),
+                          "evaluation_ahead_in_the_tail": os.environ.get("CKR_PREFETCH", "1") != "0",   # whole_run / single-game legs; never on in the timed window
                           "streams": "%d part-batches of %d slots on %d HIP streams" % (n_parts, nb, n_parts) if n_parts > 1 else "1",
                           "parallelism": "games sharded x%d, no per-step collective, one gather of the tuples" % world},
                "parity": "pi, v within 1e-5 of the float64 restatement (tests/test_net_pipeline_gpu.py; Keras's own arithmetic unpinned: TensorFlow "
