@@ -457,7 +457,7 @@ def arena_leg(a, dev):
     from checkers_mcts_amd.net import make_net
     from checkers_mcts_amd.pipeline import SplitRunner, StepRunner, make_leaf_cache, split_parts
     kw = dict(MCTS_KWARGS, BUDGET=800, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
-    parts = 1 if a.no_split else split_parts(a.slots)
+    parts = 1 if a.no_split else split_parts(a.slots, two_from=2048)
     cache = make_leaf_cache(cache_log2_of(a, dev), dev, n_engines=parts)
     nets = (make_net(128, seed=0, device=dev, dtype=torch.float32), make_net(128, seed=1, device=dev, dtype=torch.float32))
 

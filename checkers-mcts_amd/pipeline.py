@@ -348,15 +348,20 @@ class StepRunner:
 SPLIT_MIN_SLOTS = 1024          # a part below 1 024 slots (2 per CU-resident conv workgroup) no longer fills 256 CUs
 
 
-def split_parts(n_slots):
-    """Into how many engines / HIP streams SplitRunner divides n_slots concurrent games: 1 below 2 048 slots, 2, and 3 from 3 072
-    slots on.  Measured on cfg3 (4 096 slots) with ONE leaf cache shared by the parts: 2 parts 6.51-6.81 M expansions/s, 3 parts
-    6.75-7.00 M (+3 %), 4 parts 5.87 M (profiles/r04_split_parts.txt; round 3, with a private cache per part: 3 parts -1.4 %).
+def split_parts(n_slots, two_from=257):
+    """Into how many engines / HIP streams SplitRunner divides n_slots concurrent games: 1 up to 256 slots (small jobs: one engine
+    with rows for evaluation ahead of the search, lookahead_rows), 2, and 3 from 3 072 slots on.  Measured on cfg3 (4 096 slots) with
+    ONE leaf cache shared by the parts: 2 parts 6.51-6.81 M expansions/s, 3 parts 6.75-7.00 M (+3 %), 4 parts 5.87 M
+    (profiles/r04_split_parts.txt; round 3, with a private cache per part: 3 parts -1.4 %).  Below 2 048 slots a part no longer fills the
+    chip, but two latency-bound chains side by side still beat one: self-play of 300 / 800 / 1 600 / 2 000 games at 200 simulations/move
+    4.5 -> 3.9 s / 5.2 -> 4.7 / 8.6 -> 6.2 / 8.3 -> 7.1 s with 2 parts (3 parts: no better; profiles/r04_small_jobs_lookahead.jsonl).
+    Tournaments (two conv launches per step) gain nothing below 2 048 concurrent games: they pass two_from = 2 048.
     CKR_SPLIT_PARTS overrides."""
     forced = os.environ.get("CKR_SPLIT_PARTS")
     if forced:
         return max(1, int(forced))
-    return max(1, min(3, int(n_slots) // SPLIT_MIN_SLOTS))
+    n = int(n_slots)
+    return 3 if n >= 3 * SPLIT_MIN_SLOTS else 2 if n >= int(two_from) else 1
 
 
 LOOKAHEAD_BATCH = 1024          # boards one conv launch of an un-split engine computes in ONE round of workgroups (2 per workgroup, 2 per CU)
@@ -717,9 +722,10 @@ class tournament_Checkers:
             timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
             slots = count if (timed or not self.slots) else min(count, int(self.slots))
             plan = EvaluatorPlan(self.nn1_fn, dev, self.nn_dtype, spec_old=self.nn2_fn, networks=self.networks)
-            split = bool(self.split_streams) and split_parts(slots) >= 2 and not timed
+            n_parts = split_parts(slots, two_from=2 * SPLIT_MIN_SLOTS)
+            split = bool(self.split_streams) and n_parts >= 2 and not timed
             log2 = default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)
-            cache = make_leaf_cache(log2, dev, n_engines=split_parts(slots) if split else 1)
+            cache = make_leaf_cache(log2, dev, n_engines=n_parts if split else 1)
             batch_rows = slots if split else lookahead_rows(slots, plan.fused and plan.feature_dtype == ckengine.BOARDS and bool(self.dense_rows)
                                                             and cache is not None and not timed, up_to=512)
 
@@ -734,7 +740,7 @@ class tournament_Checkers:
                 # part-batches on their own HIP streams, as in generate_Checkers_data: while one part's leaves are in the two
                 # networks' conv stacks, the other parts' tree, partition and head kernels run beside them (results do not
                 # depend on the division: workers are sharded by contiguous id blocks, dist.py)
-                runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots)
+                runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots, n_parts=n_parts)
                 runner.run_to_completion()
                 engines = runner.engines
             else:

@@ -505,7 +505,7 @@ def test_large_tournament_on_part_batches_equals_one_engine():
     from checkers_mcts_amd import pipeline as P
     kw = dict(KW, BUDGET=16, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
     tk = dict(TOURNEY_GAMES=2, NUM_CPUS=2100, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=4)
-    assert P.split_parts(2100) == 2
+    assert P.split_parts(2100, two_from=2048) == 2 and P.split_parts(600, two_from=2048) == 1 and P.split_parts(600) == 2
     one = P.tournament_Checkers(dict(tk, SPLIT_STREAMS=False), dict(kw))
     a = one._start_tournament()
     parts = P.tournament_Checkers(dict(tk), dict(kw))
