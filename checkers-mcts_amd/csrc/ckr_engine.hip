@@ -1659,6 +1659,9 @@ int ckr_leaf_cache_flush(ckr_leaf_cache* lc, void* stream) {
     if (!lc) return fail(CKR_ERR_INVALID, "ckr_leaf_cache_flush: null cache");
     // every claim back to "never used": nothing written so far can be served again, whatever the launch numbers do later
     CKR_HIP(hipMemsetAsync(lc->claim, 0, (lc->capacity + CACHE_PROBES) * sizeof(unsigned long long), (hipStream_t)stream));
+    // no engine attached (a table kept for the next job): the launch clock starts over as well, so that the next job behaves exactly
+    // like one on a new table (the same launches fall into the same generations)
+    if (!lc->attached) CKR_HIP(hipMemsetAsync(lc->shared, 0, sizeof(CacheShared), (hipStream_t)stream));
     return CKR_OK;
 }
 

@@ -504,6 +504,65 @@ def default_leaf_cache_log2(n_slots, device=None, sharers=None):
     return log2
 
 
+def job_leaf_cache_log2(n_slots, device, games, budget, plies=100):
+    """default_leaf_cache_log2 bounded by what the JOB can write: about half of its games x plies x BUDGET expansions reach the
+    network (the other half is served by the cache), and a table twice that many records keeps every probe neighbourhood open.
+    A self-play job of 1 600 games at 200 simulations/move gets 2^25 records (8.9 GB) instead of 2^27 (35 GB): allocating device
+    memory costs 30-60 ms per GB, 1-2 s of that job's 8 (measured: tools notes in profiles/r04_small_jobs_lookahead.jsonl)."""
+    log2 = default_leaf_cache_log2(n_slots, device)
+    # (small jobs look ahead from their first step: the children of every expanded node get records too, ~4 x as many)
+    ahead = 4.0 if int(n_slots) <= 512 else 1.25
+    want = max(1.0, float(games) * float(plies) * float(min(int(budget), 1 << 20)) * 0.5 * 2.0 * ahead)
+    return int(min(log2, max(22, int(np.ceil(np.log2(want))))))
+
+
+_CACHE_POOL = {}                # (device index, log2 records, log2 generation) -> a LeafCache a finished job of this process released
+CACHE_POOL_TABLES = 2           # tables kept per device (a training iteration alternates between a self-play and a tournament shape)
+
+
+def acquire_leaf_cache(log2, device, n_engines=1):
+    """make_leaf_cache, re-using a table of the same shape that an earlier job on this device released: flushed (every claim zeroed,
+    the launch clock reset: nothing of the previous job or network can be served, and the job runs as on a new table) instead of
+    freed and allocated again.  CKR_CACHE_POOL=0: no pooling."""
+    if not log2:
+        return None
+    dev = int(device.index if isinstance(device, torch.device) else device)
+    gen = min(20, max(11, int(log2) - 14) + int(np.ceil(np.log2(max(1, int(n_engines))))))
+    old = _CACHE_POOL.pop((dev, int(log2), gen), None)
+    if old is not None and getattr(old, "_h", None):
+        old.flush()
+        torch.cuda.synchronize(dev)
+        old._next_index = 0
+        return old
+    c = make_leaf_cache(log2, device, n_engines)
+    c.pool_key = (dev, int(log2), gen)
+    return c
+
+
+def release_leaf_cache(cache):
+    """The job is over (its engines are closed): keep the table for a later job of this process, or free it."""
+    if cache is None:
+        return
+    key = getattr(cache, "pool_key", None)
+    if os.environ.get("CKR_CACHE_POOL", "1") == "0" or key is None:
+        cache.close()
+        return
+    same_dev = [k for k in _CACHE_POOL if k[0] == key[0]]
+    while len(same_dev) >= CACHE_POOL_TABLES:                  # (dicts keep insertion order: the oldest goes)
+        _CACHE_POOL.pop(same_dev.pop(0)).close()
+    stale = _CACHE_POOL.pop(key, None)
+    if stale is not None and stale is not cache:
+        stale.close()
+    _CACHE_POOL[key] = cache
+
+
+def release_caches():
+    """Free the pooled leaf-cache tables (device memory) of this process."""
+    for c in list(_CACHE_POOL.values()):
+        c.close()
+    _CACHE_POOL.clear()
+
+
 def make_leaf_cache(log2, device, n_engines=1):
     """The GPU's leaf cache for `n_engines` engines stepping side by side (None when log2 is 0): launch numbers advance
     n_engines times per step, so a generation is as many launches longer."""
@@ -605,8 +664,9 @@ class generate_Checkers_data:
         timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
         slots = count if (self.dynamic_queue or timed or not self.slots) else min(count, int(self.slots))
         split = (neural and self.split_streams and split_parts(slots) >= 2 and not self.dynamic_queue and not timed)
-        log2 = (default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)) if neural else 0
-        cache = make_leaf_cache(log2, dev, n_engines=split_parts(slots) if split else 1)
+        log2 = ((job_leaf_cache_log2(slots, dev, count * self.NUM_SELFPLAY_GAMES, self.mcts_kwargs["BUDGET"] if not timed else 1 << 20)
+                 if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)) if neural else 0)
+        cache = acquire_leaf_cache(log2, dev, n_engines=split_parts(slots) if split else 1)
         plan = EvaluatorPlan(self.nn_fn, dev, self.nn_dtype, kind=kind, networks=self.networks) if neural else None
         fdt = plan.feature_dtype if neural else self.nn_dtype
 
@@ -653,8 +713,7 @@ class generate_Checkers_data:
         raw_dev = torch.cat([e.pack_tuples_device() for e in engines], dim=0)
         for e in engines:
             e.close()
-        if cache is not None:
-            cache.close()
+        release_leaf_cache(cache)
         return raw_dev
 
     def generate_data(self):
@@ -724,8 +783,9 @@ class tournament_Checkers:
             plan = EvaluatorPlan(self.nn1_fn, dev, self.nn_dtype, spec_old=self.nn2_fn, networks=self.networks)
             n_parts = split_parts(slots, two_from=2 * SPLIT_MIN_SLOTS)
             split = bool(self.split_streams) and n_parts >= 2 and not timed
-            log2 = default_leaf_cache_log2(slots, dev) if self.leaf_cache_log2 is None else int(self.leaf_cache_log2)
-            cache = make_leaf_cache(log2, dev, n_engines=n_parts if split else 1)
+            log2 = (job_leaf_cache_log2(slots, dev, count * self.NUM_GAMES, self.mcts_kwargs["BUDGET"] if not timed else 1 << 20, plies=150)
+                    if self.leaf_cache_log2 is None else int(self.leaf_cache_log2))
+            cache = acquire_leaf_cache(log2, dev, n_engines=n_parts if split else 1)
             batch_rows = slots if split else lookahead_rows(slots, plan.fused and plan.feature_dtype == ckengine.BOARDS and bool(self.dense_rows)
                                                             and cache is not None and not timed, up_to=512)
 
@@ -756,8 +816,7 @@ class tournament_Checkers:
             res = [r for e in engines for r in e.results()]
             for e in engines:
                 e.close()
-            if cache is not None:
-                cache.close()
+            release_leaf_cache(cache)
             rows = torch.tensor([[r[k] for k in ("worker", "game", "outcome", "move_count", "adjudicated",
                                                  "p1_net", "n_tuples", "failed")] for r in res],
                                 dtype=torch.int32, device=dev).reshape(-1, 8)

@@ -332,3 +332,42 @@ def test_attach_rules_and_flush_forgets_everything(E):
         assert (got.tobytes() == plain_b.tobytes()) == (flushes > 0), flushes
     eng.close()
     cache.close()
+
+
+def test_pipeline_jobs_reuse_one_table_and_forget_the_previous_network(monkeypatch):
+    """The drop-in classes keep the leaf-cache table of a finished job for the next one on the same device (allocating device memory
+    costs more than a small job) -- flushed: a job with ANOTHER network must give what it gives on a table of its own.  Also: the
+    table is sized by what the job can write (job_leaf_cache_log2), and release_caches() frees it."""
+    import torch
+    from checkers_mcts_amd import pipeline as P
+    kw = dict(mk(30, eps=0.25, tau=1.0))
+    sp = dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=60, NUM_CPUS=200, SEED=9)
+
+    def job(net):
+        g = P.generate_Checkers_data(dict(sp, NN_FN=net), dict(kw))
+        t = g.generate_tuples().cpu().numpy().view(np.uint8).reshape(-1, 288)
+        rows = np.ascontiguousarray(t).view(np.dtype((np.void, 288))).ravel().copy()
+        rows.sort()
+        return rows.tobytes(), dict(g.stats)
+    P.release_caches()
+    monkeypatch.setenv("CKR_CACHE_POOL", "0")
+    fresh = [job("random:0"), job("random:1")]
+    assert not P._CACHE_POOL
+    monkeypatch.setenv("CKR_CACHE_POOL", "1")
+    pooled = [job("random:0")]
+    assert len(P._CACHE_POOL) == 1
+    table = next(iter(P._CACHE_POOL.values()))
+    pooled.append(job("random:1"))
+    assert len(P._CACHE_POOL) == 1 and next(iter(P._CACHE_POOL.values())) is table    # the same allocation served both jobs
+    for a, b in zip(fresh, pooled):
+        assert a[0] == b[0]                                                  # the same tuples, byte for byte
+        for k in SEARCH_COUNTERS:                                            # (how many leaves the cache served depends on which of the
+            assert a[1][k] == b[1][k], k                                     # two part-batches asked first: not compared)
+        assert b[1]["dup_leaves"] > 0.2 * b[1]["expansions"]
+    assert fresh[0][0] != fresh[1][0]                                        # (the two networks do play different games)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    assert P.job_leaf_cache_log2(200, dev, 200, 30) == 22 < P.default_leaf_cache_log2(200, dev)       # 200 x 100 x 30 x 0.5 x 2 x 4 = 2.4 M records: the floor of 2^22
+    assert P.job_leaf_cache_log2(1600, dev, 1600, 200) == 26 < P.default_leaf_cache_log2(1600, dev)
+    assert P.job_leaf_cache_log2(4096, dev, 16384, 100) == P.default_leaf_cache_log2(4096, dev)
+    P.release_caches()
+    assert not P._CACHE_POOL
