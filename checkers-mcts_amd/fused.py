@@ -15,6 +15,7 @@ the streams and the HIP graph; no torch operator runs in the inference step.
 Weights come from a float32 `net.PolicyValueNet`.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -177,6 +178,7 @@ class FusedEvaluator:
         self._L.ckr_conv_stack_f16x3_boards.argtypes = self._L.ckr_conv_stack_f16x3.argtypes
         self.overflow = None
         self.row_cap = None                     # set_row_cap()
+        self.two_streams = os.environ.get("CKR_ARENA_STREAMS", "2") != "1"      # arena: the second network's launches on a stream of their own
         self.timing = None                      # a list: every forward appends (event before, event after) its conv-stack launch (bench.py)
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -341,8 +343,25 @@ class FusedEvaluator:
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(self._L.ckr_arena_partition(engine.net_id.data_ptr(), S, x.data_ptr(), x[0].numel() * x.element_size(),
                                                self._dest.data_ptr(), self._ranges.data_ptr(), self._xg.data_ptr(), stream))
-        p, v = self._forward(self.nets[0], self._xg, self._ranges[0:2])
-        p2, v2 = self._forward(self.nets[1], self._xg, self._ranges[2:4])
+        # the two networks' launches are independent: the second one runs on a stream of its own (forked and joined with events, so
+        # that it captures into the step's graph) -- in a small tournament each launch covers a fraction of the chip, and the step
+        # is as long as one of them instead of both
+        if self.two_streams:
+            cur = torch.cuda.current_stream(dev)
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            self._side.wait_event(fork)
+            p, v = self._forward(self.nets[0], self._xg, self._ranges[0:2])
+            with torch.cuda.stream(self._side):
+                p2, v2 = self._forward(self.nets[1], self._xg, self._ranges[2:4])
+                join = torch.cuda.Event()
+                join.record(self._side)
+            cur.wait_event(join)
+        else:
+            p, v = self._forward(self.nets[0], self._xg, self._ranges[0:2])
+            p2, v2 = self._forward(self.nets[1], self._xg, self._ranges[2:4])
         _lib.check(self._L.ckr_arena_merge(p.data_ptr(), v.data_ptr(), p2.data_ptr(), v2.data_ptr(), self._dest.data_ptr(),
                                            self._ranges.data_ptr(), S, self._p.data_ptr(), self._v.data_ptr(), stream))
         return self._p, self._v
