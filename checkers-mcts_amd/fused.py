@@ -346,7 +346,9 @@ class FusedEvaluator:
         # the two networks' launches are independent: the second one runs on a stream of its own (forked and joined with events, so
         # that it captures into the step's graph) -- in a small tournament each launch covers a fraction of the chip, and the step
         # is as long as one of them instead of both
-        if self.two_streams:
+        # (only while a launch covers at most 1 024 boards -- small tournaments, the tail of a large one: two chip-filling launches side
+        # by side are 22 % SLOWER than one after the other, 13.5 against 17.3 M simulations/s on cfg5's shape)
+        if self.two_streams and self._rows(self.nets[0]) <= 1024:
             cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=dev)
