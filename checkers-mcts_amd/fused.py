@@ -347,7 +347,8 @@ class FusedEvaluator:
         # that it captures into the step's graph) -- in a small tournament each launch covers a fraction of the chip, and the step
         # is as long as one of them instead of both
         # (only while a launch covers at most 1 024 boards -- small tournaments, the tail of a large one: two chip-filling launches side
-        # by side are 22 % SLOWER than one after the other, 13.5 against 17.3 M simulations/s on cfg5's shape)
+        # by side are 22 % SLOWER than one after the other, 13.5 against 17.3 M simulations/s on cfg5's shape; and only for an engine
+        # that runs alone: pipeline.SplitRunner turns it off for its parts, whose graphs replay side by side on their own streams)
         if self.two_streams and self._rows(self.nets[0]) <= 1024:
             cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side", None) is None:
