@@ -178,7 +178,10 @@ class FusedEvaluator:
         self._L.ckr_conv_stack_f16x3_boards.argtypes = self._L.ckr_conv_stack_f16x3.argtypes
         self.overflow = None
         self.row_cap = None                     # set_row_cap()
-        self.two_streams = os.environ.get("CKR_ARENA_STREAMS", "2") != "1"      # arena: the second network's launches on a stream of their own
+        # arena: the second network's launches on a stream of their own -- opt-in (CKR_ARENA_STREAMS=2): a step's graph then has two
+        # branches, and this HIP runtime faults in hipGraphLaunch (hip::Graph::UpdateStreams) when such graphs are destroyed and
+        # captured again beside other live ones (profiles/r04_arena_streams_fault.txt)
+        self.two_streams = os.environ.get("CKR_ARENA_STREAMS", "1") in ("2", "parts")
         self.timing = None                      # a list: every forward appends (event before, event after) its conv-stack launch (bench.py)
         self._L.ckr_value_mlp.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_float, vp, vp]
         self._L.ckr_policy_head.argtypes = [vp, C.c_int64, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -343,9 +346,9 @@ class FusedEvaluator:
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(self._L.ckr_arena_partition(engine.net_id.data_ptr(), S, x.data_ptr(), x[0].numel() * x.element_size(),
                                                self._dest.data_ptr(), self._ranges.data_ptr(), self._xg.data_ptr(), stream))
-        # the two networks' launches are independent: the second one runs on a stream of its own (forked and joined with events, so
-        # that it captures into the step's graph) -- in a small tournament each launch covers a fraction of the chip, and the step
-        # is as long as one of them instead of both
+        # the two networks' launches are independent: with CKR_ARENA_STREAMS=2 the second one runs on a stream of its own (forked and
+        # joined with events, so that it captures into the step's graph) -- in a small tournament each launch covers a fraction of
+        # the chip, and the step is as long as one of them instead of both
         # (only while a launch covers at most 1 024 boards -- small tournaments, the tail of a large one: two chip-filling launches side
         # by side are 22 % SLOWER than one after the other, 13.5 against 17.3 M simulations/s on cfg5's shape; and only for an engine
         # that runs alone: pipeline.SplitRunner turns it off for its parts, whose graphs replay side by side on their own streams)

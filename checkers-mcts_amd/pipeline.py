@@ -411,7 +411,7 @@ class SplitRunner:
             with torch.cuda.stream(stream):
                 runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
             runner.solo = False                              # the parts share the chip: smaller lookahead batches (tail_mode)
-            if hasattr(runner.evaluator, "two_streams"):        # arena: the two networks' launches stay on the part's one stream -- the other
+            if hasattr(runner.evaluator, "two_streams") and os.environ.get("CKR_ARENA_STREAMS") != "parts":   # arena: the two networks' launches stay on the part's one stream -- the other
                 runner.evaluator.two_streams = False         # parts' steps already run beside them, and each part's graph stays a chain
             self.parts.append((eng, runner, stream))
         self.device = self.parts[0][0].device

@@ -1,7 +1,8 @@
 """Stress for the arena evaluator's two-stream launches inside HIP graphs (fused.FusedEvaluator, CKR_ARENA_STREAMS): the same large
 tournament on part-batches (pipeline.SplitRunner: one graph per part, re-captured through the tail of the run) again and again in
-one process, with another seed each time.  Prints one line per repetition; run it under `rocgdb -batch -ex run -ex bt` to get the
-native stack if a replay faults.
+one process (one engine, then the parts), with another seed each time.  CKR_ARENA_STREAMS=parts keeps the second stream on in
+the parts as well (the configuration in which one full-suite run faulted inside hipGraphLaunch; experiment only).  Prints one line
+per tournament; run it under `rocgdb -batch -ex run -ex bt` to get the native stack if a replay faults.
 
     python tools/arena_streams_stress.py [repetitions] [concurrent games]
 """
@@ -11,7 +12,6 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-import torch                                              # noqa: E402
 from checkers_mcts_amd import pipeline as P               # noqa: E402
 
 KW = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=16, MULTIPROC=False, NEURAL_NET=True, VERBOSE=False, TRAINING=False,
@@ -23,11 +23,13 @@ def main():
     games = int(sys.argv[2]) if len(sys.argv) > 2 else 2100
     print("CKR_ARENA_STREAMS=%s, %d repetitions, %d concurrent games" % (os.environ.get("CKR_ARENA_STREAMS", "(default)"), reps, games), flush=True)
     for r in range(reps):
-        t0 = time.perf_counter()
-        t = P.tournament_Checkers(dict(TOURNEY_GAMES=2, NUM_CPUS=games, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=4 + r), dict(KW))
-        out = t._start_tournament()
-        torch.cuda.synchronize()
-        print("rep %d: %d games, %d steps, %.2f s" % (r, len(out), t.stats["steps"], time.perf_counter() - t0), flush=True)
+        for split in (False, True):                       # as tests/test_net_pipeline_gpu.py does: one engine, then the parts
+            t0 = time.perf_counter()
+            t = P.tournament_Checkers(dict(TOURNEY_GAMES=2, NUM_CPUS=games, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=4 + r,
+                                           SPLIT_STREAMS=split), dict(KW))
+            out = t._start_tournament()
+            print("rep %d, %s: %d games, %d steps, %.2f s" % (r, "parts" if split else "one engine", len(out), t.stats["steps"],
+                                                              time.perf_counter() - t0), flush=True)
 
 
 if __name__ == "__main__":
