@@ -351,14 +351,14 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
 }
 
 template <int TL>
-__device__ __forceinline__ void conv_stack_body(const Args& A, char* smem) {
+__device__ __forceinline__ void conv_stack_body(const Args& A, char* smem, const unsigned tile) {
     typedef Cfg<TL> K;
     constexpr int TILE = K::TILE, XP = K::XP, PT = K::PT, ACT_BYTES = K::ACT_BYTES;
     char* act = smem;
     float* prm = reinterpret_cast<float*>(smem + ACT_BYTES);
     float* stage = reinterpret_cast<float*>(smem + ACT_BYTES + PRM_BYTES);
     const int tid = threadIdx.x, wc = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const long long board0 = (long long)blockIdx.x * TILE;
+    const long long board0 = (long long)tile * TILE;
     if (A.range && (board0 >= A.range[1] || board0 + TILE <= A.range[0])) return;   // arena / tail: not this launch's share
     const int rows_valid = (int)min((long long)XP, (A.n_boards - board0) * 64);
     if (rows_valid <= 0) return;
@@ -443,11 +443,25 @@ __device__ __forceinline__ void conv_stack_body(const Args& A, char* smem) {
 
 __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[Cfg<2>::LDS_BYTES];
-    conv_stack_body<2>(A, smem);
+    conv_stack_body<2>(A, smem, blockIdx.x);
 }
 __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_small(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[Cfg<1>::LDS_BYTES];
-    conv_stack_body<1>(A, smem);
+    conv_stack_body<1>(A, smem, blockIdx.x);
+}
+// Arena: TWO networks in one launch.  Workgroups [0, tiles) evaluate network A's share of the batch, [tiles, 2 tiles) network B's
+// (each share is a device-side board range: tiles outside it exit at once, as in two launches) -- in a small tournament either
+// launch alone covers a fraction of the chip, and the step is as long as one of them instead of both.
+struct ArgsPair { Args net[2]; };
+__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_pair(const ArgsPair P, const unsigned tiles) {
+    __shared__ __attribute__((aligned(16))) char smem[Cfg<2>::LDS_BYTES];
+    const unsigned second = blockIdx.x >= tiles ? 1u : 0u;
+    conv_stack_body<2>(P.net[second], smem, blockIdx.x - second * tiles);
+}
+__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_small_pair(const ArgsPair P, const unsigned tiles) {
+    __shared__ __attribute__((aligned(16))) char smem[Cfg<1>::LDS_BYTES];
+    const unsigned second = blockIdx.x >= tiles ? 1u : 0u;
+    conv_stack_body<1>(P.net[second], smem, blockIdx.x - second * tiles);
 }
 
 }  // namespace ckrx
@@ -470,16 +484,13 @@ extern "C" int ckr_conv_stack_f16x3_boards(const ckr_board* d_boards, int64_t n_
     return conv_stack_f16x3(nullptr, d_boards, n_boards, layers, n_layers, heads, x_scale, act_scales, d_board_range, d_overflow, stream);
 }
 
-static int conv_stack_f16x3(const float* d_x, const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
-                            const ckr_conv_heads* heads, float x_scale, const float* act_scales,
-                            const int32_t* d_board_range, int32_t* d_overflow, void* stream) {
+// checks one network's arguments and fills the kernel's argument block
+static int fill_args(Args& A, const float* d_x, const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
+                     const ckr_conv_heads* heads, float x_scale, const float* act_scales, const int32_t* d_board_range, int32_t* d_overflow) {
     if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
         return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: bad n_boards / n_layers");
     if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: x_scale must be positive");
-    if (int rc = ckr::require_device()) return rc;
-    if (n_boards == 0) return CKR_OK;
     if (!d_x && !d_boards) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: null input");
-    Args A;
     A.x = d_x; A.xb = reinterpret_cast<const uint4*>(d_boards); A.n_boards = n_boards; A.n_layers = n_layers; A.xs = x_scale;
     // the scale of each layer's stored output (folded into its bias / scale / shift by the host) matters to the kernel only
     // where float32 values leave the stack: the two 1x1 head convolutions
@@ -515,6 +526,19 @@ static int conv_stack_f16x3(const float* d_x, const ckr_board* d_boards, int64_t
     }
     A.w = (const uint4*)layers[0].weights;
     A.w_bytes = (long long)(expect - (const char*)layers[0].weights) + (long long)(RING - 1) * SLOT_BYTES;
+    return CKR_OK;
+}
+
+static int conv_stack_f16x3(const float* d_x, const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers, int32_t n_layers,
+                            const ckr_conv_heads* heads, float x_scale, const float* act_scales,
+                            const int32_t* d_board_range, int32_t* d_overflow, void* stream) {
+    if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: bad n_boards / n_layers");
+    if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3: x_scale must be positive");
+    if (int rc = ckr::require_device()) return rc;
+    if (n_boards == 0) return CKR_OK;
+    Args A;
+    if (int rc = fill_args(A, d_x, d_boards, n_boards, layers, n_layers, heads, x_scale, act_scales, d_board_range, d_overflow)) return rc;
     // n_boards <= SMALL_BOARDS: the single-board kernel (callers that know only few rows of a larger batch are in use -- the
     // tail of a run -- pass that bound as n_boards).  (-DCKR_EXPERIMENTS builds: CKR_X3_SMALL=0 keeps everything on the two-board kernel.)
     // (Launching both and letting the device range decide which computes was measured: the idle launch costs 7 us per step.)
@@ -550,6 +574,33 @@ static int conv_stack_f16x3(const float* d_x, const ckr_board* d_boards, int64_t
 #endif
     if (small_only) hipLaunchKernelGGL(k_conv_stack_x3_small, dim3((unsigned)n_boards), dim3(NT), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(k_conv_stack_x3, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+extern "C" int ckr_conv_stack_f16x3_boards_pair(const ckr_board* d_boards, int64_t n_boards, int32_t n_layers, float x_scale,
+                                                const ckr_conv_layer* layers_a, const ckr_conv_heads* heads_a, const float* act_scales_a,
+                                                const int32_t* d_board_range_a,
+                                                const ckr_conv_layer* layers_b, const ckr_conv_heads* heads_b, const float* act_scales_b,
+                                                const int32_t* d_board_range_b, int32_t* d_overflow, void* stream) {
+    if (!d_board_range_a || !d_board_range_b)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3_boards_pair: each network needs its device-side board range");
+    if (n_boards < 0 || n_layers < 1 || n_layers > MAX_LAYERS || !layers_a || !layers_b)
+        return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3_boards_pair: bad n_boards / n_layers");
+    if (!(x_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_conv_stack_f16x3_boards_pair: x_scale must be positive");
+    if (int rc = ckr::require_device()) return rc;
+    if (n_boards == 0) return CKR_OK;
+    ArgsPair P;
+    Args &A = P.net[0], &B = P.net[1];
+    if (int rc = fill_args(A, nullptr, d_boards, n_boards, layers_a, n_layers, heads_a, x_scale, act_scales_a, d_board_range_a, d_overflow)) return rc;
+    if (int rc = fill_args(B, nullptr, d_boards, n_boards, layers_b, n_layers, heads_b, x_scale, act_scales_b, d_board_range_b, d_overflow)) return rc;
+    if (n_boards <= SMALL_BOARDS) {
+        const unsigned tiles = (unsigned)n_boards;
+        hipLaunchKernelGGL(k_conv_stack_x3_small_pair, dim3(2 * tiles), dim3(NT), 0, (hipStream_t)stream, P, tiles);
+    } else {
+        const unsigned tiles = (unsigned)((n_boards + 1) / 2);
+        hipLaunchKernelGGL(k_conv_stack_x3_pair, dim3(2 * tiles), dim3(NT), 0, (hipStream_t)stream, P, tiles);
+    }
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -53,6 +53,8 @@ def pack_conv_weights(w, first):
 
 
 XS = 8.0                     # scale of the input planes (0 / 1 and k / 80) in the split-fp16 path
+PAIR_ROWS = 2048             # arena: both networks' conv stacks in ONE launch while a launch covers at most this many boards (every engine the
+                             # pipeline classes build; measured up to 1 365: tournaments of 64 ... 4 096 games 17 ... 5 % faster, same game lists)
 HI_TARGET = 16384.0          # operands are scaled by powers of two so that the largest magnitude seen lands in [8 192, 16 384]: four
                              # times below the largest fp16 (the hi term), and small values keep their lo terms out of the subnormals
 
@@ -176,6 +178,12 @@ class FusedEvaluator:
         self._L.ckr_conv_stack_f16x3.argtypes = [vp, C.c_int64, C.POINTER(ConvLayer), C.c_int32, C.POINTER(ConvHeads),
                                                  C.c_float, vp, vp, vp, vp]
         self._L.ckr_conv_stack_f16x3_boards.argtypes = self._L.ckr_conv_stack_f16x3.argtypes
+        self._L.ckr_conv_stack_f16x3_boards_pair.argtypes = [vp, C.c_int64, C.c_int32, C.c_float,
+                                                             C.POINTER(ConvLayer), C.POINTER(ConvHeads), vp, vp,
+                                                             C.POINTER(ConvLayer), C.POINTER(ConvHeads), vp, vp, vp, vp]
+        # arena: both networks' conv stacks in ONE launch while a launch covers at most PAIR_ROWS boards (CKR_ARENA_PAIR=0: two launches;
+        # another number: that many boards)
+        self.pair_rows = int(os.environ.get("CKR_ARENA_PAIR", PAIR_ROWS))
         self.overflow = None
         self.row_cap = None                     # set_row_cap()
         # arena: the second network's launches on a stream of their own -- opt-in (CKR_ARENA_STREAMS=2): a step's graph then has two
@@ -314,6 +322,9 @@ class FusedEvaluator:
             self.timing.append((e0, e1))
         else:
             self._conv(n, x, stream, board_range)
+        return self._heads(n, x, stream)
+
+    def _heads(self, n, x, stream):
         t = n["tail"]
         # Dense(512) + softmax and the value MLP: one launch
         _lib.check(self._L.ckr_heads_tail(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), self._rows(n), t["fc_packed"].data_ptr(),
@@ -352,7 +363,19 @@ class FusedEvaluator:
         # (only while a launch covers at most 1 024 boards -- small tournaments, the tail of a large one: two chip-filling launches side
         # by side are 22 % SLOWER than one after the other, 13.5 against 17.3 M simulations/s on cfg5's shape; and only for an engine
         # that runs alone: pipeline.SplitRunner turns it off for its parts, whose graphs replay side by side on their own streams)
-        if self.two_streams and self._rows(self.nets[0]) <= 1024:
+        n0, n1 = self.nets
+        if (self.mode == "f16x3" and self._xg.dtype == torch.int32 and self.timing is None and not self.two_streams
+                and self._rows(n0) <= self.pair_rows and n0["n"] == n1["n"]):
+            # one launch for both conv stacks (ckr_conv_stack_f16x3_boards_pair): in a small tournament either network's launch
+            # covers a fraction of the chip, and the step is as long as one of them instead of both -- the graph stays a chain
+            _lib.check(self._L.ckr_conv_stack_f16x3_boards_pair(
+                self._xg.data_ptr(), self._rows(n0), n0["n"], XS,
+                n0["layers"], C.byref(n0["heads"]), n0["xs_arr"], self._ranges[0:2].data_ptr(),
+                n1["layers"], C.byref(n1["heads"]), n1["xs_arr"], self._ranges[2:4].data_ptr(),
+                self._overflow_ptr(dev), stream))
+            p, v = self._heads(n0, self._xg, stream)
+            p2, v2 = self._heads(n1, self._xg, stream)
+        elif self.two_streams and self._rows(self.nets[0]) <= 1024:
             cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=dev)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 122          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces) */
+#define CKR_VERSION 123          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair */
 
 typedef enum {
     CKR_OK = 0,
@@ -172,6 +172,18 @@ int ckr_conv_stack_f16x3(const float* d_x, int64_t n_boards, const ckr_conv_laye
 int ckr_conv_stack_f16x3_boards(const ckr_board* d_boards, int64_t n_boards, const ckr_conv_layer* layers,
                          int32_t n_layers, const ckr_conv_heads* heads, float x_scale, const float* act_scales,
                          const int32_t* d_board_range, int32_t* d_overflow, void* stream);
+/* Arena: BOTH networks' shares of one batch of board records in ONE launch (tournament_Checkers, training_pipeline.py:529-546:
+ * every leaf belongs to one of two networks; ckr_arena_partition has sorted the rows new | old | idle and written the two DEVICE
+ * board ranges).  Workgroups [0, T) evaluate network A on the boards of d_board_range_a, workgroups [T, 2 T) network B on
+ * those of d_board_range_b (T = tiles of n_boards; a tile outside its network's range exits at once): results are those of two
+ * ckr_conv_stack_f16x3_boards calls, bit for bit, but a small tournament's step is as long as one of them instead of both --
+ * without a second stream (and so without a second branch in the caller's HIP graph).  Both networks: n_layers layers, the same
+ * x_scale; each with its own weight stream, per-layer scales and head outputs. */
+int ckr_conv_stack_f16x3_boards_pair(const ckr_board* d_boards, int64_t n_boards, int32_t n_layers, float x_scale,
+                         const ckr_conv_layer* layers_a, const ckr_conv_heads* heads_a, const float* act_scales_a,
+                         const int32_t* d_board_range_a,
+                         const ckr_conv_layer* layers_b, const ckr_conv_heads* heads_b, const float* act_scales_b,
+                         const int32_t* d_board_range_b, int32_t* d_overflow, void* stream);
 
 /* Arena batches (tournament_Checkers swaps game_env.neural_net per side, training_pipeline.py:
  * 529,536,546): every leaf belongs to one of two networks.  ckr_arena_partition sorts the batch

@@ -316,6 +316,52 @@ def test_arena_evaluates_each_leaf_with_one_network_only():
         eng.close()
 
 
+@pytest.mark.parametrize("S", [77, 600])
+def test_arena_one_launch_for_both_networks_equals_two_launches(S):
+    """ckr_conv_stack_f16x3_boards_pair (both networks' shares of a batch of board records in ONE launch: the single-board
+    instantiation for S <= 256, the two-board one above) against two ckr_conv_stack_f16x3_boards launches and against each
+    network evaluated alone on the planes of every leaf: bit for bit."""
+    import torch
+    from checkers_mcts_amd import engine as E, net as N, rules
+    from checkers_mcts_amd.fused import FusedEvaluator
+    kw = dict(KW, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0, BUDGET=24)
+    new, old = N.make_net(128, seed=1), N.make_net(128, seed=2)
+    eng = E.Engine(E.config_from_kwargs(kw, n_slots=S, games_per_slot=2, tournament=True, feature_dtype=E.BOARDS, seed=9, dynamic_queue=True,
+                                        leaf_cache_log2=14, dense_rows=True))
+    pair, two = FusedEvaluator(new, S, net_old=old, mode="f16x3"), FusedEvaluator(new, S, net_old=old, mode="f16x3")
+    two.pair_rows = 0
+    assert pair.pair_rows >= S and not pair.two_streams
+    only_new, only_old = FusedEvaluator(new, S, mode="f16x3"), FusedEvaluator(old, S, mode="f16x3")
+    p = v = None
+    seen = set()
+    for _ in range(60):
+        eng.step(p, v)
+        p2, v2 = (t.clone() for t in two(eng))
+        p, v = pair(eng)
+        live, sel = eng.net_id >= 0, eng.net_id == 1
+        assert torch.equal(p[live], p2[live]) and torch.equal(v[live], v2[live])
+        planes = rules.features(eng.x).contiguous()
+        pa, va = only_new.forward_features(planes)
+        pb, vb = only_old.forward_features(planes)
+        assert torch.equal(p[live], torch.where(sel[:, None], pb, pa)[live]) and torch.equal(v[live], torch.where(sel, vb, va)[live])
+        seen.add((int(sel.sum()), int(live.sum())))
+    assert len({a for a, _ in seen}) >= 2 and any(0 < a < b for a, b in seen)      # mixed batches: both networks own a share
+    eng.close()
+
+
+def test_small_tournament_is_the_same_with_one_launch_or_two(monkeypatch):
+    """tournament_Checkers with the paired conv launch (default) and with CKR_ARENA_PAIR=0 (one launch per network): same game list."""
+    from checkers_mcts_amd import pipeline as P
+    kw = dict(KW, BUDGET=16, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    tk = dict(TOURNEY_GAMES=2, NUM_CPUS=150, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=4)
+    lists = []
+    for pair in ("1024", "0"):
+        monkeypatch.setenv("CKR_ARENA_PAIR", pair)
+        t = P.tournament_Checkers(dict(tk), dict(kw))
+        lists.append((t._start_tournament(), {k: t.stats[k] for k in ("expansions", "terminal_visits", "plies", "games")}))
+    assert lists[0] == lists[1] and len(lists[0][0]) == 300
+
+
 def test_tail_compaction_keeps_results():
     """Engine.compact_rows (active slots moved to the front of the network batch, conv kernel bounded
     by a device-side row range) changes nothing but the cost of the last steps: identical tuples and
