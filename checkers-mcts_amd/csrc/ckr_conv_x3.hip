@@ -645,13 +645,13 @@ struct ValueTail {
 // run two k-steps ahead of the MFMAs in a 3-deep register ring (the loads are L2 hits with ~1 us
 // latency and nothing else hides them).  Every workgroup reads the whole 1 MB weight image from L2.
 template <int MT>
-__global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ feat, long long n, const uint4* __restrict__ wp,
-                                                     const float* __restrict__ bias, float x_scale, float inv_scale,
-                                                     float* __restrict__ p, int32_t* __restrict__ overflow, const ValueTail V) {
+__device__ __forceinline__ void policy_head_body(const float* __restrict__ feat, long long n, const uint4* __restrict__ wp,
+                                                 const float* __restrict__ bias, float x_scale, float inv_scale,
+                                                 float* __restrict__ p, int32_t* __restrict__ overflow, const ValueTail& V, const unsigned tile) {
     __shared__ float red[2][8][16 * MT];
     __shared__ uint4 a_hi[16][4][16 * MT], a_lo[16][4][16 * MT];      // A fragments [k-step][k-group][position]: 16 B each
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, grp = lane >> 4;
-    const long long row0 = (long long)blockIdx.x * (16 * MT);
+    const long long row0 = (long long)tile * (16 * MT);
     const uint4* wb = wp + ((size_t)(wave * 4) * 16 * 2) * 64 + lane;
     f32x4 acc[MT][4];
 #pragma unroll
@@ -796,6 +796,30 @@ __global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ f
     }
 }
 
+template <int MT>
+__global__ __launch_bounds__(512) void k_policy_head(const float* __restrict__ feat, long long n, const uint4* __restrict__ wp,
+                                                     const float* __restrict__ bias, float x_scale, float inv_scale,
+                                                     float* __restrict__ p, int32_t* __restrict__ overflow, const ValueTail V) {
+    policy_head_body<MT>(feat, n, wp, bias, x_scale, inv_scale, p, overflow, V, blockIdx.x);
+}
+
+// Arena: the heads of BOTH networks in one launch (as k_conv_stack_x3_pair): workgroups [0, tiles) = network 0, [tiles, 2 tiles) =
+// network 1, each on the row tiles that overlap its network's device-side row range (the others exit at once).
+struct HeadNet {
+    const float* feat; const uint4* wp; const float* bias; float x_scale, inv_scale; float* p;
+    const int32_t* range;      // DEVICE [lo, hi): the network's rows of the batch
+    ValueTail V;
+};
+struct HeadPair { HeadNet net[2]; };
+template <int MT>
+__global__ __launch_bounds__(512) void k_policy_head_pair(const HeadPair P, long long n, const unsigned tiles, int32_t* __restrict__ overflow) {
+    const unsigned second = blockIdx.x >= tiles ? 1u : 0u, tile = blockIdx.x - second * tiles;
+    const HeadNet& H = P.net[second];
+    const long long row0 = (long long)tile * (16 * MT);
+    if (row0 >= H.range[1] || row0 + 16 * MT <= H.range[0]) return;
+    policy_head_body<MT>(H.feat, n, H.wp, H.bias, H.x_scale, H.inv_scale, H.p, overflow, H.V, tile);
+}
+
 }  // namespace ckrp
 
 extern "C" int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_packed, const float* d_bias, float x_scale,
@@ -808,6 +832,35 @@ extern "C" int ckr_policy_head(const float* d_feat, int64_t n, const void* d_w_p
     hipLaunchKernelGGL(ckrp::k_policy_head<1>, dim3((unsigned)((n + 15) / 16)), dim3(512), 0,
                        (hipStream_t)stream, d_feat, (long long)n, (const uint4*)d_w_packed, d_bias, x_scale,
                        1.0f / (x_scale * w_scale), d_p, d_overflow, ckrp::ValueTail{});
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+// one network's arguments of ckr_heads_tail_pair (include/ckr.h: ckr_heads_tail_net)
+struct HeadsTailNet {
+    const float* pol_feat; const float* val_feat; const void* w_packed; const float* bias; float x_scale, w_scale;
+    const float* w1t; const float* b1; const float* scale; const float* shift; const float* w2; float b2;
+    float* p; float* v; const int32_t* row_range;
+};
+
+extern "C" int ckr_heads_tail_pair(const ckr_heads_tail_net* a, const ckr_heads_tail_net* b, int64_t n, int32_t* d_overflow, void* stream) {
+    static_assert(sizeof(ckr_heads_tail_net) == sizeof(HeadsTailNet), "ckr_heads_tail_net mirrors HeadsTailNet");
+    if (!a || !b || n < 0) return ckr::fail(CKR_ERR_INVALID, "ckr_heads_tail_pair: bad argument");
+    if (int rc = ckr::require_device()) return rc;
+    if (n == 0) return CKR_OK;
+    ckrp::HeadPair P;
+    const ckr_heads_tail_net* src[2] = {a, b};
+    for (int i = 0; i < 2; ++i) {
+        HeadsTailNet t;
+        memcpy(&t, src[i], sizeof(t));
+        if (!(t.x_scale > 0.0f) || !(t.w_scale > 0.0f)) return ckr::fail(CKR_ERR_INVALID, "ckr_heads_tail_pair: scales must be positive");
+        if (!t.pol_feat || !t.val_feat || !t.w_packed || !t.bias || !t.w1t || !t.b1 || !t.scale || !t.shift || !t.w2 || !t.p || !t.v || !t.row_range)
+            return ckr::fail(CKR_ERR_INVALID, "ckr_heads_tail_pair: null pointer (network %d)", i);
+        P.net[i] = ckrp::HeadNet{t.pol_feat, (const uint4*)t.w_packed, t.bias, t.x_scale, 1.0f / (t.x_scale * t.w_scale), t.p, t.row_range,
+                                 ckrp::ValueTail{t.val_feat, t.w1t, t.b1, t.scale, t.shift, t.w2, t.b2, t.v}};
+    }
+    const unsigned tiles = (unsigned)((n + 15) / 16);
+    hipLaunchKernelGGL(ckrp::k_policy_head_pair<1>, dim3(2 * tiles), dim3(512), 0, (hipStream_t)stream, P, (long long)n, tiles, d_overflow);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -27,6 +27,13 @@ class ConvLayer(C.Structure):
                 ("out", C.c_void_p), ("cin_pad", C.c_int32)]
 
 
+class HeadsTailNet(C.Structure):
+    """ckr_heads_tail_net (include/ckr.h): one network's arguments of ckr_heads_tail_pair."""
+    _fields_ = [("pol_feat", C.c_void_p), ("val_feat", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("x_scale", C.c_float),
+                ("w_scale", C.c_float), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_float), ("p", C.c_void_p), ("v", C.c_void_p), ("row_range", C.c_void_p)]
+
+
 class ConvHeads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("pol_w", "pol_b", "pol_scale", "pol_shift", "pol_out",
                                           "val_w", "val_b", "val_scale", "val_shift", "val_out")]
@@ -181,6 +188,7 @@ class FusedEvaluator:
         self._L.ckr_conv_stack_f16x3_boards_pair.argtypes = [vp, C.c_int64, C.c_int32, C.c_float,
                                                              C.POINTER(ConvLayer), C.POINTER(ConvHeads), vp, vp,
                                                              C.POINTER(ConvLayer), C.POINTER(ConvHeads), vp, vp, vp, vp]
+        self._L.ckr_heads_tail_pair.argtypes = [C.POINTER(HeadsTailNet), C.POINTER(HeadsTailNet), C.c_int64, vp, vp]
         # arena: both networks' conv stacks in ONE launch while a launch covers at most PAIR_ROWS boards (CKR_ARENA_PAIR=0: two launches;
         # another number: that many boards)
         self.pair_rows = int(os.environ.get("CKR_ARENA_PAIR", PAIR_ROWS))
@@ -373,8 +381,14 @@ class FusedEvaluator:
                 n0["layers"], C.byref(n0["heads"]), n0["xs_arr"], self._ranges[0:2].data_ptr(),
                 n1["layers"], C.byref(n1["heads"]), n1["xs_arr"], self._ranges[2:4].data_ptr(),
                 self._overflow_ptr(dev), stream))
-            p, v = self._heads(n0, self._xg, stream)
-            p2, v2 = self._heads(n1, self._xg, stream)
+            for n, lo in ((n0, 0), (n1, 2)):                  # ... and both heads' tails in one (ckr_heads_tail_pair)
+                if "tail_pair" not in n:
+                    t = n["tail"]
+                    n["tail_pair"] = HeadsTailNet(n["pol_feat"].data_ptr(), n["val_feat"].data_ptr(), t["fc_packed"].data_ptr(), t["fc_b"].data_ptr(),
+                                                  t["fc_xs"], t["fc_ws"], t["w1t"].data_ptr(), t["b1"].data_ptr(), t["sc"].data_ptr(), t["sh"].data_ptr(),
+                                                  t["w2"].data_ptr(), t["b2"], n["p"].data_ptr(), n["v"].data_ptr(), self._ranges[lo:lo + 2].data_ptr())
+            _lib.check(self._L.ckr_heads_tail_pair(C.byref(n0["tail_pair"]), C.byref(n1["tail_pair"]), self._rows(n0), self._overflow_ptr(dev), stream))
+            p, v, p2, v2 = n0["p"], n0["v"], n1["p"], n1["v"]
         elif self.two_streams and self._rows(self.nets[0]) <= 1024:
             cur = torch.cuda.current_stream(dev)
             if getattr(self, "_side", None) is None:

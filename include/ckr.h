@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 123          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair */
+#define CKR_VERSION 124          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair */
 
 typedef enum {
     CKR_OK = 0,
@@ -218,6 +218,15 @@ int ckr_heads_tail(const float* d_pol_feat, const float* d_val_feat, int64_t n, 
                    const float* d_bias, float x_scale, float w_scale, const float* w1t, const float* b1,
                    const float* scale, const float* shift, const float* w2, float b2, float* d_p, float* d_v,
                    int32_t* d_overflow, void* stream);
+/* Arena: the heads of BOTH networks in one launch (as ckr_conv_stack_f16x3_boards_pair): each network's arguments as in
+ * ckr_heads_tail, plus row_range = DEVICE int32 [lo, hi), the network's rows of the batch (ckr_arena_partition's d_ranges): row
+ * tiles outside it are skipped.  Rows inside the ranges get the results of two ckr_heads_tail calls, bit for bit. */
+typedef struct ckr_heads_tail_net {
+    const float* d_pol_feat; const float* d_val_feat; const void* d_w_packed; const float* d_bias; float x_scale, w_scale;
+    const float* w1t; const float* b1; const float* scale; const float* shift; const float* w2; float b2;
+    float* d_p; float* d_v; const int32_t* d_row_range;
+} ckr_heads_tail_net;
+int ckr_heads_tail_pair(const ckr_heads_tail_net* a, const ckr_heads_tail_net* b, int64_t n, int32_t* d_overflow, void* stream);
 
 /* ---- batched self-play / arena engine ----------------------------------- */
 
