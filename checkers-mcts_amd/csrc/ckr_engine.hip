@@ -231,7 +231,12 @@ __device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_
 // as an inverse-CDF pick over the children in tree order; `ev` = 64 doubles of LDS.  All lanes return the pick.
 __device__ __forceinline__ int temperature_pick(const Dev& D, double* ev, int cn, bool act, int n, double tau,
                                                 uint32_t worker, uint32_t ctr, int lane) {
-    ev[lane] = act ? (double)pow_fast((float)cn, (float)(1.0 / tau)) : 0.0;
+    // weights relative to the most-visited child: (N / Nmax)^(1/tau) <= 1, the same distribution as N^(1/tau) / sum.  The
+    // reference exponentiates in float64 (finite up to 1e308); N^(1/tau) itself leaves float32 at tau = 0.04 with 40 visits
+    // (ADVICE r4), after which every comparison below is false and the pick falls through to the last child.
+    const int cmax = wave_max_i32(act ? cn : 0);
+    ev[lane] = (act && cn > 0)
+        ? (double)__builtin_amdgcn_exp2f((float)(1.0 / tau) * (__builtin_amdgcn_logf((float)cn) - __builtin_amdgcn_logf((float)cmax))) : 0.0;
     __builtin_amdgcn_wave_barrier();
     double cum = 0.0;
     for (int j = 0; j <= lane && j < n; ++j) cum += ev[j];

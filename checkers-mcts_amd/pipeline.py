@@ -108,6 +108,19 @@ class EvaluatorPlan:
         self.mode = "bf16" if dtype == torch.bfloat16 else "f16x3"
         if kind == "fused" and not self.fused:
             raise ValueError("the fused conv stack needs NN_DTYPE bfloat16 or float32 and a 128-kernel network")
+        # never a silent change of backend on the hot path: the hand-written MFMA kernels are built for create_nn's recorded
+        # width (NUM_KERNELS = 128, train_Checkers.py:120; training_pipeline.py:56-62 takes any) and for float32 / bfloat16
+        self.backend_reason = None
+        if not self.fused and kind != "torch" and not all(isinstance(n, HashNet) for n in (self.new, self.old) if n is not None):
+            widths = sorted({int(n.body[0]["conv"].weight.shape[0]) for n in (self.new, self.old)
+                             if n is not None and not isinstance(n, HashNet)})
+            self.backend_reason = ("NN_DTYPE %s" % str(dtype).replace("torch.", "") if not want_fused
+                                   else "NUM_KERNELS %s" % "/".join(str(w) for w in widths))
+            import warnings
+            warnings.warn("network inference runs on PyTorch / MIOpen, not on the hand-written gfx950 kernels (%s: they are built for "
+                          "NUM_KERNELS = 128 in float32-grade or bfloat16 mode); results are the PyTorch module's, throughput is several "
+                          "times lower.  EVALUATOR='torch' selects this path explicitly and silences the warning" % self.backend_reason,
+                          RuntimeWarning, stacklevel=3)
         if not self.fused and first != dtype:
             self.new = load_network(self.new, device=device, dtype=dtype)
             self.old = load_network(self.old, device=device, dtype=dtype) if self.old is not None else None

@@ -95,6 +95,21 @@ def test_temperature_pick_frequencies(L, tau):
         assert np.abs(cnt / n - ref / n).max() < 0.01
 
 
+def test_temperature_pick_survives_exponents_beyond_float32(L):
+    """The reference evaluates N ** (1 / tau) in float64 (MCTS.py:240-246), finite up to 1e308: a finer decay than the
+    recorded runs' (tau 0.04, 0.02) or visit counts in the thousands at tau 0.1 put N^(1/tau) beyond float32's 3.4e38.
+    The device pick works on (N / Nmax)^(1/tau): same distribution, largest weight 1."""
+    n = 20000
+    for visits, tau in (([200, 190, 40, 3], 0.02), ([40, 39, 1], 0.04), ([7080, 7000, 6000, 10], 0.1), ([1600, 1599, 2], 0.01)):
+        v = np.array(visits, np.float64)
+        p = (v / v.max()) ** (1.0 / tau)
+        p = p / p.sum()
+        got = picks(L, visits, tau, n, seed=5)
+        cnt = np.bincount(got, minlength=len(visits)).astype(np.float64)
+        assert np.abs(cnt / n - p).max() < 0.012, (visits, tau, cnt / n, p)
+        assert cnt[-1] < 0.01 * n                                         # never the fall-through to the last child
+
+
 def test_temperature_schedule_matches_reference_arithmetic(L):
     """tau -= TEMPERATURE_DECAY once move_count > TEMP_DECAY_DELAY, snapped to 0 by np.isclose; the
     class attribute is never reset (MCTS.py:243-245)."""
