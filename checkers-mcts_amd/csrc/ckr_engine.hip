@@ -6,10 +6,12 @@
 // network evaluation (plus any number of network-free simulations that end on
 // terminal children), so the network always sees one leaf per slot.
 //
-// Layout in HBM: structure-of-arrays node pool, two trees per slot (one per
+// Layout in HBM: node pool of 48-byte records (round 5: array of structures -- board | N, P, W | status, child range,
+// parent: everything a PUCT scan reads of a child sits in ONE record, and a slot's whole tree in one contiguous region,
+// where rounds 1-4 kept seven arrays and touched seven pages per node), two trees per slot (one per
 // player, training_pipeline.py:353-386), each tree a pair of semispaces of
 // `nodes_per_tree` nodes; the children of a node are contiguous so that the
-// PUCT scan of a node is one coalesced read of N/W/P by the lanes of a wave.
+// PUCT scan of a node is one coalesced read of 48 B per lane by the lanes of a wave.
 // One wavefront owns one slot: lanes = children for select / expand, lanes =
 // board cells for the feature build.  No inter-workgroup communication exists
 // (a slot's memory is touched by its own wave only).
@@ -86,11 +88,11 @@ struct Dev {
     int n_slots, games_per_slot, first_worker, budget, terminate_cnt, training, tournament, tau_decay_delay;
     int reset_tau, C, feature_dtype, max_sims, record_root, tuples_per_game, margin, sqrt_n, manual, dynamic, total_games, neural, rollout_first, ln_n, uct_n;
     int tail_sims, tail_shift;   // network-free simulations per step once <= n_slots >> tail_shift slots still play (0: max_sims throughout)
-    int w64;                     // ckr_config.w_accum: n_W holds double (1) or float (0); the kernels are instantiated for either
+    int w64;                     // ckr_config.w_accum: W of a node record is a double (1) or a float (0); the kernels are instantiated for either
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
-    // node pool, index = ((slot*2 + tree)*2 + half)*C + local
-    uint4* n_board; int32_t* n_parent; uint32_t* n_kids; int32_t* n_N; void* n_W; float* n_P; uint32_t* n_status;
+    // node pool, index = ((slot*2 + tree)*2 + half)*C + local; record i = nodes[3 i .. 3 i + 2] (see the accessors below)
+    uint4* nodes;
     // per slot
     uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
@@ -147,6 +149,26 @@ struct WaveLds {
     uint32_t cnt[CNT_N];                                         // per-wave event counters (lane 0), flushed once
 };
 
+// ---- node records (48 B = three 16-byte quads; index i of the pool = nodes[3 i ...]):
+//   quad 0  board: p1, p2, kings, meta                         (ckr_board)
+//   quad 1  x = N (visits), y = P (prior, float bits), z | w = W: float32 bits in z (w unused), or a double in (z = low, w = high)
+//   quad 2  x = status (outcome, legal count, draw k, ST_EXPANDED, mover), y = child range (base : 24 | count : 8), z = parent, w = 0
+// A PUCT scan reads quads 1 and 2 (and 0: the chosen child's board comes with the scan instead of costing a dependent round) of
+// consecutive records; a backup is a read-modify-write of quad 1 alone.
+__device__ __forceinline__ uint4* nq(const Dev& D, size_t i) { return D.nodes + i * 3; }
+template <typename WT> __device__ __forceinline__ WT q1_w(const uint4 q);
+template <> __device__ __forceinline__ float q1_w<float>(const uint4 q) { return __uint_as_float(q.z); }
+template <> __device__ __forceinline__ double q1_w<double>(const uint4 q) { return __hiloint2double((int)q.w, (int)q.z); }
+__device__ __forceinline__ void q1_set_w(uint4& q, float w) { q.z = __float_as_uint(w); }
+__device__ __forceinline__ void q1_set_w(uint4& q, double w) { q.z = (uint32_t)__double2loint(w); q.w = (uint32_t)__double2hiint(w); }
+// one visit with `reward` (MCTS_Node.backpropagation, MCTS.py:419-430): N += 1, W += reward in W's type
+template <typename WT> __device__ __forceinline__ void node_visit(const Dev& D, size_t i, float reward) {
+    uint4* p = nq(D, i) + 1;
+    uint4 q = *p;
+    q.x += 1u; q1_set_w(q, (WT)(q1_w<WT>(q) + (WT)reward));
+    *p = q;
+}
+
 // WT = the type MCTS_Node._total_reward accumulates in (MCTS.py:419-430): float under NumPy >= 2 (NEP 50), double under the
 // reference's pinned NumPy 1.19 (requirements.txt:68; python int + np.float32 -> float64); q = w / n (MCTS.py:389-394) has the
 // same type.  Every search function is a template over the wave type so that each mode is its own straight-line code.
@@ -158,7 +180,6 @@ template <typename WT> struct WaveT {
                                       // the handle itself -- a dynamically indexed member would pin the whole handle to scratch memory)
     int wk = 0;                  // the worker this slot hosts (local id; global id = D.first_worker + wk)
     __device__ uint32_t worker() const { return (uint32_t)(D.first_worker + wk); }
-    __device__ WT* nW() const { return static_cast<WT*>(D.n_W); }
     __device__ __forceinline__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
     __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
     __device__ size_t tb(int t) const { return tbase(t, D.t_half[slot * 2 + t]); }
@@ -263,26 +284,26 @@ template <class Wave> __device__ void backup_value(Wave& w, int t, int node, flo
     const size_t tb = w.tb(t);
     const int root = w.D.t_cursor[w.slot * 2 + t];
     for (int n = node;;) {
-        const uint32_t st = w.D.n_status[tb + n];
-        const uint32_t mover = (st >> 4) & 1u;
+        const uint4 q2 = nq(w.D, tb + n)[2];
+        const uint32_t mover = (q2.x >> 4) & 1u;
         const float reward = (sim_player != mover) ? -1.0f * v : v;
-        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.nW()[tb + n] += (typename Wave::wtype)reward; }
+        if (w.lane == 0) node_visit<typename Wave::wtype>(w.D, tb + n, reward);
         if (n == root) break;
-        n = w.D.n_parent[tb + n];
+        n = (int)q2.z;
     }
 }
 template <class Wave> __device__ void backup_outcome(Wave& w, int t, int node, uint32_t outcome) {
     const size_t tb = w.tb(t);
     const int root = w.D.t_cursor[w.slot * 2 + t];
     for (int n = node;;) {
-        const uint32_t st = w.D.n_status[tb + n];
-        const uint32_t mover = (st >> 4) & 1u;
+        const uint4 q2 = nq(w.D, tb + n)[2];
+        const uint32_t mover = (q2.x >> 4) & 1u;
         float reward = 0.0f;
         if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
         else if (outcome == 2u) reward = mover == 1u ? 1.0f : -1.0f;
-        if (w.lane == 0) { w.D.n_N[tb + n] += 1; w.nW()[tb + n] += (typename Wave::wtype)reward; }
+        if (w.lane == 0) node_visit<typename Wave::wtype>(w.D, tb + n, reward);
         if (n == root) break;
-        n = w.D.n_parent[tb + n];
+        n = (int)q2.z;
     }
 }
 
@@ -294,7 +315,7 @@ template <class Wave> __device__ __forceinline__ void backup_value_path(Wave& w,
     if (w.lane < len) {
         const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
         const float reward = (sim_player != ((entry >> 30) & 1u)) ? -1.0f * v : v;
-        w.D.n_N[i] += 1; w.nW()[i] += (typename Wave::wtype)reward;
+        node_visit<typename Wave::wtype>(w.D, i, reward);
     }
 }
 template <class Wave> __device__ __forceinline__ void backup_outcome_path(Wave& w, int t, uint32_t entry, int len, uint32_t outcome) {
@@ -304,7 +325,7 @@ template <class Wave> __device__ __forceinline__ void backup_outcome_path(Wave& 
         float reward = 0.0f;
         if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
         else if (outcome == 2u) reward = mover == 1u ? 1.0f : -1.0f;
-        w.D.n_N[i] += 1; w.nW()[i] += (typename Wave::wtype)reward;
+        node_visit<typename Wave::wtype>(w.D, i, reward);
     }
 }
 
@@ -336,10 +357,10 @@ template <int GAME> __device__ __forceinline__ uint32_t rules_initial_status() {
 
 // ---- tree bookkeeping
 template <class Wave> __device__ __forceinline__ void write_node(const Wave& w, size_t idx, const ckr_board b, int parent, float prior, uint32_t status) {
-    const Dev& D = w.D;
-    st_board(&D.n_board[idx], b);
-    D.n_parent[idx] = parent; D.n_kids[idx] = 0u; D.n_N[idx] = 0; w.nW()[idx] = 0; D.n_P[idx] = prior;
-    D.n_status[idx] = status;
+    uint4* p = nq(w.D, idx);
+    p[0] = make_uint4(b.p1, b.p2, b.kings, b.meta);
+    p[1] = make_uint4(0u, __float_as_uint(prior), 0u, 0u);          // N = 0, W = 0 (the all-zero bits of either type)
+    p[2] = make_uint4(status, 0u, (uint32_t)parent, 0u);
 }
 
 // MCTS_Node(state) for a tree that has no node for the live game state
@@ -369,9 +390,11 @@ template <class Wave> __device__ int compact(Wave& w, int t, int track = -1) {
     const size_t src = w.tbase(t, half), dst = w.tbase(t, half ^ 1);
     const int root = D.t_cursor[ti];
     if (w.lane == 0) {
-        D.n_board[dst] = D.n_board[src + root]; D.n_parent[dst] = -1; D.n_kids[dst] = D.n_kids[src + root];
-        D.n_N[dst] = D.n_N[src + root]; w.nW()[dst] = w.nW()[src + root]; D.n_P[dst] = D.n_P[src + root];
-        D.n_status[dst] = D.n_status[src + root];
+        const uint4* sp = nq(D, src + root);
+        uint4* dp = nq(D, dst);
+        uint4 q2 = sp[2];
+        q2.z = 0xFFFFFFFFu;                                   // parent = -1
+        dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = q2;
     }
     wave_mem_fence();
     int moved = track == root ? 0 : -1;
@@ -379,8 +402,9 @@ template <class Wave> __device__ int compact(Wave& w, int t, int track = -1) {
     while (q < free_) {
         const int cnt = min(64, free_ - q), idx = q + w.lane;
         const bool valid = w.lane < cnt;
-        const uint32_t kids = valid ? D.n_kids[dst + idx] : 0u;
-        const uint32_t st = valid ? D.n_status[dst + idx] : 0u;
+        uint4 q2 = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) q2 = nq(D, dst + idx)[2];
+        const uint32_t kids = q2.y, st = q2.x;
         const bool exp = valid && (st & ST_EXPANDED);
         const int nk = exp ? (int)(kids >> 24) : 0, ob = (int)(kids & 0xFFFFFFu);
         // rollout mode adds children one at a time into a block reserved for all legal successors
@@ -388,14 +412,16 @@ template <class Wave> __device__ int compact(Wave& w, int t, int track = -1) {
         const int incl = wave_incl_scan(reserve);
         const int total = bcast_i32(incl, 63);
         const int nb = free_ + incl - reserve;
-        if (exp) D.n_kids[dst + idx] = (uint32_t)nb | ((uint32_t)nk << 24);
+        if (exp) { q2.y = (uint32_t)nb | ((uint32_t)nk << 24); nq(D, dst + idx)[2] = q2; }
         for (int c = 0; c < nk; ++c) {
-            const size_t s = src + ob + c, d = dst + nb + c;
-            D.n_board[d] = D.n_board[s]; D.n_parent[d] = idx; D.n_kids[d] = D.n_kids[s];
-            D.n_N[d] = D.n_N[s]; w.nW()[d] = w.nW()[s]; D.n_P[d] = D.n_P[s]; D.n_status[d] = D.n_status[s];
+            const uint4* sp = nq(D, src + ob + c);
+            uint4* dp = nq(D, dst + nb + c);
+            uint4 c2 = sp[2];
+            c2.z = (uint32_t)idx;
+            dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = c2;
             if (ob + c == track) moved = nb + c;
         }
-        for (int c = nk; c < reserve; ++c) { D.n_kids[dst + nb + c] = 0u; D.n_status[dst + nb + c] = 0u; }
+        for (int c = nk; c < reserve; ++c) nq(D, dst + nb + c)[2] = make_uint4(0u, 0u, 0u, 0u);
         free_ += total; q += cnt;
         wave_mem_fence();
     }
@@ -634,25 +660,30 @@ struct ExpandPre { int half, used, plen; uint32_t entry; };
 
 // CACHED: the priors come from the leaf cache (cached_prior: child `lane`), prow is not read.  net: the network that
 // evaluated the leaf (key of the cache record written when !CACHED and a place was reserved for it: cslot >= 0).
-template <bool CACHED, class Wave> __device__ __forceinline__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
-                                                           float cached_prior, int cached_n, int net, int cslot = -1, unsigned long long cword = 0ull) {
+// KNOWN: the leaf's board and status word are in registers already (kb, kst: the descent that found the leaf read them with
+// its parent's child scan), nothing of the leaf is loaded.
+template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
+                                                           float cached_prior, int cached_n, int net, int cslot = -1, unsigned long long cword = 0ull,
+                                                           const ckr_board kb = ckr_board{0u, 0u, 0u, 0u}, uint32_t kst = 0u) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const size_t tb = w.tbase(t, pre.half);
-    // second (and last) round of loads: the leaf's board and status, the network's p row, and N / W of
+    // second (and last) round of loads: the leaf's record (board, status), the network's p row, and quad 1 (N, W) of
     // the nodes on the recorded path (their updates are stored at the end; nothing in between touches them)
-    const ckr_board b = ld_board(&D.n_board[tb + leaf]);
-    const uint32_t leaf_status = D.n_status[tb + leaf];
+    uint4* lp = nq(D, tb + leaf);
+    ckr_board b = kb;
+    uint32_t leaf_status = kst;
+    if (!KNOWN) { b = ld_board(lp); leaf_status = lp[2].x; }
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
     if (!CACHED) {
         const float4* src = reinterpret_cast<const float4*>(prow);
         p0 = src[w.lane]; p1 = src[w.lane + 64];
     }
     const bool on_path = pre.plen <= 64 && w.lane < pre.plen;
-    const size_t pnode = tb + (pre.entry & 0x3FFFFFFFu);
+    uint4* pq = nq(D, tb + (pre.entry & 0x3FFFFFFFu)) + 1;
     using WT = typename Wave::wtype;
-    int path_n = 0; WT path_w = 0;
-    if (on_path) { path_n = D.n_N[pnode]; path_w = w.nW()[pnode]; }
+    uint4 path_q = make_uint4(0u, 0u, 0u, 0u);
+    if (on_path) path_q = *pq;
     uint32_t m[8], st;
     movegen(b, m, st);
     float total = 1.0f;
@@ -683,8 +714,7 @@ template <bool CACHED, class Wave> __device__ __forceinline__ bool expand(Wave& 
     }
     if (w.lane == 0) {
         w.L.kn = (uint32_t)n;
-        D.n_kids[tb + leaf] = (uint32_t)used | ((uint32_t)n << 24);
-        D.n_status[tb + leaf] = leaf_status | ST_EXPANDED;
+        *reinterpret_cast<uint2*>(lp + 2) = make_uint2(leaf_status | ST_EXPANDED, (uint32_t)used | ((uint32_t)n << 24));   // status, child range
         D.t_used[ti] = used + n;
     }
     w.count(CNT_EXP); w.count(CNT_NODES, (uint32_t)n);
@@ -692,7 +722,8 @@ template <bool CACHED, class Wave> __device__ __forceinline__ bool expand(Wave& 
     if (pre.plen <= 64) {                                     // backup along the recorded path (cf. backup_value_path)
         if (on_path) {
             const float reward = (sim_player != ((pre.entry >> 30) & 1u)) ? -1.0f * v : v;
-            D.n_N[pnode] = path_n + 1; w.nW()[pnode] = path_w + (WT)reward;
+            path_q.x += 1u; q1_set_w(path_q, (WT)(q1_w<WT>(path_q) + (WT)reward));
+            *pq = path_q;
         }
     } else {
         wave_mem_fence();
@@ -707,16 +738,24 @@ template <bool CACHED, class Wave> __device__ __forceinline__ bool expand(Wave& 
 // child (:93-94).  Scores are float64 exactly as NumPy evaluates them:
 //   q32 + ((c * P') * N_parent**0.5) / (1 + N_child),
 //   P' = float32((1-eps) * P) + eps * dirichlet.
-template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int& plen_out, uint32_t& entry_out) {
+// leaf_b / leaf_st: the leaf's board record and status word, read with its parent's child scan (the root's own when the
+// root is the leaf).
+template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int& plen_out, uint32_t& entry_out, ckr_board& leaf_b, uint32_t& leaf_st) {
     const Dev& D = w.D;
     const size_t tb = w.tb(t);
     int node = D.t_cursor[w.slot * 2 + t];
     const float one_minus = (float)(1.0 - D.epsilon);
-    // One dependent memory round per tree level: a node's status / child range / visit count come
-    // with its parent's child scan (lanes = children), the noise counter lives in a register, and
-    // the path is kept (lane l = level l) for the backup.
-    uint32_t st = D.n_status[tb + node], kids = D.n_kids[tb + node];
-    int np = D.n_N[tb + node];
+    // One dependent memory round per tree level: a node's status / child range / visit count / board come
+    // with its parent's child scan (lanes = children: three 16-byte loads of consecutive 48-byte records), the noise
+    // counter lives in a register, and the path is kept (lane l = level l) for the backup.
+    uint4 nb;
+    uint32_t st, kids;
+    int np;
+    {
+        const uint4* rp = nq(D, tb + node);
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        nb = r0; st = r2.x; kids = r2.y; np = (int)r1.x;
+    }
     uint32_t ctr = D.epsilon != 0.0 ? D.g_rng[w.slot] : 0u;
     uint32_t entry = 0u;
     int lvl = 0;
@@ -727,15 +766,17 @@ template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int
             if (w.lane == 0) { D.g_plen[w.slot] = lvl; if (D.epsilon != 0.0) D.g_rng[w.slot] = ctr; }
             if (lvl <= 64) D.g_path[(size_t)w.slot * 64 + w.lane] = entry;
             plen_out = lvl; entry_out = entry;
+            leaf_b = ckr_board{nb.x, nb.y, nb.z, nb.w}; leaf_st = st;
             return node;
         }
         const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
         const bool act = w.lane < n;
-        const size_t ci = tb + base + (act ? w.lane : 0);
-        const int cn = D.n_N[ci];
-        const typename Wave::wtype cw = w.nW()[ci];
-        const float cp = D.n_P[ci];
-        const uint32_t cst = D.n_status[ci], ckids = D.n_kids[ci];
+        const uint4* cp4 = nq(D, tb + base + (act ? w.lane : 0));
+        const uint4 c0 = cp4[0], c1 = cp4[1], c2 = cp4[2];
+        const int cn = (int)c1.x;
+        const typename Wave::wtype cw = q1_w<typename Wave::wtype>(c1);
+        const float cp = __uint_as_float(c1.y);
+        const uint32_t cst = c2.x, ckids = c2.y;
         double dir = 0.0;
         if (D.epsilon != 0.0) {
             dir = dirichlet_lane(D, act, w.worker(), ctr, w.lane);
@@ -762,6 +803,8 @@ template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int
         node = child; st = bst;
         kids = (uint32_t)bcast_i32((int)ckids, best);
         np = bcast_i32(cn, best);
+        nb = make_uint4((uint32_t)bcast_i32((int)c0.x, best), (uint32_t)bcast_i32((int)c0.y, best),
+                        (uint32_t)bcast_i32((int)c0.z, best), (uint32_t)bcast_i32((int)c0.w, best));
     }
 }
 
@@ -847,23 +890,27 @@ template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
     const size_t tb = w.tb(t);
     int node = D.t_cursor[ti];
     for (;;) {
-        const uint32_t st = D.n_status[tb + node];
+        const uint4* np4 = nq(D, tb + node);
+        const uint4 n0 = np4[0], n1 = np4[1], n2 = np4[2];
+        const uint32_t st = n2.x;
         if (st_outcome(st) != 0u) {                          // MCTS.py:97-99 (terminal root)
             backup_outcome(w, t, node, st_outcome(st));
             w.count(CNT_TERM);
             wave_mem_fence();
             return true;
         }
-        const uint32_t kids = D.n_kids[tb + node];
+        const uint32_t kids = n2.y;
         const int created = (int)(kids >> 24), nleg = (int)st_nlegal(st);
         int base = (int)(kids & 0xFFFFFFu);
         if (created < nleg) {                                // MCTS.py:79-81: pop ONE successor from the end of the list
+            uint32_t nst = st;
             if (created == 0) {
                 base = D.t_used[ti];
                 if (base + nleg > D.C) return false;
-                if (w.lane == 0) { D.t_used[ti] = base + nleg; D.n_status[tb + node] = st | ST_EXPANDED; }
+                nst = st | ST_EXPANDED;
+                if (w.lane == 0) D.t_used[ti] = base + nleg;
             }
-            const ckr_board b = ld_board(&D.n_board[tb + node]);
+            const ckr_board b{n0.x, n0.y, n0.z, n0.w};
             uint32_t m[8], bst;
             rules_movegen<GAME>(b, m, bst);
             const ckr_board c = rules_child<GAME>(b, m, nleg - 1 - created);
@@ -872,7 +919,7 @@ template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
             const int ci = base + created;
             if (w.lane == 0) {
                 write_node(w, tb + ci, c, node, 0.0f, cst | ((b.meta & 1u) << 4));
-                D.n_kids[tb + node] = (uint32_t)base | ((uint32_t)(created + 1) << 24);
+                *reinterpret_cast<uint2*>(nq(D, tb + node) + 2) = make_uint2(nst, (uint32_t)base | ((uint32_t)(created + 1) << 24));
             }
             wave_mem_fence();
             const uint32_t outcome = playout<GAME>(w, c);          // MCTS.py:89 child_node.simulation()
@@ -882,12 +929,13 @@ template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
             return true;
         }
         // MCTS.select_child, MCTS.py:112-116: q + 2c * (2 ln(N) / n) ** 0.5, first maximum
-        const int np = D.n_N[tb + node];
+        const int np = (int)n1.x;
         const bool act = w.lane < nleg;
-        const size_t ci = tb + base + (act ? w.lane : 0);
-        const int cn = D.n_N[ci];
-        const double cw = (double)w.nW()[ci];                 // a python int in this mode (exact in either type)
-        const uint32_t cst = D.n_status[ci];
+        const uint4* cp4 = nq(D, tb + base + (act ? w.lane : 0));
+        const uint4 c1 = cp4[1], c2 = cp4[2];
+        const int cn = (int)c1.x;
+        const double cw = (double)q1_w<typename Wave::wtype>(c1);   // a python int in this mode (exact in either type)
+        const uint32_t cst = c2.x;
         double root;
         if (np < D.uct_n) root = D.uct_tab[(size_t)np * (size_t)(np + 1) / 2 + (size_t)(act ? cn : 1)];
         else {
@@ -998,10 +1046,13 @@ template <int GAME = 0, class Wave> __device__ __attribute__((noinline)) void fi
     const int t = (int)(gb.meta & 1u), ti = w.slot * 2 + t;
     const size_t tb = w.tb(t);
     const int root = D.t_cursor[ti];
-    const uint32_t kids = D.n_kids[tb + root];
+    const uint4 r0 = nq(D, tb + root)[0], r1 = nq(D, tb + root)[1], r2 = nq(D, tb + root)[2];
+    const uint32_t kids = r2.y;
     const int n = (int)(kids >> 24), base = (int)(kids & 0xFFFFFFu);
     const bool act = w.lane < n;
-    const int cn = act ? D.n_N[tb + base + w.lane] : -1;
+    uint4 k0 = make_uint4(0u, 0u, 0u, 0u), k1 = k0;
+    if (act) { k0 = nq(D, tb + base + w.lane)[0]; k1 = nq(D, tb + base + w.lane)[1]; }
+    const int cn = act ? (int)k1.x : -1;
     const int moves = D.g_moves[w.slot];
     int pick;
     double tau = D.g_tau[w.slot];
@@ -1018,24 +1069,25 @@ template <int GAME = 0, class Wave> __device__ __attribute__((noinline)) void fi
         }
     }
     const int chosen = base + pick;
-    const ckr_board cb = ld_board(&D.n_board[tb + chosen]);
-    const uint32_t cst = D.n_status[tb + chosen];
+    const ckr_board cb{(uint32_t)bcast_i32((int)k0.x, pick), (uint32_t)bcast_i32((int)k0.y, pick),
+                       (uint32_t)bcast_i32((int)k0.z, pick), (uint32_t)bcast_i32((int)k0.w, pick)};
+    const uint32_t cst = nq(D, tb + chosen)[2].x;
     if (!D.tournament) {
-        const ckr_board rb = ld_board(&D.n_board[tb + root]);
+        const ckr_board rb{r0.x, r0.y, r0.z, r0.w};
         uint32_t m[8], st;
         rules_movegen<GAME>(rb, m, st);
         const size_t tix = tuple_index(w, moves);
         ckr_tuple* T = &D.tuples[tix];
         if (w.lane < 8) T->mask[w.lane] = sel8(m, w.lane);
-        if (act) T->pi[w.lane] = (meta_action(ld_board(&D.n_board[tb + base + w.lane]).meta) << 23) | (uint32_t)cn;
+        if (act) T->pi[w.lane] = (meta_action(k0.w) << 23) | (uint32_t)cn;
         if (D.record_root && act) {
-            D.rs_w[tix * CKR_MAX_CHILDREN + w.lane] = (double)w.nW()[tb + base + w.lane];
-            D.rs_p[tix * CKR_MAX_CHILDREN + w.lane] = D.n_P[tb + base + w.lane];
+            D.rs_w[tix * CKR_MAX_CHILDREN + w.lane] = (double)q1_w<typename Wave::wtype>(k1);
+            D.rs_p[tix * CKR_MAX_CHILDREN + w.lane] = __uint_as_float(k1.y);
         }
         if (w.lane == 0) {
-            const int rn = D.n_N[tb + root];
+            const int rn = (int)r1.x;
             using WT = typename Wave::wtype;
-            const WT rw = w.nW()[tb + root];
+            const WT rw = q1_w<WT>(r1);
             const WT q = rn ? rw / (WT)rn : (WT)0;
             const bool neg = meta_mover(rb.meta) != (rb.meta & 1u);     // qval = -root.q / root.q, :365-368
             T->board = rb; T->status = st; T->worker = (int32_t)w.worker(); T->game = D.g_game[w.slot];
@@ -1058,13 +1110,14 @@ template <int GAME = 0, class Wave> __device__ __attribute__((noinline)) void fi
         const int oc = D.t_cursor[oi];
         if (oc >= 0) {
             const size_t ob = w.tb(o);
-            const uint32_t ost = D.n_status[ob + oc];
+            const uint4 o2 = nq(D, ob + oc)[2];
+            const uint32_t ost = o2.x;
             int nc = -1;
             if (ost & ST_EXPANDED) {
-                const uint32_t ok = D.n_kids[ob + oc];
+                const uint32_t ok = o2.y;
                 const int on = (int)(ok >> 24), obase = (int)(ok & 0xFFFFFFu);
                 const bool oa = w.lane < on;
-                const uint32_t ameta = oa ? D.n_board[ob + obase + w.lane].w : 0u;
+                const uint32_t ameta = oa ? nq(D, ob + obase + w.lane)[0].w : 0u;
                 const unsigned long long hit = __ballot(oa && meta_action(ameta) == meta_action(cb.meta));
                 if (hit) nc = obase + first_lane(hit);
             }
@@ -1272,7 +1325,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
         if (slot == 0) w.count(CNT_STALL);
         if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
             leaf = pending; cslot = cslot0; cword = cword0;
-            lb = ld_board(&D.n_board[w.tbase(t0, pre.half) + pending]);
+            lb = ld_board(nq(D, w.tbase(t0, pre.half) + pending));
             net = D.tournament ? (t0 == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
         } else if (resume >= 0) parked = true;                             // still waiting: keeps its leaf
     } else if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
@@ -1323,10 +1376,11 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
         const int t = (int)(D.g_board[slot].w & 1u);
         int plen = pre.plen; uint32_t pentry = pre.entry;
         int found = resume;
-        if (resume < 0) { found = descend(w, t, plen, pentry); park_count = 0; }
+        uint32_t lst_node = 0u;                                          // the leaf's status word (node record)
+        if (resume < 0) { found = descend(w, t, plen, pentry, lb, lst_node); park_count = 0; }
+        else { const uint4* fp = nq(D, w.tb(t) + found); lb = ld_board(fp); lst_node = fp[2].x; }   // a parked leaf, looked up again
         resume = -1;
         if (found < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
-        lb = ld_board(&D.n_board[w.tb(t) + found]);
         if (D.tournament) {
             const int p1_net = p1_net_of(D, slot);
             net = t == 0 ? p1_net : 1 - p1_net;                          // training_pipeline.py:523-529,536,546
@@ -1339,7 +1393,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             const int res = cache_probe(w, cache_key(lb, lst, net), may_park, cprior, cv, cn, cslot, cword);
             if (res == CACHE_HIT) {
                 const ExpandPre now{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], plen, pentry};
-                if (expand<true>(w, t, found, nullptr, cv, now, cprior, cn, net)) {
+                if (expand<true, true>(w, t, found, nullptr, cv, now, cprior, cn, net, -1, 0ull, lb, lst_node)) {
                     w.count(CNT_HIT);
                     if (w.lane == 0) { D.g_sims[slot] += 1; if (D.cache_park) { D.g_pending[slot] = -1; D.g_parked[slot] = 0; } }
                     wave_mem_fence();
@@ -1427,11 +1481,12 @@ template <class Wave> __device__ int apply_action(Wave& w, int action) {
         int nc = -1;
         if (c >= 0) {
             const size_t tb = w.tb(t);
-            if (D.n_status[tb + c] & ST_EXPANDED) {
-                const uint32_t k = D.n_kids[tb + c];
+            const uint4 c2 = nq(D, tb + c)[2];
+            if (c2.x & ST_EXPANDED) {
+                const uint32_t k = c2.y;
                 const int n = (int)(k >> 24), base = (int)(k & 0xFFFFFFu);
                 const bool a = w.lane < n;
-                const uint32_t ameta = a ? D.n_board[tb + base + w.lane].w : 0u;
+                const uint32_t ameta = a ? nq(D, tb + base + w.lane)[0].w : 0u;
                 const unsigned long long hit = __ballot(a && meta_action(ameta) == (uint32_t)action);
                 if (hit) nc = base + first_lane(hit);
             }
@@ -1742,9 +1797,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C;
     int rc = CKR_OK;
 #define A(ptr, count, zero) if (rc == CKR_OK) rc = dalloc(e, &ptr, (count), (zero))
-    A(D.n_board, NN, false); A(D.n_parent, NN, false); A(D.n_kids, NN, false); A(D.n_N, NN, false);
-    A(D.n_P, NN, false); A(D.n_status, NN, false);
-    if (D.w64) { double* nw = nullptr; A(nw, NN, false); D.n_W = nw; } else { float* nw = nullptr; A(nw, NN, false); D.n_W = nw; }
+    A(D.nodes, NN * 3, false);                                    // 48-byte node records (W as float32 or float64 inside quad 1)
     A(D.g_board, S, true); A(D.g_status, S, true); A(D.g_moves, S, true); A(D.g_game, S, true); A(D.g_phase, S, true);
     A(D.g_tau, S, true); A(D.g_sims, S, true); A(D.g_pending, S, true); A(D.g_rng, S, true);
     A(D.g_path, S * 64, true); A(D.g_plen, S, true); A(D.g_row, S, true); A(e->d_row_tmp, S, true);
@@ -2140,14 +2193,23 @@ int ckr_engine_game(ckr_engine* e, int32_t slot, ckr_board* board, uint32_t* sta
     return CKR_OK;
 }
 
-static int read_node(ckr_engine* e, size_t idx, ckr_node_info* out) {
-    CKR_HIP(hipMemcpy(&out->board, e->dev.n_board + idx, sizeof(ckr_board), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(&out->status, e->dev.n_status + idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(&out->n, e->dev.n_N + idx, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (e->dev.w64) CKR_HIP(hipMemcpy(&out->w, static_cast<const double*>(e->dev.n_W) + idx, sizeof(double), hipMemcpyDeviceToHost));
-    else { float wf = 0.0f; CKR_HIP(hipMemcpy(&wf, static_cast<const float*>(e->dev.n_W) + idx, sizeof(float), hipMemcpyDeviceToHost)); out->w = (double)wf; }
-    CKR_HIP(hipMemcpy(&out->p, e->dev.n_P + idx, sizeof(float), hipMemcpyDeviceToHost));
-    out->status &= ~(ST_EXPANDED | ST_MOVER);
+// node record (three quads, see the accessors at the top) -> ckr_node_info; kids / raw status for the callers that walk the tree
+static void unpack_node(const ckr_engine* e, const uint4* q, ckr_node_info* out, uint32_t* kids, uint32_t* raw_status) {
+    out->board = ckr_board{q[0].x, q[0].y, q[0].z, q[0].w};
+    out->status = q[2].x & ~(ST_EXPANDED | ST_MOVER);
+    out->n = (int32_t)q[1].x;
+    float pf; memcpy(&pf, &q[1].y, sizeof(float)); out->p = pf;
+    if (e->dev.w64) { const uint64_t bits = (uint64_t)q[1].z | ((uint64_t)q[1].w << 32); double wd; memcpy(&wd, &bits, sizeof(double)); out->w = wd; }
+    else { float wf; memcpy(&wf, &q[1].z, sizeof(float)); out->w = (double)wf; }
+    out->reserved = 0;
+    if (kids) *kids = q[2].y;
+    if (raw_status) *raw_status = q[2].x;
+}
+
+static int read_node(ckr_engine* e, size_t idx, ckr_node_info* out, uint32_t* kids = nullptr, uint32_t* raw_status = nullptr) {
+    uint4 q[3];
+    CKR_HIP(hipMemcpy(q, e->dev.nodes + idx * 3, sizeof(q), hipMemcpyDeviceToHost));
+    unpack_node(e, q, out, kids, raw_status);
     return CKR_OK;
 }
 
@@ -2162,9 +2224,7 @@ int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* ro
     if (cursor < 0) { *n_children = -1; return CKR_OK; }
     const size_t tb = ((size_t)(ti * 2 + half)) * (size_t)e->dev.C;
     uint32_t kids = 0, st = 0;
-    CKR_HIP(hipMemcpy(&st, e->dev.n_status + tb + cursor, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(&kids, e->dev.n_kids + tb + cursor, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (int rc = read_node(e, tb + (size_t)cursor, root)) return rc;
+    if (int rc = read_node(e, tb + (size_t)cursor, root, &kids, &st)) return rc;
     int n = (st & ST_EXPANDED) ? (int)(kids >> 24) : 0;
     const size_t base = tb + (kids & 0xFFFFFFu);
     for (int i = 0; i < n; ++i)
@@ -2185,18 +2245,10 @@ int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_de
     *n = 0;
     if (cursor < 0 || used <= 0) return CKR_OK;
     const size_t tb = ((size_t)(ti * 2 + half)) * (size_t)e->dev.C, U = (size_t)used;
-    std::vector<ckr_board> board(U); std::vector<uint32_t> kids(U), status(U); std::vector<int32_t> cnt(U); std::vector<float> prior(U);
-    std::vector<double> wd(U); std::vector<float> wf(e->dev.w64 ? 0 : U);
-    CKR_HIP(hipMemcpy(board.data(), e->dev.n_board + tb, U * sizeof(ckr_board), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(kids.data(), e->dev.n_kids + tb, U * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(status.data(), e->dev.n_status + tb, U * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(cnt.data(), e->dev.n_N + tb, U * sizeof(int32_t), hipMemcpyDeviceToHost));
-    CKR_HIP(hipMemcpy(prior.data(), e->dev.n_P + tb, U * sizeof(float), hipMemcpyDeviceToHost));
-    if (e->dev.w64) CKR_HIP(hipMemcpy(wd.data(), static_cast<const double*>(e->dev.n_W) + tb, U * sizeof(double), hipMemcpyDeviceToHost));
-    else {
-        CKR_HIP(hipMemcpy(wf.data(), static_cast<const float*>(e->dev.n_W) + tb, U * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < U; ++i) wd[i] = (double)wf[i];
-    }
+    std::vector<uint4> raw(U * 3);
+    CKR_HIP(hipMemcpy(raw.data(), e->dev.nodes + tb * 3, U * 3 * sizeof(uint4), hipMemcpyDeviceToHost));
+    std::vector<ckr_node_info> info(U); std::vector<uint32_t> kids(U), status(U);
+    for (size_t i = 0; i < U; ++i) unpack_node(e, &raw[i * 3], &info[i], &kids[i], &status[i]);
     // depth first, the LAST child of a node first: the order in which MCTS.traverse_tree prints (MCTS.py:336-341)
     std::vector<std::pair<int32_t, int32_t>> stack{{cursor, 0}};
     int64_t k = 0;
@@ -2204,9 +2256,7 @@ int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_de
         const auto [node, d] = stack.back();
         stack.pop_back();
         if (out && depth && k < cap) {
-            ckr_node_info& o = out[k];
-            o.board = board[(size_t)node]; o.status = status[(size_t)node] & ~(ST_EXPANDED | ST_MOVER); o.n = cnt[(size_t)node];
-            o.w = wd[(size_t)node]; o.p = prior[(size_t)node]; o.reserved = 0;
+            out[k] = info[(size_t)node];
             depth[k] = d;
         }
         ++k;

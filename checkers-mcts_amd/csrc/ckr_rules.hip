@@ -290,6 +290,31 @@ int ckr_device_count(void) {
     return n;
 }
 
+// A HIP stream with a hardware queue of its own.  The HIP runtime maps ordinary streams onto at most GPU_MAX_HW_QUEUES (default 4)
+// HSA queues per priority, least-used first: two of a job's part-batch streams (pipeline.SplitRunner) can land on ONE queue,
+// where their step chains run one behind the other instead of side by side -- measured in round 5 (profiles/r05_step_timeline_*):
+// the bf16 leg's 0.366 / 0.563 ms per step from run to run, and four parts at 5.6 instead of 6.6 M expansions/s.  A stream
+// created with a CU mask always gets a new HSA queue; the mask here names every CU, so nothing else changes.
+int ckr_stream_create(int32_t device, void** out) {
+    if (!out) return fail(CKR_ERR_INVALID, "ckr_stream_create: null argument");
+    if (int rc = require_device()) return rc;
+    CKR_HIP(hipSetDevice(device));
+    uint32_t mask[32];
+    for (int i = 0; i < 32; ++i) mask[i] = 0xFFFFFFFFu;               // every CU of the device (bits beyond the CU count are ignored)
+    hipDeviceProp_t prop;
+    CKR_HIP(hipGetDeviceProperties(&prop, device));
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    hipStream_t st = nullptr;
+    CKR_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)(words > 0 && words <= 32 ? words : 32), mask));
+    *out = (void*)st;
+    return CKR_OK;
+}
+int ckr_stream_destroy(void* stream) {
+    if (!stream) return CKR_OK;
+    CKR_HIP(hipStreamDestroy((hipStream_t)stream));
+    return CKR_OK;
+}
+
 #define CKR_CHECK_ARGS(cond, what)                                         \
     do { if (!(cond)) return fail(CKR_ERR_INVALID, "%s: %s", __func__, what); } while (0)
 

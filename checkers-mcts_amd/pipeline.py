@@ -393,6 +393,30 @@ def lookahead_rows(n_slots, fused_boards=True, up_to=256):
     return int(min(LOOKAHEAD_BATCH, max(64, 8 * int(n_slots))))
 
 
+_PART_STREAMS = {}              # device index -> [torch.cuda.ExternalStream, ...] created by ckr_stream_create, kept for the process
+
+
+def part_streams(device, n):
+    """The HIP streams the part-batches of a job step on: n streams of `device`, each with a hardware queue of its own
+    (ckr_stream_create), created once per process and device and re-used by every job.  torch.cuda.Stream() hands out pool streams
+    that the HIP runtime maps onto at most GPU_MAX_HW_QUEUES = 4 hardware queues shared with everything else in the process: two parts
+    on one queue run their step chains one behind the other (profiles/r05_step_timeline_*: the same leg at 0.37 or 0.56 ms per step
+    depending on which pool streams it drew; four parts 5.6 instead of 6.6 M expansions/s).  CKR_TORCH_STREAMS=1: pool streams, as
+    until round 4."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if os.environ.get("CKR_TORCH_STREAMS") == "1":
+        return [torch.cuda.Stream(device=dev) for _ in range(n)]
+    have = _PART_STREAMS.setdefault(idx, [])
+    import ctypes
+    L = _lib.load()
+    while len(have) < n:
+        h = ctypes.c_void_p()
+        _lib.check(L.ckr_stream_create(idx, ctypes.byref(h)))
+        have.append(torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx)))
+    return have[:n]
+
+
 class SplitRunner:
     """Part-batches on their own HIP streams: the slots of a job are divided between two or three engines (split_parts;
     contiguous worker-id blocks -- results do not depend on the division, see dist.py) that step independently, each with its own
@@ -411,6 +435,7 @@ class SplitRunner:
         wb = [n_workers * i // n_parts for i in range(n_parts + 1)]
         sb = [n_slots * i // n_parts for i in range(n_parts + 1)]
         self.parts = []
+        streams = None
         for i in range(n_parts):
             first, workers, slots = wb[i], wb[i + 1] - wb[i], min(sb[i + 1] - sb[i], wb[i + 1] - wb[i])
             if workers <= 0 or slots <= 0:
@@ -419,8 +444,9 @@ class SplitRunner:
                 eng = make_engine(first, slots)                  # (offset, n_slots): one worker per slot
             else:
                 eng = make_engine(first, workers, slots)
-            prio = [int(x) for x in os.environ.get("CKR_STREAM_PRIORITIES", "").split(",") if x.strip()]      # tuning experiments
-            stream = torch.cuda.Stream(device=eng.device, priority=prio[i] if i < len(prio) else 0)
+            if streams is None:
+                streams = part_streams(eng.device, n_parts)         # one hardware queue per part
+            stream = streams[i]
             with torch.cuda.stream(stream):
                 runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
             runner.solo = False                              # the parts share the chip: smaller lookahead batches (tail_mode)

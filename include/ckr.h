@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 124          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair */
+#define CKR_VERSION 125          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy */
 
 typedef enum {
     CKR_OK = 0,
@@ -57,6 +57,13 @@ typedef struct { uint32_t p1, p2, kings, meta; } ckr_board;
 const char* ckr_last_error(void);
 int  ckr_version(void);
 int  ckr_device_count(void);
+
+/* A HIP stream that owns a hardware queue (no reference counterpart: the reference's unit of concurrency is a worker process,
+ * training_pipeline.py:325-329; here the concurrent game batches of one GPU step on such streams).  The HIP runtime shares at most
+ * GPU_MAX_HW_QUEUES (4) hardware queues between all ordinary streams of a process, so two batches' step chains can end up in one
+ * queue and serialise; these streams never share.  *out is a hipStream_t (usable as torch.cuda.ExternalStream).              */
+int  ckr_stream_create(int32_t device, void** out);
+int  ckr_stream_destroy(void* stream);
 
 /* ---- rules kernels ------------------------------------------------------ */
 
