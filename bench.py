@@ -416,14 +416,22 @@ def timed_window(leg, dev, steps, barrier=lambda: None):
     t0 = time.perf_counter()
     if marked:
         leg.mark()
-    leg.step(steps)
+    # host cost of issuing a step: the first steps of the window go into empty hardware queues, so the time the host needs to hand
+    # them over is its own (later replays may block on a full queue, i.e. wait for the GPU)
+    k = min(steps, 32)
+    leg.step(k)
+    t_issue = (time.perf_counter() - t0) / k
+    if steps > k:
+        leg.step(steps - k)
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
     s1 = leg.stats()
     if marked:
         s0 = leg.stats_at_mark()
-    return dt, {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves", "parked", "stalled_steps")}
+    d = {k: s1[k] - s0[k] for k in ("expansions", "terminal_visits", "plies", "games", "nn_evals", "dup_leaves", "parked", "stalled_steps")}
+    d["host_issue_seconds_per_step"] = t_issue
+    return dt, d
 
 
 def throughput_leg(a, dev, mode, cache_log2=None):
@@ -652,6 +660,12 @@ def main():
     ckdist.barrier()
     dev = ckdist.local_device(local_rank)
     torch.cuda.set_device(dev)
+    # host placement: this rank's Python thread (it only replays HIP graphs) on cores of its GPU's NUMA node
+    try:
+        affinity0 = os.sched_getaffinity(0)
+    except AttributeError:
+        affinity0 = None
+    placement = ckdist.pin_to_gpu(local_rank, world)
     mode = a.nn_dtype
     pre = preroll_steps(a)
     # the job: slots x games-per-slot games per GPU.  Default: that many WORKERS of one game each, hosted on the slots one after
@@ -681,6 +695,10 @@ def main():
     dt_local, d = timed_window(leg, dev, a.steps, ckdist.barrier)
     dt = ckdist.max_over_ranks(dt_local, dev)
     dt_by_rank = ckdist.all_ranks(dt_local, dev)
+    issue_by_rank = ckdist.all_ranks(d["host_issue_seconds_per_step"], dev)
+    placement_by_rank = [dict(zip(("numa_node", "cpus", "first_cpu", "last_cpu", "pinned"), vals)) for vals in zip(
+        *[[int(x) for x in ckdist.all_ranks(-1 if placement[k] is None else int(placement[k]), dev)]
+          for k in ("numa_node", "cpus", "first_cpu", "last_cpu", "pinned")])]
     exp_by_rank = ckdist.all_ranks(d["expansions"], dev)
     exp_total = sum(exp_by_rank)
     term_total = ckdist.sum_over_ranks(d["terminal_visits"], dev)
@@ -842,6 +860,8 @@ def main():
             extra["training_step_batch_1024"] = training_leg(dev, batch=1024, reps=10)
         cpu = None
         if world == 1 and a.cpu_seconds > 0:
+            if affinity0 is not None:
+                os.sched_setaffinity(0, affinity0)                  # the CPU baseline runs on ALL host cores this process may use
             cpu = cpu_baseline(a.budget, a.cpu_seconds)
         out = {"metric": "MCTS node-expansions/sec (whole node) at %d sims/move" % a.budget, "value": value,   # BASELINE's metric at the default --budget 100
                "unit": "node-expansions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -866,6 +886,10 @@ def main():
                          "bit-exact vs the reference golden vectors (NumPy >= 2 promotion rules; the vectors regenerate bit-identically under NumPy 1.26 legacy rules)" if mode == "fp32" else
                          "throughput mode (not a parity claim)",
                "ms_per_step_by_rank": [t / a.steps * 1e3 for t in dt_by_rank], "expansions_by_rank": exp_by_rank, "nn_evals_by_rank": nn_by_rank,
+               # host side of a multi-rank job: how long a rank's Python thread needs to ISSUE one step (its graph replays) -- measured over the window's first <= 32 steps, issued into empty queues -- it must stay
+               # well below ms_per_step, else the rank is host-bound however fast its GPU is -- and where that thread was placed
+               "host_issue_ms_per_step_by_rank": [t * 1e3 for t in issue_by_rank],
+               "host_placement_by_rank": placement_by_rank,
                "nn_evals": nn_total, "dup_leaves": dup_total, "duplicate_rate": dup_total / max(1.0, exp_total),
                "nn_evals_per_s": nn_total / dt, "cache_served_per_s": dup_total / dt, "parked_slot_steps": parked_total,
                "stalled_steps_in_window": d["stalled_steps"],

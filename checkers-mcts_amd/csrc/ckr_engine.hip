@@ -29,6 +29,21 @@ enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play sl
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS,
        CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_STALL, CNT_AHEAD, CNT_N };
 constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
+// Phase timing of the tree kernel (a measurement build, -DCKR_KSTEP_PROF; never the product): ticks of the 100-MHz wall clock per
+// phase, summed per wave and added to Dev.prof at the end of the launch.
+enum { PR_ENTRY = 0, PR_EXPAND, PR_DESCEND, PR_PROBE, PR_HITEXP, PR_PREFETCH, PR_FINISH, PR_EXIT, PR_TOTAL, PR_NDESC, PR_NLEVEL, PR_NWAVES, PR_N };
+#ifdef CKR_KSTEP_PROF
+#define PROF_DECL unsigned long long prof_acc[PR_N] = {0}; unsigned long long prof_t = wall_clock64(); const unsigned long long prof_t0 = prof_t;
+#define PROF_LAP(which) { const unsigned long long prof_now = wall_clock64(); prof_acc[which] += prof_now - prof_t; prof_t = prof_now; }
+#define PROF_COUNT(which, by) prof_acc[which] += (unsigned long long)(by);
+#define PROF_FLUSH(D, lane) { prof_acc[PR_TOTAL] = wall_clock64() - prof_t0; prof_acc[PR_NWAVES] = 1; \
+    if ((lane) == 0 && (D).prof) for (int pi = 0; pi < PR_N; ++pi) atomicAdd(&(D).prof[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + pi], prof_acc[pi]); }
+#else
+#define PROF_DECL
+#define PROF_LAP(which)
+#define PROF_COUNT(which, by)
+#define PROF_FLUSH(D, lane)
+#endif
 
 // ---- leaf cache: network outputs by position.  Checkers.predict is a pure function of planes 0-13 (Checkers.py:425-438),
 // i.e. of (p1, p2, kings, side to move, draw numerator k) and of the network that evaluates it; the reference nevertheless
@@ -138,6 +153,7 @@ struct Dev {
     int32_t* pf_counter;         // DEVICE: prefetched positions handed out in this step (zeroed by the step's prologue)
     int32_t* g_pf_net;           // [row] network id of the position handed out in that row by the last step (-1: none)
     uint4* g_pf_board;           // [row] its board record
+    unsigned long long* prof;    // -DCKR_KSTEP_PROF builds only (tools/kstep_phases.py): per-phase 100-MHz ticks of the tree kernel, else null
 };
 
 struct WaveLds {
@@ -147,6 +163,7 @@ struct WaveLds {
     uint32_t kn;                                                 // ... and their number
     uint32_t mask[8];
     uint32_t cnt[CNT_N];                                         // per-wave event counters (lane 0), flushed once
+    uint32_t ep[1 + CACHE_MAX_ENGINES];                          // this launch's number and the engines' published numbers (EpochState)
 };
 
 // ---- node records (48 B = three 16-byte quads; index i of the pool = nodes[3 i ...]):
@@ -243,9 +260,10 @@ __device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint
 
 // np.random.dirichlet([alpha] * n) for the n children of a node, one component per lane: independent
 // gamma(alpha) variates divided by their sum (MCTS.py:107-108).  Philox counters: (worker, draw, lane).
-__device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_t worker, uint32_t ctr, int lane) {
+// n = number of active lanes (wave-uniform; the active lanes are [0, n)): up to 16 children are summed within the first row of lanes
+__device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_t worker, uint32_t ctr, int lane, int n = 64) {
     const double g = act ? gamma_sample(D, D.alpha, worker, ctr, (uint32_t)lane) : 0.0;
-    return g / wave_sum_f64(g);
+    return g / (n <= 16 ? row_sum_f64(g) : wave_sum_f64(g));
 }
 
 // MCTS.best_child with TRAINING and tau > 0 (MCTS.py:240-246): np.random.choice(children, p = N^(1/tau) / sum)
@@ -311,16 +329,16 @@ template <class Wave> __device__ void backup_outcome(Wave& w, int t, int node, u
 // lane): every node of a path is distinct, so the read-modify-writes are independent and issue in
 // one round instead of one dependent round trip per tree level.  Per node the order of the float32
 // accumulation over simulations is unchanged.
-template <class Wave> __device__ __forceinline__ void backup_value_path(Wave& w, int t, uint32_t entry, int len, float v, uint32_t sim_player) {
+template <class Wave> __device__ __forceinline__ void backup_value_path(Wave& w, size_t tb, uint32_t entry, int len, float v, uint32_t sim_player) {
     if (w.lane < len) {
-        const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
+        const size_t i = tb + (entry & 0x3FFFFFFFu);
         const float reward = (sim_player != ((entry >> 30) & 1u)) ? -1.0f * v : v;
         node_visit<typename Wave::wtype>(w.D, i, reward);
     }
 }
-template <class Wave> __device__ __forceinline__ void backup_outcome_path(Wave& w, int t, uint32_t entry, int len, uint32_t outcome) {
+template <class Wave> __device__ __forceinline__ void backup_outcome_path(Wave& w, size_t tb, uint32_t entry, int len, uint32_t outcome) {
     if (w.lane < len) {
-        const size_t i = w.tb(t) + (entry & 0x3FFFFFFFu);
+        const size_t i = tb + (entry & 0x3FFFFFFFu);
         const uint32_t mover = (entry >> 30) & 1u;
         float reward = 0.0f;
         if (outcome == 1u) reward = mover == 0u ? 1.0f : -1.0f;
@@ -651,9 +669,36 @@ template <class Wave> __device__ __attribute__((noinline)) void prefetch_childre
     }
 }
 
+// ---- the searching tree of a slot, kept in registers across the simulations of one step (round 5).  Until round 4 every
+// simulation re-read the slot's phase / simulation count / side to move, then the tree's cursor and semispace, then the root's
+// record -- three dependent memory rounds before the first child scan, and the tree kernel is nothing but a chain of such rounds
+// (profiles/r05_step_timeline_*: 65 us alone, ~200 us beside two conv stacks).  All of it changes only through this wave's own
+// expansions and backups (tracked below) or at the end of a ply (live_load).
+struct Live {
+    int t, cursor, half, used;          // side to move (= tree), the tree's root, live semispace, bump pointer
+    uint32_t root_st, root_kids;        // the root's status word and child range
+    int root_n;                         // its visit count
+    uint4 root_b;                       // its board record
+};
+template <class Wave> __device__ __forceinline__ void live_root(const Wave& w, Live& lv) {       // one round: the root's record
+    const uint4* rp = nq(w.D, w.tbase(lv.t, lv.half) + lv.cursor);
+    const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+    lv.root_b = r0; lv.root_n = (int)r1.x; lv.root_st = r2.x; lv.root_kids = r2.y;
+}
+template <class Wave> __device__ __forceinline__ void live_load(const Wave& w, Live& lv, int& phase, int& sims) {
+    const Dev& D = w.D;
+    phase = __builtin_amdgcn_readfirstlane(D.g_phase[w.slot]); sims = __builtin_amdgcn_readfirstlane(D.g_sims[w.slot]);
+    lv.t = __builtin_amdgcn_readfirstlane((int)(D.g_board[w.slot].w & 1u));
+    const int ti = w.slot * 2 + lv.t;
+    lv.cursor = __builtin_amdgcn_readfirstlane(D.t_cursor[ti]); lv.half = __builtin_amdgcn_readfirstlane(D.t_half[ti]);
+    lv.used = __builtin_amdgcn_readfirstlane(D.t_used[ti]);
+    lv.root_st = lv.root_kids = 0u; lv.root_n = 0; lv.root_b = make_uint4(0u, 0u, 0u, 0u);
+    if (phase == PH_PLAYING && lv.cursor >= 0) live_root(w, lv);
+}
+
 // ---- expansion: MCTS.tree_policy expand branch (MCTS.py:70-77) with
 // Checkers.predict's mask/renormalise (Checkers.py:435-437) and
-// set_prior_probs (:440-452).  Returns false on pool overflow.
+// set_prior_probs (:440-452).  Returns the number of children created, -1 on pool overflow (nothing written).
 // Per-slot values expand() needs, loaded at kernel entry in the same memory round as the slot's
 // phase / pending leaf (one dependent round less per item than loading them where they are used).
 struct ExpandPre { int half, used, plen; uint32_t entry; };
@@ -662,7 +707,7 @@ struct ExpandPre { int half, used, plen; uint32_t entry; };
 // evaluated the leaf (key of the cache record written when !CACHED and a place was reserved for it: cslot >= 0).
 // KNOWN: the leaf's board and status word are in registers already (kb, kst: the descent that found the leaf read them with
 // its parent's child scan), nothing of the leaf is loaded.
-template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline__ bool expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
+template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline__ int expand(Wave& w, int t, int leaf, const float* __restrict__ prow, float v, const ExpandPre& pre,
                                                            float cached_prior, int cached_n, int net, int cslot = -1, unsigned long long cword = 0ull,
                                                            const ckr_board kb = ckr_board{0u, 0u, 0u, 0u}, uint32_t kst = 0u) {
     const Dev& D = w.D;
@@ -697,8 +742,8 @@ template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline_
     const int n = wave_children(b, m, w.L.kids, true);
     __builtin_amdgcn_wave_barrier();
     const int used = pre.used;
-    if (used + n > D.C) return false;
-    if (CACHED && n != cached_n) return false;                // cannot happen (the successor list is a function of the key)
+    if (used + n > D.C) return -1;
+    if (CACHED && n != cached_n) return -1;                // cannot happen (the successor list is a function of the key)
     float prior = cached_prior;
     if (w.lane < n) {
         const ckr_board c = w.L.kids[w.lane];
@@ -730,7 +775,7 @@ template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline_
         backup_value(w, t, leaf, v, sim_player);
     }
     wave_mem_fence();
-    return true;
+    return n;
 }
 
 // ---- selection: MCTS.select_child (MCTS.py:102-116) repeated down the tree
@@ -740,22 +785,19 @@ template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline_
 //   P' = float32((1-eps) * P) + eps * dirichlet.
 // leaf_b / leaf_st: the leaf's board record and status word, read with its parent's child scan (the root's own when the
 // root is the leaf).
-template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int& plen_out, uint32_t& entry_out, ckr_board& leaf_b, uint32_t& leaf_st) {
+// The root's record comes from `lv` (registers): the first memory round of a descent is the root's child scan.
+template <class Wave> __device__ __forceinline__ int descend(Wave& w, Live& lv, int& plen_out, uint32_t& entry_out, ckr_board& leaf_b, uint32_t& leaf_st) {
     const Dev& D = w.D;
-    const size_t tb = w.tb(t);
-    int node = D.t_cursor[w.slot * 2 + t];
+    const int t = lv.t;
+    const size_t tb = w.tbase(t, lv.half);
+    int node = lv.cursor;
     const float one_minus = (float)(1.0 - D.epsilon);
     // One dependent memory round per tree level: a node's status / child range / visit count / board come
     // with its parent's child scan (lanes = children: three 16-byte loads of consecutive 48-byte records), the noise
     // counter lives in a register, and the path is kept (lane l = level l) for the backup.
-    uint4 nb;
-    uint32_t st, kids;
-    int np;
-    {
-        const uint4* rp = nq(D, tb + node);
-        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        nb = r0; st = r2.x; kids = r2.y; np = (int)r1.x;
-    }
+    uint4 nb = lv.root_b;
+    uint32_t st = lv.root_st, kids = lv.root_kids;
+    int np = lv.root_n;
     uint32_t ctr = D.epsilon != 0.0 ? D.g_rng[w.slot] : 0u;
     uint32_t entry = 0u;
     int lvl = 0;
@@ -779,7 +821,7 @@ template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int
         const uint32_t cst = c2.x, ckids = c2.y;
         double dir = 0.0;
         if (D.epsilon != 0.0) {
-            dir = dirichlet_lane(D, act, w.worker(), ctr, w.lane);
+            dir = dirichlet_lane(D, act, w.worker(), ctr, w.lane, n);
             ++ctr;
         }
         const double sqrt_n = np < D.sqrt_n ? D.sqrt_tab[np] : sqrt((double)np);
@@ -794,9 +836,10 @@ template <class Wave> __device__ __forceinline__ int descend(Wave& w, int t, int
         if (st_outcome(bst) != 0u) {
             if (w.lane == lvl) entry = (uint32_t)child | (((bst >> 4) & 1u) << 30);
             if (w.lane == 0 && D.epsilon != 0.0) D.g_rng[w.slot] = ctr;
-            if (lvl + 1 <= 64) backup_outcome_path(w, t, entry, lvl + 1, st_outcome(bst));
+            if (lvl + 1 <= 64) backup_outcome_path(w, tb, entry, lvl + 1, st_outcome(bst));
             else backup_outcome(w, t, child, st_outcome(bst));
             w.count(CNT_TERM);
+            lv.root_n += 1;                                        // every backup passes through the root
             wave_mem_fence();
             return -1;
         }
@@ -1284,33 +1327,53 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
         if (D.cache && threadIdx.x == 0) { epoch_advance(D, &s_epoch); *D.estate = s_epoch; }
         if (D.pf_counter && threadIdx.x == 1) *D.pf_counter = 0;
         __syncthreads();
-    } else if (D.cache) {                                      // written by the prologue kernel in front of this launch
-        if (threadIdx.x < 1 + CACHE_MAX_ENGINES) (&s_epoch.E)[threadIdx.x] = (&D.estate->E)[threadIdx.x];
-        __syncthreads();
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     WaveT<WT> w{D, lds[wave], slot, lane_id()};
-    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
-    if (slot == 0) w.count(CNT_STEPS);
-    if (D.cache) {
-        w.epoch = s_epoch.E;
-        w.view = s_epoch.view;
-    }
-    // A. consume the network output for the leaf handed out by the previous step
+    PROF_DECL
+    // ---- round 1 of loads: everything the step needs to know about its slot, in ONE memory round (no workgroup barrier in
+    // front of it: each wave fetches the launch number the prologue kernel wrote for itself)
+    uint32_t ep = 0u;
+    if (D.cache && w.lane < 1 + CACHE_MAX_ENGINES) ep = (flags & 2) ? (&s_epoch.E)[w.lane] : (&D.estate->E)[w.lane];
     const int pending = D.g_pending[slot];
     const int row = D.g_row[slot];
-    const int phase0 = D.g_phase[slot];
-    const int t0 = (int)(D.g_board[slot].w & 1u);
+    const int phase0 = __builtin_amdgcn_readfirstlane(D.g_phase[slot]);
+    const int t0 = __builtin_amdgcn_readfirstlane((int)(D.g_board[slot].w & 1u));
     const int parked0 = D.g_parked[slot];
     const int cslot0 = D.g_cslot[slot];
     const unsigned long long cword0 = D.g_cword[slot];
     w.wk = D.g_worker[slot];
-    ExpandPre pre;                                             // same round of loads (unused if nothing is pending)
-    pre.half = D.t_half[slot * 2 + t0]; pre.used = D.t_used[slot * 2 + t0]; pre.plen = D.g_plen[slot];
+    int sims = __builtin_amdgcn_readfirstlane(D.g_sims[slot]);
+    const int2 cur2 = reinterpret_cast<const int2*>(D.t_cursor)[slot], half2 = reinterpret_cast<const int2*>(D.t_half)[slot],
+               used2 = reinterpret_cast<const int2*>(D.t_used)[slot];             // both trees: the side to move arrives in the same round
+    const int finished = D.tail_sims > 0 ? *D.n_finished : 0;
+    const bool stalled = D.eval_flag != nullptr && *D.eval_flag != 0;
+    ExpandPre pre;                                             // (unused if nothing is pending)
+    pre.plen = D.g_plen[slot];
     pre.entry = D.g_path[(size_t)slot * 64 + w.lane];
-    asm volatile("" :: "v"(pre.half), "v"(pre.used), "v"(pre.plen), "v"(pre.entry));   // keep the loads up here
+    Live lv;
+    lv.t = t0;
+    lv.cursor = __builtin_amdgcn_readfirstlane(t0 ? cur2.y : cur2.x);
+    lv.half = __builtin_amdgcn_readfirstlane(t0 ? half2.y : half2.x);
+    lv.used = __builtin_amdgcn_readfirstlane(t0 ? used2.y : used2.x);
+    lv.root_st = lv.root_kids = 0u; lv.root_n = 0; lv.root_b = make_uint4(0u, 0u, 0u, 0u);
+    pre.half = lv.half; pre.used = lv.used;
+    if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
+    if (D.cache) {
+        if (w.lane < 1 + CACHE_MAX_ENGINES) w.L.ep[w.lane] = ep;
+        __builtin_amdgcn_wave_barrier();
+        w.epoch = w.L.ep[0];
+        w.view = &w.L.ep[1];
+    }
+    if (slot == 0) w.count(CNT_STEPS);
+    // ---- round 2: the root's record (for the descents below), together with what the expansion of the pending leaf reads
+    if (phase0 == PH_PLAYING && lv.cursor >= 0) live_root(w, lv);
+    asm volatile("" :: "v"(lv.root_n), "v"(pending));            // (prof builds: the entry phase ends when round 1 has arrived)
+    PROF_LAP(PR_ENTRY)
+    // A. consume the network output for the leaf handed out by the previous step
     int leaf = -1, net = -1, free_sims = 0;
+    int phase = phase0;
     bool parked = false;                                       // the slot ends this step waiting for another requester's evaluation
     int cslot = -1; unsigned long long cword = 0ull;           // place reserved in the leaf cache for the leaf handed out in this step
     ckr_board lb{0u, 0u, 0u, 0u};
@@ -1320,7 +1383,6 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     int park_count = resume >= 0 ? parked0 : 0;
     // the network's answer to the last batch is void (see Dev.eval_flag): nothing is expanded, nothing descends; a slot with a
     // leaf at the network hands the same leaf out again (same reservation in the leaf cache), the others idle for this step
-    const bool stalled = D.eval_flag != nullptr && *D.eval_flag != 0;
     if (stalled) {
         if (slot == 0) w.count(CNT_STALL);
         if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
@@ -1331,56 +1393,69 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
     } else if (pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0) {
         const int t = t0;
         const int pnet = D.tournament ? (t == 0 ? p1_net_of(D, slot) : 1 - p1_net_of(D, slot)) : 0;
-        bool ok = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
-        if (!ok) {
+        int n = expand<false>(w, t, pending, p + (size_t)row * 512, v[row], pre, 0.0f, 0, pnet, cslot0, cword0);
+        if (n >= 0) {                                                     // the tree as this wave just changed it
+            if (pending == lv.cursor) { lv.root_st |= ST_EXPANDED; lv.root_kids = (uint32_t)lv.used | ((uint32_t)n << 24); }
+            lv.used += n; lv.root_n += 1;
+        } else {
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
             // to 48 children): drop the garbage now and retry; the recorded path is stale after the move, so the
             // backup walks the parent links (plen > 64)
             const int moved = compact(w, t, pending);
             ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
-            ok = moved >= 0 && expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet, cslot0, cword0);
+            n = moved >= 0 ? expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet, cslot0, cword0) : -1;
+            if (n >= 0) { int ph, sm; live_load(w, lv, ph, sm); }          // (everything moved: the live state anew)
         }
-        if (ok) {
-            if (w.lane == 0) D.g_sims[slot] += 1;
+        if (n >= 0) {
+            sims += 1;
+            if (w.lane == 0) D.g_sims[slot] = sims;
+            PROF_LAP(PR_EXPAND)
             if (D.pf_rows > 0 && (flags & 5) == 0) { wave_mem_fence(); prefetch_children(w, pnet, x, net_out); }
+            PROF_LAP(PR_PREFETCH)
         } else {                                                          // the live subtree itself does not fit: give up on this game
             w.count(CNT_OVERFLOW);
             WaveT<WT> wc = w;                                                 // (a copy: see finish_ply below)
             end_game(wc, 0u, 0, 1);
             w.wk = wc.wk;
+            live_load(w, lv, phase, sims);
         }
-        if (w.lane == 0 && D.g_pending[slot] == pending) D.g_pending[slot] = -1;
         wave_mem_fence();
     }
     // B. advance until a leaf needs the network
     // The tail of a run (most workers have played their games): the step's time is the latency of one network launch whatever
     // its few rows, so the slots that still play chain more network-free simulations per step.  Results do not depend on the cap.
-    const int max_sims = (flags & 4) ? 1 : D.pf_rows > 0 && (flags & 1) == 0 ? D.pf_sims : D.tail_sims > 0 && (D.n_slots - *D.n_finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
+    const int max_sims = (flags & 4) ? 1 : D.pf_rows > 0 && (flags & 1) == 0 ? D.pf_sims : D.tail_sims > 0 && (D.n_slots - finished) <= (D.n_slots >> D.tail_shift) ? D.tail_sims : D.max_sims;
     bool did_sim = (flags & 4) != 0 && pending >= 0 && phase0 == PH_PLAYING && parked0 <= 0 && !stalled;   // single-simulation step: the expansion above completed one
-    while (!stalled && !did_sim && D.g_phase[slot] == PH_PLAYING) {
+    while (!stalled && !did_sim && phase == PH_PLAYING) {
         asm volatile("" : "+v"(w.lane));     // lane-dependent addresses are recomputed per iteration, not kept (and spilled) across the loop
-        const int sims_done = D.g_sims[slot];
         const bool clock_up = end_ply != 0 || (D.time_ticks != 0 && (long long)(wall_clock64() - D.g_start[slot]) >= D.time_ticks);
-        const bool out_of_time = clock_up && sims_done >= 2;             // a root with visited children exists
+        const bool out_of_time = clock_up && sims >= 2;                  // a root with visited children exists
         end_ply = out_of_time ? 0 : end_ply;                             // one ply per time window
-        if (resume < 0 && (sims_done >= D.budget || out_of_time)) {      // MCTS.computational_budget, :189-201
-            if (D.manual) { if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
+        if (resume < 0 && (sims >= D.budget || out_of_time)) {           // MCTS.computational_budget, :189-201
+            if (D.manual) { phase = PH_IDLE; if (w.lane == 0) D.g_phase[slot] = PH_IDLE; wave_mem_fence(); break; }
             // (the end of a ply is a real call, once per BUDGET simulations: it gets a COPY of the wave's handle, so that the
             // handle the hot path uses never has its address taken and stays in registers instead of scratch memory)
             WaveT<WT> wc = w;
+            PROF_LAP(PR_EXIT)
             finish_ply(wc);
             w.wk = wc.wk;
+            live_load(w, lv, phase, sims);                               // next ply (or next game, or none): the live state anew
+            asm volatile("" :: "v"(lv.root_n));
+            PROF_LAP(PR_FINISH)
             continue;
         }
         if (free_sims >= max_sims) break;
-        const int t = (int)(D.g_board[slot].w & 1u);
+        const int t = lv.t;
         int plen = pre.plen; uint32_t pentry = pre.entry;
         int found = resume;
         uint32_t lst_node = 0u;                                          // the leaf's status word (node record)
-        if (resume < 0) { found = descend(w, t, plen, pentry, lb, lst_node); park_count = 0; }
-        else { const uint4* fp = nq(D, w.tb(t) + found); lb = ld_board(fp); lst_node = fp[2].x; }   // a parked leaf, looked up again
+        PROF_LAP(PR_EXIT)
+        if (resume < 0) { found = descend(w, lv, plen, pentry, lb, lst_node); park_count = 0; }
+        else { const uint4* fp = nq(D, w.tbase(t, lv.half) + found); lb = ld_board(fp); lst_node = fp[2].x; }   // a parked leaf, looked up again
         resume = -1;
-        if (found < 0) { if (w.lane == 0) D.g_sims[slot] += 1; wave_mem_fence(); ++free_sims; continue; }
+        asm volatile("" :: "v"(found));
+        PROF_LAP(PR_DESCEND) PROF_COUNT(PR_NDESC, 1) PROF_COUNT(PR_NLEVEL, plen)
+        if (found < 0) { sims += 1; if (w.lane == 0) D.g_sims[slot] = sims; wave_mem_fence(); ++free_sims; continue; }
         if (D.tournament) {
             const int p1_net = p1_net_of(D, slot);
             net = t == 0 ? p1_net : 1 - p1_net;                          // training_pipeline.py:523-529,536,546
@@ -1391,13 +1466,21 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             float cprior = 0.0f, cv = 0.0f; int cn = 0;
             const bool may_park = D.cache_park != 0 && (flags & 1) == 0 && park_count < CACHE_PARK_MAX;
             const int res = cache_probe(w, cache_key(lb, lst, net), may_park, cprior, cv, cn, cslot, cword);
+            asm volatile("" :: "v"(res));
+            PROF_LAP(PR_PROBE)
             if (res == CACHE_HIT) {
-                const ExpandPre now{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], plen, pentry};
-                if (expand<true, true>(w, t, found, nullptr, cv, now, cprior, cn, net, -1, 0ull, lb, lst_node)) {
+                const ExpandPre now{lv.half, lv.used, plen, pentry};
+                const int n = expand<true, true>(w, t, found, nullptr, cv, now, cprior, cn, net, -1, 0ull, lb, lst_node);
+                if (n >= 0) {
+                    if (found == lv.cursor) { lv.root_st |= ST_EXPANDED; lv.root_kids = (uint32_t)lv.used | ((uint32_t)n << 24); }
+                    lv.used += n; lv.root_n += 1;
                     w.count(CNT_HIT);
-                    if (w.lane == 0) { D.g_sims[slot] += 1; if (D.cache_park) { D.g_pending[slot] = -1; D.g_parked[slot] = 0; } }
+                    sims += 1;
+                    if (w.lane == 0) { D.g_sims[slot] = sims; if (D.cache_park) { D.g_pending[slot] = -1; D.g_parked[slot] = 0; } }
                     wave_mem_fence();
+                    PROF_LAP(PR_HITEXP)
                     if (D.pf_rows > 0 && (flags & 5) == 0) prefetch_children(w, net, x, net_out);
+                    PROF_LAP(PR_PREFETCH)
                     ++free_sims;
                     continue;
                 }                                                        // pool full: let the network path compact and retry
@@ -1428,6 +1511,8 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
         else write_features(w, lb, x, out_row);
     }
     flush_counters(w);
+    PROF_LAP(PR_EXIT)
+    PROF_FLUSH(D, w.lane)
 }
 
 // Random-rollout mode: up to `sims` complete simulations per slot and launch (select, expand one
@@ -1814,6 +1899,9 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     A(D.results, (size_t)e->n_games_total, true);
     A(D.counters, (size_t)CNT_SHARDS * CNT_STRIDE, true); A(e->d_mark, (size_t)CNT_SHARDS * CNT_STRIDE, true);
     A(D.leaves, S, true);
+#ifdef CKR_KSTEP_PROF
+    A(D.prof, (size_t)CNT_SHARDS * CNT_STRIDE, true);
+#endif
     // node.n ** 0.5 is C pow() in the reference (python int ** float), which is
     // NOT always sqrt(): keep a host-computed table for the counts that occur.
     D.sqrt_n = 1 << 16;
@@ -2270,6 +2358,19 @@ int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_de
     if (out && k > cap) return fail(CKR_ERR_INVALID, "ckr_engine_subtree: buffer too small (%lld > %lld)", (long long)k, (long long)cap);
     return CKR_OK;
 }
+
+#ifdef CKR_KSTEP_PROF
+// measurement builds only (not declared in ckr.h): the tree kernel's per-phase tick sums, PR_N values; reset on read
+int ckr_engine_prof(ckr_engine* e, unsigned long long* out) {
+    if (!e || !out || !e->dev.prof) return fail(CKR_ERR_INVALID, "ckr_engine_prof: bad argument");
+    CKR_HIP(hipDeviceSynchronize());
+    unsigned long long shards[CNT_SHARDS * CNT_STRIDE];
+    CKR_HIP(hipMemcpy(shards, e->dev.prof, sizeof(shards), hipMemcpyDeviceToHost));
+    CKR_HIP(hipMemset(e->dev.prof, 0, sizeof(shards)));
+    for (int i = 0; i < PR_N; ++i) { out[i] = 0; for (int s = 0; s < CNT_SHARDS; ++s) out[i] += shards[s * CNT_STRIDE + i]; }
+    return CKR_OK;
+}
+#endif
 
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out) {
     if (!e || !out) return fail(CKR_ERR_INVALID, "ckr_engine_leaves: null argument");

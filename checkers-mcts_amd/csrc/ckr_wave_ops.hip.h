@@ -87,8 +87,8 @@ __device__ __forceinline__ float wave_masked_sum(const float* p_lds, const uint3
     r = r + xchg_f32<2>(r);
     r = r + xchg_f32<4>(r);
     r = r + xchg_f32<8>(r);
-    r = r + xchg_f32<16>(r);
-    return r;        // identical in all 64 lanes (upper half mirrors the lower)
+    // the xor-16 step as scalars: both rows of a half hold their row totals now, B0 + B1 and B2 + B3 in NumPy's terms
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 16));   // every lane
 }
 
 // Network input of one position, lane = cell (x = lane>>3, y = lane&7):

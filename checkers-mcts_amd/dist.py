@@ -42,6 +42,70 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index):
+    """NUMA node of a GPU from sysfs (PCI bus id -> /sys/bus/pci/devices/<id>/numa_node); None when the host does not say."""
+    try:
+        bus = torch.cuda.get_device_properties(int(device_index)).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(int(device_index)), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(int(device_index)), "pci_device_id", 0)
+        path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (dom, bus, dev)
+        with open(path) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def pin_to_gpu(local_rank, ranks_on_node=1):
+    """Host placement of one rank (the reference gives every worker process a core of its own, training_pipeline.py:325-329; here a
+    rank is ONE Python thread replaying HIP graphs, and an unpinned thread wanders between the sockets of an 8-GPU node): restrict
+    the process to cores of its GPU's NUMA node -- the node's cores are divided between the ranks whose GPUs share it -- or, when
+    sysfs names no node, to an equal share of the cores the process may use.  Returns what was chosen, for the bench line:
+    {"numa_node", "cpus" (count), "first_cpu", "last_cpu", "pinned"}.  CKR_NO_PIN=1: report only."""
+    info = {"numa_node": None, "cpus": None, "first_cpu": None, "last_cpu": None, "pinned": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return info
+    dev = local_device(local_rank).index if torch.cuda.is_available() else None
+    node = gpu_numa_node(dev) if dev is not None else None
+    share = None
+    if node is not None:
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                cpus = sorted(_parse_cpulist(f.read()) & set(allowed))
+            # ranks whose GPUs sit on the same node split its cores
+            n_gpu = max(1, torch.cuda.device_count())
+            same = [r for r in range(int(ranks_on_node)) if gpu_numa_node(r % n_gpu) == node]
+            k = same.index(int(local_rank)) if int(local_rank) in same else 0
+            per = max(1, len(cpus) // max(1, len(same)))
+            share = cpus[k * per:(k + 1) * per] or cpus
+        except Exception:
+            share = None
+    if not share:
+        per = max(1, len(allowed) // max(1, int(ranks_on_node)))
+        k = int(local_rank) % max(1, int(ranks_on_node))
+        share = allowed[k * per:(k + 1) * per] or allowed
+    info.update(numa_node=node, cpus=len(share), first_cpu=share[0], last_cpu=share[-1])
+    if os.environ.get("CKR_NO_PIN") != "1":
+        try:
+            os.sched_setaffinity(0, share)
+            info["pinned"] = True
+        except OSError:
+            pass
+    return info
+
+
 def shard_range(n_workers, rank, world):
     """Contiguous block of worker ids owned by `rank`: (first, count)."""
     base, rem = divmod(int(n_workers), int(world))

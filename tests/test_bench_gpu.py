@@ -31,6 +31,13 @@ def check_line(d, world):
     assert len(d["ms_per_step_by_rank"]) == len(d["expansions_by_rank"]) == world
     assert abs(sum(d["expansions_by_rank"]) - d["expansions"]) < 0.5 and min(d["expansions_by_rank"]) > 0
     assert abs(max(d["ms_per_step_by_rank"]) - d["ms_per_step"]) < 1e-6
+    # the host side of every rank: issuing a step's graph replays takes well under the step's own time (a host-bound rank would
+    # otherwise hide behind the GPU figures), and every rank reports where its thread was placed
+    assert len(d["host_issue_ms_per_step_by_rank"]) == len(d["host_placement_by_rank"]) == world
+    for issue, ms in zip(d["host_issue_ms_per_step_by_rank"], d["ms_per_step_by_rank"]):
+        assert 0 < issue < 0.5 * ms, (d["host_issue_ms_per_step_by_rank"], d["ms_per_step_by_rank"])
+    for pl in d["host_placement_by_rank"]:
+        assert pl["cpus"] >= 1 and pl["first_cpu"] <= pl["last_cpu"]
     w = d["whole_run"]
     assert w["games"] == world * 256 * 2 and len(w["seconds_by_rank"]) == world and w["pool_overflows"] == 0
     g = w["gather"]
