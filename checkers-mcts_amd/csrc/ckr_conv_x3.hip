@@ -110,47 +110,8 @@ template <int PT> __device__ __forceinline__ void load_b(const char* __restrict_
 }
 
 template <int PT> __device__ __forceinline__ void mfma_block(const AF& a, const BF<PT>& b, f32x16 (&acc)[PT]) {
-#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 4
-    // probe 4: the activation fragment stays in place for two consecutive MFMAs (wh xh, wl xh), then wh xl -- another operand order
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
-    return;
-#endif
-#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 7
-    // probe 7: the present order with the operands in each other's slots (the fragment that stays in place is the B operand)
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[pt], a.h, acc[pt], 0, 0, 0);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[pt], a.h, acc[pt], 0, 0, 0);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[pt], a.l, acc[pt], 0, 0, 0);
-    return;
-#endif
-#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 6
-    // probe 6: hh, lh, hl by groups of PT (the activation hi fragments are used by two consecutive groups)
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
-    return;
-#endif
-#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 5
-    // probe 5: per position tile all three products back to back (dependent accumulator chain of three)
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
-    }
-    return;
-#endif
+    // wh xh for the wave's position tiles, then wh xl, then wl xh: the weight fragment stays in the A slot for eight consecutive MFMAs
+    // (the cheapest of the orders and operand assignments measured: profiles/r04_x3_lds_probe.txt, tools/x3_probes.patch)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
 #pragma unroll
@@ -294,36 +255,9 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
     load_b(act, 0, rowaddr, b0);
     __builtin_amdgcn_sched_barrier(0);
     auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BF<PT>& bc, BF<PT>& bn) {
-#if defined(CKR_X3_PROBE) && CKR_X3_PROBE == 3
-        if (s & 1) apf = ac; else                                  // probe 3: every other weight fragment pair is a register copy (half the L2 -> register stream)
-#endif
         load_a(rsrc, voff, g0 + s + RING - 1, apf);               // beyond the layer: the next layer's first slots / the padding
         if (s + 1 < NSLOTS) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
-#if defined(CKR_X3_PROBE) && CKR_X3_PROBE != 3
-            // timing probe (tools/x3_lds_probe.py; results are WRONG): what the kernel would cost if the activation fragments of the
-            // taps with dx != 0 came from the dx = 0 fragments (1: for free -- an upper bound; 2: through one DPP wave shift and one
-            // mask per register, the price of deriving them in registers) instead of from LDS
-            const int ntap = c8 == CPT - 1 ? tap + 1 : tap;
-            if (CPT > 1 && ntap % 3 != 1) {
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-#if CKR_X3_PROBE == 1
-                    bn.h[pt] = bc.h[pt]; bn.l[pt] = bc.l[pt];
-#else
-                    const u32x4 sh = *reinterpret_cast<const u32x4*>(&bc.h[pt]), sl = *reinterpret_cast<const u32x4*>(&bc.l[pt]);
-                    u32x4 dh, dl;
-                    const unsigned keep = (lane & 7) == 7 ? 0u : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        dh[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sh[j], 0x130, 0xF, 0xF, false) & keep;
-                        dl[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sl[j], 0x130, 0xF, 0xF, false) & keep;
-                    }
-                    bn.h[pt] = *reinterpret_cast<const f16x8*>(&dh); bn.l[pt] = *reinterpret_cast<const f16x8*>(&dl);
-#endif
-                }
-            } else
-#endif
             load_b(act, c8 == CPT - 1 ? 0 : c8 + 1, rowaddr, bn);
         }
         mfma_block<PT>(ac, bc, acc);

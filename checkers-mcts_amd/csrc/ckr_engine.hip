@@ -2040,7 +2040,9 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     // live (found by the arena tail test: more rows with a network id than leaves handed out, the two networks' shares grew
     // past the rows in use); it is also one graph node instead of two.
     if (e->dev.pf_rows > 0 && d_p && d_v)                            // the answers to what the previous step handed out ahead of the search
-        hipLaunchKernelGGL(k_prefetch_consume, dim3((e->dev.pf_rows - e->dev.pf_base + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v);
+        // (one wave per ROW OF THE BATCH, not per row beyond pf_base: a captured step stays valid when ckr_engine_set_prefetch moves
+        // pf_base later -- the waves beyond the positions handed out return at once)
+        hipLaunchKernelGGL(k_prefetch_consume, dim3((e->dev.pf_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v);
     const int n_rows = e->pf_capacity > e->cfg.n_slots ? e->pf_capacity : e->cfg.n_slots;     // rows whose network id the prologue resets
     if (prologue && e->cfg.n_slots > 4)
         hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (n_rows + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,

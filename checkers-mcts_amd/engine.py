@@ -237,7 +237,12 @@ class Engine:
         at most first_row slots still play; the evaluator must compute rows [0, rows) at every step (`eval_range`).  rows = 0: off.
         Results do not depend on it."""
         _lib.check(self._L.ckr_engine_set_prefetch(self._h, int(first_row), int(rows), int(sims_per_step), int(self.rows)))
-        self._prefetch_range = (torch.tensor([0, int(rows)], dtype=torch.int32, device=self.device) if rows else None)
+        # (the same device tensor while `rows` stays: a step graph captured with it remains valid when only first_row moves)
+        if not rows:
+            self._prefetch_range, self._prefetch_rows = None, 0
+        elif getattr(self, "_prefetch_rows", 0) != int(rows) or getattr(self, "_prefetch_range", None) is None:
+            self._prefetch_range = torch.tensor([0, int(rows)], dtype=torch.int32, device=self.device)
+            self._prefetch_rows = int(rows)
 
     @property
     def eval_range(self):

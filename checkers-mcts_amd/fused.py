@@ -433,15 +433,24 @@ class FusedEvaluator:
         n = int(getattr(engine, "eval_range", engine.row_range)[1].item()) if getattr(engine, "dense_rows", False) else x.shape[0]
         rows = x[:max(1, n)]
         planes = rules.features(rows.contiguous()) if getattr(engine, "leaf_records", False) else rows.float()
+        self.recalibrate(planes, engine)
+        return True
+
+    def recalibrate(self, planes, engine=None):
+        """New per-layer scales from the synthetic calibration set plus `planes` (the batch that tripped the range flag, with twice
+        the usual headroom); with `engine`, its current batch is evaluated again at the new scales.  The evaluators of a job's other
+        part-batches call this with the SAME planes (pipeline.StepRunner.check_evaluator): one set of scales per network and job, so
+        that every record the parts write into their shared leaf cache comes from the same arithmetic."""
         self.overflow.zero_()
         self.nets = [self._prepare(m, extra=planes, target=HI_TARGET / 2.0) for m in self.sources]
         self.recoveries += 1
-        self(engine)
-        torch.cuda.synchronize(x.device)
-        if int(self.overflow.item()):
-            raise OverflowError("split-fp16 kernels: activations out of range even after re-calibration on the batch (layer scales %s)"
-                                % (self.nets[0]["act_scales"],))
-        return True
+        self.last_planes = planes
+        if engine is not None:
+            self(engine)
+            torch.cuda.synchronize(planes.device)
+            if int(self.overflow.item()):
+                raise OverflowError("split-fp16 kernels: activations out of range even after re-calibration on the batch (layer scales %s)"
+                                    % (self.nets[0]["act_scales"],))
 
     def check_range(self):
         """Assertion on the float32-grade kernels' operand range: raises if an activation exceeded the fp16 range of its hi

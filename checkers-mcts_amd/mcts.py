@@ -296,6 +296,12 @@ class MCTS:
         if cls.constraint not in ("rollout", "time"):
             raise ValueError("Invalid MCTS computational constraint!")
         cls._sync()
+        # the evaluator is built BEFORE the search starts: packing the weights, the calibration passes and the graph capture of a new
+        # (or changed) network take hundreds of milliseconds, and the device clock of a CONSTRAINT == 'time' search starts with
+        # CMD_SEARCH -- as MCTS.start_time is set immediately before the search loop (MCTS.py:216)
+        runner = cls._search_runner() if cls.neural_net else None
+        if runner is not None and runner.use_graph and runner.graph is None and not cls._engine.game(0)[3]:
+            runner.warmup(0)                                 # (the slot is idle: a step does nothing but gets captured)
         if cls._engine.command(CMD_SEARCH)[0]:
             raise ValueError("begin_tree_search on a finished game")
         timed = cls.constraint == "time"                     # BUDGET seconds of wall clock instead of BUDGET rollouts (:196-198):
@@ -307,7 +313,6 @@ class MCTS:
                 if not cls._engine.game(0)[3] or out_of_time():
                     break
         else:
-            runner = cls._search_runner()                    # nothing is pending when a search starts: p, v unused
             chunk = 1 if timed else 32                       # steps issued per look at the slot (steps after the search has
             while True:                                      # parked are no-ops in the tree kernel)
                 runner.step(chunk)
@@ -370,6 +375,10 @@ class MCTS:
         first and max_tree_depth levels deep -- what the reference's print_tree / traverse_tree print (MCTS.py:312-342).  The
         nodes come from the engine in that order (ckr_engine_subtree); root_node must be the root of the live position's tree."""
         cls._sync()
+        if getattr(root_node, "parent", None) is not None:
+            # the engine exports the subtree under its cursor: printing it for another node would show the WRONG tree (ADVICE r4)
+            raise ValueError("MCTS.print_tree: root_node must be the root of the live position's tree (MCTS.py:312-319 prints any "
+                             "node's subtree; the engine exports the live root's)")
         tree = int(cls.game_env.state[4, 0, 0])
         for info, level in cls._engine.subtree(0, tree, max_tree_depth):
             w, n = info["w"], info["n"]

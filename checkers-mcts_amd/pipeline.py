@@ -199,22 +199,35 @@ class StepRunner:
             if hasattr(ev, "check_range"):
                 ev.check_range()
             return False
-        torch.cuda.synchronize(self.eng.device)
+        torch.cuda.synchronize(self.eng.device)                 # (every part of the job is idle from here on: the caller steps them all)
         if not ev.recover(self.eng):
             return False
         self.recoveries += 1
-        if getattr(ev, "static_outputs", False):
-            self.p, self.v = ev.nets[0]["p"], ev.nets[0]["v"]
-            if len(ev.nets) > 1:
-                self.p, self.v = ev._p, ev._v
+        self._adopt_outputs()
+        # the job's other part-batches share the leaf cache: they take the same new scales and evaluate their pending batches again,
+        # then the table (records computed at the old scales) is emptied while nothing runs -- ckr_leaf_cache_flush's contract
+        for sib in getattr(self, "siblings", ()):
+            if sib is not self and hasattr(sib.evaluator, "recalibrate"):
+                with torch.cuda.stream(sib.stream):
+                    sib.evaluator.recalibrate(ev.last_planes, sib.eng if sib.steps else None)
+                sib._adopt_outputs()
+                sib.graph = None
         if self.eng.cache is not None or self.eng.cfg.leaf_cache_log2:
             self.eng.cache_flush()
+            torch.cuda.synchronize(self.eng.device)
         import warnings
         warnings.warn("float32-grade kernels: activations left the calibrated range; operand scales re-calibrated on the batch (no search "
                       "used the flagged evaluations)", RuntimeWarning)
         if self.graph is not None:
             self.graph = None
         return True
+
+    def _adopt_outputs(self):
+        ev = self.evaluator
+        if getattr(ev, "static_outputs", False):
+            self.p, self.v = ev.nets[0]["p"], ev.nets[0]["v"]
+            if len(ev.nets) > 1:
+                self.p, self.v = ev._p, ev._v
 
     def _eval_into_buffers(self):
         p, v = self.evaluator(self.eng)
@@ -258,12 +271,15 @@ class StepRunner:
             rows = self.TAIL_ROWS if active * self.PREFETCH_SHARE <= self.TAIL_ROWS < rows_have else big
             base = 1 << max(0, int(active - 1).bit_length())                 # rows [0, base) for the leaves: re-set when the playing slots halve
             state = ("prefetch", rows, min(base, rows - 1))
-            if getattr(self, "_tail_state", None) == state:
+            prev = getattr(self, "_tail_state", None)
+            if prev == state:
                 return False
             torch.cuda.synchronize(eng.device)
             eng.set_prefetch(state[2], rows, self.PREFETCH_SIMS_SOLO if solo else self.PREFETCH_SIMS)
-            self.set_row_cap(rows, force=True)                  # drops the step's graph and captures it again: new rows, new range pointer
             self._tail_state = state
+            if prev is not None and prev[:2] == state[:2] and self.graph is not None:
+                return False                                    # only the leaves' share of the rows moved: the captured step reads it from device memory
+            self.set_row_cap(rows, force=True)                  # drops the step's graph and captures it again: new rows, new range pointer
             return True
         if active <= self.TAIL_ROWS < rows_have:
             self._tail_state = ("cap", self.TAIL_ROWS)
@@ -300,6 +316,7 @@ class StepRunner:
             self._eager_step()
         if self.use_graph and self.graph is None:
             torch.cuda.synchronize(self.eng.device)
+            t_cap = time.perf_counter()
             side = torch.cuda.Stream(device=self.eng.device)
             side.wait_stream(torch.cuda.current_stream(self.eng.device))
             with torch.cuda.stream(side):                   # one more eager step on the capture stream
@@ -311,6 +328,8 @@ class StepRunner:
                 self.eng.step(self.p, self.v)
                 self._eval_into_buffers()
             self.graph = g
+            self.captures = getattr(self, "captures", 0) + 1
+            self.capture_seconds = getattr(self, "capture_seconds", 0.0) + (time.perf_counter() - t_cap)
 
     def step(self, n=1):
         if self.graph is None and self.use_graph:
@@ -450,10 +469,13 @@ class SplitRunner:
             with torch.cuda.stream(stream):
                 runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
             runner.solo = False                              # the parts share the chip: smaller lookahead batches (tail_mode)
+            runner.stream = stream
             if hasattr(runner.evaluator, "two_streams") and os.environ.get("CKR_ARENA_STREAMS") != "parts":   # arena: the two networks' launches stay on the part's one stream -- the other
                 runner.evaluator.two_streams = False         # parts' steps already run beside them, and each part's graph stays a chain
             self.parts.append((eng, runner, stream))
         self.device = self.parts[0][0].device
+        for _, runner, _ in self.parts:                          # a range-flag recovery of one part re-calibrates them all
+            runner.siblings = [r for _, r, _ in self.parts]
 
     @property
     def engines(self):
@@ -591,6 +613,15 @@ def release_leaf_cache(cache):
     same_dev = [k for k in _CACHE_POOL if k[0] == key[0]]
     while len(same_dev) >= CACHE_POOL_TABLES:                  # (dicts keep insertion order: the oldest goes)
         _CACHE_POOL.pop(same_dev.pop(0)).close()
+    try:                                                       # never more pooled bytes than a quarter of the device: training runs in this process too
+        total = torch.cuda.mem_get_info(key[0])[1]
+        while same_dev and sum(264 << k[1] for k in same_dev) + (264 << key[1]) > total // 4:
+            _CACHE_POOL.pop(same_dev.pop(0)).close()
+        if (264 << key[1]) > total // 4:
+            cache.close()
+            return
+    except Exception:
+        pass
     stale = _CACHE_POOL.pop(key, None)
     if stale is not None and stale is not cache:
         stale.close()
@@ -723,35 +754,35 @@ class generate_Checkers_data:
                 leaf_cache_log2=0, dense_rows=bool(self.dense_rows) and neural)
             return ckengine.Engine(cfg, cache=cache, extra_rows=max(0, rows - n) if not split else 0)
 
-        if not neural:                             # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
-            eng = make_engine(0, count, slots)
-            eng.set_ln_table()
-            eng.run_rollouts(sims_per_launch=64 if timed else None)      # 'time': every search is timed on the device (time_budget_us)
-            engines = [eng]
-        elif split:
-            runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots)
-            try:
+        engines = []
+        try:                                       # (whatever happens, the engines' node pools and the leaf-cache table are given back)
+            if not neural:                         # iteration-0 data: random-rollout MCTS, no network (train_Checkers.py:78)
+                eng = make_engine(0, count, slots)
+                engines = [eng]
+                eng.set_ln_table()
+                eng.run_rollouts(sims_per_launch=64 if timed else None)      # 'time': every search is timed on the device (time_budget_us)
+            elif split:
+                runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots)
+                engines = runner.engines
                 runner.run_to_completion()
-            except OverflowError:
-                runner.close()
-                raise
-            engines = runner.engines
-        else:
-            eng = make_engine(0, count, slots)
-            runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
-            try:
+            else:
+                eng = make_engine(0, count, slots)
+                engines = [eng]
+                runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
                 runner.run_to_completion()
-            except OverflowError:
-                eng.close()
-                raise
-            engines = [eng]
-        self.stats = {}
-        for e in engines:
-            for k, v in e.stats().items():
-                self.stats[k] = self.stats.get(k, 0) + v
-        self.results = [r for e in engines for r in e.results()]
-        _warn_pool_overflows(self.stats, "self-play")
-        raw_dev = torch.cat([e.pack_tuples_device() for e in engines], dim=0)
+            self.stats = {}
+            for e in engines:
+                for k, v in e.stats().items():
+                    self.stats[k] = self.stats.get(k, 0) + v
+            self.results = [r for e in engines for r in e.results()]
+            _warn_pool_overflows(self.stats, "self-play")
+            raw_dev = torch.cat([e.pack_tuples_device() for e in engines], dim=0)
+        except BaseException:
+            for e in engines:
+                e.close()
+            if cache is not None:
+                cache.close()                      # a job that failed does not leave its table in the pool
+            raise
         for e in engines:
             e.close()
         release_leaf_cache(cache)
@@ -803,6 +834,10 @@ class tournament_Checkers:
         self.slots = tourney_kwargs.get("SLOTS", 4096)                   # concurrent games per GPU (virtual workers, as in generate_Checkers_data)
         self.split_streams = tourney_kwargs.get("SPLIT_STREAMS", True)   # part-batches on their own HIP streams from 2 048 slots on
         self.stats = None
+        # measurement hooks (bench.py's arena leg): before_run(runner, device) is called once the engines exist, before the games are
+        # played to their end; trace, if a list, receives (step, slots still playing, perf_counter seconds) at every look
+        self.before_run = None
+        self.trace = None
 
     def start_tournament(self):
         game_outcomes = self._start_tournament()
@@ -837,24 +872,33 @@ class tournament_Checkers:
                     seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
                 return ckengine.Engine(cfg, cache=cache, extra_rows=0 if split else max(0, batch_rows - n))
 
-            if split:
-                # part-batches on their own HIP streams, as in generate_Checkers_data: while one part's leaves are in the two
-                # networks' conv stacks, the other parts' tree, partition and head kernels run beside them (results do not
-                # depend on the division: workers are sharded by contiguous id blocks, dist.py)
-                runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots, n_parts=n_parts)
-                runner.run_to_completion()
-                engines = runner.engines
-            else:
-                eng = make_engine(0, count, slots)
-                runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
-                runner.run_to_completion()
-                engines = [eng]
-            self.stats = {}
-            for e in engines:
-                for k, v in e.stats().items():
-                    self.stats[k] = self.stats.get(k, 0) + v
-            _warn_pool_overflows(self.stats, "tournament")
-            res = [r for e in engines for r in e.results()]
+            engines = []
+            try:                                   # (whatever happens, the engines' node pools and the leaf-cache table are given back)
+                if split:
+                    # part-batches on their own HIP streams, as in generate_Checkers_data: while one part's leaves are in the two
+                    # networks' conv stacks, the other parts' tree, partition and head kernels run beside them (results do not
+                    # depend on the division: workers are sharded by contiguous id blocks, dist.py)
+                    runner = SplitRunner(make_engine, plan.build, count, use_graph=self.use_graph, n_slots=slots, n_parts=n_parts)
+                    engines = runner.engines
+                else:
+                    eng = make_engine(0, count, slots)
+                    engines = [eng]
+                    runner = StepRunner(eng, plan.build(eng.rows), use_graph=self.use_graph, time_budget=ckengine.host_clock_budget(eng.cfg, self.mcts_kwargs))
+                if self.before_run is not None:
+                    self.before_run(runner, dev)
+                runner.run_to_completion(trace=self.trace)
+                self.stats = {}
+                for e in engines:
+                    for k, v in e.stats().items():
+                        self.stats[k] = self.stats.get(k, 0) + v
+                _warn_pool_overflows(self.stats, "tournament")
+                res = [r for e in engines for r in e.results()]
+            except BaseException:
+                for e in engines:
+                    e.close()
+                if cache is not None:
+                    cache.close()
+                raise
             for e in engines:
                 e.close()
             release_leaf_cache(cache)

@@ -544,6 +544,82 @@ def test_range_flag_stalls_the_engine_and_recovery_recalibrates(oracle):
     assert np.abs(raw1["q"] - raw0["q"]).max() < 1e-5 and np.abs(raw1["root_w"] - raw0["root_w"]).max() < 1e-3
 
 
+def test_other_widths_run_on_pytorch_and_say_so():
+    """create_nn takes any NUM_KERNELS (training_pipeline.py:56-62); the hand-written MFMA kernels are built for the recorded 128.
+    A job with another width -- or with NN_DTYPE float16 -- plays on the PyTorch module and announces the change of backend with a
+    RuntimeWarning that names the reason; EVALUATOR='torch' selects that path on purpose, silently; 128 kernels warn about nothing."""
+    import warnings
+    import torch
+    from checkers_mcts_amd import net as N, pipeline as P
+    from checkers_mcts_amd.fused import FusedEvaluator
+    dev = torch.device("cuda", 0)
+
+    def plan(net, dtype=torch.float32, kind=None):
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            pl = P.EvaluatorPlan(net, dev, dtype, kind=kind)
+        return pl, [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
+
+    for width in (64, 256):
+        pl, msgs = plan(N.make_net(width, seed=1, device=dev))
+        assert not pl.fused and len(msgs) == 1 and "NUM_KERNELS %d" % width in msgs[0] and "PyTorch" in msgs[0]
+        assert pl.backend_reason == "NUM_KERNELS %d" % width and isinstance(pl.build(8), N.NetEvaluator)
+    pl, msgs = plan(N.make_net(128, seed=1, device=dev), dtype=torch.float16)
+    assert not pl.fused and len(msgs) == 1 and "float16" in msgs[0]
+    pl, msgs = plan(N.make_net(64, seed=1, device=dev), kind="torch")
+    assert not pl.fused and msgs == []
+    pl, msgs = plan(N.make_net(128, seed=1, device=dev))
+    assert pl.fused and msgs == [] and pl.backend_reason is None and isinstance(pl.build(8), FusedEvaluator)
+    with pytest.raises(ValueError, match="128-kernel"):
+        P.EvaluatorPlan(N.make_net(64, seed=1, device=dev), dev, torch.float32, kind="fused")
+    # a whole (tiny) job through the drop-in class on a 64-kernel network: it plays, and warns
+    kw = dict(KW, BUDGET=8)
+    g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=12, NUM_CPUS=4, NN_FN=N.make_net(64, seed=2, device=dev),
+                                      SEED=1), kw)
+    with pytest.warns(RuntimeWarning, match="NUM_KERNELS 64"):
+        tup = g.generate_tuples()
+    assert tup.shape[0] >= 4 * 12
+
+
+def test_range_flag_recovery_recalibrates_every_part_of_a_job():
+    """The same with a job divided between two part-batch engines that share ONE leaf cache (pipeline.SplitRunner): the part that
+    notices the flag re-calibrates, the other part takes the same scales and evaluates its pending batch again, and the table is
+    emptied while nothing runs (records computed at two different sets of operand scales must never be served side
+    by side).  Same games as the properly calibrated job, move for move."""
+    import warnings
+    import torch
+    from checkers_mcts_amd import engine as E, net as N
+    from checkers_mcts_amd.fused import FusedEvaluator
+    from checkers_mcts_amd.pipeline import SplitRunner, make_leaf_cache
+    from test_engine_gpu import mk, sorted_tuples
+    m = N.PolicyValueNet(128).keras_init(3).perturb_bn(7).eval().cuda()
+    kw = mk(30, eps=0.25, tau=1.0)
+    runs = []
+    for target in (None, 2.0 ** 19):
+        cache = make_leaf_cache(16, torch.device("cuda", 0), n_engines=2)
+
+        def make_engine(offset, workers, n):
+            cfg = E.config_from_kwargs(kw, n_slots=n, n_workers=workers, games_per_slot=1, terminate_cnt=40, seed=4, first_worker_id=offset,
+                                       feature_dtype=E.BOARDS, leaf_cache_log2=0, dense_rows=True)
+            return E.Engine(cfg, cache=cache)
+        runner = SplitRunner(make_engine, lambda n: FusedEvaluator(m, n, mode="f16x3", calib_target=target), 128, n_parts=2, n_slots=128)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            runner.run_to_completion(check_every=16)
+        evs = [r.evaluator for _, r, _ in runner.parts]
+        raw = np.concatenate([sorted_tuples(e) for e in runner.engines])
+        runs.append((raw, [ev.recoveries for ev in evs], [tuple(ev.nets[0]["act_scales"]) for ev in evs],
+                     len([w for w in caught if "re-calibrated" in str(w.message)]), sum(e.stats()["games"] for e in runner.engines)))
+        runner.close()
+        cache.close()
+    (raw0, rec0, sc0, w0, g0), (raw1, rec1, sc1, w1, g1) = runs
+    assert rec0 == [0, 0] and w0 == 0 and g0 == g1 == 128
+    assert w1 >= 1 and min(rec1) >= 1 and sc1[0] == sc1[1] and sc1[0] != sc0[0]        # both parts ended on the same new scales
+    assert len(raw1) == len(raw0)
+    for f in ("board", "mask", "status", "worker", "game", "ply", "n_children", "chosen", "z", "root_n", "pi"):
+        assert (raw1[f] == raw0[f]).all(), f
+
+
 def test_large_tournament_on_part_batches_equals_one_engine():
     """tournament_Checkers from 2 048 concurrent games on divides them between engines that step on their own HIP streams (as
     generate_Checkers_data does): the game list equals the one of a single engine -- workers are sharded by contiguous id blocks and every

@@ -4,7 +4,7 @@ operands is the LDS traffic of the activation fragments?  Builds libckr with -DC
 dx != 0 are copies of the dx = 0 fragments: 2/3 of the ds_read_b128 gone, nothing in their place) and =2 (derived through a DPP wave
 shift + mask per register: the price of making them in registers) and =3 (every other pair of weight fragments is a register copy: half
 the L2 -> register weight stream) and =4 / 5 / 6 (other orders of the three MFMAs per multiply-add) and =7 (the operands in each other's MFMA slots), and times the float32-grade conv stack on 4 096 boards of random
-planes with each.
+planes with each.  The variants are kept as a patch (tools/x3_probes.patch) that this script applies to a temporary copy of the sources.
 
     python tools/x3_lds_probe.py build     # here (hipcc cross-compiles)
     python tools/x3_lds_probe.py run       # on the GPU: one JSON line per build"""
@@ -15,11 +15,20 @@ sys.path.insert(0, ROOT)
 
 
 def build():
+    """The probe variants live in tools/x3_probes.patch, not in the product source: csrc/ is copied next to a copy of include/,
+    the patch applied there, and one library built per probe."""
+    import shutil, tempfile
     from checkers_mcts_amd import build as ckbuild
     os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="x3probe_")
+    shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+    shutil.copytree(ckbuild.CSRC, os.path.join(tmp, "checkers-mcts_amd", "csrc"))
+    subprocess.check_call(["patch", "-p1", "-d", tmp, "-i", os.path.join(ROOT, "tools", "x3_probes.patch")])
+    srcs = [os.path.join(tmp, "checkers-mcts_amd", "csrc", os.path.basename(f)) for f in ckbuild.sources()]
     for k in (0, 1, 2, 3, 4, 5, 6, 7):
         extra = ["-DCKR_X3_PROBE=%d" % k] if k else []
-        subprocess.check_call([ckbuild.HIPCC] + ckbuild.FLAGS + extra + ckbuild.sources() + ["-o", os.path.join(OUT, "libckr_probe%d.so" % k)])
+        subprocess.check_call([ckbuild.HIPCC] + ckbuild.FLAGS + extra + srcs + ["-o", os.path.join(OUT, "libckr_probe%d.so" % k)])
+    shutil.rmtree(tmp)
 
 
 def run_one(k):
