@@ -18,6 +18,10 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 burn = int(os.environ.get("BURN", "0"))
 burned = [torch.cuda.Stream(device=dev) for _ in range(burn)]
+for st in burned:                     # a stream gets its hardware queue at its first USE (least-used queue at that moment)
+    with torch.cuda.stream(st):
+        torch.zeros(8, device=dev).add_(1)
+torch.cuda.synchronize(dev)
 mode = os.environ.get("MODE", "bf16")
 leg = bench.Leg(a, dev, mode, 0, a.slots, 64, True)
 leg.warmup(3)
