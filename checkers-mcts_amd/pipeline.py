@@ -248,7 +248,9 @@ class StepRunner:
     # expands (~6 positions per slot and expansion not in the cache yet); later leaves are then served by the cache inside the step.
     # (profiles/r04_prefetch_sweep.txt: rows 512 / 1 024, share 3 / 4 / 6, 5 / 8 / 16 simulations per step: 19.03-19.38 s for the
     # bench's run of 16 384 games against 19.78 s without; CKR_PREFETCH=0 switches it off)
-    PREFETCH_ROWS = 512
+    # Round 5 (tools/r05_arena_tail_sweep.sh): 1 024 rows per part instead of 512 -- cfg5's share (800 simulations/move, games up to
+    # 900 plies: a long tail) 79.8 -> 76.6-77.0 s, the bench's self-play run unchanged within its run-to-run spread (18.7-19.0 s)
+    PREFETCH_ROWS = 1024
     PREFETCH_SIMS = 16                                    # network-free simulations per slot and step while it is on
     PREFETCH_SIMS_SOLO = 10                               # ... for an un-split engine (small jobs: the tree kernel's time shows)
     PREFETCH_SHARE = 4                                    # it starts when (slots still playing) x PREFETCH_SHARE fit into the rows

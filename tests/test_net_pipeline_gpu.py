@@ -544,6 +544,42 @@ def test_range_flag_stalls_the_engine_and_recovery_recalibrates(oracle):
     assert np.abs(raw1["q"] - raw0["q"]).max() < 1e-5 and np.abs(raw1["root_w"] - raw0["root_w"]).max() < 1e-3
 
 
+def test_part_batch_streams_own_their_hardware_queues():
+    """pipeline.part_streams: the streams a job's part-batches step on come from ckr_stream_create (a HIP stream with a hardware queue
+    of its own -- two parts on one queue would run their step chains one behind the other, profiles/r05_queue_collision_demo.jsonl),
+    are created once per process and device, and are what SplitRunner uses; kernels launched on them run and synchronise."""
+    import torch
+    from checkers_mcts_amd import pipeline as P, rules
+    dev = torch.device("cuda", 0)
+    a = P.part_streams(dev, 3)
+    b = P.part_streams(dev, 4)
+    assert len({s.cuda_stream for s in b}) == 4 and [s.cuda_stream for s in a] == [s.cuda_stream for s in b[:3]]      # cached, distinct
+    pool = {torch.cuda.Stream(device=dev).cuda_stream for _ in range(40)}                                           # torch's whole pool
+    assert not pool & {s.cuda_stream for s in b}
+    boards = torch.from_numpy(np.array([[0x00000FFF, 0xFFF00000, 0, 1 << 19 | 2]], np.uint32).view(np.int32)).to(dev).repeat(4096, 1).contiguous()
+    outs = []
+    for s in b:
+        with torch.cuda.stream(s):
+            outs.append(rules.movegen(boards)[1])
+    for s in b:
+        s.synchronize()
+    assert all(((o >> 8) & 0xFF == 7).all().item() for o in outs)                   # seven legal opening moves, on every stream
+    kw = dict(KW, BUDGET=8)
+    g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=6, NUM_CPUS=600, NN_FN="random:0", SEED=1), kw)
+    runners = []
+    orig = P.SplitRunner.__init__
+
+    def spy(self, *args, **kwargs):
+        orig(self, *args, **kwargs)
+        runners.append(self)
+    P.SplitRunner.__init__ = spy
+    try:
+        g.generate_tuples()
+    finally:
+        P.SplitRunner.__init__ = orig
+    assert runners and [st.cuda_stream for _, _, st in runners[0].parts] == [s.cuda_stream for s in b[:len(runners[0].parts)]]
+
+
 def test_other_widths_run_on_pytorch_and_say_so():
     """create_nn takes any NUM_KERNELS (training_pipeline.py:56-62); the hand-written MFMA kernels are built for the recorded 128.
     A job with another width -- or with NN_DTYPE float16 -- plays on the PyTorch module and announces the change of backend with a

@@ -9,6 +9,10 @@ import torch
 import bench
 
 if __name__ == "__main__":
+    from checkers_mcts_amd import pipeline as P
+    for name in ("PREFETCH_ROWS", "PREFETCH_SIMS", "PREFETCH_SIMS_SOLO", "PREFETCH_SHARE", "TAIL_ROWS"):      # tuning: TAIL_<NAME>=value
+        if os.environ.get("TAIL_" + name):
+            setattr(P.StepRunner, name, int(os.environ["TAIL_" + name]))
     a = bench.parse()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
