@@ -246,7 +246,7 @@ class MCTS:
     @staticmethod
     def _fusable(net):
         from .net import PolicyValueNet
-        return (isinstance(net, PolicyValueNet) and net.num_kernels == 128 and not net.training
+        return (isinstance(net, PolicyValueNet) and net.num_kernels <= 128 and not net.training
                 and next(net.parameters()).is_cuda)
 
     @classmethod
@@ -276,7 +276,8 @@ class MCTS:
         if cls._runner is None or cls._runner_key != key:
             if fused:
                 from .fused import FusedEvaluator
-                ev = FusedEvaluator(net, cls._engine.rows, mode="f16x3")
+                from .net import widen_to_128
+                ev = FusedEvaluator(widen_to_128(net), cls._engine.rows, mode="f16x3")     # (narrower networks: extra channels exactly zero)
             else:
                 ev = cls._evaluator()
             if cls._engine.can_prefetch:                     # children of expanded nodes evaluated ahead of the search (fused kernels only)

@@ -87,6 +87,40 @@ class PolicyValueNet(nn.Module):
         return self
 
 
+def widen_to_128(net):
+    """A NUM_KERNELS < 128 network (create_nn takes any width, training_pipeline.py:56-62) as a 128-kernel one with the SAME
+    outputs: the extra output channels of every conv block get zero kernels, zero bias and a BatchNorm of gamma 0 / beta 0 (they
+    are exactly 0 after the block), and every layer reads them with zero weights.  Adding exact zeros changes no float32 sum, so the
+    hand-written 128-wide MFMA kernels evaluate the narrow network within the same 1e-5 of float64 as a native 128-wide one -- at
+    the cost of the 128-wide arithmetic.  Returns a new module (eval mode, on net's device); 128-wide networks come back as they are."""
+    K = int(net.num_kernels)
+    if K == 128:
+        return net
+    if K > 128:
+        raise ValueError("widen_to_128: NUM_KERNELS %d does not fit the 128-wide kernels" % K)
+    dev = next(net.parameters()).device
+    wide = PolicyValueNet(128).to(dev).float().eval()
+
+    def block(dst, src):
+        co, ci = src["conv"].weight.shape[:2]
+        with torch.no_grad():
+            dst["conv"].weight.zero_(); dst["conv"].bias.zero_()
+            dst["conv"].weight[:co, :ci] = src["conv"].weight.float(); dst["conv"].bias[:co] = src["conv"].bias.float()
+            dst["bn"].weight.zero_(); dst["bn"].bias.zero_(); dst["bn"].running_mean.zero_(); dst["bn"].running_var.fill_(1.0)
+            dst["bn"].weight[:co] = src["bn"].weight.float(); dst["bn"].bias[:co] = src["bn"].bias.float()
+            dst["bn"].running_mean[:co] = src["bn"].running_mean.float(); dst["bn"].running_var[:co] = src["bn"].running_var.float()
+    for d, s in zip(wide.body, net.body):
+        block(d, s)
+    block(wide.pol1, net.pol1); block(wide.pol2, net.pol2); block(wide.val1, net.val1)
+    with torch.no_grad():
+        for name in ("pol_fc", "val_fc1", "val_bn", "val_fc2"):
+            getattr(wide, name).load_state_dict({k: v.float() for k, v in getattr(net, name).state_dict().items()})
+    for p_ in wide.parameters():
+        p_.requires_grad_(False)
+    wide.widened_from = K
+    return wide.to(memory_format=torch.channels_last) if dev.type != "cpu" else wide
+
+
 def make_net(num_kernels=128, seed=0, device="cuda", dtype=torch.float32):
     net = PolicyValueNet(num_kernels).keras_init(seed).eval()
     net = net.to(device=device, dtype=dtype)

@@ -104,6 +104,12 @@ class EvaluatorPlan:
         first = torch.float32 if want_fused else dtype
         self.new = load_network(spec, device=device, dtype=first)
         self.old = load_network(spec_old, device=device, dtype=first) if spec_old is not None else None
+        # narrower networks (create_nn takes any NUM_KERNELS, training_pipeline.py:56-62) run on the 128-wide kernels with their extra
+        # channels exactly zero (net.widen_to_128: same outputs); wider ones do not fit
+        if want_fused and _widths_at_most_128(self.new, self.old):
+            from .net import widen_to_128
+            self.new = widen_to_128(self.new)
+            self.old = widen_to_128(self.old) if self.old is not None else None
         self.fused = want_fused and _is_128_wide(self.new, self.old)
         self.mode = "bf16" if dtype == torch.bfloat16 else "f16x3"
         if kind == "fused" and not self.fused:
@@ -118,7 +124,7 @@ class EvaluatorPlan:
                                    else "NUM_KERNELS %s" % "/".join(str(w) for w in widths))
             import warnings
             warnings.warn("network inference runs on PyTorch / MIOpen, not on the hand-written gfx950 kernels (%s: they are built for "
-                          "NUM_KERNELS = 128 in float32-grade or bfloat16 mode); results are the PyTorch module's, throughput is several "
+                          "NUM_KERNELS <= 128 in float32-grade or bfloat16 mode); results are the PyTorch module's, throughput is several "
                           "times lower.  EVALUATOR='torch' selects this path explicitly and silences the warning" % self.backend_reason,
                           RuntimeWarning, stacklevel=3)
         if not self.fused and first != dtype:
@@ -136,6 +142,14 @@ class EvaluatorPlan:
 def make_evaluator(spec, device, dtype, n_slots, spec_old=None, kind=None, networks=None):
     """Evaluator for one engine of n_slots (see EvaluatorPlan); accepts planes or board records from the engine."""
     return EvaluatorPlan(spec, device, dtype, spec_old=spec_old, kind=kind, networks=networks).build(n_slots)
+
+
+def _widths_at_most_128(*nets):
+    """True if every network is a PolicyValueNet of at most 128 kernels and at least one is narrower (then widen_to_128 applies)."""
+    nets = [n for n in nets if n is not None]
+    if not nets or not all(isinstance(n, PolicyValueNet) for n in nets):
+        return False
+    return all(n.num_kernels <= 128 for n in nets) and any(n.num_kernels < 128 for n in nets)
 
 
 def _is_128_wide(*specs):

@@ -580,14 +580,17 @@ def test_part_batch_streams_own_their_hardware_queues():
     assert runners and [st.cuda_stream for _, _, st in runners[0].parts] == [s.cuda_stream for s in b[:len(runners[0].parts)]]
 
 
-def test_other_widths_run_on_pytorch_and_say_so():
-    """create_nn takes any NUM_KERNELS (training_pipeline.py:56-62); the hand-written MFMA kernels are built for the recorded 128.
-    A job with another width -- or with NN_DTYPE float16 -- plays on the PyTorch module and announces the change of backend with a
-    RuntimeWarning that names the reason; EVALUATOR='torch' selects that path on purpose, silently; 128 kernels warn about nothing."""
+def test_other_widths_never_change_backend_silently(oracle):
+    """create_nn takes any NUM_KERNELS (training_pipeline.py:56-62); the hand-written MFMA kernels are 128 channels wide.  Narrower
+    networks run on them with their extra channels exactly zero (net.widen_to_128: the same outputs) -- pi, v within 1e-5 of the
+    float64 restatement of the NARROW network, through FusedEvaluator -- and a whole job plays on them.  Wider networks, and NN_DTYPE
+    float16, play on the PyTorch module and announce the change of backend with a RuntimeWarning that names the reason;
+    EVALUATOR='torch' selects that path on purpose, silently; 128 kernels warn about nothing."""
     import warnings
     import torch
-    from checkers_mcts_amd import net as N, pipeline as P
-    from checkers_mcts_amd.fused import FusedEvaluator
+    import net_ref
+    from checkers_mcts_amd import net as N, pipeline as P, rules
+    from checkers_mcts_amd.fused import FusedEvaluator, calibration_boards
     dev = torch.device("cuda", 0)
 
     def plan(net, dtype=torch.float32, kind=None):
@@ -596,25 +599,39 @@ def test_other_widths_run_on_pytorch_and_say_so():
             pl = P.EvaluatorPlan(net, dev, dtype, kind=kind)
         return pl, [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning)]
 
-    for width in (64, 256):
-        pl, msgs = plan(N.make_net(width, seed=1, device=dev))
-        assert not pl.fused and len(msgs) == 1 and "NUM_KERNELS %d" % width in msgs[0] and "PyTorch" in msgs[0]
-        assert pl.backend_reason == "NUM_KERNELS %d" % width and isinstance(pl.build(8), N.NetEvaluator)
+    for width in (64, 96):
+        m = N.PolicyValueNet(width).keras_init(width).perturb_bn(3).eval().to(dev)
+        pl, msgs = plan(m)
+        assert pl.fused and msgs == [] and pl.new.num_kernels == 128 and pl.new.widened_from == width
+        ev = pl.build(256)
+        assert isinstance(ev, FusedEvaluator)
+        boards = calibration_boards(256, dev, seed=11).contiguous()
+        x = rules.features(boards)
+        p, v = ev.forward_features(x.contiguous())
+        rp, rv = net_ref.forward({k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}, x.cpu().numpy())
+        assert np.abs(p.cpu().numpy() - rp).max() < 1e-5 and np.abs(v.cpu().numpy() - rv.reshape(-1)).max() < 1e-5, width
+    pl, msgs = plan(N.make_net(256, seed=1, device=dev))
+    assert not pl.fused and len(msgs) == 1 and "NUM_KERNELS 256" in msgs[0] and "PyTorch" in msgs[0]
+    assert pl.backend_reason == "NUM_KERNELS 256" and isinstance(pl.build(8), N.NetEvaluator)
     pl, msgs = plan(N.make_net(128, seed=1, device=dev), dtype=torch.float16)
     assert not pl.fused and len(msgs) == 1 and "float16" in msgs[0]
-    pl, msgs = plan(N.make_net(64, seed=1, device=dev), kind="torch")
+    pl, msgs = plan(N.make_net(256, seed=1, device=dev), kind="torch")
     assert not pl.fused and msgs == []
     pl, msgs = plan(N.make_net(128, seed=1, device=dev))
     assert pl.fused and msgs == [] and pl.backend_reason is None and isinstance(pl.build(8), FusedEvaluator)
     with pytest.raises(ValueError, match="128-kernel"):
-        P.EvaluatorPlan(N.make_net(64, seed=1, device=dev), dev, torch.float32, kind="fused")
-    # a whole (tiny) job through the drop-in class on a 64-kernel network: it plays, and warns
+        P.EvaluatorPlan(N.make_net(256, seed=1, device=dev), dev, torch.float32, kind="fused")
+    # whole (tiny) jobs through the drop-in class: 64 kernels on the hand-written path (no warning), 256 on PyTorch (warns)
     kw = dict(KW, BUDGET=8)
-    g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=12, NUM_CPUS=4, NN_FN=N.make_net(64, seed=2, device=dev),
-                                      SEED=1), kw)
-    with pytest.warns(RuntimeWarning, match="NUM_KERNELS 64"):
-        tup = g.generate_tuples()
-    assert tup.shape[0] >= 4 * 12
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=12, NUM_CPUS=4,
+                                          NN_FN=N.make_net(64, seed=2, device=dev), SEED=1), kw)
+        assert g.generate_tuples().shape[0] >= 4 * 12
+    g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=12, NUM_CPUS=4,
+                                      NN_FN=N.make_net(256, seed=2, device=dev), SEED=1), kw)
+    with pytest.warns(RuntimeWarning, match="NUM_KERNELS 256"):
+        assert g.generate_tuples().shape[0] >= 4 * 12
 
 
 def test_range_flag_recovery_recalibrates_every_part_of_a_job():
