@@ -88,7 +88,8 @@ struct Args {
 __device__ __forceinline__ int act_addr(int r, int ks) { return r * AROW + ((ks ^ (r & 15)) << 4); }
 
 struct AF { f16x8 h, l; };                                       // this lane's A fragment (32 channels x 16 k): hi, lo
-template <int PT> struct BF { f16x8 h[PT], l[PT]; };             // B fragments of the wave's position tiles
+template <int PT> struct BH { f16x8 h[PT]; };                   // hi B fragments of the wave's position tiles (double-buffered)
+template <int PT> struct BL { f16x8 l[PT]; };                   // lo B fragments (ONE buffer: see run_layer)
 
 // A fragments of global slot g: two fully coalesced 1-KB loads per wave (buffer addressing: the slot offset
 // lives in an SGPR, hi / lo are immediate offsets)
@@ -100,31 +101,38 @@ __device__ __forceinline__ void load_a(__amdgpu_buffer_rsrc_t rsrc, int voff, in
 }
 
 // the slot's 16 input channels are k-slots 2*c8 and 2*c8 + 1 of an activation row; rowaddr = act_addr(row, half)
-template <int PT> __device__ __forceinline__ void load_b(const char* __restrict__ act, int c8, const int (&rowaddr)[PT], BF<PT>& f) {
+template <int PT> __device__ __forceinline__ void load_bh(const char* __restrict__ act, int c8, const int (&rowaddr)[PT], BH<PT>& f) {
     const int kc = (2 * c8) << 4;
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        f.h[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc));
-        f.l[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc) + LO);
-    }
+    for (int pt = 0; pt < PT; ++pt) f.h[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc));
+}
+template <int PT> __device__ __forceinline__ void load_bl(const char* __restrict__ act, int c8, const int (&rowaddr)[PT], BL<PT>& f) {
+    const int kc = (2 * c8) << 4;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) f.l[pt] = *reinterpret_cast<const f16x8*>(act + (rowaddr[pt] ^ kc) + LO);
 }
 
-template <int PT> __device__ __forceinline__ void mfma_block(const AF& a, const BF<PT>& b, f32x16 (&acc)[PT]) {
-    // wh xh for the wave's position tiles, then wh xl, then wl xh: the weight fragment stays in the A slot for eight consecutive MFMAs
-    // (the cheapest of the orders and operand assignments measured: profiles/r04_x3_lds_probe.txt, tools/x3_probes.patch)
+// The three products of a k-chunk, in the order the matrix pipe runs cheapest (profiles/r04_x3_lds_probe.txt, tools/x3_probes.patch):
+// wh xh for the wave's position tiles, then wh xl, then wl xh -- the weight fragment stays in the A slot for eight consecutive MFMAs.
+template <int PT> __device__ __forceinline__ void mfma_hh(const AF& a, const BH<PT>& b, f32x16 (&acc)[PT]) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h[pt], acc[pt], 0, 0, 0);
+}
+template <int PT> __device__ __forceinline__ void mfma_hl(const AF& a, const BL<PT>& b, f32x16 (&acc)[PT]) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l[pt], acc[pt], 0, 0, 0);
+}
+template <int PT> __device__ __forceinline__ void mfma_lh(const AF& a, const BH<PT>& b, f32x16 (&acc)[PT]) {
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h[pt], acc[pt], 0, 0, 0);
 }
 
-// one k-chunk: 12 MFMAs with the next chunk's 8 ds_read_b128 and the two weight loads of the chunk RING - 1 ahead
-// spread between them
+// one k-chunk = 3 PT MFMAs: the first PT (wh xh) with the next chunk's PT hi-fragment reads between them, the middle PT (wh xl)
+// with the two weight loads of the chunk RING - 1 ahead, the last PT (wl xh) with the next chunk's PT lo-fragment reads -- which
+// overwrite the ONE lo buffer the middle MFMAs have just consumed
 template <int PT> __device__ __forceinline__ void interleave() {
 #pragma unroll
-    for (int i = 0; i < 2 * PT; ++i) {
+    for (int i = 0; i < PT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
     }
@@ -133,7 +141,12 @@ template <int PT> __device__ __forceinline__ void interleave() {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // 1 VMEM read
     }
-    if constexpr (PT > 2) __builtin_amdgcn_sched_group_barrier(0x008, 3 * PT - 2 * PT - 2, 0);
+    if constexpr (PT > 2) __builtin_amdgcn_sched_group_barrier(0x008, PT - 2, 0);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
 }
 
 // Row addresses (k-slot `half`) of the B-tile rows this lane reads for tap (dy, dx); out-of-board taps read the
@@ -249,18 +262,28 @@ __device__ __forceinline__ void run_layer(const Args& A, int l, char* act, float
     }
     // the wave's own 32 channels of the BatchNorm constants: written and read by this wave only (no barrier)
     if (lane < 32) { prm[32 * wc + lane] = L.scale[32 * wc + lane]; prm[128 + 32 * wc + lane] = L.shift[32 * wc + lane]; }
-    BF<PT> b0, b1;
+    // hi fragments double-buffered, lo fragments in ONE buffer (round 5: 16 VGPRs less -- 192 instead of 208, so that two waves of
+    // this kernel leave a 128-register tree-kernel wave room on their SIMD): the lo fragments are consumed by the middle third of a
+    // chunk's MFMAs only, and the next chunk's are read during the last third -- two thirds of a chunk (> 250 cycles) before their use
+    BH<PT> b0, b1;
+    BL<PT> bl;
     int rowaddr[PT];
     tap_rows(prow0, 0, half, rowaddr);
-    load_b(act, 0, rowaddr, b0);
+    load_bh(act, 0, rowaddr, b0);
+    load_bl(act, 0, rowaddr, bl);
     __builtin_amdgcn_sched_barrier(0);
-    auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BF<PT>& bc, BF<PT>& bn) {
+    auto step = [&](int s, int tap, int c8, const AF& ac, AF& apf, const BH<PT>& bc, BH<PT>& bn) {
         load_a(rsrc, voff, g0 + s + RING - 1, apf);               // beyond the layer: the next layer's first slots / the padding
-        if (s + 1 < NSLOTS) {
+        const bool more = s + 1 < NSLOTS;
+        const int nc8 = c8 == CPT - 1 ? 0 : c8 + 1;
+        if (more) {
             if (c8 == CPT - 1) tap_rows(prow0, tap + 1, half, rowaddr);
-            load_b(act, c8 == CPT - 1 ? 0 : c8 + 1, rowaddr, bn);
+            load_bh(act, nc8, rowaddr, bn);
         }
-        mfma_block<PT>(ac, bc, acc);
+        mfma_hh<PT>(ac, bc, acc);
+        mfma_hl<PT>(ac, bl, acc);
+        if (more) load_bl(act, nc8, rowaddr, bl);
+        mfma_lh<PT>(ac, bc, acc);
         interleave<PT>();
     };
     if constexpr (CPT == 1) {
@@ -375,7 +398,12 @@ __device__ __forceinline__ void conv_stack_body(const Args& A, char* smem, const
     }
 }
 
-__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3(const Args A) {
+// 192 VGPRs (amdgpu_num_vgpr counts the architectural half of the unified file: 96 = 192 of 512): two waves of this kernel and ONE
+// 128-register wave of the tree kernel fit on a SIMD (2 x 192 + 128 = 512; LDS 2 x 71 296 + 18 680 <= 163 840), so a tree-kernel
+// workgroup can start beside two resident conv workgroups instead of waiting for one to retire.  The allocator keeps two values of
+// the kernel's prologue in scratch for it (two 16-byte stores before the first MFMA, two loads after the first layer): nothing in a loop.
+#define CKR_X3_VGPRS __attribute__((amdgpu_num_vgpr(96)))
+__global__ __launch_bounds__(NT, 2) CKR_X3_VGPRS void k_conv_stack_x3(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[Cfg<2>::LDS_BYTES];
     conv_stack_body<2>(A, smem, blockIdx.x);
 }
@@ -387,7 +415,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_small(const Args A) {
 // (each share is a device-side board range: tiles outside it exit at once, as in two launches) -- in a small tournament either
 // launch alone covers a fraction of the chip, and the step is as long as one of them instead of both.
 struct ArgsPair { Args net[2]; };
-__global__ __launch_bounds__(NT, 2) void k_conv_stack_x3_pair(const ArgsPair P, const unsigned tiles) {
+__global__ __launch_bounds__(NT, 2) CKR_X3_VGPRS void k_conv_stack_x3_pair(const ArgsPair P, const unsigned tiles) {
     __shared__ __attribute__((aligned(16))) char smem[Cfg<2>::LDS_BYTES];
     const unsigned second = blockIdx.x >= tiles ? 1u : 0u;
     conv_stack_body<2>(P.net[second], smem, blockIdx.x - second * tiles);
