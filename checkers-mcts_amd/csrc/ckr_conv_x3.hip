@@ -376,9 +376,7 @@ __device__ __forceinline__ void conv_stack_body(const Args& A, char* smem, const
         if (A.overflow && amax > 60000.0f) *A.overflow = 1;
     }
     lds_barrier();
-    for (int l = 0; l < A.n_layers; ++l) {
-        if (l == 0) run_layer<PT, 1, 0>(A, l, act, prm, rsrc, voff, 0, ring, wc, lane);
-        else run_layer<PT, 8, 9 % RING>(A, l, act, prm, rsrc, voff, 9 + 72 * (l - 1), ring, wc, lane);
+    auto after_layer = [&](int l) {
         float* out = A.L[l].out;
         if (out) {                                                // (tests) activation * XS as float32
             float* dst = out + board0 * 64 * 128;
@@ -395,13 +393,25 @@ __device__ __forceinline__ void conv_stack_body(const Args& A, char* smem, const
                 head_1x1<8>(act, stage, A.H.pol_w, A.H.pol_b, A.H.pol_scale, A.H.pol_shift,
                             A.H.pol_out, board0, rows_valid, tid, A.inv_xs_pol);
         }
+    };
+    // the first layer (14 planes in one 16-channel slice per tap) stands in front of the loop over the 128-channel layers: inside one
+    // loop the two instantiations' weight-ring registers met in a phi that the 192-register allocation resolved through scratch memory
+    // (two 16-byte values per lane stored and re-loaded per workgroup: +16 MB of L2 <-> fabric traffic per 880-row launch)
+    if (A.n_layers > 0) {
+        run_layer<PT, 1, 0>(A, 0, act, prm, rsrc, voff, 0, ring, wc, lane);
+        after_layer(0);
+    }
+    for (int l = 1; l < A.n_layers; ++l) {
+        run_layer<PT, 8, 9 % RING>(A, l, act, prm, rsrc, voff, 9 + 72 * (l - 1), ring, wc, lane);
+        after_layer(l);
     }
 }
 
-// 192 VGPRs (amdgpu_num_vgpr counts the architectural half of the unified file: 96 = 192 of 512): two waves of this kernel and ONE
-// 128-register wave of the tree kernel fit on a SIMD (2 x 192 + 128 = 512; LDS 2 x 71 296 + 18 680 <= 163 840), so a tree-kernel
-// workgroup can start beside two resident conv workgroups instead of waiting for one to retire.  The allocator keeps two values of
-// the kernel's prologue in scratch for it (two 16-byte stores before the first MFMA, two loads after the first layer): nothing in a loop.
+
+// At most 192 VGPRs (amdgpu_num_vgpr counts the architectural half of the unified file: 96 = 192 of 512; the kernel needs 188, nothing
+// in scratch): two waves of this kernel and ONE 128-register wave of the tree kernel fit on a SIMD (2 x 192 + 128 = 512; LDS
+// 2 x 71 296 + 18 680 <= 163 840), so a tree-kernel workgroup can start beside two resident conv workgroups instead of waiting for
+// one to retire.
 #define CKR_X3_VGPRS __attribute__((amdgpu_num_vgpr(96)))
 __global__ __launch_bounds__(NT, 2) CKR_X3_VGPRS void k_conv_stack_x3(const Args A) {
     __shared__ __attribute__((aligned(16))) char smem[Cfg<2>::LDS_BYTES];
