@@ -1307,12 +1307,12 @@ __global__ __launch_bounds__(256) void k_prefetch_consume(const Dev* __restrict_
 // One lock-step simulation for every slot (see ckr_engine_step in ckr.h).
 // end_ply != 0 (CONSTRAINT == 'time', MCTS.py:196-198: the wall-clock budget of the running searches is used up): every
 // searching slot completes its simulation in flight and then ends its ply as if its rollout budget were reached.
-// 127 VGPRs, nothing spilled, 4 waves per SIMD: every slot of a 4 096-slot engine is resident at once.  (Round 3's build needed
-// 168: the OCML double-precision pow() of the sampling paths, a callee, set the allocation.  At 96 VGPRs -- which would let a
-// wave share a SIMD with the two 208-VGPR waves of the float32-grade conv stack -- 48 values spill, and an A/B on one box
-// showed no gain from the co-residency: profiles/r04_kstep_launch_bounds.txt.)  The wave's handle `w` must never have its address
-// taken on the hot path (real calls get a copy) nor be indexed dynamically: either pins it to scratch memory, ~300 scratch
-// loads in this kernel.
+// 128 VGPRs, 4 waves per SIMD: every slot of a 4 096-slot engine is resident at once, and ONE wave fits on a SIMD beside two waves of
+// the float32-grade conv stack (188 VGPRs each since round 5, ckr_conv_x3.hip): a workgroup of this kernel starts beside two resident
+// conv workgroups of a CU (LDS: 2 x 71 296 + 18 680 B) instead of waiting for one to retire -- profiles/r05_conv_192_vgprs.txt.  (At 96
+// VGPRs, which the 208-register conv kernel of rounds 2-4 would have needed, 48-86 values spill: profiles/r04_kstep_launch_bounds.txt,
+// r05_coresidency_probe.txt.)  The wave's handle `w` must never have its address taken on the hot path (real calls get a copy) nor be
+// indexed dynamically: either pins it to scratch memory, ~300 scratch loads in this kernel.
 template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const Dev* __restrict__ Dp, const float* __restrict__ p,
                                               const float* __restrict__ v, void* x, int32_t* net_out, int flags) {
     const Dev& D = *Dp;
