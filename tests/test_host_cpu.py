@@ -134,3 +134,28 @@ def test_bench_refuses_world_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_rank_placement_divides_the_cores_between_ranks():
+    """dist.pin_to_gpu without a GPU: every rank of a node gets an equal, disjoint share of the cores the process may use (the
+    reference gives every worker process a core of its own, training_pipeline.py:325-329; here a rank is one graph-replaying
+    thread and must not wander between sockets).  CKR_NO_PIN=1: the share is reported, the affinity left alone."""
+    from checkers_mcts_amd import dist as ckdist
+    assert ckdist._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and ckdist._parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    os.environ["CKR_NO_PIN"] = "1"
+    try:
+        world = min(4, len(before))
+        shares = [ckdist.pin_to_gpu(r, world) for r in range(world)]
+    finally:
+        os.environ.pop("CKR_NO_PIN")
+    assert os.sched_getaffinity(0) == before                            # report only
+    assert all(s["pinned"] is False and s["cpus"] >= 1 and s["first_cpu"] <= s["last_cpu"] for s in shares)
+    assert sum(s["cpus"] for s in shares) <= len(before)
+    firsts = [s["first_cpu"] for s in shares]
+    assert firsts == sorted(firsts) and len(set(firsts)) == world        # disjoint, in rank order
+    try:
+        info = ckdist.pin_to_gpu(0, 1)
+        assert info["pinned"] is True and len(os.sched_getaffinity(0)) == info["cpus"]
+    finally:
+        os.sched_setaffinity(0, before)
