@@ -984,6 +984,34 @@ class RoundRobinEvaluator:
         return p.contiguous(), v.contiguous()
 
 
+class RoundRobinFusedEvaluator(RoundRobinEvaluator):
+    """The same with every network in the hand-written float32-grade kernels (fused.FusedEvaluator per model; networks narrower than
+    128 kernels zero-padded, net.widen_to_128): each model evaluates the batch of board records, and every row keeps the output of
+    the model that owns its leaf.  A round-robin is a handful of games: the M conv launches per step are latency, not throughput."""
+
+    def __init__(self, nets, model_of, rows):
+        from .fused import FusedEvaluator
+        from .net import widen_to_128
+        self.evs = [FusedEvaluator(widen_to_128(n), rows, mode="f16x3") for n in nets]
+        self.model_of = model_of
+
+    def check_range(self):
+        """The operand-range assertion of every model's kernels (StepRunner.check_evaluator calls it between steps)."""
+        for ev in self.evs:
+            ev.check_range()
+
+    @torch.no_grad()
+    def __call__(self, engine):
+        which = self.model_of.gather(1, engine.net_id.clamp(min=0).long()[:, None])[:, 0]
+        p, v = self.evs[0](engine)
+        for m in range(1, len(self.evs)):
+            pm, vm = self.evs[m](engine)
+            sel = which == m
+            p = torch.where(sel[:, None], pm, p)
+            v = torch.where(sel, vm, v)
+        return p.contiguous(), v.contiguous()
+
+
 class final_evaluation:
     """Round-robin between the models of several training iterations: every pair plays
     two games, one with each colour (reference: training_pipeline.py:603-718).  All pairs
@@ -1028,14 +1056,23 @@ class final_evaluation:
         tk = self.tourney_kwargs
         dtype = tk.get("NN_DTYPE", torch.float32)
         dev = torch.device("cuda", torch.cuda.current_device())
+        nets = [load_network(self._spec(fn), device=dev, dtype=dtype, networks=tk.get("NETWORKS")) for fn in self.model_fn_list]
+        # the hand-written float32-grade kernels where they apply (as in tournament_Checkers); otherwise the PyTorch modules, announced
+        fused = (dtype == torch.float32 and tk.get("EVALUATOR") != "torch"
+                 and all(isinstance(n, PolicyValueNet) and n.num_kernels <= 128 for n in nets))
+        if not fused and tk.get("EVALUATOR") != "torch" and not all(isinstance(n, HashNet) for n in nets):
+            import warnings
+            warnings.warn("final_evaluation: network inference runs on PyTorch / MIOpen, not on the hand-written gfx950 kernels (they take "
+                          "float32 networks of at most 128 kernels); EVALUATOR='torch' selects this path explicitly", RuntimeWarning, stacklevel=2)
+        fdt = ckengine.BOARDS if fused else dtype
         cfg = ckengine.config_from_kwargs(
-            self.mcts_kwargs, n_slots=len(pairs), games_per_slot=2, tournament=True, feature_dtype=dtype,
+            self.mcts_kwargs, n_slots=len(pairs), games_per_slot=2, tournament=True, feature_dtype=fdt,
             nodes_per_tree=tk.get("NODES_PER_TREE"), seed=tk.get("SEED", int.from_bytes(os.urandom(4), "little")),
             device=dev.index)
-        eng = ckengine.Engine(cfg, feature_dtype=dtype)
-        nets = [load_network(self._spec(fn), device=dev, dtype=dtype, networks=tk.get("NETWORKS")) for fn in self.model_fn_list]
+        eng = ckengine.Engine(cfg, feature_dtype=fdt)
         model_of = torch.tensor(pairs, dtype=torch.long, device=dev)
-        StepRunner(eng, RoundRobinEvaluator(nets, model_of), use_graph=tk.get("USE_GRAPH", True)).run_to_completion()
+        ev = RoundRobinFusedEvaluator(nets, model_of, eng.rows) if fused else RoundRobinEvaluator(nets, model_of)
+        StepRunner(eng, ev, use_graph=tk.get("USE_GRAPH", True)).run_to_completion()
         self.stats = eng.stats()
         res = eng.results()
         eng.close()
