@@ -280,6 +280,12 @@ class MCTS:
                 ev = FusedEvaluator(widen_to_128(net), cls._engine.rows, mode="f16x3")     # (narrower networks: extra channels exactly zero)
             else:
                 ev = cls._evaluator()
+                from .net import PolicyValueNet
+                if isinstance(net, PolicyValueNet) and cls._evaluator_kind != "torch":      # never a silent change of backend
+                    import warnings
+                    warnings.warn("MCTS: this PolicyValueNet is evaluated by PyTorch / MIOpen, not by the hand-written gfx950 kernels (they "
+                                  "take networks of at most 128 kernels, in eval() mode, on the GPU); EVALUATOR='torch' in the MCTS kwargs "
+                                  "selects this path explicitly", RuntimeWarning, stacklevel=3)
             if cls._engine.can_prefetch:                     # children of expanded nodes evaluated ahead of the search (fused kernels only)
                 if fused and cls._engine.rows > 1:
                     cls._engine.set_prefetch(1, cls._engine.rows, cls.LOOKAHEAD_SIMS)

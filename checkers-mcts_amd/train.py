@@ -309,6 +309,11 @@ def train_nn(training_data, neural_network, **kwargs):
                                                      and BATCH_SIZE % 2 == 0) else "torch")
     if backend == "hip" and n_train < BATCH_SIZE:
         backend = "torch"               # fewer rows than one batch: every step would take the torch path and leave the HIP weights untouched
+    if backend == "torch" and "TRAIN_BACKEND" not in kwargs and dev.type == "cuda":
+        import warnings                 # never a silent change of backend (as for inference: pipeline.EvaluatorPlan)
+        warnings.warn("train_nn: the optimisation step runs on PyTorch autograd / MIOpen, not on the hand-written kernels of ckr_train.hip "
+                      "(they take the 128-kernel network in float32, an even BATCH_SIZE and at least one full batch of rows); "
+                      "TRAIN_BACKEND='torch' selects this path explicitly", RuntimeWarning, stacklevel=2)
     hip = None
     if backend == "hip":
         from .train_hip import HipTrainStep
