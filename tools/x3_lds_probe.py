@@ -11,6 +11,7 @@ planes with each.  The variants are kept as a patch (tools/x3_probes.patch) that
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "build", "x3probe")
+PROBED_REVISION = "a234e69"          # the commit that moved the probes out of csrc/ckr_conv_x3.hip: tools/x3_probes.patch applies to its file
 sys.path.insert(0, ROOT)
 
 
@@ -23,6 +24,10 @@ def build():
     tmp = tempfile.mkdtemp(prefix="x3probe_")
     shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
     shutil.copytree(ckbuild.CSRC, os.path.join(tmp, "checkers-mcts_amd", "csrc"))
+    # the probes were written for the 208-VGPR kernel of rounds 2-4 (both activation-fragment halves double-buffered): the patch
+    # applies to that revision of the conv stack's source, taken from the repository's history; the other sources are today's
+    x3 = subprocess.check_output(["git", "-C", ROOT, "show", PROBED_REVISION + ":checkers-mcts_amd/csrc/ckr_conv_x3.hip"])
+    open(os.path.join(tmp, "checkers-mcts_amd", "csrc", "ckr_conv_x3.hip"), "wb").write(x3)
     subprocess.check_call(["patch", "-p1", "-d", tmp, "-i", os.path.join(ROOT, "tools", "x3_probes.patch")])
     srcs = [os.path.join(tmp, "checkers-mcts_amd", "csrc", os.path.basename(f)) for f in ckbuild.sources()]
     for k in (0, 1, 2, 3, 4, 5, 6, 7):
