@@ -563,6 +563,36 @@ def arena_leg(a, dev):
                     "AND network; pipeline.tournament_Checkers as a user calls it"}
 
 
+def small_jobs_leg(a, dev):
+    """The reference's own job sizes (train_Checkers.py:180-186: tournaments of a few hundred games; self-play batches of 50-1 600):
+    a 400-game tournament and a 128-game self-play batch at 200 simulations/move through the drop-in classes, wall seconds of the
+    whole call (engine creation, calibration, every game to its end).  The chip is never full there: every step is one latency-bound
+    chain tree kernel -> conv stack -> heads, and the batch's spare rows evaluate children ahead of the search."""
+    import zlib
+    from checkers_mcts_amd import pipeline as P
+    kw = dict(MCTS_KWARGS, BUDGET=200, TRAINING=False, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    kw2 = dict(MCTS_KWARGS, BUDGET=200)
+
+    def tournament(n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        t = P.tournament_Checkers(dict(TOURNEY_GAMES=1, NUM_CPUS=n, NEW_NN_FN="random:0", OLD_NN_FN="random:1", SEED=5), dict(kw))
+        out = t._start_tournament()
+        torch.cuda.synchronize(dev)
+        return {"games": n, "seconds": time.perf_counter() - t0, "steps": t.stats["steps"], "plies": int(sum(o[4] for o in out)),
+                "game_list_crc32": zlib.crc32(repr(out).encode())}
+    tournament(64)                                         # code objects, first calibration
+    res = {"tournament_400_games": tournament(400), "budget": 200, "dtype": DTYPE_LABEL["fp32"]}
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=TERMINATE_CNT, NUM_CPUS=128, NN_FN="random:0", SEED=3), kw2)
+    tup = g.generate_tuples()
+    torch.cuda.synchronize(dev)
+    res["selfplay_128_games"] = {"games": 128, "seconds": time.perf_counter() - t0, "steps": g.stats["steps"], "tuples": int(tup.shape[0])}
+    P.release_caches()
+    return res
+
+
 def single_game_leg(a, dev):
     """The reference's own mode of use -- ONE game, one search at a time (play_Checkers.py, MCTS.begin_tree_search): the latency
     of a simulation when nothing can be batched.  One slot, float32-grade network, BUDGET 400 (play_Checkers.py:73)."""
@@ -914,6 +944,7 @@ def main():
             extra["bf16_throughput_mode" if other == "bf16" else "fp32_grade_mode"] = throughput_leg(a, dev, other)
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
             extra["random_rollout_mode"] = rollout_leg(a, dev)
+            extra["small_jobs"] = small_jobs_leg(a, dev)
             extra["single_game_search"] = single_game_leg(a, dev)
             extra["training_step"] = training_leg(dev)
             extra["training_step_batch_1024"] = training_leg(dev, batch=1024, reps=10)

@@ -182,16 +182,33 @@ def network_width(path):
     return int(sd["body.0.conv.weight"].shape[0])
 
 
+def _on_runner_stream(method):
+    """StepRunner methods run with the runner's own stream as torch's current stream (Engine / evaluator launches take it from there)."""
+    import functools
+
+    @functools.wraps(method)
+    def on_stream(self, *args, **kwargs):
+        with torch.cuda.stream(self.stream):
+            return method(self, *args, **kwargs)
+    return on_stream
+
+
 class StepRunner:
     """Drives engine + evaluator; the per-step launch sequence (tree kernel,
     network kernels, output copies) is captured once into a HIP graph and
     replayed, so the host only issues one graph launch per simulation step."""
 
-    def __init__(self, eng, evaluator, use_graph=True, time_budget=None):
+    def __init__(self, eng, evaluator, use_graph=True, time_budget=None, stream=None):
         """time_budget (seconds; CONSTRAINT == 'time', MCTS.py:196-198, for engines created with device_clock=False: ONE host
         clock for all slots): run_to_completion searches every ply for that long and then ends the plies of all slots in one step
         (Engine.step(end_ply=True)).  Engines with ckr_config.time_budget_us time every search themselves: time_budget None."""
         self.eng, self.evaluator, self.use_graph, self.time_budget = eng, evaluator, use_graph, time_budget
+        # The runner's steps are issued on a stream that owns its hardware queue (part_streams), never on the process's default
+        # stream: the streams of ckr_stream_create are ordinary ("blocking") HIP streams, and once one exists every launch on the
+        # DEFAULT stream synchronises with all of them -- a 400-game tournament stepping on the default stream took 10.4 s in a process
+        # that had played a split job before, 6.5 s in a fresh one (round 5).  Work the caller issued on the default stream before
+        # (engine creation, weight packing) is ordered in front of this stream's by the same rule.
+        self.stream = stream if stream is not None else part_streams(eng.device, 1)[0]
         S = getattr(eng, "rows", eng.cfg.n_slots)                  # rows of the network batch (>= one per slot)
         self.p = torch.zeros((S, 512), dtype=torch.float32, device=eng.device)
         self.v = torch.zeros((S,), dtype=torch.float32, device=eng.device)
@@ -203,6 +220,7 @@ class StepRunner:
         if flag is not None:
             eng.set_eval_flag(flag)
 
+    @_on_runner_stream
     def check_evaluator(self):
         """Between steps: if the evaluator's range flag is up (an activation beyond the calibrated operand scales of the float32-grade
         kernels), widen the scales and re-evaluate the batch (FusedEvaluator.recover), forget the leaf cache's records (computed
@@ -269,6 +287,7 @@ class StepRunner:
     PREFETCH_SIMS_SOLO = 10                               # ... for an un-split engine (small jobs: the tree kernel's time shows)
     PREFETCH_SHARE = 4                                    # it starts when (slots still playing) x PREFETCH_SHARE fit into the rows
 
+    @_on_runner_stream
     def tail_mode(self, active):
         """The tail of a dense-rows run, decided from the number of slots that still play (it never grows once the work queue is
         empty): <= TAIL_ROWS slots -> the evaluator launches for TAIL_ROWS boards (low-latency kernel); once PREFETCH_SHARE rows per
@@ -302,6 +321,7 @@ class StepRunner:
             return self.set_row_cap(self.TAIL_ROWS)
         return False
 
+    @_on_runner_stream
     def set_row_cap(self, cap, force=False):
         """The tail of a run: at most `cap` rows of the batch can be in use from now on (dense rows: a step's leaves occupy rows
         [0, number of leaves) and no more slots play than that).  The evaluator launches its kernels for that many boards and
@@ -318,6 +338,7 @@ class StepRunner:
                 self.warmup(0)
         return True
 
+    @_on_runner_stream
     def end_tail(self):
         """The run is over: whole batches again (a runner may be stepped further, e.g. by a test)."""
         if getattr(self, "_tail_state", None) and self._tail_state[0] == "prefetch":
@@ -327,6 +348,7 @@ class StepRunner:
         self._tail_state = None
         self.set_row_cap(None)
 
+    @_on_runner_stream
     def warmup(self, n=3):
         for _ in range(n):
             self._eager_step()
@@ -347,6 +369,7 @@ class StepRunner:
             self.captures = getattr(self, "captures", 0) + 1
             self.capture_seconds = getattr(self, "capture_seconds", 0.0) + (time.perf_counter() - t_cap)
 
+    @_on_runner_stream
     def step(self, n=1):
         if self.graph is None and self.use_graph:
             self.warmup()
@@ -357,6 +380,7 @@ class StepRunner:
             else:
                 self._eager_step()
 
+    @_on_runner_stream
     def run_to_completion(self, check_every=50, compact_tail=True, trace=None):
         """Steps until every game is over.  Tail handling: once fewer slots are active than the
         batch has rows (by more than ~3 %), the active slots are moved to the front of the batch
@@ -483,9 +507,8 @@ class SplitRunner:
                 streams = part_streams(eng.device, n_parts)         # one hardware queue per part
             stream = streams[i]
             with torch.cuda.stream(stream):
-                runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph)
+                runner = StepRunner(eng, make_evaluator(slots), use_graph=use_graph, stream=stream)
             runner.solo = False                              # the parts share the chip: smaller lookahead batches (tail_mode)
-            runner.stream = stream
             if hasattr(runner.evaluator, "two_streams") and os.environ.get("CKR_ARENA_STREAMS") != "parts":   # arena: the two networks' launches stay on the part's one stream -- the other
                 runner.evaluator.two_streams = False         # parts' steps already run beside them, and each part's graph stays a chain
             self.parts.append((eng, runner, stream))

@@ -35,6 +35,9 @@ def render(path=LINE):
          "**%.1f s, %.2f M simulations/s over the whole share** (new / old / draws %d / %d / %d); %.1f M simulations/s in mid-game while every slot plays"
          % (ar["whole_share"]["seconds"], ar["whole_share"]["sims_per_s"] / 1e6, ar["whole_share"]["new_net_wins"], ar["whole_share"]["old_net_wins"],
             ar["whole_share"]["draws"], ar["mid_game_window"]["sims_per_s"] / 1e6)),
+        ("small jobs through the drop-in classes, 200 sims/move (`extra.small_jobs`: the reference's own job sizes)",
+         "tournament of 400 games **%.1f s**, self-play batch of 128 games %.1f s (whole calls, engine creation and calibration included)"
+         % (e["small_jobs"]["tournament_400_games"]["seconds"], e["small_jobs"]["selfplay_128_games"]["seconds"])),
         ("one game, one search at a time (`MCTS.begin_tree_search`)", "%.0f k simulations/s, %.1f ms per 400-simulation search"
          % (e["single_game_search"]["sims_per_s"] / 1e3, e["single_game_search"]["search_api_ms_per_400_simulations"])),
         ("random-rollout MCTS (`NEURAL_NET=False`)", "%.1f M complete random playouts/s" % (e["random_rollout_mode"]["rollouts_per_s"] / 1e6)),
