@@ -66,12 +66,16 @@ def gpu_numa_node(device_index):
         return None
 
 
-def pin_to_gpu(local_rank, ranks_on_node=1):
+def pin_to_gpu(local_rank, ranks_on_node=1, cpu_threads=1):
     """Host placement of one rank (the reference gives every worker process a core of its own, training_pipeline.py:325-329; here a
     rank is ONE Python thread replaying HIP graphs, and an unpinned thread wanders between the sockets of an 8-GPU node): restrict
     the process to cores of its GPU's NUMA node -- the node's cores are divided between the ranks whose GPUs share it -- or, when
     sysfs names no node, to an equal share of the cores the process may use.  Returns what was chosen, for the bench line:
-    {"numa_node", "cpus" (count), "first_cpu", "last_cpu", "pinned"}.  CKR_NO_PIN=1: report only."""
+    {"numa_node", "cpus" (count), "first_cpu", "last_cpu", "pinned"}.  CKR_NO_PIN=1: report only.
+    cpu_threads: PyTorch's CPU thread count from here on (None: left alone).  A rank's host work is graph replays plus a few small
+    tensor operations when a job is set up (building a network, packing its weights); with the process pinned, PyTorch's pool of
+    one thread per core of the WHOLE host turns each of them into a pile-up -- a 400-game tournament's set-up 0.3 -> 3.9 s, measured
+    with tools/small_jobs_context_check.py -- and one thread is the fastest setting even unpinned (6.4 against 6.7 s)."""
     info = {"numa_node": None, "cpus": None, "first_cpu": None, "last_cpu": None, "pinned": False}
     try:
         allowed = sorted(os.sched_getaffinity(0))
@@ -101,6 +105,9 @@ def pin_to_gpu(local_rank, ranks_on_node=1):
         try:
             os.sched_setaffinity(0, share)
             info["pinned"] = True
+            if cpu_threads:
+                torch.set_num_threads(int(cpu_threads))
+                info["torch_threads"] = int(cpu_threads)
         except OSError:
             pass
     return info

@@ -154,8 +154,11 @@ def test_rank_placement_divides_the_cores_between_ranks():
     assert sum(s["cpus"] for s in shares) <= len(before)
     firsts = [s["first_cpu"] for s in shares]
     assert firsts == sorted(firsts) and len(set(firsts)) == world        # disjoint, in rank order
+    threads = torch.get_num_threads()
     try:
         info = ckdist.pin_to_gpu(0, 1)
         assert info["pinned"] is True and len(os.sched_getaffinity(0)) == info["cpus"]
+        assert torch.get_num_threads() == 1 == info["torch_threads"]      # a pinned rank keeps PyTorch's CPU pool out of its way
     finally:
         os.sched_setaffinity(0, before)
+        torch.set_num_threads(threads)
