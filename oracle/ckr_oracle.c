@@ -486,11 +486,62 @@ static double rng_gamma(rng_t* r, double a)
     }
 }
 
+/* ---- injected test noise (ckro_config.noise_mode 1; ckr_oracle.h) ---------- */
+uint32_t ckro_noise_hash(uint64_t seed, uint32_t worker, uint32_t ctr, uint32_t lane)
+{
+    uint32_t h = fmix32((uint32_t)seed ^ 0x9E3779B9u) + 0x7F4A7C15u;
+    h = fmix32(h ^ (uint32_t)(seed >> 32)) + 0x7F4A7C15u;
+    h = fmix32(h ^ worker) + 0x7F4A7C15u;
+    h = fmix32(h ^ ctr) + 0x7F4A7C15u;
+    return fmix32(h ^ lane);
+}
+void ckro_noise_dirichlet(uint64_t seed, uint32_t worker, uint32_t ctr, int n, double* out)
+{
+    double tot = 0.0;                                        /* integers below 2^24 each: exact in any order */
+    for (int i = 0; i < n; ++i) { out[i] = (double)((ckro_noise_hash(seed, worker, ctr, (uint32_t)i) >> 8) + 1u); tot += out[i]; }
+    for (int i = 0; i < n; ++i) out[i] /= tot;
+}
+double ckro_noise_uniform(uint64_t seed, uint32_t worker, uint32_t ctr)
+{
+    return (double)ckro_noise_hash(seed, worker, ctr, 0xFFFFFFFFu) * (1.0 / 4294967296.0);
+}
+
+/* numpy's float64 pairwise summation for n <= 128 (np.sum of a 1-D float64 array: 8 strided accumulators) */
+static double pairwise_sum_f64(const double* a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+int ckro_choice_index(const double* p, int n, double u)
+{
+    double cdf[CKRO_MAX_CHILDREN * 2];
+    if (n > CKRO_MAX_CHILDREN * 2) n = CKRO_MAX_CHILDREN * 2;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) { acc += p[i]; cdf[i] = acc; }            /* p.cumsum(): sequential */
+    const double last = cdf[n - 1];
+    int idx = 0;
+    for (int i = 0; i < n; ++i) { cdf[i] /= last; if (cdf[i] <= u) idx = i + 1; }   /* searchsorted(u, side='right') */
+    return idx < n ? idx : n - 1;
+}
+
 enum { PH_NEW_GAME, PH_PLY_BEGIN, PH_SEARCH, PH_PLY_END, PH_GAME_END, PH_FINISHED };
 
 struct ckro_worker {
     ckro_config cfg;
     rng_t rng;
+    uint32_t noise_ctr;              /* noise_mode 1: draws made so far by this worker (ckr_oracle.h) */
     double tau;                      /* MCTS.tau: class attribute, never reset (MCTS.py:53) */
     /* game_env */
     ckro_board* history; int hist_len, hist_cap;
@@ -589,7 +640,9 @@ static onode* select_child(ckro_worker* w, onode* node)
     int nc = node->n_children;
     double dir[CKRO_MAX_CHILDREN], uct[CKRO_MAX_CHILDREN];
     double eps = w->cfg.epsilon;
-    if (eps != 0.0) {
+    if (eps != 0.0 && w->cfg.noise_mode) {
+        ckro_noise_dirichlet(w->cfg.seed, w->cfg.worker, w->noise_ctr++, nc, dir);
+    } else if (eps != 0.0) {
         double tot = 0.0;
         for (int i = 0; i < nc; ++i) { dir[i] = rng_gamma(&w->rng, w->cfg.alpha); tot += dir[i]; }
         for (int i = 0; i < nc; ++i) dir[i] /= tot;
@@ -735,6 +788,14 @@ static onode* best_child(ckro_worker* w, onode* node)
     if (w->move_count > w->cfg.tau_decay_delay) {
         w->tau -= w->cfg.tau_decay;
         if (fabs(w->tau) <= 1e-8) w->tau = 0.0;              /* np.isclose(tau, 0) */
+    }
+    if (w->cfg.noise_mode) {
+        /* exactly as the reference evaluates it: n ** (1 / tau) is C pow() on python floats, total = np.sum(list) (pairwise),
+         * probs = [n / total], then np.random.choice's inverse CDF with the injected uniform */
+        double p[CKRO_MAX_CHILDREN];
+        const double tot = pairwise_sum_f64(ev, nc);
+        for (int i = 0; i < nc; ++i) p[i] = ev[i] / tot;
+        return node->children[ckro_choice_index(p, nc, ckro_noise_uniform(w->cfg.seed, w->cfg.worker, w->noise_ctr++))];
     }
     double u = rng_uniform(&w->rng) * total, acc = 0.0;
     for (int i = 0; i < nc; ++i) { acc += ev[i]; if (u < acc) return node->children[i]; }

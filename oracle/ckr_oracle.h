@@ -115,6 +115,13 @@ typedef struct {
     int    game;             /* 0 = Checkers; 1 = Tic-Tac-Toe (TicTacToe.py), random-rollout mode only (README:100-168) */
     int    w_accum;          /* MCTS_Node._total_reward / .q arithmetic (MCTS.py:389-394,419-430): 0 = float32 (the reference
                                 under NumPy >= 2), 1 = float64 (under its pinned NumPy 1.19, requirements.txt:68) */
+    int    noise_mode;       /* 0: the stochastic paths draw from this file's own generator (distribution-level parity only).
+                                1: INJECTED NOISE -- np.random.dirichlet's vector (MCTS.py:107-108) and the uniform that
+                                np.random.choice consumes (MCTS.py:246) come from ckro_noise_* below, a pure function of
+                                (seed, worker, draw counter, component) that tests/golden/ref_shim.NoiseInjector feeds to the
+                                imported reference and libckr.so (ckr_config.noise_mode) evaluates on the device: the
+                                epsilon > 0 / tau > 0 search is then compared bit for bit on identical inputs */
+    uint32_t worker;         /* global worker id (the noise key next to seed); noise_mode 1 only */
 } ckro_config;
 
 typedef struct {
@@ -167,6 +174,21 @@ void ckro_worker_stats(const ckro_worker* w, uint64_t out[8]);
  * order; returns count.  For the search fixtures. */
 int  ckro_worker_last_root(const ckro_worker* w, uint16_t* action, int32_t* n,
                            double* wsum, float* prior, int32_t* root_n, double* root_w);
+
+/* ---- injected test noise (noise_mode 1) -----------------------------------
+ * draw counter: per worker, starts at 0 with the worker's first game and advances by one with every Dirichlet draw that
+ * enters a score (one per MCTS.select_child call while epsilon != 0) and every temperature pick (one per
+ * np.random.choice call), in the order the reference makes those calls.
+ *   hash(seed, worker, ctr, lane): five rounds of murmur3's fmix32 (ckro_noise_hash)
+ *   Dirichlet vector of n components, draw ctr:  g_i = (hash(.., i) >> 8) + 1  (an integer in [1, 2^24]),
+ *       dir_i = (double)g_i / (double)(g_0 + ... + g_{n-1})   -- one correctly rounded float64 division, the sum is exact
+ *   uniform of pick ctr:  hash(.., 0xFFFFFFFF) * 2^-32 */
+uint32_t ckro_noise_hash(uint64_t seed, uint32_t worker, uint32_t ctr, uint32_t lane);
+void     ckro_noise_dirichlet(uint64_t seed, uint32_t worker, uint32_t ctr, int n, double* out);
+double   ckro_noise_uniform(uint64_t seed, uint32_t worker, uint32_t ctr);
+/* np.random.choice(n, p = p) given the uniform it draws (numpy/random/mtrand.pyx, RandomState.choice with p):
+ * cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(u, side='right') */
+int      ckro_choice_index(const double* p, int n, double u);
 
 /* batch helpers (CPU baseline): advance / submit an array of workers */
 int  ckro_workers_advance(ckro_worker** ws, int n, float* x, int* active);

@@ -31,7 +31,7 @@ class Config(C.Structure):
                 ("tau_decay_delay", C.c_int), ("terminate_cnt", C.c_int),
                 ("num_games", C.c_int), ("tournament", C.c_int), ("seed", C.c_uint64),
                 ("neural_net", C.c_int), ("rollout_first", C.c_int), ("ln_table", C.c_void_p), ("ln_table_n", C.c_int),
-                ("game", C.c_int), ("w_accum", C.c_int)]
+                ("game", C.c_int), ("w_accum", C.c_int), ("noise_mode", C.c_int), ("worker", C.c_uint32)]
 
 
 class Tuple(C.Structure):
@@ -83,8 +83,31 @@ def lib():
         L.ckro_worker_last_root.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_double), f32p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.ckro_worker_last_root.restype = C.c_int
+        L.ckro_noise_hash.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.ckro_noise_hash.restype = C.c_uint32
+        L.ckro_noise_dirichlet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+        L.ckro_noise_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.ckro_noise_uniform.restype = C.c_double
+        L.ckro_choice_index.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double]
+        L.ckro_choice_index.restype = C.c_int
         _lib = L
     return _lib
+
+
+def noise_dirichlet(seed, worker, ctr, n):
+    """The injected Dirichlet vector of draw `ctr` (ckr_oracle.h, noise_mode 1)."""
+    out = np.zeros(n, np.float64)
+    lib().ckro_noise_dirichlet(seed, worker, ctr, n, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def noise_uniform(seed, worker, ctr):
+    return float(lib().ckro_noise_uniform(seed, worker, ctr))
+
+
+def choice_index(p, u):
+    p = np.ascontiguousarray(p, np.float64)
+    return int(lib().ckro_choice_index(p.ctypes.data_as(C.POINTER(C.c_double)), len(p), float(u)))
 
 
 def _u32(a):
@@ -149,7 +172,7 @@ W_ACCUM = {"float32": 0, "float64": 1, "np2": 0, "np1": 1, 0: 0, 1: 1}
 
 
 def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, seed=0, rollout_first=False, ln_table=None,
-                game="checkers", w_accum="float32"):
+                game="checkers", w_accum="float32", noise_mode=0, worker=0):
     """Config from the reference's kwargs dict (MCTS.py:43-55).  w_accum: 'float32' = the reference under NumPy >= 2,
     'float64' = under its pinned NumPy 1.19 (legacy promotion)."""
     k = mcts_kwargs
@@ -161,7 +184,7 @@ def make_config(mcts_kwargs, terminate_cnt=0, num_games=1, tournament=False, see
                   neural_net=int(bool(k.get("NEURAL_NET", True))), rollout_first=int(bool(rollout_first)),
                   ln_table=(ln_table.ctypes.data if ln_table is not None else None),
                   ln_table_n=(len(ln_table) if ln_table is not None else 0), game={"checkers": 0, "tictactoe": 1}[game],
-                  w_accum=W_ACCUM[w_accum])
+                  w_accum=W_ACCUM[w_accum], noise_mode=int(noise_mode), worker=int(worker))
 
 
 class Worker:

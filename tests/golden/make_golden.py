@@ -160,12 +160,15 @@ def _action_of(state):
     return (int(state[14, 0, 0]) - 6) * 64 + 8 * int(state[14, 0, 1]) + int(state[14, 0, 2])
 
 
-def _drive_searches(net, budget, max_plies):
+def _drive_searches(net, budget, max_plies, training=False, eps=0.0, tau=0.0, arena_decay=False):
     """Drive MCTS / MCTS_Node exactly as training_pipeline.py:353-386 does; per ply: the root's children in tree order
     (action, N, W, P), the root's (N, W, chosen action, side); W kept as the reference holds it (its type is reported)."""
     env = rt.new_env()
     env.neural_net = net
-    MCTS(**mcts_kwargs(budget, training=False, env=env))
+    mk = mcts_kwargs(budget, eps=eps, tau=tau, training=training, env=env)
+    if arena_decay:                                                                  # train_Checkers.py:199-201
+        mk["TEMPERATURE_DECAY"] = 0; mk["TEMP_DECAY_DELAY"] = 0
+    MCTS(**mk)
     rows, acts, ns, ws, ps, off, wtypes = [], [], [], [], [], [0], set()
     initial = env.state
     root1 = MCTS_Node(initial, parent=None)
@@ -282,6 +285,129 @@ def gen_selfplay_inexact(cases=((25, 60, 1, 7), (40, 1000, 1, 2), (60, 30, 2, 3)
     out["n_cases"] = np.array(len(cases))
     out["numpy_version"] = np.array(np.__version__)
     np.savez_compressed(os.path.join(OUT, "selfplay_inexact_%s.npz" % regime), **out)
+
+
+
+# --------------------------------------------------------------------------- injected noise: epsilon > 0, tau > 0 on identical inputs
+NOISE_SEED = 20260930
+
+
+def _pack_search(out, ci, r, cfg):
+    env, rows = r["env"], r["rows"]
+    out["c%d_cfg" % ci] = np.array(list(cfg) + [env.move_count, rt.OUTCOME_CODE[env.outcome]], np.int64)
+    out["c%d_root_n" % ci] = np.array([x[0] for x in rows], np.int64)
+    out["c%d_root_w" % ci] = np.array([float(x[1]) for x in rows], np.float64)
+    out["c%d_chosen" % ci] = np.array([x[2] for x in rows], np.int64)
+    out["c%d_side" % ci] = np.array([x[3] for x in rows], np.int64)
+    out["c%d_off" % ci] = np.array(r["off"], np.int64)
+    out["c%d_action" % ci] = np.array(r["acts"], np.int64)
+    out["c%d_n" % ci] = np.array(r["ns"], np.int64)
+    out["c%d_w" % ci] = np.array([float(x) for x in r["ws"]], np.float64)
+    out["c%d_p" % ci] = np.array(r["ps"], np.float32)
+    out["c%d_wtypes" % ci] = np.array(sorted(r["wtypes"]))
+
+
+def gen_search_noise(cases=((100, 3, 30, 1, 0), (40, 5, 400, 1, 1), (60, 1, 60, 0, 2), (200, 7, 14, 1, 3))):
+    """Searches through the MCTS API with the reference driver's own stochastic settings and INJECTED noise
+    (ref_shim.NoiseInjector): self-play kwargs of train_Checkers.py:88-102 (epsilon 0.25, alpha 1, tau 1, decay 0.1 after 10
+    moves, TRAINING True: best_child samples) -- `selfplay` 1 -- or its arena kwargs (:188-202: epsilon 0.25, tau 0, TRAINING
+    False) -- `selfplay` 0.  InexactNet, so that W depends on the accumulation type: run under both interpreters
+    (search_noise_np{1,2}.npz).  Per ply the root's children (action, N, W, P) after the search and the child best_child
+    returned.  cases: (BUDGET, net salt, max plies, selfplay, noise worker id)."""
+    out = {}
+    regime = promotion_regime()
+    for ci, (budget, salt, max_plies, selfplay, worker) in enumerate(cases):
+        with ref_shim.NoiseInjector(NOISE_SEED, worker) as inj:
+            if selfplay:
+                r = _drive_searches(ref_shim.InexactNet(salt), budget, max_plies, training=True, eps=0.25, tau=1.0)
+            else:
+                r = _drive_searches(ref_shim.InexactNet(salt), budget, max_plies, training=False, eps=0.25, tau=0, arena_decay=True)
+        _pack_search(out, ci, r, (budget, salt, max_plies, selfplay, worker))
+        out["c%d_draws" % ci] = np.array([inj.n_dirichlet, inj.n_choice, inj.ctr], np.int64)
+        print("noise search case", ci, "budget", budget, "plies", len(r["rows"]), "outcome", r["env"].outcome,
+              "draws", inj.n_dirichlet, "picks", inj.n_choice, "W types", sorted(r["wtypes"]))
+    out["n_cases"] = np.array(len(cases))
+    out["noise_seed"] = np.array(NOISE_SEED, np.int64)
+    out["numpy_version"] = np.array(np.__version__)
+    np.savez_compressed(os.path.join(OUT, "search_noise_%s.npz" % regime), **out)
+
+
+def _selfplay_noise_cases(out, cases, net_prefix):
+    """generate_Checkers_data._generate_data per (BUDGET, TERMINATE_CNT, games, salt, worker) under the injector of `worker`."""
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "training_data"))
+    os.chdir(tmp)
+    try:
+        for ci, (budget, terminate, games, salt, worker) in enumerate(cases):
+            sk = dict(NUM_SELFPLAY_GAMES=games, TRAINING_ITERATION=0, TERMINATE_CNT=terminate, NUM_CPUS=1,
+                      NN_FN="%s_salt%d.h5" % (net_prefix, salt))
+            with ref_shim.NoiseInjector(NOISE_SEED, worker) as inj:
+                mem = pickle.load(open(tp.generate_Checkers_data(sk, mcts_kwargs(budget, eps=0.25, tau=1.0)).generate_data(), "rb"))
+            out["c%d_cfg" % ci] = np.array([budget, terminate, games, salt, worker], np.int64)
+            out["c%d_state" % ci] = np.array([m[0] for m in mem], np.float64)
+            out["c%d_pi" % ci] = np.array([m[1] for m in mem], np.float64)
+            out["c%d_q" % ci] = np.array([float(m[2]) for m in mem], np.float64)
+            out["c%d_q_is_int" % ci] = np.array([type(m[2]) is int for m in mem], np.bool_)
+            out["c%d_qtypes" % ci] = np.array(sorted({type(m[2]).__name__ for m in mem}))
+            out["c%d_z" % ci] = np.array([m[3] for m in mem], np.int64)
+            out["c%d_draws" % ci] = np.array([inj.n_dirichlet, inj.n_choice, inj.ctr], np.int64)
+            print("noise selfplay case", ci, (budget, terminate, games, salt, worker), len(mem), "tuples, draws", inj.n_dirichlet,
+                  "picks", inj.n_choice, file=sys.stderr)
+    finally:
+        os.chdir(cwd)
+    out["n_cases"] = np.array(len(cases))
+    out["noise_seed"] = np.array(NOISE_SEED, np.int64)
+    out["numpy_version"] = np.array(np.__version__)
+
+
+def gen_selfplay_noise(cases=((100, 200, 1, 2, 0), (30, 60, 3, 4, 1), (60, 1000, 1, 6, 2))):
+    """_generate_data with train_Checkers.py:88-102's kwargs (cfg3's: epsilon 0.25, alpha 1, tau 1 -> 0 by 0.1 after move 10)
+    and injected noise; InexactNet; two or three games per worker where given (tau is never reset within a worker, Q18; the
+    draw counter runs on).  Run under both interpreters (selfplay_noise_np{1,2}.npz)."""
+    out = {}
+    _selfplay_noise_cases(out, cases, "inexact")
+    np.savez_compressed(os.path.join(OUT, "selfplay_noise_%s.npz" % promotion_regime()), **out)
+
+
+def _tournament_cases(out, cases, eps):
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "tournament_results"))
+    os.chdir(tmp)
+    try:
+        for ci, (budget, games, salt_new, salt_old, worker) in enumerate(cases):
+            mk = mcts_kwargs(budget, eps=eps, training=False)
+            mk["TEMPERATURE_DECAY"] = 0; mk["TEMP_DECAY_DELAY"] = 0
+            tk = dict(NEW_NN_FN="data/model/new_salt%d.h5" % salt_new, OLD_NN_FN="data/model/old_salt%d.h5" % salt_old,
+                      TOURNEY_GAMES=games, NUM_CPUS=1)
+            out["c%d_cfg" % ci] = np.array([budget, games, salt_new, salt_old, worker], np.int64)
+            with ref_shim.NoiseInjector(NOISE_SEED, worker) as inj:
+                try:
+                    res = tp.tournament_Checkers(tk, mk)._start_tournament()
+                except ValueError as e:      # reply node missing (MCTS.py:292): the reference aborts; not a fixture
+                    print("case", ci, "reference raised", e, file=sys.stderr)
+                    out["c%d_raised" % ci] = np.array(True)
+                    continue
+            out["c%d_raised" % ci] = np.array(False)
+            out["c%d_p1_is_new" % ci] = np.array([r[1].startswith("new") for r in res], np.bool_)
+            out["c%d_outcome" % ci] = np.array([rt.OUTCOME_CODE[r[3]] for r in res], np.int64)
+            out["c%d_moves" % ci] = np.array([r[4] for r in res], np.int64)
+            out["c%d_draws" % ci] = np.array([inj.n_dirichlet, inj.n_choice, inj.ctr], np.int64)
+            print("noise tournament case", ci, res, "draws", inj.n_dirichlet, file=sys.stderr)
+    finally:
+        os.chdir(cwd)
+    out["n_cases"] = np.array(len(cases))
+    out["noise_seed"] = np.array(NOISE_SEED, np.int64)
+
+
+def gen_tournament_noise(cases=((60, 4, 1, 2, 0), (100, 2, 3, 5, 1), (40, 6, 7, 8, 2))):
+    """tournament_Checkers._start_tournament with the arena kwargs of train_Checkers.py:188-202 (epsilon 0.25: noise at every
+    node of every descent; TRAINING False, tau 0: the most visited child plays) and injected noise; exact hash nets (the game
+    list does not carry W).  cases: (BUDGET, TOURNEY_GAMES, salt of the new net, of the old net, noise worker id)."""
+    out = {}
+    _tournament_cases(out, cases, 0.25)
+    np.savez_compressed(os.path.join(OUT, "tournament_noise_v1.npz"), **out)
 
 
 # --------------------------------------------------------------------------- self-play tuples

@@ -127,3 +127,82 @@ class InexactNet(HashNet):
         p, v = HashNet.predict(self, x)
         p = (p * np.float32(0.7) + np.float32(1.0 / 3.0)).astype(np.float32)
         return [p, (v * np.float32(0.3)).astype(np.float32)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Injected noise: the stochastic search on IDENTICAL inputs (noise_mode 1 of oracle/ckr_oracle.h and include/ckr.h).
+# The noise the reference consumes -- the vector np.random.dirichlet returns (MCTS.py:107-108) and the uniform behind
+# np.random.choice (MCTS.py:246) -- is an input of the search.  NoiseInjector replaces those two NumPy entry points, for the
+# duration of a `with` block, by a pure function of (seed, worker, draw counter, component) that the C oracle and the HIP
+# engine evaluate as well; everything the reference does WITH the noise (the float32 / float64 mixing of the prior, PUCT,
+# argmax, the temperature weights, their sum and normalisation) stays the reference's own code.
+def noise_hash(seed, worker, ctr, lane):
+    """ckro_noise_hash / the engine's noise_hash: five rounds of murmur3's fmix32."""
+    def fm(h):
+        h &= 0xFFFFFFFF
+        h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        return h ^ (h >> 16)
+    k = 0x7F4A7C15
+    h = (fm((seed & 0xFFFFFFFF) ^ 0x9E3779B9) + k) & 0xFFFFFFFF
+    h = (fm(h ^ ((seed >> 32) & 0xFFFFFFFF)) + k) & 0xFFFFFFFF
+    h = (fm(h ^ (worker & 0xFFFFFFFF)) + k) & 0xFFFFFFFF
+    h = (fm(h ^ (ctr & 0xFFFFFFFF)) + k) & 0xFFFFFFFF
+    return fm(h ^ (lane & 0xFFFFFFFF))
+
+
+def noise_dirichlet(seed, worker, ctr, n):
+    g = np.array([(noise_hash(seed, worker, ctr, i) >> 8) + 1 for i in range(n)], np.float64)
+    return g / np.float64(sum(int(x) for x in g))
+
+
+def noise_uniform(seed, worker, ctr):
+    return noise_hash(seed, worker, ctr, 0xFFFFFFFF) / 4294967296.0
+
+
+def choice_given_uniform(a, p, u):
+    """RandomState.choice(a, p=p) with the uniform it would draw handed in (numpy/random/mtrand.pyx: cdf = p.cumsum();
+    cdf /= cdf[-1]; idx = cdf.searchsorted(uniform, side='right')) -- NumPy's own array operations on NumPy's own types.
+    tests/test_noise_cpu.py checks it against the real np.random.RandomState.choice draw by draw."""
+    p = np.array(p, dtype=np.float64)
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    idx = int(cdf.searchsorted(u, side="right"))
+    return a[idx]
+
+
+class NoiseInjector:
+    """with NoiseInjector(seed, worker): ... -- np.random.dirichlet and np.random.choice read the injected noise.
+    The draw counter starts at 0 and advances with every Dirichlet draw that enters a score (MCTS.epsilon != 0: with
+    epsilon == 0 the reference still calls np.random.dirichlet and multiplies the result by 0) and with every pick."""
+
+    def __init__(self, seed, worker=0):
+        self.seed, self.worker, self.ctr = int(seed), int(worker), 0
+        self.n_dirichlet = self.n_choice = 0
+
+    def _dirichlet(self, alpha, size=None):
+        assert size is None
+        n = len(alpha)
+        eps = sys.modules["MCTS"].MCTS.epsilon
+        if eps == 0:
+            return np.full(n, 1.0 / n)
+        self.n_dirichlet += 1
+        d = noise_dirichlet(self.seed, self.worker, self.ctr, n)
+        self.ctr += 1
+        return d
+
+    def _choice(self, a, size=None, replace=True, p=None):
+        assert size is None and p is not None
+        self.n_choice += 1
+        u = noise_uniform(self.seed, self.worker, self.ctr)
+        self.ctr += 1
+        return choice_given_uniform(a, p, u)
+
+    def __enter__(self):
+        self._real = (np.random.dirichlet, np.random.choice)
+        np.random.dirichlet, np.random.choice = self._dirichlet, self._choice
+        return self
+
+    def __exit__(self, *exc):
+        np.random.dirichlet, np.random.choice = self._real
+        return False

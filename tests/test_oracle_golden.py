@@ -235,3 +235,95 @@ def test_tictactoe_root_statistics_bit_exact(oracle, golden_dir):
         res = w.results()
         assert [r["outcome"] for r in res] == list(g["c%d_outcome" % ci])
         assert [r["move_count"] for r in res] == list(g["c%d_plies" % ci])
+
+
+# ---- the STOCHASTIC search on identical inputs: epsilon = 0.25 with per-descent Dirichlet noise at every level and tau = 1
+# sampling (train_Checkers.py:88-102, :188-202), the noise injected into the reference by ref_shim.NoiseInjector and
+# evaluated here by ckro_noise_* (ckr_oracle.h, noise_mode 1); fixtures from make_golden.gen_*_noise under both interpreters
+def _mk_noise(budget, selfplay):
+    kw = _mk(budget, training=bool(selfplay))
+    kw.update(DIRICHLET_EPSILON=0.25, DIRICHLET_ALPHA=1.0, TEMPERATURE_TAU=1.0 if selfplay else 0,
+              TEMPERATURE_DECAY=0.1 if selfplay else 0, TEMP_DECAY_DELAY=10 if selfplay else 0)
+    return kw
+
+
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_noise_search_root_statistics_bit_exact(oracle, golden_dir, regime, w_accum):
+    g = _load(golden_dir, "search_noise_%s.npz" % regime)
+    seed = int(g["noise_seed"])
+    assert w_accum in set(g["c0_wtypes"])
+    picks = 0
+    for ci in range(int(g["n_cases"])):
+        budget, salt, max_plies, selfplay, worker, moves, outcome = (int(v) for v in g["c%d_cfg" % ci])
+        w = oracle.Worker(oracle.make_config(_mk_noise(budget, selfplay), terminate_cnt=max_plies, num_games=1, w_accum=w_accum,
+                                             noise_mode=1, seed=seed, worker=worker))
+        w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+        tu = [t for t in w.tuples() if t["chosen"] >= 0]
+        off = g["c%d_off" % ci]
+        assert len(tu) == len(off) - 1 == moves
+        for i, t in enumerate(tu):
+            sl = slice(off[i], off[i + 1])
+            assert (t["action"] == g["c%d_action" % ci][sl]).all()
+            assert (t["visits"] == g["c%d_n" % ci][sl]).all(), (ci, i)
+            assert (t["wsum"].view(np.uint64) == g["c%d_w" % ci][sl].view(np.uint64)).all()          # W bits
+            assert (t["prior"].view(np.uint32) == g["c%d_p" % ci][sl].view(np.uint32)).all()
+            assert t["root_n"] == g["c%d_root_n" % ci][i]
+            assert np.float64(t["root_w"]).view(np.uint64) == g["c%d_root_w" % ci][i].view(np.uint64)
+            assert t["chosen"] == g["c%d_chosen" % ci][i], (ci, i)
+            picks += int(t["chosen"] != t["action"][int(np.argmax(t["visits"]))])
+        if outcome:
+            assert w.results()[0]["outcome"] == outcome
+    assert picks >= 10                              # the temperature really sampled moves other than the most visited one
+
+
+def test_noise_fixture_detects_a_skipped_draw(oracle, golden_dir):
+    """The draw counter is part of what is pinned: the same search with another worker's noise stream leaves the fixture at once."""
+    g = _load(golden_dir, "search_noise_np2.npz")
+    budget, salt, max_plies, selfplay, worker, moves, outcome = (int(v) for v in g["c0_cfg"])
+    w = oracle.Worker(oracle.make_config(_mk_noise(budget, selfplay), terminate_cnt=max_plies, num_games=1, noise_mode=1,
+                                         seed=int(g["noise_seed"]), worker=worker + 1))
+    w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+    t0 = [t for t in w.tuples() if t["chosen"] >= 0][0]
+    n0 = g["c0_n"][g["c0_off"][0]:g["c0_off"][1]]
+    assert len(t0["visits"]) == len(n0) and (t0["visits"] != n0).any()
+
+
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_noise_selfplay_tuples_bit_exact(oracle, golden_dir, regime, w_accum):
+    g = _load(golden_dir, "selfplay_noise_%s.npz" % regime)
+    seed = int(g["noise_seed"])
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games, salt, worker = (int(v) for v in g["c%d_cfg" % ci])
+        assert w_accum in set(g["c%d_qtypes" % ci])
+        w = oracle.Worker(oracle.make_config(_mk_noise(budget, 1), terminate_cnt=terminate, num_games=games, w_accum=w_accum,
+                                             noise_mode=1, seed=seed, worker=worker))
+        w.run(lambda x, net: oracle.hashnet(x, salt, inexact=True))
+        tu = w.tuples()
+        assert len(tu) == len(g["c%d_z" % ci])
+        st = codec.records_to_planes(np.array([t["board"] for t in tu]), np.array([t["mask"] for t in tu]),
+                                     np.array([t["status"] for t in tu], np.uint32))
+        assert (st == g["c%d_state" % ci]).all()
+        for i, t in enumerate(tu):
+            assert (codec.pi_planes(t["action"], t["visits"]) == g["c%d_pi" % ci][i]).all()
+            q = float(t["q"]) if (t["q_is_int"] or w_accum == "float32") else t["q64"]
+            assert np.float64(q).view(np.uint64) == g["c%d_q" % ci][i].view(np.uint64)
+            assert t["q_is_int"] == bool(g["c%d_q_is_int" % ci][i]) and t["z"] == g["c%d_z" % ci][i]
+
+
+def test_noise_tournament_outcomes(oracle, golden_dir):
+    g = _load(golden_dir, "tournament_noise_v1.npz")
+    seed = int(g["noise_seed"])
+    checked = 0
+    for ci in range(int(g["n_cases"])):
+        if bool(g["c%d_raised" % ci]):
+            continue
+        budget, games, salt_new, salt_old, worker = (int(v) for v in g["c%d_cfg" % ci])
+        w = oracle.Worker(oracle.make_config(_mk_noise(budget, 0), num_games=games, tournament=True, noise_mode=1, seed=seed,
+                                             worker=worker))
+        w.run(lambda x, net: oracle.hashnet(x, salt_new if net == 0 else salt_old))
+        res = w.results()
+        assert [r["outcome"] for r in res] == list(g["c%d_outcome" % ci])
+        assert [r["move_count"] for r in res] == list(g["c%d_moves" % ci])
+        assert [r["p1_net"] == 0 for r in res] == list(g["c%d_p1_is_new" % ci])
+        checked += 1
+    assert checked >= 2
