@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
-VERSION = 125                      # CKR_VERSION of include/ckr.h this binding was written against
+VERSION = 126                      # CKR_VERSION of include/ckr.h this binding was written against
 Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
@@ -26,7 +26,7 @@ class Config(C.Structure):
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
                 ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
                 ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32), ("dense_rows", C.c_int32), ("n_workers", C.c_int32),
-                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32)]
+                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32), ("noise_mode", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class NodeInfo(C.Structure):
@@ -58,7 +58,7 @@ EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_stream_crea
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_single", "ckr_engine_step_end_ply", "ckr_engine_subtree", "ckr_engine_stats", "ckr_engine_mark", "ckr_engine_stats_at_mark", "ckr_engine_cache_flush", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves",
            "ckr_engine_command", "ckr_engine_game", "ckr_engine_root", "ckr_engine_rollout", "ckr_engine_rollout_end_ply", "ckr_engine_set_ln_table",
-           "ckr_probe_dirichlet", "ckr_probe_temperature", "ckr_probe_tau_schedule",
+           "ckr_probe_dirichlet", "ckr_probe_temperature", "ckr_probe_tau_schedule", "ckr_probe_noise_dirichlet", "ckr_probe_noise_pick",
            "ckr_gemm_nt", "ckr_conv_gemm", "ckr_conv_gemm_pieces", "ckr_split_pieces", "ckr_conv_wsplit", "ckr_conv_wgrad", "ckr_conv_wflip", "ckr_conv_bias_relu_bn", "ckr_conv_bn_relu_backward", "ckr_conv_bias_grad",
            "ckr_gemm_small", "ckr_gemm_tall", "ckr_im2col", "ckr_bn_forward", "ckr_bn_backward",
            "ckr_policy_loss", "ckr_value_loss", "ckr_loss_sums", "ckr_adam_step", "ckr_sum_rows", "ckr_value_head_step", "ckr_policy_head_step"]
@@ -127,6 +127,8 @@ def load():
     L.ckr_probe_dirichlet.argtypes = [C.c_double, C.c_int32, C.c_int32, C.c_uint64, vp]
     L.ckr_probe_temperature.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, C.c_uint64, vp]
     L.ckr_probe_tau_schedule.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_int32, vp]
+    L.ckr_probe_noise_dirichlet.argtypes = [C.c_int32, C.c_int32, C.c_uint64, vp]
+    L.ckr_probe_noise_pick.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, C.c_uint64, vp]
     _lib = L
     return L
 

@@ -106,6 +106,7 @@ struct Dev {
     int w64;                     // ckr_config.w_accum: W of a node record is a double (1) or a float (0); the kernels are instantiated for either
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
+    int noise_mode;              // ckr_config.noise_mode: 1 = the Dirichlet variates and the pick's uniform are the injected test noise (noise_hash)
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local; record i = nodes[3 i .. 3 i + 2] (see the accessors below)
     uint4* nodes;
     // per slot
@@ -221,10 +222,23 @@ __device__ __forceinline__ float pow_fast(float x, float y) { return x <= 0.0f ?
 __device__ __forceinline__ float ln_fast(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float u01f(uint32_t r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-08f; }   // (0, 1), 24 bits
 
-// ---- gamma / Dirichlet noise (MCTS.py:107-108); distribution-level parity only
+// ---- injected test noise (ckr_config.noise_mode 1; include/ckr.h): the function of (seed, worker, draw counter, component) that
+// tests/golden/ref_shim.NoiseInjector feeds to the imported reference and the tests' CPU restatement evaluates on the host
+__device__ __forceinline__ uint32_t noise_hash(uint32_t seed_lo, uint32_t seed_hi, uint32_t worker, uint32_t ctr, uint32_t lane) {
+    uint32_t h = fmix32(seed_lo ^ 0x9E3779B9u) + 0x7F4A7C15u;
+    h = fmix32(h ^ seed_hi) + 0x7F4A7C15u;
+    h = fmix32(h ^ worker) + 0x7F4A7C15u;
+    h = fmix32(h ^ ctr) + 0x7F4A7C15u;
+    return fmix32(h ^ lane);
+}
+
+// ---- gamma / Dirichlet noise (MCTS.py:107-108).  Production: Philox variates, distribution-level parity.  noise_mode 1: the
+// variates are the injected integers (1 .. 2^24; their sum is exact in any order), everything after them -- the division by the sum,
+// the mixing with the prior, PUCT -- is the production code, which the tests then compare bit for bit with the reference
 __device__ __attribute__((noinline)) double gamma_general(uint32_t seed_lo, uint32_t seed_hi, double a, uint32_t c0, uint32_t c1, uint32_t c2);
 
 __device__ __forceinline__ double gamma_sample(const Dev& D, double a, uint32_t c0, uint32_t c1, uint32_t c2) {
+    if (D.noise_mode) return (double)((noise_hash(D.seed_lo, D.seed_hi, c0, c1, c2) >> 8) + 1u);
     if (a == 1.0) {                                        // exponential variate; float32 log (noise, not parity arithmetic)
         const u32x4 r = philox(D.seed_lo, D.seed_hi, c0, c1, c2, 0u);
         const float uf = ((float)(r.x >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1), 24 bits
@@ -266,23 +280,47 @@ __device__ __forceinline__ double dirichlet_lane(const Dev& D, bool act, uint32_
     return g / (n <= 16 ? row_sum_f64(g) : wave_sum_f64(g));
 }
 
+// 2^t in float64 (|t| < 1000; relative error ~1e-15): t = k + f, |f| <= 1/2, e^(f ln 2) by its Taylor series to degree 13
+// (|f ln 2|^14 / 14! < 5e-18), scaled by v_ldexp_f64.  With log2_f64 it replaces OCML's pow() in the temperature pick: that callee cost
+// ~100 VGPRs and set the register allocation of the whole tree kernel ("Step pipeline"); this is ~20 and inline.
+__device__ __forceinline__ double exp2_f64(double t) {
+    if (t < -1000.0) return 0.0;
+    const double k = __builtin_rint(t);
+    const double x = (t - k) * 0.6931471805599453;
+    double s = 1.6059043836821613e-10;                                        // 1 / 13!
+    s = s * x + 2.08767569878681e-09;  s = s * x + 2.505210838544172e-08; s = s * x + 2.755731922398589e-07;
+    s = s * x + 2.7557319223985893e-06; s = s * x + 2.48015873015873e-05;  s = s * x + 0.0001984126984126984;
+    s = s * x + 0.001388888888888889;  s = s * x + 0.008333333333333333;  s = s * x + 0.041666666666666664;
+    s = s * x + 0.16666666666666666;   s = s * x + 0.5;                   s = s * x + 1.0; s = s * x + 1.0;
+    return ldexp(s, (int)k);
+}
+// log2(x) for 0 < x <= 1 in float64: the hardware's float32 log2 (|error| < 1e-5 here) refined by one step on 2^L = x:
+// d = x / 2^L0 - 1 is below 1e-5, log2(1 + d) = (d - d^2/2 + d^3/3) / ln 2 to 1e-21
+__device__ __forceinline__ double log2_f64(double x) {
+    const double l0 = (double)__builtin_amdgcn_logf((float)x);
+    const double d = x / exp2_f64(l0) - 1.0;
+    return l0 + (d - 0.5 * d * d + d * d * d * (1.0 / 3.0)) * 1.4426950408889634;
+}
+
 // MCTS.best_child with TRAINING and tau > 0 (MCTS.py:240-246): np.random.choice(children, p = N^(1/tau) / sum)
 // as an inverse-CDF pick over the children in tree order; `ev` = 64 doubles of LDS.  All lanes return the pick.
 __device__ __forceinline__ int temperature_pick(const Dev& D, double* ev, int cn, bool act, int n, double tau,
                                                 uint32_t worker, uint32_t ctr, int lane) {
-    // weights relative to the most-visited child: (N / Nmax)^(1/tau) <= 1, the same distribution as N^(1/tau) / sum.  The
-    // reference exponentiates in float64 (finite up to 1e308); N^(1/tau) itself leaves float32 at tau = 0.04 with 40 visits
-    // (ADVICE r4), after which every comparison below is false and the pick falls through to the last child.
+    // weights relative to the most-visited child: (N / Nmax)^(1/tau) <= 1, the same distribution as N^(1/tau) / sum (the reference
+    // exponentiates in float64, finite up to 1e308; N^(1/tau) itself leaves float32 at tau = 0.04 with 40 visits: ADVICE r4), evaluated
+    // in float64 to ~1e-15 since round 6: with the uniform of the draw handed in (noise_mode 1) the pick is then the child
+    // np.random.choice returns -- cdf = cumsum(p) / cumsum(p)[-1], first index with cdf > u -- unless u lies within 1e-15 of a step of
+    // the cdf (the float32 weights of rounds 3-5 moved the steps by 1e-6: one pick in ~10^5 differed)
     const int cmax = wave_max_i32(act ? cn : 0);
-    ev[lane] = (act && cn > 0)
-        ? (double)__builtin_amdgcn_exp2f((float)(1.0 / tau) * (__builtin_amdgcn_logf((float)cn) - __builtin_amdgcn_logf((float)cmax))) : 0.0;
+    ev[lane] = (act && cn > 0) ? (cn == cmax ? 1.0 : exp2_f64((1.0 / tau) * log2_f64((double)cn / (double)cmax))) : 0.0;
     __builtin_amdgcn_wave_barrier();
     double cum = 0.0;
     for (int j = 0; j <= lane && j < n; ++j) cum += ev[j];
     const double total = __hiloint2double(bcast_i32(__double2hiint(cum), 63), bcast_i32(__double2loint(cum), 63));
-    const u32x4 r = philox(D.seed_lo, D.seed_hi, worker, ctr, 0xFFFFFFFFu, 0x7A0u);
-    const double uu = u01(r.x, r.y) * total;
-    const unsigned long long hit = __ballot(act && uu < cum);
+    double uu;
+    if (D.noise_mode) uu = (double)noise_hash(D.seed_lo, D.seed_hi, worker, ctr, 0xFFFFFFFFu) * (1.0 / 4294967296.0);
+    else { const u32x4 r = philox(D.seed_lo, D.seed_hi, worker, ctr, 0xFFFFFFFFu, 0x7A0u); uu = u01(r.x, r.y); }
+    const unsigned long long hit = __ballot(act && uu < cum / total);
     __builtin_amdgcn_wave_barrier();
     return hit ? first_lane(hit) : n - 1;
 }
@@ -1759,7 +1797,7 @@ template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool
 }
 
 static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
-static_assert(sizeof(ckr_config) == 152, "ckr_config layout is mirrored by _lib.Config (ctypes)");
+static_assert(sizeof(ckr_config) == 160, "ckr_config layout is mirrored by _lib.Config (ctypes)");
 
 extern "C" {
 
@@ -1877,7 +1915,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.margin = c->budget > (1 << 20) ? D.C / 2 : c->budget * 16 + 64;    // unbounded (time-limited) searches: compact early
     if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
-    D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32);
+    D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32); D.noise_mode = c->noise_mode ? 1 : 0;
     e->n_games_total = (int64_t)D.n_workers * c->games_per_slot;
     const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C;
     int rc = CKR_OK;
@@ -2420,6 +2458,41 @@ int ckr_probe_temperature(const int32_t* visits, int32_t n, double tau, int32_t 
     }
     (void)hipFree(d_buf); (void)hipFree(d_dev);
     return e == hipSuccess ? CKR_OK : fail(CKR_ERR_HIP, "ckr_probe_temperature: %s", hipGetErrorString(e));
+}
+
+int ckr_probe_noise_dirichlet(int32_t n, int32_t samples, uint64_t seed, double* out) {
+    if (n < 1 || n > 64 || samples < 1 || !out) return fail(CKR_ERR_INVALID, "ckr_probe_noise_dirichlet: bad argument");
+    if (int rc = require_device()) return rc;
+    Dev D; Dev* d_dev = nullptr; double* d_out = nullptr;
+    if (int rc = probe_dev(D, &d_dev, seed, 1.0)) return rc;
+    D.noise_mode = 1;
+    const size_t bytes = (size_t)samples * n * sizeof(double);
+    hipError_t e = hipMalloc((void**)&d_out, bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_dirichlet, dim3((samples + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)d_dev, (int)n, (int)samples, d_out);
+        e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_out); (void)hipFree(d_dev);
+    return e == hipSuccess ? CKR_OK : fail(CKR_ERR_HIP, "ckr_probe_noise_dirichlet: %s", hipGetErrorString(e));
+}
+
+int ckr_probe_noise_pick(const int32_t* visits, int32_t n, double tau, int32_t samples, uint64_t seed, int32_t* picks) {
+    if (!visits || n < 1 || n > 64 || !(tau > 0.0) || samples < 1 || !picks) return fail(CKR_ERR_INVALID, "ckr_probe_noise_pick: bad argument");
+    if (int rc = require_device()) return rc;
+    Dev D; Dev* d_dev = nullptr; int32_t* d_buf = nullptr;
+    if (int rc = probe_dev(D, &d_dev, seed, 1.0)) return rc;
+    D.noise_mode = 1;
+    hipError_t e = hipMalloc((void**)&d_buf, ((size_t)samples + 64) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_dev, &D, sizeof(Dev), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_buf, visits, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_temperature, dim3((samples + 3) / 4), dim3(256), 0, (hipStream_t)0, (const Dev*)d_dev,
+                           (const int32_t*)d_buf, (int)n, tau, (int)samples, d_buf + 64);
+        e = hipMemcpy(picks, d_buf + 64, (size_t)samples * sizeof(int32_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_buf); (void)hipFree(d_dev);
+    return e == hipSuccess ? CKR_OK : fail(CKR_ERR_HIP, "ckr_probe_noise_pick: %s", hipGetErrorString(e));
 }
 
 int ckr_probe_tau_schedule(double tau0, double tau_decay, int32_t tau_decay_delay, int32_t moves, double* out) {

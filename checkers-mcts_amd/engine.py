@@ -28,7 +28,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=0, device=0,
                        manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0, dense_rows=False,
-                       n_workers=None, leaf_cache_park=False, device_clock=True):
+                       n_workers=None, leaf_cache_park=False, device_clock=True, noise_mode=0):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -55,6 +55,10 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     (games_per_slot games each, global ids first_worker_id + [0, n_workers)) on n_slots concurrent slots; a slot whose worker is
     done takes the next unplayed worker.  The output equals that of n_slots = n_workers bit for bit (streams, tau and tuple regions
     are keyed by worker id).  None = n_slots.
+
+    noise_mode: 0 = production (Philox noise); 1 = the injected test noise of include/ckr.h (ckr_config.noise_mode): Dirichlet
+    vectors and pick uniforms are a published hash of (seed, worker, draw counter), the same the fixture generator hands to the
+    imported reference -- parity tests of the epsilon > 0 / tau > 0 search.  Also read from mcts_kwargs["NOISE_MODE"].
 
     game: "checkers", or "tictactoe" -- the reference's second environment (GAME_ENV = TicTacToe(), play_TTT.py:47-60),
     random-rollout self-play only (NEURAL_NET False): the README's known-answer validation of the search core."""
@@ -102,7 +106,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], w_accum=W_ACCUM[w_accum], seed=int(seed),
                        leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2),
                        dense_rows=int(bool(dense_rows)), n_workers=int(n_workers or 0), leaf_cache_park=int(bool(leaf_cache_park)),
-                       time_budget_us=int(time_budget_us))
+                       time_budget_us=int(time_budget_us), noise_mode=int(noise_mode or k.get("NOISE_MODE", 0)))
 
 
 def time_budget_of(mcts_kwargs):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 125          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy */
+#define CKR_VERSION 126          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_* */
 
 typedef enum {
     CKR_OK = 0,
@@ -317,6 +317,20 @@ typedef struct {
                                     microseconds (and two simulations) have passed -- no host clock, plain ckr_engine_step /
                                     ckr_engine_rollout calls.  0: none (rollout budgets; or the host ends the plies of ALL slots
                                     at once with ckr_engine_step_end_ply) */
+    int32_t  noise_mode;         /* 0 = production: Dirichlet noise (MCTS.py:107-108) and temperature picks (MCTS.py:246) draw from
+                                    Philox4x32-10 keyed by (seed, worker) -- NumPy's MT19937 stream cannot be matched, so these paths
+                                    are pinned distributionally (ckr_probe_dirichlet / _temperature).  1 = INJECTED NOISE (parity
+                                    tests): the gamma variates behind a Dirichlet vector and the uniform of a pick are a published
+                                    integer hash of (seed, global worker id, draw counter, component) -- g_i = (hash >> 8) + 1,
+                                    dir_i = g_i / sum g; u = hash(.., 0xFFFFFFFF) * 2^-32; the counter starts at 0 with a worker's
+                                    first game and advances with every select_child call (epsilon != 0) and every sampled move --
+                                    which the fixture generator feeds to the IMPORTED REFERENCE through np.random.dirichlet /
+                                    np.random.choice (tests/golden/ref_shim.NoiseInjector) and the CPU oracle evaluates too.  Every
+                                    operation on the noise (normalisation, float32((1 - eps) P) + eps dir, PUCT, argmax, the
+                                    temperature weights and their inverse CDF) is the production code: the epsilon = 0.25 / tau = 1
+                                    search of every BASELINE config is then bit-identical to the reference on identical inputs
+                                    (tests/golden/{search,selfplay,tournament}_noise_*.npz) */
+    int32_t  reserved0;
 } ckr_config;
 
 /* One training tuple, compact form (training_pipeline.py:364-369,406-410,
@@ -666,6 +680,12 @@ int ckr_probe_temperature(const int32_t* visits, int32_t n, double tau, int32_t 
 /* tau in force at move 0 .. moves-1 of a worker whose every move is sampled (MCTS.py:243-245: decay after
  * TEMP_DECAY_DELAY moves, snap to 0 at np.isclose): out[moves]. */
 int ckr_probe_tau_schedule(double tau0, double tau_decay, int32_t tau_decay_delay, int32_t moves, double* out);
+/* ckr_config.noise_mode 1 through the same device functions: sample s = the draw with worker id (s & 1023), counter (s >> 10).
+ * out[samples][n]: the Dirichlet vectors of n components (bit-identical to the fixture generator's and the oracle's). */
+int ckr_probe_noise_dirichlet(int32_t n, int32_t samples, uint64_t seed, double* out);
+/* ... and the children best_child samples for visit counts visits[n] at temperature tau with the injected uniform of draw s:
+ * picks[samples] -- the index np.random.choice(children, p = visits^(1/tau) / sum) returns for that uniform. */
+int ckr_probe_noise_pick(const int32_t* visits, int32_t n, double tau, int32_t samples, uint64_t seed, int32_t* picks);
 
 #ifdef __cplusplus
 }

@@ -1029,6 +1029,18 @@ void ckro_worker_submit(ckro_worker* w, const float* p512, float v)
     w->rollout_count++;
 }
 
+/* a whole worker with the integer hash nets (salt0: network 0, the only one in self-play; salt1: the tournament's second net):
+ * the loop oracle.Worker.run makes through ctypes, for the whole-game comparisons at BASELINE budgets (millions of evaluations) */
+void ckro_worker_run_hashnet(ckro_worker* w, uint32_t salt0, uint32_t salt1, int inexact)
+{
+    float x[896], p[512], v;
+    int net = 0;
+    while (ckro_worker_advance(w, x, &net, NULL)) {
+        ckro_hashnet_ex(x, net ? salt1 : salt0, inexact, p, &v);
+        ckro_worker_submit(w, p, v);
+    }
+}
+
 int ckro_worker_num_tuples(const ckro_worker* w) { return w->n_tuples; }
 const ckro_tuple* ckro_worker_tuples(const ckro_worker* w) { return w->tuples; }
 int ckro_worker_num_results(const ckro_worker* w) { return w->n_results; }

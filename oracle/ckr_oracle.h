@@ -161,6 +161,9 @@ int  ckro_worker_advance(ckro_worker* w, float* x896, int* net, ckro_board* leaf
  * output, before masking) and v. */
 void ckro_worker_submit(ckro_worker* w, const float* p512, float v);
 
+/* advance / submit until the worker is finished, evaluating with ckro_hashnet_ex(salt0 | salt1 by network id) */
+void ckro_worker_run_hashnet(ckro_worker* w, uint32_t salt0, uint32_t salt1, int inexact);
+
 int  ckro_worker_num_tuples(const ckro_worker* w);
 const ckro_tuple* ckro_worker_tuples(const ckro_worker* w);
 int  ckro_worker_num_results(const ckro_worker* w);

@@ -83,6 +83,7 @@ def lib():
         L.ckro_worker_last_root.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_double), f32p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.ckro_worker_last_root.restype = C.c_int
+        L.ckro_worker_run_hashnet.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         L.ckro_noise_hash.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.ckro_noise_hash.restype = C.c_uint32
         L.ckro_noise_dirichlet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
@@ -224,6 +225,24 @@ class Worker:
         while self.advance():
             p, v = net_fn(self.x.reshape(8, 8, 14), self.net)
             self.submit(p, v)
+
+    def run_hashnet(self, salt0, salt1=0, inexact=False):
+        """run() with the hash nets, entirely in C (ctypes releases the GIL: workers can run on host threads)."""
+        self._L.ckro_worker_run_hashnet(self._h, int(salt0), int(salt1), int(bool(inexact)))
+
+    def tuples_array(self):
+        """The tuples as one NumPy structured array (a copy), fields as ckro_tuple."""
+        n = self._L.ckro_worker_num_tuples(self._h)
+        arr = self._L.ckro_worker_tuples(self._h)
+        dt = np.dtype([("board", np.uint32, 4), ("mask", np.uint32, 8), ("status", np.uint32), ("game", np.int32), ("ply", np.int32),
+                       ("n_children", np.int32), ("action", np.uint16, MAX_CHILDREN), ("visits", np.uint32, MAX_CHILDREN),
+                       ("wsum", np.float64, MAX_CHILDREN), ("prior", np.float32, MAX_CHILDREN), ("root_n", np.int32), ("pad0", np.int32),
+                       ("root_w", np.float64), ("chosen", np.int32), ("q", np.float32), ("q64", np.float64), ("q_is_int", np.int32),
+                       ("z", np.int32)])
+        assert dt.itemsize == C.sizeof(Tuple), (dt.itemsize, C.sizeof(Tuple))
+        if n == 0:
+            return np.zeros(0, dt)
+        return np.ctypeslib.as_array(C.cast(arr, C.POINTER(C.c_uint8)), shape=(n * dt.itemsize,)).view(dt).copy()
 
     def tuples(self):
         n = self._L.ckro_worker_num_tuples(self._h)

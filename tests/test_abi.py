@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.ckr_version() == 125
+    assert lib.ckr_version() == 126
     assert isinstance(lib.ckr_last_error(), bytes)
 
 
@@ -36,7 +36,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Tuple) == 288
     assert C.sizeof(_lib.GameResult) == 32
     assert C.sizeof(_lib.Stats) == 136
-    assert C.sizeof(_lib.Config) == 152
+    assert C.sizeof(_lib.Config) == 160
     assert C.sizeof(_lib.NodeInfo) == 40
 
 

@@ -126,17 +126,20 @@ def test_tournament_matches_reference_golden(E, golden_dir):
     assert checked >= 1
 
 
-def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts_old=None, inexact=False, w_accum="float32", **kw):
+def lockstep(E, oracle, kwargs, salts, games, terminate, tournament=False, salts_old=None, inexact=False, w_accum="float32",
+             noise_seed=None, first_worker_id=0, **kw):
     """Engine slots and oracle workers advanced one evaluation at a time; the
-    leaf every slot asks for must be the oracle's, at every step."""
+    leaf every slot asks for must be the oracle's, at every step.
+    noise_seed: both sides read the injected test noise (noise_mode 1) of that seed, worker ids first_worker_id + slot."""
     import torch
     from checkers_mcts_amd import rules
+    noise = dict(noise_mode=1, seed=noise_seed) if noise_seed is not None else {}
     cfg = E.config_from_kwargs(kwargs, n_slots=len(salts), games_per_slot=games, terminate_cnt=terminate,
                                tournament=tournament, record_root_stats=not tournament,
-                               max_sims_per_step=1 << 30, w_accum=w_accum, **kw)
+                               max_sims_per_step=1 << 30, w_accum=w_accum, first_worker_id=first_worker_id, **noise, **kw)
     eng = E.Engine(cfg)
     workers = [oracle.Worker(oracle.make_config(kwargs, terminate_cnt=terminate, num_games=games, tournament=tournament,
-                                                w_accum=w_accum)) for _ in salts]
+                                                w_accum=w_accum, worker=first_worker_id + i, **noise)) for i in range(len(salts))]
     p = v = None
     steps = 0
     while True:
@@ -175,9 +178,10 @@ def compare_final(E, eng, workers, tournament=False, w_accum="float32"):
         raw = eng.tuples_raw()
         order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
         rw_all, rp_all = rw_all[order], rp_all[order]
+    first = min((r["worker"] for r in res), default=0)                   # engines created with first_worker_id report global ids
     for i, w in enumerate(workers):
         ores = w.results()
-        eres = [r for r in res if r["worker"] == i]
+        eres = [r for r in res if r["worker"] == first + i]
         assert [(r["outcome"], r["move_count"], int(r["adjudicated"]), r["p1_net"]) for r in ores] == \
                [(r["outcome"], r["move_count"], r["adjudicated"], r["p1_net"]) for r in eres]
         for k, val in w.stats().items():
@@ -185,7 +189,7 @@ def compare_final(E, eng, workers, tournament=False, w_accum="float32"):
                 tot[k] += val
         if tournament:
             continue
-        sel = t_all["worker"] == i
+        sel = t_all["worker"] == first + i
         et, ew, ep = t_all[sel], rw_all[sel], rp_all[sel]
         ot = w.tuples()
         assert len(et) == len(ot)
