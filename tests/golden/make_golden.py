@@ -410,6 +410,23 @@ def gen_tournament_noise(cases=((60, 4, 1, 2, 0), (100, 2, 3, 5, 1), (40, 6, 7, 
     np.savez_compressed(os.path.join(OUT, "tournament_noise_v1.npz"), **out)
 
 
+def gen_selfplay_budgets(cases=((50, 200, 1, 11, 5), (400, 200, 1, 12, 6))):
+    """Whole games at the BASELINE budgets with the reference driver's own kwargs and injected noise: cfg1's single self-play game
+    (50 simulations per move, TERMINATE_CNT 200, train_Checkers.py:79-102) and one game at cfg4's 400 simulations per move.  InexactNet;
+    run under both interpreters (selfplay_budgets_np{1,2}.npz)."""
+    out = {}
+    _selfplay_noise_cases(out, cases, "inexact")
+    np.savez_compressed(os.path.join(OUT, "selfplay_budgets_%s.npz" % promotion_regime()), **out)
+
+
+def gen_tournament_budgets(cases=((800, 2, 21, 22, 7),)):
+    """cfg5: one arena pair (each network plays player 1 once) at 800 simulations per move with the arena kwargs of
+    train_Checkers.py:188-202 and injected noise, played to the natural end (no move limit in a tournament)."""
+    out = {}
+    _tournament_cases(out, cases, 0.25)
+    np.savez_compressed(os.path.join(OUT, "tournament_budgets_v1.npz"), **out)
+
+
 # --------------------------------------------------------------------------- self-play tuples
 def gen_selfplay(cases=((30, 40, 2, 0), (20, 1000, 1, 1), (8, 1000, 1, 4), (25, 1000, 1, 6), (50, 12, 3, 9))):
     out = {}
@@ -733,12 +750,14 @@ def gen_console(budget=30, salt=0, plies=4, depth=2, n_selections=12):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rules", "predict", "search", "search_inexact", "selfplay", "selfplay_inexact", "tournament", "rollout", "training", "text", "ttt"]
+    which = sys.argv[1:] or ["rules", "predict", "search", "search_inexact", "selfplay", "selfplay_inexact", "tournament", "rollout", "training", "text", "ttt",
+                             "console", "search_noise", "selfplay_noise", "tournament_noise", "selfplay_budgets", "tournament_budgets"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:
         fn = globals()["gen_" + w]
-        sys.stdout = devnull if w in ("selfplay", "selfplay_inexact", "tournament", "rollout") else real_stdout   # the reference prints per game
+        sys.stdout = devnull if w in ("selfplay", "selfplay_inexact", "tournament", "rollout", "selfplay_noise", "tournament_noise", "selfplay_budgets",
+                                        "tournament_budgets") else real_stdout   # the reference prints per game
         try:
             fn()
         finally:

@@ -327,3 +327,39 @@ def test_noise_tournament_outcomes(oracle, golden_dir):
         assert [r["p1_net"] == 0 for r in res] == list(g["c%d_p1_is_new" % ci])
         checked += 1
     assert checked >= 2
+
+
+# ---- the BASELINE budgets: cfg1's complete game (50 simulations per move), one game at cfg4's 400, one arena pair at cfg5's 800
+# played to its natural end -- the reference driver's own kwargs on injected noise (make_golden.gen_selfplay_budgets / gen_tournament_budgets)
+@pytest.mark.parametrize("regime,w_accum", REGIMES)
+def test_selfplay_at_baseline_budgets_bit_exact(oracle, golden_dir, regime, w_accum):
+    g = _load(golden_dir, "selfplay_budgets_%s.npz" % regime)
+    seed = int(g["noise_seed"])
+    for ci in range(int(g["n_cases"])):
+        budget, terminate, games, salt, worker = (int(v) for v in g["c%d_cfg" % ci])
+        w = oracle.Worker(oracle.make_config(_mk_noise(budget, 1), terminate_cnt=terminate, num_games=games, w_accum=w_accum,
+                                             noise_mode=1, seed=seed, worker=worker))
+        w.run_hashnet(salt, inexact=True)
+        tu = w.tuples()
+        assert len(tu) == len(g["c%d_z" % ci])
+        st = codec.records_to_planes(np.array([t["board"] for t in tu]), np.array([t["mask"] for t in tu]),
+                                     np.array([t["status"] for t in tu], np.uint32))
+        assert (st == g["c%d_state" % ci]).all()
+        for i, t in enumerate(tu):
+            assert (codec.pi_planes(t["action"], t["visits"]) == g["c%d_pi" % ci][i]).all()
+            q = float(t["q"]) if (t["q_is_int"] or w_accum == "float32") else t["q64"]
+            assert np.float64(q).view(np.uint64) == g["c%d_q" % ci][i].view(np.uint64)
+            assert t["q_is_int"] == bool(g["c%d_q_is_int" % ci][i]) and t["z"] == g["c%d_z" % ci][i]
+        assert int(g["c%d_draws" % ci][2]) > 5000                      # thousands of injected draws were consumed in step
+
+
+def test_arena_pair_at_800_simulations(oracle, golden_dir):
+    g = _load(golden_dir, "tournament_budgets_v1.npz")
+    budget, games, salt_new, salt_old, worker = (int(v) for v in g["c0_cfg"])
+    assert budget == 800 and not bool(g["c0_raised"])
+    w = oracle.Worker(oracle.make_config(_mk_noise(budget, 0), num_games=games, tournament=True, noise_mode=1, seed=int(g["noise_seed"]),
+                                         worker=worker))
+    w.run_hashnet(salt_new, salt_old)
+    res = w.results()
+    assert [r["outcome"] for r in res] == list(g["c0_outcome"]) and [r["move_count"] for r in res] == list(g["c0_moves"])
+    assert [r["p1_net"] == 0 for r in res] == list(g["c0_p1_is_new"])
