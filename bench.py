@@ -746,7 +746,7 @@ def main():
         affinity0 = os.sched_getaffinity(0)
     except AttributeError:
         affinity0 = None
-    placement = ckdist.pin_to_gpu(local_rank, world)
+    placement = ckdist.pin_to_gpu(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))    # ranks of THIS node (multi-node: not the global world size)
     mode = a.nn_dtype
     pre = preroll_steps(a)
     # the job: slots x games-per-slot games per GPU.  Default: that many WORKERS of one game each, hosted on the slots one after

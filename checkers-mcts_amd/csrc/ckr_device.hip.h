@@ -150,13 +150,16 @@ __device__ __forceinline__ ckr_board make_child(const ckr_board b, int d, int s)
 // ---- wave64 helpers -------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
-// xor-butterfly exchange.  Within a row of 16 lanes: DPP lane permutations on the VALU operand path (round 5; rounds 1-4 went through
+// STEP `XOR` OF AN XOR-BUTTERFLY -- not a general lane exchange: bfly_*<4> and <8> return the partner's value only when
+// the steps 1, 2 (and 4) of the same butterfly have been applied to `v` before, in that order, and every lane of the wave is active
+// (DPP with bound_ctrl = 0 hands a lane its OWN value for an EXEC-disabled source lane).  Every caller is a reduction below or in
+// ckr_wave_ops.hip.h that runs all steps in order under full EXEC.  Within a row of 16 lanes: DPP lane permutations on the VALU operand path (round 5; rounds 1-4 went through
 // the LDS crossbar with ds_swizzle: ~60+ cycles per exchange against ~8, and the tree kernel's descents are one dependent chain of
 // two such reductions per tree level).  quad_perm gives xor 1 and xor 2 exactly; row_half_mirror (lane 7 - i of each 8) and
 // row_mirror (15 - i) stand in for xor 4 and xor 8, which is the same thing for the values a butterfly exchanges at those steps --
 // after the xor-1 and xor-2 steps every quad is uniform, after the xor-4 step every group of 8.  Across rows: ds_swizzle / ds_bpermute
-// (xchg_i32<16 / 32>), or the row totals through v_readlane (wave_*_f64 / _i32 below).
-template <int XOR> __device__ __forceinline__ int xchg_i32(int v) {
+// (bfly_i32<16 / 32>), or the row totals through v_readlane (wave_*_f64 / _i32 below).
+template <int XOR> __device__ __forceinline__ int bfly_i32(int v) {
     if constexpr (XOR == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);          // quad_perm [1, 0, 3, 2]
     else if constexpr (XOR == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);     // quad_perm [2, 3, 0, 1]
     else if constexpr (XOR == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);    // row_half_mirror
@@ -164,10 +167,10 @@ template <int XOR> __device__ __forceinline__ int xchg_i32(int v) {
     else if constexpr (XOR < 32) return __builtin_amdgcn_ds_swizzle(v, (XOR << 10) | 0x1F);
     else return __builtin_amdgcn_ds_bpermute((lane_id() ^ 32) << 2, v);
 }
-template <int XOR> __device__ __forceinline__ float xchg_f32(float v) { return __int_as_float(xchg_i32<XOR>(__float_as_int(v))); }
-template <int XOR> __device__ __forceinline__ double xchg_f64(double v) {
+template <int XOR> __device__ __forceinline__ float bfly_f32(float v) { return __int_as_float(bfly_i32<XOR>(__float_as_int(v))); }
+template <int XOR> __device__ __forceinline__ double bfly_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(xchg_i32<XOR>(hi), xchg_i32<XOR>(lo));
+    return __hiloint2double(bfly_i32<XOR>(hi), bfly_i32<XOR>(lo));
 }
 __device__ __forceinline__ double row_total_f64(double v, int row) {              // lane 16 * row of a row-uniform value, as a scalar
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * row), __builtin_amdgcn_readlane(__double2loint(v), 16 * row));
@@ -175,28 +178,28 @@ __device__ __forceinline__ double row_total_f64(double v, int row) {            
 // Reductions over the wave; every lane returns the result.  The butterfly's association order is kept: (t0 + t1) + (t2 + t3) over
 // the four row totals is what the xor-16 and xor-32 steps compute in every lane (additions commute).
 __device__ __forceinline__ double wave_max_f64(double v) {
-    v = fmax(v, xchg_f64<1>(v));  v = fmax(v, xchg_f64<2>(v));  v = fmax(v, xchg_f64<4>(v)); v = fmax(v, xchg_f64<8>(v));
+    v = fmax(v, bfly_f64<1>(v));  v = fmax(v, bfly_f64<2>(v));  v = fmax(v, bfly_f64<4>(v)); v = fmax(v, bfly_f64<8>(v));
     return fmax(fmax(row_total_f64(v, 0), row_total_f64(v, 1)), fmax(row_total_f64(v, 2), row_total_f64(v, 3)));
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-    v += xchg_f64<1>(v); v += xchg_f64<2>(v); v += xchg_f64<4>(v); v += xchg_f64<8>(v);
+    v += bfly_f64<1>(v); v += bfly_f64<2>(v); v += bfly_f64<4>(v); v += bfly_f64<8>(v);
     return (row_total_f64(v, 0) + row_total_f64(v, 1)) + (row_total_f64(v, 2) + row_total_f64(v, 3));
 }
 // ... over the first row only (lanes 0-15; the other lanes' results are undefined): the children of a node when it has <= 16
 __device__ __forceinline__ double row_max_f64(double v) {
-    v = fmax(v, xchg_f64<1>(v));  v = fmax(v, xchg_f64<2>(v));  v = fmax(v, xchg_f64<4>(v)); v = fmax(v, xchg_f64<8>(v));
+    v = fmax(v, bfly_f64<1>(v));  v = fmax(v, bfly_f64<2>(v));  v = fmax(v, bfly_f64<4>(v)); v = fmax(v, bfly_f64<8>(v));
     return v;
 }
 __device__ __forceinline__ double row_sum_f64(double v) {
-    v += xchg_f64<1>(v); v += xchg_f64<2>(v); v += xchg_f64<4>(v); v += xchg_f64<8>(v);
+    v += bfly_f64<1>(v); v += bfly_f64<2>(v); v += bfly_f64<4>(v); v += bfly_f64<8>(v);
     return v;
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-    v = max(v, xchg_i32<1>(v));  v = max(v, xchg_i32<2>(v));  v = max(v, xchg_i32<4>(v)); v = max(v, xchg_i32<8>(v));
+    v = max(v, bfly_i32<1>(v));  v = max(v, bfly_i32<2>(v));  v = max(v, bfly_i32<4>(v)); v = max(v, bfly_i32<8>(v));
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-    v += xchg_i32<1>(v); v += xchg_i32<2>(v); v += xchg_i32<4>(v); v += xchg_i32<8>(v);
+    v += bfly_i32<1>(v); v += bfly_i32<2>(v); v += bfly_i32<4>(v); v += bfly_i32<8>(v);
     return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ int bcast_i32(int v, int src) { return __builtin_amdgcn_readlane(v, src); }

@@ -298,14 +298,20 @@ int ckr_device_count(void) {
 int ckr_stream_create(int32_t device, void** out) {
     if (!out) return fail(CKR_ERR_INVALID, "ckr_stream_create: null argument");
     if (int rc = require_device()) return rc;
+    int prev = 0;
+    CKR_HIP(hipGetDevice(&prev));                                      // the caller's current device is left as it was
     CKR_HIP(hipSetDevice(device));
     uint32_t mask[32];
     for (int i = 0; i < 32; ++i) mask[i] = 0xFFFFFFFFu;               // every CU of the device (bits beyond the CU count are ignored)
     hipDeviceProp_t prop;
-    CKR_HIP(hipGetDeviceProperties(&prop, device));
-    const int words = (prop.multiProcessorCount + 31) / 32;
     hipStream_t st = nullptr;
-    CKR_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)(words > 0 && words <= 32 ? words : 32), mask));
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) {
+        const int words = (prop.multiProcessorCount + 31) / 32;
+        e = hipExtStreamCreateWithCUMask(&st, (uint32_t)(words > 0 && words <= 32 ? words : 32), mask);
+    }
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return fail(CKR_ERR_HIP, "ckr_stream_create: %s", hipGetErrorString(e));
     *out = (void*)st;
     return CKR_OK;
 }

@@ -83,10 +83,10 @@ __device__ __forceinline__ float wave_masked_sum(const float* p_lds, const uint3
         const float v = action_legal(m_lds, a) ? p_lds[a] : p_lds[a] * 0.0f;
         r = (i == 0) ? v : r + v;
     }
-    r = r + xchg_f32<1>(r);
-    r = r + xchg_f32<2>(r);
-    r = r + xchg_f32<4>(r);
-    r = r + xchg_f32<8>(r);
+    r = r + bfly_f32<1>(r);
+    r = r + bfly_f32<2>(r);
+    r = r + bfly_f32<4>(r);
+    r = r + bfly_f32<8>(r);
     // the xor-16 step as scalars: both rows of a half hold their row totals now, B0 + B1 and B2 + B3 in NumPy's terms
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 16));   // every lane
 }

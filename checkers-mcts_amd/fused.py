@@ -418,6 +418,18 @@ class FusedEvaluator:
         self._overflow_ptr(dev)
         return self.overflow
 
+    def tripped(self):
+        """True while the range flag is up (the engine consumes nothing from such a batch)."""
+        return self.overflow is not None and bool(int(self.overflow.item()))
+
+    def batch_planes(self, engine):
+        """The float32 planes of the batch `engine` has handed out (its leaves' rows, and the rows evaluated ahead of the search)."""
+        from . import rules
+        x = engine.x
+        n = int(getattr(engine, "eval_range", engine.row_range)[1].item()) if getattr(engine, "dense_rows", False) else x.shape[0]
+        rows = x[:max(1, n)]
+        return rules.features(rows.contiguous()) if getattr(engine, "leaf_records", False) else rows.float()
+
     def recover(self, engine):
         """If the range flag is up: re-calibrate every network's per-layer scales on the synthetic set PLUS the batch that tripped
         (with twice the usual headroom), rebuild the kernels' constants, and evaluate the engine's current batch again -- the
@@ -425,22 +437,19 @@ class FusedEvaluator:
         after this call p / v hold valid answers for them and the searches continue as if the scales had been right from the
         start.  Returns True if it had to act (the caller then drops its captured graph: scale-dependent constants are baked into
         the launches, and p / v are new buffers).  Raises OverflowError only if the network's activations cannot be represented at
-        any scale (not finite)."""
-        if self.overflow is None or not int(self.overflow.item()):
+        any scale (not finite).  (A runner that drives several part-batches pools the tripping batches of the whole job instead:
+        pipeline.StepRunner.check_evaluator.)"""
+        if not self.tripped():
             return False
-        from . import rules
-        x = engine.x
-        n = int(getattr(engine, "eval_range", engine.row_range)[1].item()) if getattr(engine, "dense_rows", False) else x.shape[0]
-        rows = x[:max(1, n)]
-        planes = rules.features(rows.contiguous()) if getattr(engine, "leaf_records", False) else rows.float()
-        self.recalibrate(planes, engine)
+        self.recalibrate(self.batch_planes(engine), engine)
         return True
 
-    def recalibrate(self, planes, engine=None):
-        """New per-layer scales from the synthetic calibration set plus `planes` (the batch that tripped the range flag, with twice
-        the usual headroom); with `engine`, its current batch is evaluated again at the new scales.  The evaluators of a job's other
-        part-batches call this with the SAME planes (pipeline.StepRunner.check_evaluator): one set of scales per network and job, so
-        that every record the parts write into their shared leaf cache comes from the same arithmetic."""
+    def recalibrate(self, planes, engine=None, strict=True):
+        """New per-layer scales from the synthetic calibration set plus `planes` (every batch of the job that has tripped the range
+        flag so far, with twice the usual headroom); with `engine`, its current batch is evaluated again at the new scales.  The
+        evaluators of a job's part-batches are all called with the SAME planes (pipeline.StepRunner.check_evaluator): one set of scales
+        per network and job, so that every record the parts write into their shared leaf cache comes from the same arithmetic.
+        Returns False -- or raises OverflowError if `strict` -- when the engine's batch still leaves the range at the new scales."""
         self.overflow.zero_()
         self.nets = [self._prepare(m, extra=planes, target=HI_TARGET / 2.0) for m in self.sources]
         self.recoveries += 1
@@ -449,8 +458,11 @@ class FusedEvaluator:
             self(engine)
             torch.cuda.synchronize(planes.device)
             if int(self.overflow.item()):
-                raise OverflowError("split-fp16 kernels: activations out of range even after re-calibration on the batch (layer scales %s)"
-                                    % (self.nets[0]["act_scales"],))
+                if strict:
+                    raise OverflowError("split-fp16 kernels: activations out of range even after re-calibration on the batch (layer scales %s)"
+                                        % (self.nets[0]["act_scales"],))
+                return False
+        return True
 
     def check_range(self):
         """Assertion on the float32-grade kernels' operand range: raises if an activation exceeded the fp16 range of its hi

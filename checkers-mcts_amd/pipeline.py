@@ -215,43 +215,74 @@ class StepRunner:
         self.graph = None
         self.steps = 0
         self.recoveries = 0
+        self.calib_pool = {"planes": None}                # tripping batches of this job (SplitRunner: one pool for its parts)
+        if os.environ.get("CKR_TORCH_STREAMS") == "1":    # pool streams are non-blocking: order them behind the caller's set-up work
+            self.stream.wait_stream(torch.cuda.current_stream(eng.device))
         # float32-grade kernels: the engine consumes nothing from a batch on which the evaluator raised its range flag
         flag = evaluator.flag() if hasattr(evaluator, "flag") else None
         if flag is not None:
             eng.set_eval_flag(flag)
 
+    CALIB_POOL_ROWS = 8192                                # positions kept for re-calibration per job (the most recent tripping batches)
+
     @_on_runner_stream
     def check_evaluator(self):
         """Between steps: if the evaluator's range flag is up (an activation beyond the calibrated operand scales of the float32-grade
-        kernels), widen the scales and re-evaluate the batch (FusedEvaluator.recover), forget the leaf cache's records (computed
-        at the old scales) and drop the captured graph.  No search has used the flagged batch: the engine stalls while the flag is
-        up.  The reference's float32 predict has no range limit (Checkers.py:433); neither has this path any more."""
+        kernels), widen the scales and re-evaluate the batch, forget the leaf cache's records (computed at the old scales) and drop the
+        captured graph.  No search has used the flagged batch: the engine stalls while the flag is up.  The reference's float32
+        predict has no range limit (Checkers.py:433); neither has this path any more.
+
+        The scales are calibrated on the synthetic set plus EVERY batch that has tripped the flag in this job so far (`calib_pool`,
+        shared by the job's part-batches, bounded): a later recovery by another part keeps what an earlier one widened, two parts
+        that trip in the same window on different positions both end up inside the range, and every part of the job runs at the
+        same scales (calibrating on the latest batch alone let the parts undo each other's widening)."""
         ev = self.evaluator
         if not hasattr(ev, "recover"):
             if hasattr(ev, "check_range"):
                 ev.check_range()
             return False
         torch.cuda.synchronize(self.eng.device)                 # (every part of the job is idle from here on: the caller steps them all)
-        if not ev.recover(self.eng):
+        if not (ev.tripped() if hasattr(ev, "tripped") else False):
             return False
-        self.recoveries += 1
-        self._adopt_outputs()
-        # the job's other part-batches share the leaf cache: they take the same new scales and evaluate their pending batches again,
-        # then the table (records computed at the old scales) is emptied while nothing runs -- ckr_leaf_cache_flush's contract
-        for sib in getattr(self, "siblings", ()):
-            if sib is not self and hasattr(sib.evaluator, "recalibrate"):
+        pool = self.calib_pool
+
+        def add(planes):
+            have = pool.get("planes")
+            cat = planes if have is None else torch.cat([have, planes.to(have.dtype)], dim=0)
+            pool["planes"] = cat[-self.CALIB_POOL_ROWS:].contiguous()
+            return pool["planes"]
+
+        parts = [sib for sib in getattr(self, "siblings", ()) if sib is not self and hasattr(sib.evaluator, "recalibrate")]
+        # every part whose own pending batch is out of range contributes it (they may have tripped in the same window on other positions)
+        union = add(ev.batch_planes(self.eng))
+        for sib in parts:
+            if sib.steps and sib.evaluator.tripped():
                 with torch.cuda.stream(sib.stream):
-                    sib.evaluator.recalibrate(ev.last_planes, sib.eng if sib.steps else None)
-                sib._adopt_outputs()
-                sib.graph = None
+                    union = add(sib.evaluator.batch_planes(sib.eng))
+        for attempt in range(3):
+            still = []
+            for r in [self] + parts:
+                with torch.cuda.stream(r.stream):
+                    if not r.evaluator.recalibrate(union, r.eng if r.steps else None, strict=False):
+                        still.append(r)
+            if not still:
+                break
+            if attempt == 2:
+                raise OverflowError("split-fp16 kernels: activations out of range even after re-calibration on every batch of the job "
+                                    "(layer scales %s)" % (ev.nets[0]["act_scales"],))
+            for r in still:                                    # (a batch just inside the old range can leave the new, coarser grid's: add it too)
+                with torch.cuda.stream(r.stream):
+                    union = add(r.evaluator.batch_planes(r.eng))
+        self.recoveries += 1
+        for r in [self] + parts:
+            r._adopt_outputs()
+            r.graph = None
         if self.eng.cache is not None or self.eng.cfg.leaf_cache_log2:
             self.eng.cache_flush()
             torch.cuda.synchronize(self.eng.device)
         import warnings
         warnings.warn("float32-grade kernels: activations left the calibrated range; operand scales re-calibrated on the batch (no search "
                       "used the flagged evaluations)", RuntimeWarning)
-        if self.graph is not None:
-            self.graph = None
         return True
 
     def _adopt_outputs(self):
@@ -513,8 +544,10 @@ class SplitRunner:
                 runner.evaluator.two_streams = False         # parts' steps already run beside them, and each part's graph stays a chain
             self.parts.append((eng, runner, stream))
         self.device = self.parts[0][0].device
+        pool = {"planes": None}
         for _, runner, _ in self.parts:                          # a range-flag recovery of one part re-calibrates them all
             runner.siblings = [r for _, r, _ in self.parts]
+            runner.calib_pool = pool
 
     @property
     def engines(self):
@@ -1087,18 +1120,32 @@ class final_evaluation:
             import warnings
             warnings.warn("final_evaluation: network inference runs on PyTorch / MIOpen, not on the hand-written gfx950 kernels (they take "
                           "float32 networks of at most 128 kernels); EVALUATOR='torch' selects this path explicitly", RuntimeWarning, stacklevel=2)
-        fdt = ckengine.BOARDS if fused else dtype
-        cfg = ckengine.config_from_kwargs(
-            self.mcts_kwargs, n_slots=len(pairs), games_per_slot=2, tournament=True, feature_dtype=fdt,
-            nodes_per_tree=tk.get("NODES_PER_TREE"), seed=tk.get("SEED", int.from_bytes(os.urandom(4), "little")),
-            device=dev.index)
-        eng = ckengine.Engine(cfg, feature_dtype=fdt)
+        seed = tk.get("SEED", int.from_bytes(os.urandom(4), "little"))
         model_of = torch.tensor(pairs, dtype=torch.long, device=dev)
-        ev = RoundRobinFusedEvaluator(nets, model_of, eng.rows) if fused else RoundRobinEvaluator(nets, model_of)
-        StepRunner(eng, ev, use_graph=tk.get("USE_GRAPH", True)).run_to_completion()
-        self.stats = eng.stats()
-        res = eng.results()
-        eng.close()
+
+        def play(fused):
+            fdt = ckengine.BOARDS if fused else dtype
+            cfg = ckengine.config_from_kwargs(
+                self.mcts_kwargs, n_slots=len(pairs), games_per_slot=2, tournament=True, feature_dtype=fdt,
+                nodes_per_tree=tk.get("NODES_PER_TREE"), seed=seed, device=dev.index)
+            eng = ckengine.Engine(cfg, feature_dtype=fdt)
+            try:                                             # (whatever happens, the node pool is given back)
+                ev = RoundRobinFusedEvaluator(nets, model_of, eng.rows) if fused else RoundRobinEvaluator(nets, model_of)
+                StepRunner(eng, ev, use_graph=tk.get("USE_GRAPH", True)).run_to_completion()
+                return eng.stats(), eng.results()
+            finally:
+                eng.close()
+
+        try:
+            self.stats, res = play(fused)
+        except OverflowError as e:
+            # the float32-grade kernels' operand scales are calibrated on synthetic positions; the reference's float32 predict has no
+            # range limit (Checkers.py:433).  A round-robin is a handful of games: play it again on the PyTorch modules (same seed).
+            if not fused:
+                raise
+            import warnings
+            warnings.warn("final_evaluation: %s -- the round-robin is played again on the PyTorch modules" % (e,), RuntimeWarning, stacklevel=2)
+            self.stats, res = play(False)
         by_new = {}
         for r in sorted(res, key=lambda r: (r["worker"], r["game"])):
             new, old = pairs[r["worker"]]

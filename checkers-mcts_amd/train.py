@@ -429,6 +429,113 @@ def train_nn(training_data, neural_network, **kwargs):
     return history, filepath
 
 
+# ---- names the reference driver imports beside train_nn (train_Checkers.py:65-67: run_lr_finder under FIND_LR, plot_history after every
+# train_nn): kept so that a 1:1 port of that driver imports and runs; matplotlib optional (no plot, None returned, without it)
+class LRFinder:
+    """Learning-rate range test, the schedule and stopping rule of LRFinder/keras_callback.py:6-69:
+    geometric sweep from min_lr to max_lr with one step every `batches_lr_update` batches, the
+    initial weights reloaded at every step, exponentially smoothed loss (momentum `mom`), stop
+    once the smoothed loss exceeds `stop_multiplier` x the best one."""
+
+    def __init__(self, min_lr, max_lr, mom=0.9, stop_multiplier=None, reload_weights=True, batches_lr_update=5):
+        self.min_lr, self.max_lr, self.mom = min_lr, max_lr, mom
+        self.reload_weights, self.batches_lr_update = reload_weights, batches_lr_update
+        self.stop_multiplier = -20 * mom / 3 + 10 if stop_multiplier is None else stop_multiplier
+
+    def on_train_begin(self, n_iterations, net):
+        self.learning_rates = np.geomspace(self.min_lr, self.max_lr, num=n_iterations // self.batches_lr_update + 1)
+        self.losses, self.iteration, self.best_loss, self.stop_training = [], 0, 0, False
+        self._initial = {k: v.detach().clone() for k, v in net.state_dict().items()} if self.reload_weights else None
+
+    def on_batch_end(self, loss, net, opt):
+        if self.iteration != 0:
+            loss = self.losses[-1] * self.mom + loss * (1 - self.mom)
+        if self.iteration == 0 or loss < self.best_loss:
+            self.best_loss = loss
+        if self.iteration % self.batches_lr_update == 0:
+            if self.reload_weights:
+                net.load_state_dict(self._initial)
+            lr = self.learning_rates[self.iteration // self.batches_lr_update]
+            for grp in opt.param_groups:
+                grp["lr"] = float(lr)
+            self.losses.append(loss)
+        if loss > self.best_loss * self.stop_multiplier:
+            self.stop_training = True
+        self.iteration += 1
+
+    def on_train_end(self, net, plot=True):
+        if self.reload_weights:
+            net.load_state_dict(self._initial)
+        if not plot:
+            return None
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:
+            return None
+        os.makedirs("data/plots", exist_ok=True)
+        plt.figure(figsize=(12, 6))
+        plt.plot(self.learning_rates[:len(self.losses)], self.losses)
+        plt.xlabel("Learning Rate"); plt.ylabel("Loss"); plt.xscale("log")
+        filename = "data/plots/Checkers_LRFinder_" + create_timestamp() + ".png"
+        plt.savefig(filename)
+        plt.close()
+        return filename
+
+
+def run_lr_finder(training_data, start_lr, end_lr, num_epochs, **kwargs):
+    """Learning-rate range test on a fresh network (training_pipeline.py:246-267).  Returns the LRFinder
+    (learning_rates / losses) -- the reference only shows the plot."""
+    BATCH_SIZE = kwargs["BATCH_SIZE"]
+    dev = torch.device(kwargs.get("DEVICE", "cuda"))
+    net = create_nn(**kwargs).to(dev).train()
+    data = _as_training_data(training_data, dev)
+    g = torch.Generator(device="cpu").manual_seed(int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))))
+    order = torch.randperm(len(data), generator=g).to(dev)
+    steps = int(np.ceil(len(data) / float(BATCH_SIZE)))
+    finder = LRFinder(min_lr=start_lr, max_lr=end_lr)
+    opt = torch.optim.Adam(net.parameters(), lr=start_lr, betas=(0.9, 0.999), eps=1e-7)
+    finder.on_train_begin(steps * num_epochs, net)
+    for _ in range(num_epochs):
+        for b in torch.randperm(steps, generator=g).tolist():
+            x, pi, tv = data.batch(order[b * BATCH_SIZE:(b + 1) * BATCH_SIZE])
+            opt.zero_grad(set_to_none=True)
+            loss, _, _ = losses(net, x, pi, tv)
+            loss.backward()
+            opt.step()
+            finder.on_batch_end(float(loss.detach()), net, opt)
+            if finder.stop_training:
+                break
+        if finder.stop_training:
+            break
+    finder.plot_filename = finder.on_train_end(net, plot=kwargs.get("PLOT", True))
+    return finder
+
+
+def plot_history(history, nn, TRAINING_ITERATION):
+    """Loss curves of one training run (training_pipeline.py:198-216); returns the file name."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:
+        return None
+    os.makedirs("data/plots", exist_ok=True)
+    plt.figure()
+    for key in history.history.keys():
+        plt.plot(history.history[key])
+    plt.title("Iteration {} Model Loss".format(TRAINING_ITERATION))
+    plt.ylabel("Loss"); plt.xlabel("Epoch")
+    plt.legend(list(history.history.keys()), loc="upper right")
+    plt.grid()
+    filename = "data/plots/Checkers_Model" + str(TRAINING_ITERATION + 1) + "_TrainingLoss_" + create_timestamp() + ".png"
+    plt.gcf().set_dpi(200)
+    plt.savefig(filename)
+    plt.close()
+    return filename
+
+
 def load_model(filename, **kwargs):
     """Network saved by train_nn / save_nn_to_disk, ready for further training (tensorflow.keras
     load_model in train_Checkers.py:163)."""

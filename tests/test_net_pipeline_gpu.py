@@ -660,6 +660,10 @@ def test_range_flag_recovery_recalibrates_every_part_of_a_job():
             warnings.simplefilter("always")
             runner.run_to_completion(check_every=16)
         evs = [r.evaluator for _, r, _ in runner.parts]
+        pools = [r.calib_pool for _, r, _ in runner.parts]
+        assert pools[0] is pools[1]                                          # ONE pool of tripping batches per job
+        if target:                                                           # both parts were out of range in the same window: both batches are in
+            assert pools[0]["planes"] is not None and pools[0]["planes"].shape[0] > runner.engines[0].cfg.n_slots
         raw = np.concatenate([sorted_tuples(e) for e in runner.engines])
         runs.append((raw, [ev.recoveries for ev in evs], [tuple(ev.nets[0]["act_scales"]) for ev in evs],
                      len([w for w in caught if "re-calibrated" in str(w.message)]), sum(e.stats()["games"] for e in runner.engines)))

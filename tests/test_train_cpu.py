@@ -97,3 +97,27 @@ def test_saved_model_loads_back_with_new_regularisation(tmp_path, monkeypatch):
     back = T.load_model(path, CONV_REG=2e-3)
     assert path == "data/model/Checkers_Model7_stamp.h5" and back.conv_reg == 2e-3
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), back.state_dict().values()))
+
+
+def test_lr_finder_schedule_and_plot_history(tmp_path, monkeypatch):
+    """The names train_Checkers.py:65-67 imports beside train_nn.  LRFinder: geometric sweep with one step per 5 batches, initial
+    weights restored, losses smoothed (LRFinder/keras_callback.py:6-69); plot_history: the reference's file name (or None without matplotlib)."""
+    from checkers_mcts_amd import train as T
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(1)
+    mem = []
+    for i in range(80):
+        st = np.zeros((15, 8, 8)); st[rng.integers(0, 4), rng.integers(0, 8), rng.integers(0, 8)] = 1
+        pi = np.zeros((8, 8, 8)); pi[i % 8, 1, 2] = 1.0
+        mem.append([st, pi, np.float32(0.0), 1])
+    kw = dict(BATCH_SIZE=8, NUM_KERNELS=8, CONV_REG=1e-4, DENSE_REG=1e-4, POLICY_LOSS_WEIGHT=1.0, VALUE_LOSS_WEIGHT=1.0,
+              SEED=4, DEVICE="cpu", PLOT=False)
+    f = T.run_lr_finder(mem, start_lr=1e-6, end_lr=1e-1, num_epochs=2, **kw)
+    n_iter = 2 * 10
+    assert np.allclose(f.learning_rates, np.geomspace(1e-6, 1e-1, num=n_iter // 5 + 1))
+    assert 1 <= len(f.losses) <= n_iter // 5 + 1 and f.iteration <= n_iter
+    assert f.stop_multiplier == pytest.approx(4.0)
+    assert T.LRFinder(1e-5, 1e-1, mom=0.0).stop_multiplier == 10
+    hist = T.History(); hist.add(loss=1.0, val_loss=2.0); hist.add(loss=0.5, val_loss=1.5)
+    fn = T.plot_history(hist, None, 3)
+    assert fn is None or (fn.startswith("data/plots/Checkers_Model4_TrainingLoss_") and os.path.exists(fn))
