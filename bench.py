@@ -593,6 +593,35 @@ def small_jobs_leg(a, dev):
     return res
 
 
+def dropin_leg(a, dev, games=2048):
+    """The drop-in output path end to end: generate_Checkers_data(...).generate_data() -- cfg3's kwargs, `games` games (a bounded
+    sample: the reference's format is 11.8 KB per tuple, 17 GB for the 16 384 games of the whole-run leg) -- self-play, the 288-byte
+    tuples expanded to the reference's float64 [state, pi, q, z] lists (pipeline.tuples_to_memory) and pickled to disk
+    (training_pipeline.py:457-463).  `host_tail_s` = conversion + pickle; the full-size figure: profiles/r06_dropin_generate_data.txt."""
+    import shutil
+    import tempfile
+    from checkers_mcts_amd import pipeline as P
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp(prefix="ckr_dropin_")
+    os.chdir(tmp)
+    try:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        g = P.generate_Checkers_data(dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=TERMINATE_CNT, NUM_CPUS=games, NN_FN="random:0",
+                                          SEED=3), dict(MCTS_KWARGS, BUDGET=a.budget))
+        g.generate_data()
+        total = time.perf_counter() - t0
+        t = dict(g.timings)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+        P.release_caches()
+    host = t["to_memory_s"] + t["pickle_s"]
+    return {"games": games, "budget": a.budget, "seconds": total, "tuples": t["tuples"], "selfplay_s": t["selfplay_s"], "to_memory_s": t["to_memory_s"],
+            "pickle_s": t["pickle_s"], "pickle_bytes": t["pickle_bytes"], "host_tail_s": host, "host_tail_us_per_tuple": host / max(1, t["tuples"]) * 1e6,
+            "host_tail_over_selfplay": host / t["selfplay_s"],
+            "note": "generate_tuples() hands the 288-byte tuples to train.TrainingData on the device instead (no host tail)"}
+
+
 def single_game_leg(a, dev):
     """The reference's own mode of use -- ONE game, one search at a time (play_Checkers.py, MCTS.begin_tree_search): the latency
     of a simulation when nothing can be batched.  One slot, float32-grade network, BUDGET 400 (play_Checkers.py:73)."""
@@ -945,6 +974,8 @@ def main():
             extra["arena_cfg5_shape"] = arena_leg(a, dev)
             extra["random_rollout_mode"] = rollout_leg(a, dev)
             extra["small_jobs"] = small_jobs_leg(a, dev)
+            extra["dropin_generate_data"] = dropin_leg(a, dev)
+            extra["dropin_generate_data_seconds"] = extra["dropin_generate_data"]["seconds"]
             extra["single_game_search"] = single_game_leg(a, dev)
             extra["training_step"] = training_leg(dev)
             extra["training_step_batch_1024"] = training_leg(dev, batch=1024, reps=10)

@@ -91,14 +91,17 @@ def records_to_planes(boards, masks, status):
     s = np.asarray(status, np.uint32).reshape(-1)
     n = b.shape[0]
     out = np.zeros((n, 15, 64), np.float64)
-    out[:, 0] = _unpack_bits(b[:, 0] & ~b[:, 2])
-    out[:, 1] = _unpack_bits(b[:, 0] & b[:, 2])
-    out[:, 2] = _unpack_bits(b[:, 1] & ~b[:, 2])
-    out[:, 3] = _unpack_bits(b[:, 1] & b[:, 2])
+    # the twelve bit planes (men / kings of both sides, the eight legal-move masks) in one scatter: bit s of a word = square s
+    words = np.empty((n, 12), np.uint32)
+    words[:, 0] = b[:, 0] & ~b[:, 2]
+    words[:, 1] = b[:, 0] & b[:, 2]
+    words[:, 2] = b[:, 1] & ~b[:, 2]
+    words[:, 3] = b[:, 1] & b[:, 2]
+    words[:, 4:] = m
+    bits = np.unpackbits(words.view(np.uint8).reshape(n, 12, 4), axis=2, bitorder="little")            # [n, 12, 32] 0 / 1
+    out[:, np.array((0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13))[:, None], np.asarray(SQ_FLAT)[None, :]] = bits
     out[:, 4] = meta_side(b[:, 3])[:, None]
     out[:, 5] = (status_drawk(s).astype(np.float64) / 80)[:, None]
-    for d in range(8):
-        out[:, 6 + d] = _unpack_bits(m[:, d])
     a = meta_action(b[:, 3]).astype(np.int64)
     has = meta_hasact(b[:, 3]) == 1
     out[:, 14, 0] = np.where(has, (a >> 6) + 6, 0)

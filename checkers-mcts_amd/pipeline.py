@@ -733,22 +733,38 @@ def tuples_to_memory(raw, neural_net=True):
     """Compact tuples -> the reference's list of [state(15,8,8) f64,
     pi(8,8,8) f64, q, z] (training_pipeline.py:369,409,454), ordered by
     worker, game, ply.  With NEURAL_NET=False the reference's W is a python int,
-    so q = +-W/N is a python float (float64): rebuilt here from the root's W, N."""
+    so q = +-W/N is a python float (float64): rebuilt here from the root's W, N.
+
+    Whole-array NumPy since round 6 (one scatter for all pi planes, one unpack for all states; rounds 1-5 looped over the tuples
+    in Python: ~25 us each, 37 s for cfg3's 1.46 M tuples).  The arrays of the list are views of two big blocks (11.8 KB per tuple in
+    the reference's float64 format -- 17 GB for a 16 384-game run: generate_tuples() hands the 288-byte form to training instead)."""
     order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
     raw = raw[order]
+    n = len(raw)
     states = codec.records_to_planes(raw["board"], raw["mask"], raw["status"])
-    memory = []
-    for i in range(len(raw)):
-        a, n = ckengine.tuple_actions_visits(raw[i])
-        if raw["q_kind"][i] == _lib.Q_INT or neural_net:
-            q = ckengine.tuple_q(raw[i])        # python int | np.float32 | np.float64, as the reference stores it
-        else:
-            meta = raw["board"][i][3]
-            q = float(raw["root_w"][i]) / int(raw["root_n"][i])
-            if int(codec.meta_mover(meta)) != int(codec.meta_side(meta)):        # training_pipeline.py:365-368
-                q = -q
-        memory.append([states[i], codec.pi_planes(a, n), q, int(raw["z"][i])])
-    return memory
+    # _create_prob_planes (:421-437): pi[action] = N, then / np.sum (integers: exact in any order), float64
+    nc = raw["n_children"].astype(np.int64)
+    used = np.arange(raw["pi"].shape[1])[None, :] < nc[:, None]
+    rows = np.nonzero(used)[0]
+    pis = np.zeros((n, 512), np.float64)
+    pis[rows, (raw["pi"][used] >> 23).astype(np.int64)] = (raw["pi"][used] & 0x7FFFFF).astype(np.float64)
+    total = pis.sum(axis=1)
+    np.divide(pis, total[:, None], out=pis, where=(total > 0)[:, None])
+    pis = pis.reshape(n, 8, 8, 8)
+    # q with the Python type the reference stores (:365-369, :406-409): python int for the terminal tuple, np.float32 (NEP 50) or
+    # np.float64 (legacy promotion; rollout mode: python float) otherwise
+    kind = raw["q_kind"]
+    root_n = raw["root_n"].astype(np.int64)
+    q64 = np.divide(raw["root_w"], root_n, out=np.zeros(n, np.float64), where=root_n != 0)
+    if neural_net:
+        q64 = np.where(kind == _lib.Q_F64_NEG, -q64, q64)
+        qs = [int(q) if k == _lib.Q_INT else (q if k == _lib.Q_F32 else d)
+              for q, k, d in zip(raw["q"], kind.tolist(), q64)]          # iterating the arrays yields np.float32 / np.float64 scalars
+    else:
+        meta = raw["board"][:, 3]
+        q64 = np.where(codec.meta_mover(meta) != codec.meta_side(meta), -q64, q64)        # training_pipeline.py:365-368
+        qs = [int(q) if k == _lib.Q_INT else d for q, k, d in zip(raw["q"], kind.tolist(), q64.tolist())]
+    return [[st, pi, q, z] for st, pi, q, z in zip(states, pis, qs, raw["z"].tolist())]
 
 
 class generate_Checkers_data:
@@ -864,18 +880,31 @@ class generate_Checkers_data:
         """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
         name (a str for one worker, a list otherwise, mirroring training_pipeline.py:325-332: one element, or -- FILE_PER_WORKER --
         NUM_CPUS of them); None on ranks other than 0."""
+        t0 = time.perf_counter()
         gathered = self.generate_tuples()
         if gathered is None:
             return None
-        raw = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=ckengine.TUPLE_DTYPE)
+        t1 = time.perf_counter()
+        raw = gathered.cpu().numpy().reshape(-1).view(ckengine.TUPLE_DTYPE)
         neural = bool(self.mcts_kwargs["NEURAL_NET"])
+        # where the job's time went (bench.py, tools/dropin_timing.py): playing + gather | 288-byte tuples -> the reference's
+        # float64 planes (11.8 KB per tuple) | pickle.dump
+        self.timings = {"tuples": int(len(raw)), "selfplay_s": t1 - t0, "to_memory_s": 0.0, "pickle_s": 0.0, "pickle_bytes": 0}
+
+        def save(part, process_num, stamp):
+            ta = time.perf_counter()
+            memory = tuples_to_memory(part, neural_net=neural)
+            tb = time.perf_counter()
+            fn = self._save_memory(memory, self.TRAINING_ITERATION, stamp, process_num)
+            self.timings["to_memory_s"] += tb - ta
+            self.timings["pickle_s"] += time.perf_counter() - tb
+            self.timings["pickle_bytes"] += os.path.getsize(fn)
+            return fn
+
         if self.file_per_worker and self.num_cpus > 1:                  # NUM_CPUS files, process number = worker id (:332,457-463)
             stamp = _timestamp()
-            workers = np.unique(raw["worker"])
-            return [self._save_memory(tuples_to_memory(raw[raw["worker"] == w], neural_net=neural), self.TRAINING_ITERATION, stamp, int(w))
-                    for w in workers]
-        memory = tuples_to_memory(raw, neural_net=neural)
-        filename = self._save_memory(memory, self.TRAINING_ITERATION, _timestamp(), 0)
+            return [save(raw[raw["worker"] == w], int(w), stamp) for w in np.unique(raw["worker"])]
+        filename = save(raw, 0, _timestamp())
         return [filename] if self.num_cpus > 1 else filename
 
     def _save_memory(self, memory, iteration, timestamp, process_num):

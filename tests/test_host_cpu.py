@@ -162,3 +162,56 @@ def test_rank_placement_divides_the_cores_between_ranks():
     finally:
         os.sched_setaffinity(0, before)
         torch.set_num_threads(threads)
+
+
+def test_tuples_to_memory_whole_array_form_equals_the_per_tuple_restatement():
+    """The vectorised conversion (round 6) against the per-tuple one it replaced, on synthetic tuples of every q kind, in both
+    modes; same values, same Python types, same pickle bytes."""
+    import pickle
+    from checkers_mcts_amd import _lib, codec, engine as E, pipeline
+    rng = np.random.default_rng(5)
+    n = 500
+    raw = np.zeros(n, dtype=E.TUPLE_DTYPE)
+    raw["board"] = rng.integers(0, 2 ** 32, (n, 4), dtype=np.uint64).astype(np.uint32)
+    raw["mask"] = rng.integers(0, 2 ** 32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    raw["status"] = rng.integers(0, 2 ** 24, n)
+    raw["worker"], raw["game"], raw["ply"] = rng.integers(0, 4, n), rng.integers(0, 3, n), rng.permutation(n)
+    raw["n_children"] = rng.integers(0, 20, n)
+    raw["root_n"] = rng.integers(1, 900, n)
+    raw["root_w"] = rng.normal(size=n) * 30
+    raw["q"] = rng.normal(size=n).astype(np.float32)
+    raw["q_kind"] = rng.integers(0, 4, n)
+    raw["q"][raw["q_kind"] == _lib.Q_INT] = rng.integers(-1, 1, int((raw["q_kind"] == _lib.Q_INT).sum()))
+    raw["z"] = rng.integers(-1, 2, n)
+    for i in range(n):
+        k = int(raw["n_children"][i])
+        acts = rng.choice(512, k, replace=False)
+        raw["pi"][i, :k] = (acts.astype(np.uint32) << 23) | rng.integers(0 if k > 1 else 1, 800, k).astype(np.uint32)
+        if k and (raw["pi"][i, :k] & 0x7FFFFF).sum() == 0:
+            raw["pi"][i, 0] |= 1
+
+    def per_tuple(raw, neural_net):
+        order = np.lexsort((raw["ply"], raw["game"], raw["worker"]))
+        raw = raw[order]
+        states = codec.records_to_planes(raw["board"], raw["mask"], raw["status"])
+        out = []
+        for i in range(len(raw)):
+            a, nv = E.tuple_actions_visits(raw[i])
+            if raw["q_kind"][i] == _lib.Q_INT or neural_net:
+                q = E.tuple_q(raw[i])
+            else:
+                meta = raw["board"][i][3]
+                q = float(raw["root_w"][i]) / int(raw["root_n"][i])
+                if int(codec.meta_mover(meta)) != int(codec.meta_side(meta)):
+                    q = -q
+            out.append([states[i], codec.pi_planes(a, nv), q, int(raw["z"][i])])
+        return out
+
+    for neural in (True, False):
+        got, want = pipeline.tuples_to_memory(raw.copy(), neural_net=neural), per_tuple(raw.copy(), neural)
+        assert len(got) == len(want) == n
+        for g, w in zip(got, want):
+            assert g[0].dtype == w[0].dtype == np.float64 and g[0].shape == (15, 8, 8) and (g[0] == w[0]).all()
+            assert g[1].dtype == np.float64 and g[1].shape == (8, 8, 8) and g[1].tobytes() == w[1].tobytes()
+            assert type(g[2]) is type(w[2]) and (g[2] == w[2] or (g[2] != g[2] and w[2] != w[2])) and type(g[3]) is int and g[3] == w[3]
+        assert pickle.dumps([[np.array(s), np.array(p), q, z] for s, p, q, z in got]) == pickle.dumps(want)
