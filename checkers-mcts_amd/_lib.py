@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
-VERSION = 126                      # CKR_VERSION of include/ckr.h this binding was written against
+VERSION = 127                      # CKR_VERSION of include/ckr.h this binding was written against
 Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
@@ -26,7 +26,7 @@ class Config(C.Structure):
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
                 ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
                 ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32), ("dense_rows", C.c_int32), ("n_workers", C.c_int32),
-                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32), ("noise_mode", C.c_int32), ("reserved0", C.c_int32)]
+                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32), ("noise_mode", C.c_int32), ("arena_games", C.c_int32)]
 
 
 class NodeInfo(C.Structure):

@@ -107,6 +107,7 @@ struct Dev {
     double uct_c, alpha, epsilon, tau0, tau_decay;
     uint32_t seed_lo, seed_hi;
     int noise_mode;              // ckr_config.noise_mode: 1 = the Dirichlet variates and the pick's uniform are the injected test noise (noise_hash)
+    int arena_games;             // ckr_config.arena_games: > 1 = worker id W is game W % G of reference worker W / G (concurrent arena games)
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local; record i = nodes[3 i .. 3 i + 2] (see the accessors below)
     uint4* nodes;
     // per slot
@@ -1041,6 +1042,7 @@ template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
 // tournament: which network plays player 1 (0 = NEW_NN): the first half of a worker's games
 // (training_pipeline.py:523-528); with the dynamic queue, every other game
 __device__ __forceinline__ int p1_net_of(const Dev& D, int slot) {
+    if (D.arena_games > 1) return (D.first_worker + D.g_worker[slot]) % D.arena_games >= D.arena_games / 2 ? 1 : 0;
     return D.dynamic ? (D.g_gid[slot] & 1) : (D.g_game[slot] >= D.games_per_slot / 2 ? 1 : 0);
 }
 
@@ -1871,6 +1873,8 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     if (!c || !out) return fail(CKR_ERR_INVALID, "ckr_engine_create: null argument");
     if (int rc = require_device()) return rc;
     if (c->n_slots <= 0 || c->games_per_slot <= 0) return fail(CKR_ERR_INVALID, "n_slots and games_per_slot must be positive");
+    if (c->arena_games > 1 && (!c->tournament || c->games_per_slot != 1 || c->dynamic_queue || c->noise_mode))
+        return fail(CKR_ERR_INVALID, "arena_games needs a tournament engine with games_per_slot = 1, no dynamic queue, noise_mode 0");
     if (c->budget <= 0) return fail(CKR_ERR_INVALID, "BUDGET must be a positive rollout count (CONSTRAINT == 'rollout'); for CONSTRAINT == "
                                                     "'time' pass INT32_MAX and end the plies with ckr_engine_step_end_ply");
     if (!c->tournament && !c->manual_play && c->terminate_cnt <= 0) return fail(CKR_ERR_INVALID, "self-play needs TERMINATE_CNT > 0");
@@ -1915,7 +1919,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.margin = c->budget > (1 << 20) ? D.C / 2 : c->budget * 16 + 64;    // unbounded (time-limited) searches: compact early
     if (D.margin > D.C / 2) D.margin = D.C / 2;
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
-    D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32); D.noise_mode = c->noise_mode ? 1 : 0;
+    D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32); D.noise_mode = c->noise_mode ? 1 : 0; D.arena_games = c->arena_games > 1 ? c->arena_games : 0;
     e->n_games_total = (int64_t)D.n_workers * c->games_per_slot;
     const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C;
     int rc = CKR_OK;

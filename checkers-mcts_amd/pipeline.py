@@ -934,6 +934,12 @@ class tournament_Checkers:
         self.dense_rows = tourney_kwargs.get("DENSE_ROWS", True)
         self.slots = tourney_kwargs.get("SLOTS", 4096)                   # concurrent games per GPU (virtual workers, as in generate_Checkers_data)
         self.split_streams = tourney_kwargs.get("SPLIT_STREAMS", True)   # part-batches on their own HIP streams from 2 048 slots on
+        # True (default): the TOURNEY_GAMES games of a worker run concurrently, each on a slot and with a noise stream of its own
+        # (ckr_config.arena_games) -- a worker's games are independent (training_pipeline.py:519-555: fresh environment and trees per game;
+        # the only thing they share is the process's entropy-seeded np.random stream, :511), and an arena of NUM_CPUS x TOURNEY_GAMES
+        # games then fills NUM_CPUS x TOURNEY_GAMES slots instead of NUM_CPUS.  False: back to back on the worker's slot, one stream
+        # per worker (rounds 1-5; what the injected-noise parity mode NOISE_MODE 1 always does)
+        self.concurrent_games = tourney_kwargs.get("CONCURRENT_GAMES", True)
         self.stats = None
         # measurement hooks (bench.py's arena leg): before_run(runner, device) is called once the engines exist, before the games are
         # played to their end; trace, if a list, receives (step, slots still playing, perf_counter seconds) at every look
@@ -954,13 +960,19 @@ class tournament_Checkers:
         first, count = ckdist.shard_range(self.num_cpus, rank, world)
         dev = ckdist.local_device(local_rank) if world > 1 else torch.device("cuda", torch.cuda.current_device())
         rows = torch.zeros((0, 8), dtype=torch.int32, device=dev)
+        G = int(self.NUM_GAMES)
+        spread = bool(self.concurrent_games) and G > 1 and not int(self.mcts_kwargs.get("NOISE_MODE", 0))
+        if spread:                                   # engine worker W = game W % G of reference worker W // G
+            first, count, games_each = first * G, count * G, 1
+        else:
+            games_each = G
         if count > 0:
             timed = ckengine.time_budget_of(self.mcts_kwargs) is not None
             slots = count if (timed or not self.slots) else min(count, int(self.slots))
             plan = EvaluatorPlan(self.nn1_fn, dev, self.nn_dtype, spec_old=self.nn2_fn, networks=self.networks)
             n_parts = split_parts(slots, two_from=2 * SPLIT_MIN_SLOTS)
             split = bool(self.split_streams) and n_parts >= 2 and not timed
-            log2 = (job_leaf_cache_log2(slots, dev, count * self.NUM_GAMES, self.mcts_kwargs["BUDGET"] if not timed else 1 << 20, plies=150)
+            log2 = (job_leaf_cache_log2(slots, dev, count * games_each, self.mcts_kwargs["BUDGET"] if not timed else 1 << 20, plies=150)
                     if self.leaf_cache_log2 is None else int(self.leaf_cache_log2))
             cache = acquire_leaf_cache(log2, dev, n_engines=n_parts if split else 1)
             batch_rows = slots if split else lookahead_rows(slots, plan.fused and plan.feature_dtype == ckengine.BOARDS and bool(self.dense_rows)
@@ -968,9 +980,9 @@ class tournament_Checkers:
 
             def make_engine(offset, workers, n):
                 cfg = ckengine.config_from_kwargs(
-                    self.mcts_kwargs, n_slots=n, n_workers=workers, games_per_slot=self.NUM_GAMES, tournament=True,
+                    self.mcts_kwargs, n_slots=n, n_workers=workers, games_per_slot=games_each, tournament=True,
                     first_worker_id=first + offset, nodes_per_tree=self.nodes_per_tree, feature_dtype=plan.feature_dtype,
-                    seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows))
+                    seed=self.seed, device=dev.index, leaf_cache_log2=0, dense_rows=bool(self.dense_rows), arena_games=G if spread else 0)
                 return ckengine.Engine(cfg, cache=cache, extra_rows=0 if split else max(0, batch_rows - n))
 
             engines = []
@@ -1003,6 +1015,8 @@ class tournament_Checkers:
             for e in engines:
                 e.close()
             release_leaf_cache(cache)
+            if spread:                               # back to the reference's (worker, game within the worker)
+                res = [dict(r, worker=r["worker"] // G, game=r["worker"] % G) for r in res]
             rows = torch.tensor([[r[k] for k in ("worker", "game", "outcome", "move_count", "adjudicated",
                                                  "p1_net", "n_tuples", "failed")] for r in res],
                                 dtype=torch.int32, device=dev).reshape(-1, 8)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 126          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_* */
+#define CKR_VERSION 127          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games */
 
 typedef enum {
     CKR_OK = 0,
@@ -330,7 +330,13 @@ typedef struct {
                                     temperature weights and their inverse CDF) is the production code: the epsilon = 0.25 / tau = 1
                                     search of every BASELINE config is then bit-identical to the reference on identical inputs
                                     (tests/golden/{search,selfplay,tournament}_noise_*.npz) */
-    int32_t  reserved0;
+    int32_t  arena_games;        /* 0 / 1 = off.  G > 1 (tournament engines with games_per_slot = 1 only): the engine's workers are the GAMES of an
+                                    arena whose reference workers play G games each (training_pipeline.py:519-531) -- worker id W stands for
+                                    game W % G of reference worker W / G, network NEW is player 1 in that worker's first G / 2 games (:523-528)
+                                    -- so that all games of a worker run CONCURRENTLY on their own slots instead of back to back.  Every game
+                                    then has a noise stream of its own, keyed by (seed, W); the reference draws a worker's games from one
+                                    entropy-seeded stream (np.random.seed(), :511), which fixes no relation between them either.  Not with
+                                    noise_mode 1 (the injected stream counts a worker's draws across its games) */
 } ckr_config;
 
 /* One training tuple, compact form (training_pipeline.py:364-369,406-410,

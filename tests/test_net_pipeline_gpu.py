@@ -693,3 +693,35 @@ def test_large_tournament_on_part_batches_equals_one_engine():
     for k in ("expansions", "terminal_visits", "plies", "games"):
         assert one.stats[k] == parts.stats[k], k
     assert len({g[3] for g in a}) == 3                              # wins of both colours and draws occur
+
+
+def test_concurrent_arena_games_of_a_worker():
+    """tournament_Checkers plays the TOURNEY_GAMES games of a worker concurrently, each on its own slot and noise stream (round 6:
+    ckr_config.arena_games; CONCURRENT_GAMES=False = back to back on one slot, rounds 1-5).  A worker's games are independent in
+    the reference (fresh environment and trees per game, training_pipeline.py:519-555).  Deterministic settings (epsilon 0: no noise
+    enters a score): the game list is the back-to-back one, game for game, colours included -- and the oracle's.  With noise: the
+    colour schedule of :523-528, results independent of the slot count and of the division into part-batches."""
+    import oracle as orc
+    from checkers_mcts_amd import pipeline as P
+    kw0 = dict(KW, BUDGET=24, TRAINING=False, DIRICHLET_EPSILON=0.0, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+    tk = dict(TOURNEY_GAMES=4, NUM_CPUS=5, NEW_NN_FN="hash:3", OLD_NN_FN="hash:4", SEED=9)
+    spread = P.tournament_Checkers(dict(tk), dict(kw0))._start_tournament()
+    serial = P.tournament_Checkers(dict(tk, CONCURRENT_GAMES=False), dict(kw0))._start_tournament()
+    assert spread == serial and len(spread) == 20
+    w = orc.Worker(orc.make_config(kw0, num_games=4, tournament=True))
+    w.run_hashnet(3, 4)
+    want = [["hash:3", "hash:4"] if r["p1_net"] == 0 else ["hash:4", "hash:3"] for r in w.results()]
+    for k in range(5):                                                    # every worker plays the oracle's four games
+        mine = spread[4 * k:4 * k + 4]
+        assert [g[1:3] for g in mine] == want and [g[4] for g in mine] == [r["move_count"] for r in w.results()]
+        assert [g[3] for g in mine] == [orc.OUTCOME_NAMES[r["outcome"]] for r in w.results()]
+    kw1 = dict(kw0, DIRICHLET_EPSILON=0.25, BUDGET=16)
+    tk1 = dict(TOURNEY_GAMES=2, NUM_CPUS=70, NEW_NN_FN="hash:3", OLD_NN_FN="hash:4", SEED=9)
+    a = P.tournament_Checkers(dict(tk1), dict(kw1))
+    la = a._start_tournament()
+    lb = P.tournament_Checkers(dict(tk1, SLOTS=33), dict(kw1))._start_tournament()          # virtual workers: 140 games on 33 slots
+    assert la == lb and len(la) == 140 and a.stats["games"] == 140
+    assert all(g[1] == ("hash:3" if i % 2 == 0 else "hash:4") for i, g in enumerate(la))    # NEW is player 1 in a worker's first game
+    assert len({(g[3], g[4]) for g in la}) > 20                                             # the games' noise streams differ
+    lc = P.tournament_Checkers(dict(tk1, CONCURRENT_GAMES=False), dict(kw1))._start_tournament()
+    assert len(lc) == 140 and lc != la                                                      # (another keying of the streams: other samples)
