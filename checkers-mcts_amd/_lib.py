@@ -26,7 +26,7 @@ class Config(C.Structure):
                 ("record_root_stats", C.c_int32), ("manual_play", C.c_int32), ("device", C.c_int32),
                 ("neural_net", C.c_int32), ("rollout_first", C.c_int32), ("dynamic_queue", C.c_int32), ("game", C.c_int32),
                 ("w_accum", C.c_int32), ("seed", C.c_uint64), ("leaf_cache_log2", C.c_int32), ("leaf_cache_gen_log2", C.c_int32), ("dense_rows", C.c_int32), ("n_workers", C.c_int32),
-                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32), ("noise_mode", C.c_int32), ("arena_games", C.c_int32)]
+                ("leaf_cache_park", C.c_int32), ("time_budget_us", C.c_int32), ("noise_mode", C.c_int32), ("arena_games", C.c_int32), ("pool_spares", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class NodeInfo(C.Structure):
@@ -50,7 +50,7 @@ class GameResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("expansions", "terminal_visits", "plies", "games", "reroot_misses",
                                           "nodes_created", "compactions", "pool_overflows", "steps",
-                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped", "parked", "stalled_steps", "evaluated_ahead")]
+                                          "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped", "parked", "stalled_steps", "evaluated_ahead", "pool_grown")]
 
 
 EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_stream_create", "ckr_stream_destroy", "ckr_movegen_batch", "ckr_children_batch",

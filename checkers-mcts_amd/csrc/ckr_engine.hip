@@ -27,8 +27,9 @@ namespace ckr {
 
 enum { PH_PLAYING = 0, PH_FINISHED = 1, PH_IDLE = 2 };   // IDLE: manual_play slot waiting for a command
 enum { CNT_EXP = 0, CNT_TERM, CNT_PLIES, CNT_GAMES, CNT_MISS, CNT_NODES, CNT_COMPACT, CNT_OVERFLOW, CNT_STEPS,
-       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_STALL, CNT_AHEAD, CNT_N };
-constexpr int CNT_SHARDS = 64, CNT_STRIDE = 16;          // counters[shard][16 x u64]: one atomic word saturates at ~88/us
+       CNT_NN, CNT_HIT, CNT_CINS, CNT_CDROP, CNT_PARK, CNT_STALL, CNT_AHEAD, CNT_GROWN, CNT_N };
+constexpr int CNT_SHARDS = 64, CNT_STRIDE = 32;          // counters[shard][32 x u64]: one atomic word saturates at ~88/us
+static_assert(CNT_N <= CNT_STRIDE, "a shard holds every counter");
 // Phase timing of the tree kernel (a measurement build, -DCKR_KSTEP_PROF; never the product): ticks of the 100-MHz wall clock per
 // phase, summed per wave and added to Dev.prof at the end of the launch.
 enum { PR_ENTRY = 0, PR_EXPAND, PR_DESCEND, PR_PROBE, PR_HITEXP, PR_PREFETCH, PR_FINISH, PR_EXIT, PR_TOTAL, PR_NDESC, PR_NLEVEL, PR_NWAVES, PR_N };
@@ -110,6 +111,12 @@ struct Dev {
     int arena_games;             // ckr_config.arena_games: > 1 = worker id W is game W % G of reference worker W / G (concurrent arena games)
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local; record i = nodes[3 i .. 3 i + 2] (see the accessors below)
     uint4* nodes;
+    // ... and its growth (round 6): n_big spare regions of two semispaces of Cbig = 8 C records behind the slots' own, at record big_off.
+    // A tree whose LIVE subtree leaves no room in its own semispace (the reference keeps a re-rooted subtree without limit,
+    // MCTS.py:251-295; forced lines of play retain all of it) moves into a spare region r and gives it back when its game ends: its
+    // t_half becomes 2 + 2 r + h (h = the live semispace of the region), so no state is added to the slot and `half ^ 1` still names
+    // the other semispace.  Only when no region is free (or Cbig is outgrown too) is a game abandoned (pool_overflows).
+    int Cbig, n_big; size_t big_off; int32_t* big_owner;
     // per slot
     uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
@@ -199,8 +206,11 @@ template <typename WT> struct WaveT {
                                       // the handle itself -- a dynamically indexed member would pin the whole handle to scratch memory)
     int wk = 0;                  // the worker this slot hosts (local id; global id = D.first_worker + wk)
     __device__ uint32_t worker() const { return (uint32_t)(D.first_worker + wk); }
+    __device__ __forceinline__ int cap(int half) const { return half < 2 ? D.C : D.Cbig; }      // records of semispace `half` (>= 2: a spare region's)
     __device__ __forceinline__ void count(int which, uint32_t by = 1u) { if (lane == 0) L.cnt[which] += by; }
-    __device__ size_t tbase(int t, int half) const { return ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C; }
+    __device__ size_t tbase(int t, int half) const {
+        return half < 2 ? ((size_t)((slot * 2 + t) * 2 + half)) * (size_t)D.C : D.big_off + (size_t)(half - 2) * (size_t)D.Cbig;
+    }
     __device__ size_t tb(int t) const { return tbase(t, D.t_half[slot * 2 + t]); }
 };
 
@@ -428,6 +438,7 @@ template <int GAME = 0, class Wave> __device__ void fresh_root(Wave& w, int t) {
     const ckr_board b = ld_board(&D.g_board[w.slot]);
     uint32_t m[8], st;
     rules_movegen<GAME>(b, m, st);
+    release_pool(w, t);                                     // (a tree that had grown starts afresh in its own semispace)
     if (w.lane == 0) {
         D.t_half[ti] = 0;
         write_node(w, w.tbase(t, 0), b, -1, 0.0f, st | (meta_mover(b.meta) << 4));
@@ -440,11 +451,13 @@ template <int GAME = 0, class Wave> __device__ void fresh_root(Wave& w, int t) {
 // Semispace copy of the subtree under the cursor (breadth first, children stay
 // contiguous).  64 nodes per pass: lane = node, wave scan assigns child blocks.
 // Returns the new index of node `track` (a node of the subtree; -1: none asked for).
-template <class Wave> __device__ int compact(Wave& w, int t, int track = -1) {
+// grow_region >= 0: the copy goes into semispace 0 of that spare region, which becomes the tree's pool (Dev.big_owner; t_half = 2 + 2 r + h).
+template <class Wave> __device__ int compact(Wave& w, int t, int track = -1, int grow_region = -1) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const int half = D.t_half[ti];
-    const size_t src = w.tbase(t, half), dst = w.tbase(t, half ^ 1);
+    const int nhalf = grow_region >= 0 ? 2 + 2 * grow_region : half ^ 1;
+    const size_t src = w.tbase(t, half), dst = w.tbase(t, nhalf);
     const int root = D.t_cursor[ti];
     if (w.lane == 0) {
         const uint4* sp = nq(D, src + root);
@@ -482,10 +495,36 @@ template <class Wave> __device__ int compact(Wave& w, int t, int track = -1) {
         free_ += total; q += cnt;
         wave_mem_fence();
     }
-    if (w.lane == 0) { D.t_half[ti] = half ^ 1; D.t_used[ti] = free_; D.t_cursor[ti] = 0; }
+    if (w.lane == 0) { D.t_half[ti] = nhalf; D.t_used[ti] = free_; D.t_cursor[ti] = 0; }
+    if (grow_region >= 0) w.count(CNT_GROWN);
     w.count(CNT_COMPACT);
     wave_mem_fence();
     return wave_max_i32(moved);
+}
+
+// The live subtree of tree t has outgrown its semispace: move it into a spare region (Dev.big_owner).  Returns the new index of `track`
+// (0 when none was asked for), or -1 when the tree already lives in one or none is free (the caller then gives the game up).
+template <class Wave> __device__ __attribute__((noinline)) int grow_pool(Wave& w, int t, int track = -1) {
+    const Dev& D = w.D;
+    if (D.t_half[w.slot * 2 + t] >= 2 || D.n_big <= 0) return -1;
+    int region = -1;
+    if (w.lane == 0)
+        for (int i = 0; i < D.n_big && region < 0; ++i) {                       // rare: a linear scan from a slot-dependent start
+            const int r = (int)(((unsigned)w.slot * 7u + (unsigned)i) % (unsigned)D.n_big);
+            if (atomicCAS(&D.big_owner[r], 0, 1) == 0) region = r;
+        }
+    region = bcast_i32(region, 0);
+    if (region < 0) return -1;
+    const int moved = compact(w, t, track, region);
+    return track >= 0 ? moved : 0;
+}
+// ... and the regions go back when the slot's game is over (or a tree starts afresh)
+template <class Wave> __device__ __forceinline__ void release_pool(Wave& w, int t) {
+    const Dev& D = w.D;
+    const int h = D.t_half[w.slot * 2 + t];
+    if (h < 2) return;
+    if (w.lane == 0) { D.t_half[w.slot * 2 + t] = 0; atomicExch(&D.big_owner[(h - 2) >> 1], 0); }
+    wave_mem_fence();
 }
 
 // Start of a ply's search for the side to move: (re)root its tree
@@ -498,8 +537,11 @@ template <int GAME = 0, class Wave> __device__ void start_search(Wave& w) {
     if (D.t_cursor[ti] < 0) {
         if (D.t_searched[ti]) w.count(CNT_MISS);
         fresh_root<GAME>(w, t);
-    } else if (D.C - D.t_used[ti] < D.margin) {
+    } else if (w.cap(D.t_half[ti]) - D.t_used[ti] < D.margin) {
         compact(w, t);
+        // the live subtree alone leaves less than a search's margin: a bigger pool for this tree, if one is free (else the search
+        // starts anyway and ends the game only if an expansion really finds no room)
+        if (w.cap(D.t_half[ti]) - D.t_used[ti] < D.margin) grow_pool(w, t);
     }
     if (w.lane == 0) { D.t_searched[ti] = 1; D.g_sims[w.slot] = 0; if (D.time_ticks) D.g_start[w.slot] = wall_clock64(); }
     wave_mem_fence();
@@ -507,6 +549,7 @@ template <int GAME = 0, class Wave> __device__ void start_search(Wave& w) {
 
 template <int GAME = 0, class Wave> __device__ void new_game(Wave& w) {
     const Dev& D = w.D;
+    release_pool(w, 0); release_pool(w, 1);
     if (w.lane == 0) {
         // Checkers.reset / init_board (Checkers.py:405-423); the mover into the
         // initial state is player 2 (MCTS.py:170-173)
@@ -781,7 +824,7 @@ template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline_
     const int n = wave_children(b, m, w.L.kids, true);
     __builtin_amdgcn_wave_barrier();
     const int used = pre.used;
-    if (used + n > D.C) return -1;
+    if (used + n > w.cap(pre.half)) return -1;
     if (CACHED && n != cached_n) return -1;                // cannot happen (the successor list is a function of the key)
     float prior = cached_prior;
     if (w.lane < n) {
@@ -815,6 +858,21 @@ template <bool CACHED, bool KNOWN = false, class Wave> __device__ __forceinline_
     }
     wave_mem_fence();
     return n;
+}
+
+// The node pool is full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up to 48 children): drop
+// the garbage and retry; if the LIVE subtree alone fills the semispace, move it into a spare region first (grow_pool).  The recorded
+// path is stale after the move, so the backup walks the parent links (plen 65).  Out of line: rare, and the tree kernel's main body
+// keeps its registers.  Returns the number of children, -1 if there is still no room (the caller gives the game up).
+template <class Wave> __device__ __attribute__((noinline)) int expand_after_compaction(Wave& w, int t, int pending, const float* __restrict__ prow, float v,
+                                                                                  int pnet, int cslot0, unsigned long long cword0) {
+    const Dev& D = w.D;
+    const int ti = w.slot * 2 + t;
+    int moved = compact(w, t, pending);
+    if (moved >= 0 && w.cap(D.t_half[ti]) - D.t_used[ti] < CKR_MAX_CHILDREN) moved = grow_pool(w, t, moved);
+    if (moved < 0) return -1;
+    const ExpandPre again{D.t_half[ti], D.t_used[ti], 65, 0u};
+    return expand<false>(w, t, moved, prow, v, again, 0.0f, 0, pnet, cslot0, cword0);
 }
 
 // ---- selection: MCTS.select_child (MCTS.py:102-116) repeated down the tree
@@ -988,7 +1046,7 @@ template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
             uint32_t nst = st;
             if (created == 0) {
                 base = D.t_used[ti];
-                if (base + nleg > D.C) return false;
+                if (base + nleg > w.cap(D.t_half[ti])) return false;
                 nst = st | ST_EXPANDED;
                 if (w.lane == 0) D.t_used[ti] = base + nleg;
             }
@@ -1115,6 +1173,7 @@ template <int GAME = 0, class Wave> __device__ __attribute__((noinline)) void en
         wave_mem_fence();
         new_game<GAME>(w);
     } else {
+        release_pool(w, 0); release_pool(w, 1);
         if (w.lane == 0) { D.g_phase[w.slot] = PH_FINISHED; atomicAdd(D.n_finished, 1); }
         wave_mem_fence();
     }
@@ -1441,9 +1500,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
             // to 48 children): drop the garbage now and retry; the recorded path is stale after the move, so the
             // backup walks the parent links (plen > 64)
-            const int moved = compact(w, t, pending);
-            ExpandPre again{D.t_half[slot * 2 + t], D.t_used[slot * 2 + t], 65, 0u};
-            n = moved >= 0 ? expand<false>(w, t, moved, p + (size_t)row * 512, v[row], again, 0.0f, 0, pnet, cslot0, cword0) : -1;
+            n = expand_after_compaction(w, t, pending, p + (size_t)row * 512, v[row], pnet, cslot0, cword0);
             if (n >= 0) { int ph, sm; live_load(w, lv, ph, sm); }          // (everything moved: the live state anew)
         }
         if (n >= 0) {
@@ -1580,6 +1637,7 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
         const int t = (int)(D.g_board[slot].w & 1u);
         bool ok = rollout_sim<GAME>(w, t);
         if (!ok) { compact(w, t); ok = rollout_sim<GAME>(w, t); }               // pool full: a failed simulation has changed nothing yet
+        if (!ok && grow_pool(w, t) >= 0) ok = rollout_sim<GAME>(w, t);           // ... still full: a spare region (Dev.big_owner)
         if (ok) { if (w.lane == 0) D.g_sims[slot] += 1; }
         else { w.count(CNT_OVERFLOW); end_game<GAME>(w, 0u, 0, 1); }
         wave_mem_fence();
@@ -1799,7 +1857,7 @@ template <typename T> static int dalloc(ckr_engine* e, T** p, size_t count, bool
 }
 
 static_assert(sizeof(ckr_tuple) % 16 == 0, "ckr_tuple must be a multiple of 16 bytes");
-static_assert(sizeof(ckr_config) == 160, "ckr_config layout is mirrored by _lib.Config (ctypes)");
+static_assert(sizeof(ckr_config) == 168, "ckr_config layout is mirrored by _lib.Config (ctypes)");
 
 extern "C" {
 
@@ -1921,7 +1979,19 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
     D.uct_c = c->uct_c; D.alpha = c->alpha; D.epsilon = c->epsilon; D.tau0 = c->tau; D.tau_decay = c->tau_decay;
     D.seed_lo = (uint32_t)c->seed; D.seed_hi = (uint32_t)(c->seed >> 32); D.noise_mode = c->noise_mode ? 1 : 0; D.arena_games = c->arena_games > 1 ? c->arena_games : 0;
     e->n_games_total = (int64_t)D.n_workers * c->games_per_slot;
-    const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C;
+    // spare pool regions (Dev.big_owner): one per 32 slots, at least 4, each two semispaces of 8 C records -- 1 / 8 more node memory; fewer
+    // when that would take more than an eighth of the device's memory (time-limited searches: C up to 2^18)
+    D.Cbig = (int)std::min<long long>(8ll * D.C, (1ll << 24) - 64);
+    D.n_big = c->pool_spares > 0 ? c->pool_spares : std::max(4, c->n_slots / 32);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
+        const size_t per_region = (size_t)2 * (size_t)D.Cbig * 48;
+        const size_t most = std::max<size_t>(1, (total_b / 8) / per_region);
+        if ((size_t)D.n_big > most) D.n_big = (int)most;
+    }
+    const size_t S = (size_t)c->n_slots, NN = S * 4 * (size_t)D.C + (size_t)D.n_big * 2 * (size_t)D.Cbig;
+    D.big_off = S * 4 * (size_t)D.C;
     int rc = CKR_OK;
 #define A(ptr, count, zero) if (rc == CKR_OK) rc = dalloc(e, &ptr, (count), (zero))
     A(D.nodes, NN * 3, false);                                    // 48-byte node records (W as float32 or float64 inside quad 1)
@@ -1935,6 +2005,7 @@ int ckr_engine_create(const ckr_config* c, ckr_engine** out) {
         A(D.pf_counter, (size_t)1, true);                             // (the per-row arrays: ckr_engine_set_prefetch, which knows the rows)
     }
     A(D.t_cursor, 2 * S, true); A(D.t_used, 2 * S, true); A(D.t_half, 2 * S, true); A(D.t_searched, 2 * S, true);
+    A(D.big_owner, (size_t)D.n_big, true);
     const size_t NT = (size_t)e->n_games_total * (size_t)D.tuples_per_game;
     A(D.tuples, NT ? NT : 1, true);
     if (D.record_root) { A(D.rs_w, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); A(D.rs_p, (NT ? NT : 1) * CKR_MAX_CHILDREN, true); }
@@ -2178,7 +2249,7 @@ int ckr_engine_stats_at_mark(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS];
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL]; out->evaluated_ahead = c[CNT_AHEAD];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL]; out->evaluated_ahead = c[CNT_AHEAD]; out->pool_grown = c[CNT_GROWN];
     return CKR_OK;
 }
 
@@ -2196,7 +2267,7 @@ int ckr_engine_stats(ckr_engine* e, ckr_stats* out) {
     out->expansions = c[CNT_EXP]; out->terminal_visits = c[CNT_TERM]; out->plies = c[CNT_PLIES]; out->games = c[CNT_GAMES];
     out->reroot_misses = c[CNT_MISS]; out->nodes_created = c[CNT_NODES]; out->compactions = c[CNT_COMPACT];
     out->pool_overflows = c[CNT_OVERFLOW]; out->steps = c[CNT_STEPS]; out->active_slots = active;
-    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL]; out->evaluated_ahead = c[CNT_AHEAD];
+    out->nn_evals = c[CNT_NN]; out->dup_leaves = c[CNT_HIT]; out->cache_entries = c[CNT_CINS]; out->cache_dropped = c[CNT_CDROP]; out->parked = c[CNT_PARK]; out->stalled_steps = c[CNT_STALL]; out->evaluated_ahead = c[CNT_AHEAD]; out->pool_grown = c[CNT_GROWN];
     return CKR_OK;
 }
 
@@ -2354,7 +2425,7 @@ int ckr_engine_root(ckr_engine* e, int32_t slot, int32_t tree, ckr_node_info* ro
     CKR_HIP(hipMemcpy(&cursor, e->dev.t_cursor + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
     CKR_HIP(hipMemcpy(&half, e->dev.t_half + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (cursor < 0) { *n_children = -1; return CKR_OK; }
-    const size_t tb = ((size_t)(ti * 2 + half)) * (size_t)e->dev.C;
+    const size_t tb = half < 2 ? ((size_t)(ti * 2 + half)) * (size_t)e->dev.C : e->dev.big_off + (size_t)(half - 2) * (size_t)e->dev.Cbig;
     uint32_t kids = 0, st = 0;
     if (int rc = read_node(e, tb + (size_t)cursor, root, &kids, &st)) return rc;
     int n = (st & ST_EXPANDED) ? (int)(kids >> 24) : 0;
@@ -2376,7 +2447,7 @@ int ckr_engine_subtree(ckr_engine* e, int32_t slot, int32_t tree, int32_t max_de
     CKR_HIP(hipMemcpy(&used, e->dev.t_used + ti, sizeof(int32_t), hipMemcpyDeviceToHost));
     *n = 0;
     if (cursor < 0 || used <= 0) return CKR_OK;
-    const size_t tb = ((size_t)(ti * 2 + half)) * (size_t)e->dev.C, U = (size_t)used;
+    const size_t tb = half < 2 ? ((size_t)(ti * 2 + half)) * (size_t)e->dev.C : e->dev.big_off + (size_t)(half - 2) * (size_t)e->dev.Cbig, U = (size_t)used;
     std::vector<uint4> raw(U * 3);
     CKR_HIP(hipMemcpy(raw.data(), e->dev.nodes + tb * 3, U * 3 * sizeof(uint4), hipMemcpyDeviceToHost));
     std::vector<ckr_node_info> info(U); std::vector<uint32_t> kids(U), status(U);

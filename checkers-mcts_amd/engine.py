@@ -28,7 +28,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        first_worker_id=0, nodes_per_tree=None, feature_dtype=torch.float32, seed=0,
                        reset_tau_each_game=False, record_root_stats=False, max_sims_per_step=0, device=0,
                        manual_play=False, dynamic_queue=False, rollout_first=False, game="checkers", w_accum=None, leaf_cache_log2=None, leaf_cache_gen_log2=0, dense_rows=False,
-                       n_workers=None, leaf_cache_park=False, device_clock=True, noise_mode=0, arena_games=0):
+                       n_workers=None, leaf_cache_park=False, device_clock=True, noise_mode=0, arena_games=0, pool_spares=0):
     """Build a ckr_config from the reference's kwargs dicts, with the
     reference's own error behaviour for unsupported settings.
 
@@ -59,6 +59,9 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
     noise_mode: 0 = production (Philox noise); 1 = the injected test noise of include/ckr.h (ckr_config.noise_mode): Dirichlet
     vectors and pick uniforms are a published hash of (seed, worker, draw counter), the same the fixture generator hands to the
     imported reference -- parity tests of the epsilon > 0 / tau > 0 search.  Also read from mcts_kwargs["NOISE_MODE"].
+
+    pool_spares: spare node-pool regions (include/ckr.h, ckr_config.pool_spares; 0 = one per 32 slots, at least 4): a tree whose live
+    subtree outgrows its semispace of nodes_per_tree records moves into one (8 x the size) until its game ends.
 
     arena_games: G > 1 (tournament, games_per_slot 1): the engine's workers are the games of reference workers that play G games each
     -- worker id W = game W % G of reference worker W // G -- all running concurrently (include/ckr.h, ckr_config.arena_games).
@@ -109,7 +112,7 @@ def config_from_kwargs(mcts_kwargs, n_slots, games_per_slot, terminate_cnt=0, to
                        dynamic_queue=int(bool(dynamic_queue)), game=GAMES[game], w_accum=W_ACCUM[w_accum], seed=int(seed),
                        leaf_cache_log2=int(leaf_cache_log2), leaf_cache_gen_log2=int(leaf_cache_gen_log2),
                        dense_rows=int(bool(dense_rows)), n_workers=int(n_workers or 0), leaf_cache_park=int(bool(leaf_cache_park)),
-                       time_budget_us=int(time_budget_us), noise_mode=int(noise_mode or k.get("NOISE_MODE", 0)), arena_games=int(arena_games or 0))
+                       time_budget_us=int(time_budget_us), noise_mode=int(noise_mode or k.get("NOISE_MODE", 0)), arena_games=int(arena_games or 0), pool_spares=int(pool_spares or 0))
 
 
 def time_budget_of(mcts_kwargs):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 127          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games */
+#define CKR_VERSION 127          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions) */
 
 typedef enum {
     CKR_OK = 0,
@@ -337,6 +337,9 @@ typedef struct {
                                     then has a noise stream of its own, keyed by (seed, W); the reference draws a worker's games from one
                                     entropy-seeded stream (np.random.seed(), :511), which fixes no relation between them either.  Not with
                                     noise_mode 1 (the injected stream counts a worker's draws across its games) */
+    int32_t  pool_spares;        /* spare node-pool regions of the engine (ckr_stats.pool_grown): 0 = one per 32 slots, at least 4; each is two
+                                    semispaces of 8 x nodes_per_tree records and hosts one tree whose live subtree has outgrown its own */
+    int32_t  reserved0;
 } ckr_config;
 
 /* One training tuple, compact form (training_pipeline.py:364-369,406-410,
@@ -382,6 +385,10 @@ typedef struct {
     uint64_t parked;             /* slot-steps spent waiting for another requester's evaluation of the same position (leaf_cache_park) */
     uint64_t stalled_steps;      /* steps in which nothing was expanded because the evaluation flag was raised (ckr_engine_set_eval_flag) */
     uint64_t evaluated_ahead;    /* positions handed to the network ahead of the search (ckr_engine_set_prefetch): rows beside nn_evals */
+    uint64_t pool_grown;         /* trees whose live subtree outgrew its semispace of nodes_per_tree records and moved into a spare region of
+                                    8 x that (one region per 32 slots; given back when the game ends).  The reference keeps a re-rooted
+                                    subtree without limit (MCTS.py:251-295); pool_overflows counts the games abandoned because no spare
+                                    region was free or it was outgrown too */
 } ckr_stats;
 
 typedef struct ckr_engine ckr_engine;

@@ -35,8 +35,8 @@ def test_struct_sizes_match_header():
     from checkers_mcts_amd import _lib
     assert C.sizeof(_lib.Tuple) == 288
     assert C.sizeof(_lib.GameResult) == 32
-    assert C.sizeof(_lib.Stats) == 136
-    assert C.sizeof(_lib.Config) == 160
+    assert C.sizeof(_lib.Stats) == 144
+    assert C.sizeof(_lib.Config) == 168
     assert C.sizeof(_lib.NodeInfo) == 40
 
 

@@ -544,3 +544,35 @@ def test_counter_mark_is_taken_in_stream_order(E):
     assert all(at_mark[k] == before[k] for k in keys), (at_mark, before)
     assert after["expansions"] > before["expansions"] and after["steps"] == before["steps"] + 50
     eng.close()
+
+
+@pytest.mark.parametrize("w_accum", ["float32", "float64"])
+def test_lockstep_live_subtree_outgrows_its_semispace(E, oracle, w_accum):
+    """The reference keeps a re-rooted subtree without limit (MCTS.py:251-295).  Here a tree lives in a semispace of nodes_per_tree
+    records; a live subtree that no longer fits moves into a spare region of 8 x that (round 6; until round 5 the game was abandoned
+    and counted in pool_overflows).  A pool of 256 records per tree (the smallest the engine takes) at BUDGET 80 is outgrown by every tree: every leaf still equals
+    the oracle's, the games end as the oracle's do, regions are given back at the end of a game and taken again."""
+    salts = [71, 72, 73, 74, 75, 76]
+    eng, workers, steps = lockstep(E, oracle, mk(80), salts, games=2, terminate=40, nodes_per_tree=256, pool_spares=12, inexact=True, w_accum=w_accum)
+    compare_final(E, eng, workers, w_accum=w_accum)
+    st = eng.stats()
+    assert st["pool_grown"] >= 12 and st["pool_overflows"] == 0 and st["compactions"] > st["pool_grown"]        # (12 trees, two games each)
+    eng.close()
+
+
+def test_spare_pool_regions_run_out_gracefully(E):
+    """More trees outgrow their semispaces than there are spare regions (4 for <= 128 slots): those games are abandoned and counted,
+    the others finish; nothing hangs or corrupts (the accounting identities of the finished games hold)."""
+    eng, ev = run_engine(E, mk(100, eps=0.25, tau=1.0), [5] * 32, games_per_slot=1, terminate_cnt=40, nodes_per_tree=256, seed=3)
+    eng.run(ev)
+    st, res = eng.stats(), eng.results()
+    assert st["games"] == 32 and st["active_slots"] == 0
+    failed = [r for r in res if r["failed"]]
+    assert st["pool_overflows"] == len(failed) and 0 < len(failed) < 32 and st["pool_grown"] >= 4
+    t = eng.tuples_raw()
+    ok_games = {(r["worker"], r["game"]) for r in res if not r["failed"]}
+    for e in t:
+        if (int(e["worker"]), int(e["game"])) in ok_games and e["n_children"]:
+            a, nv = E.tuple_actions_visits(e)
+            assert nv.sum() == e["root_n"] - 1
+    eng.close()
