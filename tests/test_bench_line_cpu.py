@@ -1,4 +1,4 @@
-"""CPU: the committed bench line of the round (profiles/r05_bench_default.json, written by `python bench.py` on an
+"""CPU: the committed bench line of the round (profiles/r06_bench_default.json, written by `python bench.py` on an
 MI355X) carries every field of the driver's contract, with the hot path's own metric and roofline / cpu_baseline objects; its
 roofline traffic agrees with the committed PMC table; README.md's numbers are the ones rendered from this line."""
 import json
@@ -6,7 +6,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r05_bench_default.json")
+LINE = os.path.join(ROOT, "profiles", "r06_bench_default.json")
 
 
 def load():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """README.md's measured numbers come from ONE committed bench line: this script renders the table between the
-`<!-- numbers:begin -->` / `<!-- numbers:end -->` markers from profiles/r05_bench_default.json (the output of `python bench.py` on an
+`<!-- numbers:begin -->` / `<!-- numbers:end -->` markers from profiles/r06_bench_default.json (the output of `python bench.py` on an
 MI355X), and tests/test_bench_line_cpu.py checks that README.md holds exactly what it renders.
 
     python tools/readme_numbers.py            # rewrite the block in README.md
@@ -10,7 +10,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r05_bench_default.json")
+LINE = os.path.join(ROOT, "profiles", "r06_bench_default.json")
 BEGIN, END = "<!-- numbers:begin -->", "<!-- numbers:end -->"
 
 
@@ -41,8 +41,14 @@ def render(path=LINE):
         ("one game, one search at a time (`MCTS.begin_tree_search`)", "%.0f k simulations/s, %.1f ms per 400-simulation search"
          % (e["single_game_search"]["sims_per_s"] / 1e3, e["single_game_search"]["search_api_ms_per_400_simulations"])),
         ("random-rollout MCTS (`NEURAL_NET=False`)", "%.1f M complete random playouts/s" % (e["random_rollout_mode"]["rollouts_per_s"] / 1e6)),
-        ("rules kernel K1 on 2^24 boards", "%.0f G boards/s = %.2f TB/s algorithmic (%.0f %% of the 8 TB/s spec)"
+        ("rules kernel K1 on 2^24 boards", "%.0f G boards/s = %.2f TB/s algorithmic (%.0f %% of the 8 TB/s spec; above the ~6.3 TB/s a plain copy reaches: "
+         "the 268-MB input is re-read by back-to-back launches and partly served by the 256-MB Infinity Cache)"
          % (e["movegen_k1"]["boards_per_s"] / 1e9, e["movegen_k1"]["achieved"] / 1e3, 100 * e["movegen_k1"]["frac"])),
+        ("drop-in output path: `generate_Checkers_data(...).generate_data()` end to end, %d games (`extra.dropin_generate_data`)" % e["dropin_generate_data"]["games"],
+         "%.1f s: self-play %.1f s + tuples -> the reference's float64 lists %.1f s + `pickle.dump` of %.1f GB %.1f s (host tail %.2f x the self-play; "
+         "16 384 games: 22.8 + 5.9 + 17.2 s for 17.3 GB, `profiles/r06_dropin_generate_data_16384.json`)"
+         % (e["dropin_generate_data"]["seconds"], e["dropin_generate_data"]["selfplay_s"], e["dropin_generate_data"]["to_memory_s"],
+            e["dropin_generate_data"]["pickle_bytes"] / 1e9, e["dropin_generate_data"]["pickle_s"], e["dropin_generate_data"]["host_tail_over_selfplay"])),
         ("training step, 128 boards (`csrc/ckr_train.hip`)", "%.2f ms = %.0f k samples/s, %.1f x PyTorch + MIOpen"
          % (e["training_step"]["ms_per_step"], e["training_step"]["samples_per_s"] / 1e3, e["training_step"]["speedup_vs_torch_miopen"])),
         ("CPU baseline in the same run (C oracle search + PyTorch-CPU network, %d host threads)" % c["cores"], "%.1f k node-expansions/s" % (c["value"] / 1e3)),

@@ -147,12 +147,14 @@ template <int XI> __device__ __forceinline__ void fold(const f32x16& m, f32x16 (
 }
 
 template <int XI> __device__ __forceinline__ void one_xi(char* act, char* vbuf, __amdgpu_buffer_rsrc_t rsrc, int voff, AF (&ring)[RING], int tid, int lane,
-                                                         int gbase, f32x16 (&y)[4]) {
-    transform<XI>(act, vbuf, tid);
+                                                         int gbase, f32x16 (&y)[4], int skip = 0) {
+    if (!(skip & 1)) transform<XI>(act, vbuf, tid);
     lds_barrier();                                                // V_xi complete
-    f32x16 m;
-    multiply<(XI * 8) % RING>(vbuf, rsrc, voff, gbase + XI * 8, ring, lane, m);
-    fold<XI>(m, y);
+    if (!(skip & 2)) {
+        f32x16 m;
+        multiply<(XI * 8) % RING>(vbuf, rsrc, voff, gbase + XI * 8, ring, lane, m);
+        fold<XI>(m, y);
+    }
     lds_barrier();                                                // every wave has read V_xi
 }
 
@@ -184,6 +186,11 @@ __global__ __launch_bounds__(NT, 2) void k_wino_layer(const WArgs A) {
         *reinterpret_cast<f16x8*>(act + act_addr(r, ks) + LO) = l;
     }
     lds_barrier();
+    // the two workgroups of a CU start together and take the same time per phase: they would transform together (VALU contention) and
+    // multiply together (MFMA contention).  One of them starts half a period late -> one's transform runs under the other's MFMAs.
+    if ((A.skip >> 8) && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < (A.skip >> 8); ++i) __builtin_amdgcn_s_sleep(16);                 // 16 x 64 clocks per unit
+    }
     for (int rep = 0; rep < A.reps; ++rep) {
         AF ring[RING];
 #pragma unroll
@@ -195,14 +202,14 @@ __global__ __launch_bounds__(NT, 2) void k_wino_layer(const WArgs A) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) { y[o][4 * q + 0] = bi.x; y[o][4 * q + 1] = bi.y; y[o][4 * q + 2] = bi.z; y[o][4 * q + 3] = bi.w; }
         }
-        one_xi<0>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);   one_xi<1>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<2>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);   one_xi<3>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<4>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);   one_xi<5>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<6>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);   one_xi<7>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<8>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);   one_xi<9>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<10>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);  one_xi<11>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<12>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);  one_xi<13>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
-        one_xi<14>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);  one_xi<15>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y);
+        one_xi<0>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);   one_xi<1>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<2>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);   one_xi<3>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<4>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);   one_xi<5>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<6>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);   one_xi<7>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<8>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);   one_xi<9>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<10>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);  one_xi<11>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<12>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);  one_xi<13>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
+        one_xi<14>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);  one_xi<15>(act, vbuf, rsrc, voff, ring, tid, lane, 0, y, A.skip);
         // epilogue: ReLU + BatchNorm affine (bias in the accumulators), split, store in place; tile n = lane & 31 -> positions (2 ty + a, 2 tx + b)
         const bool last = rep + 1 == A.reps;
         const int n = lane & 31, brd = n >> 4, ty = (n >> 2) & 3, tx = n & 3;
@@ -295,6 +302,11 @@ __global__ __launch_bounds__(NT, 2) void k_wino_layer_c(const WArgs A) {
         *reinterpret_cast<f16x8*>(act + act_addr(r, ks) + LO) = l;
     }
     lds_barrier();
+    // the two workgroups of a CU start together and take the same time per phase: they would transform together (VALU contention) and
+    // multiply together (MFMA contention).  One of them starts half a period late -> one's transform runs under the other's MFMAs.
+    if ((A.skip >> 8) && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < (A.skip >> 8); ++i) __builtin_amdgcn_s_sleep(16);                 // 16 x 64 clocks per unit
+    }
     for (int rep = 0; rep < A.reps; ++rep) {
         f32x16 y[4];
 #pragma unroll

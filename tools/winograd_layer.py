@@ -174,6 +174,13 @@ def main():
     for name, fn in (("direct_2_layers", direct_k(2)), ("direct_all_layers", direct_k(NL)), ("winograd_reps_1", wino_k(1)), ("winograd_reps_7", wino_k(NL - 1)),
                      ("winograd8_reps_1", wino_k(1, 1)), ("winograd8_reps_7", wino_k(NL - 1, 1)),
                      ("winogradC_reps_1", wino_k(1, 2)), ("winogradC_reps_7", wino_k(NL - 1, 2)),
+                     ("wA_stagger1_reps_1", wino_k(1, 0 + (1 << 12))), ("wA_stagger1_reps_7", wino_k(NL - 1, 0 + (1 << 12))),
+                     ("wA_stagger2_reps_1", wino_k(1, 0 + (2 << 12))), ("wA_stagger2_reps_7", wino_k(NL - 1, 0 + (2 << 12))),
+                     ("wC_stagger1_reps_1", wino_k(1, 2 + (1 << 12))), ("wC_stagger1_reps_7", wino_k(NL - 1, 2 + (1 << 12))),
+                     ("wC_stagger2_reps_1", wino_k(1, 2 + (2 << 12))), ("wC_stagger2_reps_7", wino_k(NL - 1, 2 + (2 << 12))),
+                     ("wA_no_transform_reps_1", wino_k(1, 0 + 16)), ("wA_no_transform_reps_7", wino_k(NL - 1, 0 + 16)),
+                     ("wA_no_multiply_reps_1", wino_k(1, 0 + 32)), ("wA_no_multiply_reps_7", wino_k(NL - 1, 0 + 32)),
+                     ("wA_neither_reps_1", wino_k(1, 0 + 48)), ("wA_neither_reps_7", wino_k(NL - 1, 0 + 48)),
                      ("w8_no_transform_reps_1", wino_k(1, 1 + 16)), ("w8_no_transform_reps_7", wino_k(NL - 1, 1 + 16)),
                      ("w8_no_multiply_reps_1", wino_k(1, 1 + 32)), ("w8_no_multiply_reps_7", wino_k(NL - 1, 1 + 32)),
                      ("w8_neither_reps_1", wino_k(1, 1 + 48)), ("w8_neither_reps_7", wino_k(NL - 1, 1 + 48)),
@@ -186,6 +193,8 @@ def main():
     out.update(winogradC_us_per_layer=wc_, speedupC=d / wc_)
     out.update(idle=dict(watts=idle[0], sclk_mhz=idle[1]), arms=arms, direct_us_per_layer=d, winograd_us_per_layer=wv, speedup=d / wv,
                winograd8_us_per_layer=w8, speedup8=d / w8,
+               stagger_us_per_layer={k: (arms["%s_reps_7" % k]["us"] - arms["%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("wA_stagger1", "wA_stagger2", "wC_stagger1", "wC_stagger2")},
+               wA_parts_us_per_layer={k: (arms["wA_%s_reps_7" % k]["us"] - arms["wA_%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("no_transform", "no_multiply", "neither")},
                w8_parts_us_per_layer={k: (arms["w8_%s_reps_7" % k]["us"] - arms["w8_%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("no_transform", "no_multiply", "neither")}, go=bool(max(d / wv, d / w8, d / wc_) >= 1.15))
     print(json.dumps(out))
 
