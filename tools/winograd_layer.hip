@@ -455,11 +455,182 @@ __global__ __launch_bounds__(NT8, 1) void k_wino_layer8(const WArgs A) {
     }
 }
 
+
+// ---- variant E: ONE workgroup of SIXTEEN waves per CU (four per SIMD): waves 0-7 multiply, wave wc owning output channels [16 wc, +16) of
+// all 32 tiles on v_mfma_f32_16x16x32_f16 (24 per xi); waves 8-15 transform (one k-slot of one tile per thread and xi).  V double-buffered.
+// Variant B had one producer and one consumer wave per SIMD and each role ran at its own latency; here two waves of either role share a
+// SIMD.  Weight stream: [xi][4 k-chunks of 32][8 waves][hi | lo][64 lanes] x 16 B; lane l = output channel l & 15, input channels 8 (l >> 4) .. + 7.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int NT16 = 1024, SLOT16_BYTES = 8 * 2 * 64 * 16;       // one 32-channel slice of one xi for all eight consumer waves
+
+template <int XI> __device__ __forceinline__ void transform16(const char* __restrict__ act, char* __restrict__ vbuf, int tid) {
+#pragma clang fp contract(fast)
+    constexpr int I = XI >> 2, J = XI & 3;
+    // 512 producer threads: wave w8 = tid >> 6 (0..7); lanes as in transform(): tx = lane & 3, k-class = (lane >> 2) & 3, ty = (lane >> 4) & 3
+    const int w8 = tid >> 6, lane6 = tid & 63;
+    const int tx = lane6 & 3, kclass = (lane6 >> 2) & 3, ty = (lane6 >> 4) & 3, brd = w8 & 1;
+    const int n = brd * 16 + ty * 4 + tx;
+    const int ks = (kclass & 1) + 8 * (kclass >> 1) + 2 * (w8 >> 1);          // {0, 1, 8, 9}[class] + {0, 2, 4, 6}[w8 >> 1]
+    int a[2], b[2]; float sa[2], sb[2];
+    bt_row(I, a[0], a[1], sa[0], sa[1]);
+    bt_row(J, b[0], b[1], sb[0], sb[1]);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.0f;
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int y = 2 * ty - 1 + a[ia], x = 2 * tx - 1 + b[ib];
+            const bool ok = (unsigned)y < 8u && (unsigned)x < 8u;
+            const int p = brd * 64 + (ok ? y * 8 + x : 0);
+            const f16x8 h = *reinterpret_cast<const f16x8*>(act + act_addr(p, ks));
+            const f16x8 l = *reinterpret_cast<const f16x8*>(act + act_addr(p, ks) + LO);
+            const float s = ok ? 0.25f * sa[ia] * sb[ib] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { v[c] = __builtin_fmaf((float)h[c], s, v[c]); v[c] = __builtin_fmaf((float)l[c], s, v[c]); }
+        }
+    f16x8 vh, vl;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const _Float16 hh = (_Float16)v[c]; vh[c] = hh; vl[c] = (_Float16)(v[c] - (float)hh); }
+    *reinterpret_cast<f16x8*>(vbuf + act_addr(n, ks)) = vh;
+    *reinterpret_cast<f16x8*>(vbuf + act_addr(n, ks) + LO) = vl;
+}
+
+template <int S> __device__ __forceinline__ void produce16(char* act, char* vbuf, int tid) {
+    if constexpr (S < 16) transform16<S>(act, vbuf + (S & 1) * V_BYTES, tid);
+    lds_barrier();
+    if constexpr (S < 16) produce16<S + 1>(act, vbuf, tid);
+}
+
+template <int XI> __device__ __forceinline__ void fold16(const f32x4 (&m)[2], f32x4 (&y)[4][2]) {
+    constexpr int I = XI >> 2, J = XI & 3;
+    constexpr float A0[4] = {1.f, 1.f, 1.f, 0.f}, A1[4] = {0.f, 1.f, -1.f, -1.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float c = (a ? A1[I] : A0[I]) * (b ? A1[J] : A0[J]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (c == 1.0f) y[2 * a + b][nt] += m[nt];
+                else if (c == -1.0f) y[2 * a + b][nt] -= m[nt];
+            }
+        }
+}
+
+template <int S> __device__ __forceinline__ void consume16(char* vbuf, __amdgpu_buffer_rsrc_t rsrc, int voff, int lane, f32x4 (&y)[4][2]) {
+    if constexpr (S >= 1) {
+        constexpr int XI = S - 1;
+        const char* vb = vbuf + (XI & 1) * V_BYTES;
+        AF w[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (XI * 4 + kc) * SLOT16_BYTES, 0);
+            const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024, (XI * 4 + kc) * SLOT16_BYTES, 0);
+            w[kc].h = *reinterpret_cast<const f16x8*>(&h);
+            w[kc].l = *reinterpret_cast<const f16x8*>(&l);
+        }
+        f32x4 m[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) m[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int ra = act_addr(16 * nt + (lane & 15), 4 * kc + (lane >> 4));
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(vb + ra);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(vb + ra + LO);
+                m[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kc].h, bh, m[nt], 0, 0, 0);
+                m[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kc].h, bl, m[nt], 0, 0, 0);
+                m[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[kc].l, bh, m[nt], 0, 0, 0);
+            }
+        fold16<XI>(m, y);
+    }
+    lds_barrier();
+    if constexpr (S < 16) consume16<S + 1>(vbuf, rsrc, voff, lane, y);
+}
+
+__global__ __launch_bounds__(NT16, 1) void k_wino_layer16(const WArgs A) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS8_BYTES];
+    char* act = smem;
+    char* vbuf = smem + ACT_BYTES;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool producer = wave >= 8;
+    const int wc = wave & 7;
+    const long long board0 = (long long)blockIdx.x * 2;
+    const int rows_valid = (int)min(128ll, (A.n_boards - board0) * 64);
+    if (rows_valid <= 0) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A.w, 0, (int)A.w_bytes, 0x00020000);
+    const int voff = wc * 2048 + lane * 16;
+    for (int q = tid; q < 128 * 16; q += NT16) {
+        const int r = q >> 4, ks = q & 15;
+        f16x8 h, l;
+        if (r < rows_valid) {
+            const float4* src = reinterpret_cast<const float4*>(A.x + ((board0 * 64 + r) * 128 + ks * 8));
+            const float4 v0 = src[0], v1 = src[1];
+            const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { _Float16 hh, ll; split1(vv[c], hh, ll); h[c] = hh; l[c] = ll; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { h[c] = (_Float16)0.0f; l[c] = (_Float16)0.0f; }
+        }
+        *reinterpret_cast<f16x8*>(act + act_addr(r, ks)) = h;
+        *reinterpret_cast<f16x8*>(act + act_addr(r, ks) + LO) = l;
+    }
+    lds_barrier();
+    if (producer) {
+        for (int rep = 0; rep < A.reps; ++rep) {
+            produce16<0>(act, vbuf, tid - 512);
+            lds_barrier();
+        }
+    } else {
+        for (int rep = 0; rep < A.reps; ++rep) {
+            f32x4 y[4][2];
+            const float4 bi = *reinterpret_cast<const float4*>(A.bias + 16 * wc + 4 * (lane >> 4));
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) y[o][nt] = f32x4{bi.x, bi.y, bi.z, bi.w};
+            consume16<0>(vbuf, rsrc, voff, lane, y);
+            const bool last = rep + 1 == A.reps;
+            const int c0 = 16 * wc + 4 * (lane >> 4);
+            const float4 sc = *reinterpret_cast<const float4*>(A.scale + c0);
+            const float4 sh = *reinterpret_cast<const float4*>(A.shift + c0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = 16 * nt + (lane & 15), brd = n >> 4, ty = (n >> 2) & 3, tx = n & 3;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int p = brd * 64 + (2 * ty + (o >> 1)) * 8 + 2 * tx + (o & 1);
+                    char* dst = act + act_addr(p, c0 >> 3) + ((c0 & 7) << 1);
+                    const f16x4 oh = *reinterpret_cast<const f16x4*>(dst), ol = *reinterpret_cast<const f16x4*>(dst + LO);
+                    const float r[4] = {sc.x * fmaxf(y[o][nt][0], 0.0f) + sh.x, sc.y * fmaxf(y[o][nt][1], 0.0f) + sh.y,
+                                        sc.z * fmaxf(y[o][nt][2], 0.0f) + sh.z, sc.w * fmaxf(y[o][nt][3], 0.0f) + sh.w};
+                    f16x4 h, l;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { _Float16 hh, ll; split1(r[j], hh, ll); h[j] = last ? hh : oh[j]; l[j] = last ? ll : ol[j]; }
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                    *reinterpret_cast<f16x4*>(dst + LO) = l;
+                }
+            }
+            lds_barrier();
+        }
+    }
+    for (int q = tid; q < rows_valid * 128; q += NT16) {
+        const int r = q >> 7, c = q & 127;
+        const char* src = act + act_addr(r, c >> 3) + ((c & 7) << 1);
+        A.out[(board0 * 64 + r) * 128 + c] = (float)*reinterpret_cast<const _Float16*>(src) + (float)*reinterpret_cast<const _Float16*>(src + LO);
+    }
+}
+
 extern "C" int wino_layer(const float* x, const void* w, long long w_bytes, const float* bias, const float* scale, const float* shift, float* out,
                           long long n_boards, int reps, void* stream, int variant) {
     WArgs A{x, (const uint4*)w, w_bytes, bias, scale, shift, out, n_boards, reps, variant >> 4};
     const unsigned grid = (unsigned)((n_boards + 1) / 2);
-    if ((variant & 15) == 2) hipLaunchKernelGGL(k_wino_layer_c, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
+    if ((variant & 15) == 3) hipLaunchKernelGGL(k_wino_layer16, dim3(grid), dim3(NT16), 0, (hipStream_t)stream, A);
+    else if ((variant & 15) == 2) hipLaunchKernelGGL(k_wino_layer_c, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     else if ((variant & 15) == 1) hipLaunchKernelGGL(k_wino_layer8, dim3(grid), dim3(NT8), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(k_wino_layer, dim3(grid), dim3(NT), 0, (hipStream_t)stream, A);
     return (int)hipGetLastError();

@@ -60,6 +60,19 @@ def pack_wino(w, ws):
     return torch.cat([img, pad]).contiguous(), float(U.abs().max())
 
 
+def pack_wino16(w, ws):
+    """The same U for variant E's consumers (v_mfma_f32_16x16x32_f16, wave wc = output channels [16 wc, +16)):
+    [16 xi][4 slices of 32 channels][8 waves][hi | lo][64 lanes: channel l & 15, input channels 8 (l >> 4) .. + 7][8]."""
+    U = torch.einsum("ia,ocab,jb->ijoc", G.to(w.device), w.double(), G.to(w.device)).reshape(16, 128, 128)
+    t = (U * ws).float()
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    both = torch.stack([hi, lo], dim=0).reshape(2, 16, 8, 16, 4, 4, 8)           # [hl][xi][wc][row 16][slice][k-quarter][8]
+    img = both.permute(1, 4, 2, 0, 5, 3, 6).reshape(16 * 4, 8, 2, 64, 8)          # [xi][slice][wc][hl][k-quarter][row][8]: lane = 16 * quarter + row
+    pad = torch.zeros((3, 8, 2, 64, 8), dtype=torch.float16, device=w.device)
+    return torch.cat([img, pad]).contiguous()
+
+
 def leaves(n):
     """n leaf positions of real self-play (cfg3's kwargs, hash-net evaluator, 3 000 steps in: slots spread over ply phase and game progress)."""
     kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=100, MULTIPROC=False, NEURAL_NET=True, VERBOSE=False, TRAINING=True,
@@ -150,12 +163,18 @@ def main():
         xt = (x_scaled.double() / xin).reshape(S, 8, 8, 128).permute(0, 3, 1, 2)
         ref = torch.nn.functional.conv2d(xt, w.double(), b.double(), padding=1)
         ref = (sc.double()[None, :, None, None] * torch.relu(ref) + sh.double()[None, :, None, None]).permute(0, 2, 3, 1).reshape(S, 64, 128)
+        wimg16 = pack_wino16(w, ws)
+        rc = W.wino_layer(x_scaled.data_ptr(), wimg16.data_ptr(), wimg16.numel() * 2, bias.data_ptr(), scale.data_ptr(), shift.data_ptr(), y8.data_ptr(), S, 1, stream, 3)
+        torch.cuda.synchronize()
+        err16 = float((y8.double() / xout - ref).abs().max()) / float(ref.abs().max())
+        assert rc == 0 and err16 < 2e-6, ("variant E", err16)
         direct = cal["outs"][li].reshape(S, 64, 128).double() / xout
         wino = y.double() / xout
         mag = float(ref.abs().max())
         out["layers"].append(dict(layer=li, max_abs_ref=mag, err_direct_rel=float((direct - ref).abs().max()) / mag, err_winograd_rel=float((wino - ref).abs().max()) / mag,
                                   max_U_over_max_g=umax / float(w.abs().max())))
-    keep = (x_scaled, wimg, bias, scale, shift, y)                      # the last layer's operands: the timing arms below
+    keep = (x_scaled, wimg, bias, scale, shift, y)
+    keep16 = wimg16                      # the last layer's operands: the timing arms below
     # ---- timing: direct stack with 2 and 9 layers (no heads, no debug outputs), Winograd probe with reps 1 and 8
     layers, xs_arr, ovf = n0["layers"], n0["xs_arr"], ev._overflow_ptr(dev)
 
@@ -168,11 +187,15 @@ def main():
     if os.environ.get("WINO_DEBUG"):
         for i in range(n0["n"]):
             print("layer", i, hex(layers[i].weights or 0), hex(layers[i].bias or 0), hex(layers[i].scale or 0), hex(layers[i].shift or 0), layers[i].cin_pad, file=sys.stderr)
+    def wino16_k(reps):
+        return lambda: W.wino_layer(keep[0].data_ptr(), keep16.data_ptr(), keep16.numel() * 2, keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(),
+                                    keep[5].data_ptr(), S, reps, stream, 3)
     idle = sample()
     arms = {}
     NL = n0["n"]                                                        # 8: the 14 -> 128 layer + seven 128 -> 128 layers (body + the policy head's 3x3)
     for name, fn in (("direct_2_layers", direct_k(2)), ("direct_all_layers", direct_k(NL)), ("winograd_reps_1", wino_k(1)), ("winograd_reps_7", wino_k(NL - 1)),
                      ("winograd8_reps_1", wino_k(1, 1)), ("winograd8_reps_7", wino_k(NL - 1, 1)),
+                     ("winogradE_reps_1", wino16_k(1)), ("winogradE_reps_7", wino16_k(NL - 1)),
                      ("winogradC_reps_1", wino_k(1, 2)), ("winogradC_reps_7", wino_k(NL - 1, 2)),
                      ("wA_stagger1_reps_1", wino_k(1, 0 + (1 << 12))), ("wA_stagger1_reps_7", wino_k(NL - 1, 0 + (1 << 12))),
                      ("wA_stagger2_reps_1", wino_k(1, 0 + (2 << 12))), ("wA_stagger2_reps_7", wino_k(NL - 1, 0 + (2 << 12))),
@@ -190,12 +213,13 @@ def main():
     d = (arms["direct_all_layers"]["us"] - arms["direct_2_layers"]["us"]) / (NL - 2.0)
     wv = (arms["winograd_reps_7"]["us"] - arms["winograd_reps_1"]["us"]) / (NL - 2.0)
     wc_ = (arms["winogradC_reps_7"]["us"] - arms["winogradC_reps_1"]["us"]) / (NL - 2.0)
-    out.update(winogradC_us_per_layer=wc_, speedupC=d / wc_)
+    we_ = (arms["winogradE_reps_7"]["us"] - arms["winogradE_reps_1"]["us"]) / (NL - 2.0)
+    out.update(winogradC_us_per_layer=wc_, speedupC=d / wc_, winogradE_us_per_layer=we_, speedupE=d / we_)
     out.update(idle=dict(watts=idle[0], sclk_mhz=idle[1]), arms=arms, direct_us_per_layer=d, winograd_us_per_layer=wv, speedup=d / wv,
                winograd8_us_per_layer=w8, speedup8=d / w8,
                stagger_us_per_layer={k: (arms["%s_reps_7" % k]["us"] - arms["%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("wA_stagger1", "wA_stagger2", "wC_stagger1", "wC_stagger2")},
                wA_parts_us_per_layer={k: (arms["wA_%s_reps_7" % k]["us"] - arms["wA_%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("no_transform", "no_multiply", "neither")},
-               w8_parts_us_per_layer={k: (arms["w8_%s_reps_7" % k]["us"] - arms["w8_%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("no_transform", "no_multiply", "neither")}, go=bool(max(d / wv, d / w8, d / wc_) >= 1.15))
+               w8_parts_us_per_layer={k: (arms["w8_%s_reps_7" % k]["us"] - arms["w8_%s_reps_1" % k]["us"]) / (NL - 2.0) for k in ("no_transform", "no_multiply", "neither")}, go=bool(max(d / wv, d / w8, d / wc_, d / we_) >= 1.15))
     print(json.dumps(out))
 
 
