@@ -32,7 +32,7 @@ def close_and_read(self):
 
 E.Engine.close = close_and_read
 kw = dict(GAME_ENV=None, UCT_C=4, CONSTRAINT="rollout", BUDGET=200, MULTIPROC=False, NEURAL_NET=True, VERBOSE=False, TRAINING=False,
-          DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=0.25, TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
+          DIRICHLET_ALPHA=1.0, DIRICHLET_EPSILON=float(os.environ.get("KSTEP_EPS", 0.25)), TEMPERATURE_TAU=0, TEMPERATURE_DECAY=0, TEMP_DECAY_DELAY=0)
 job, n = sys.argv[1], int(sys.argv[2])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 if job == "tournament":
