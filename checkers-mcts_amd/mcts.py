@@ -380,18 +380,33 @@ class MCTS:
     def print_tree(cls, root_node, max_tree_depth=10):
         """Tree diagram of the search tree under the root, (W/N) (win %) per node, depth first with the last child of every node
         first and max_tree_depth levels deep -- what the reference's print_tree / traverse_tree print (MCTS.py:312-342).  The
-        nodes come from the engine in that order (ckr_engine_subtree); root_node must be the root of the live position's tree."""
+        nodes come from the engine in that order (ckr_engine_subtree); root_node: the root of the live position's tree, or one of its children."""
         cls._sync()
-        if getattr(root_node, "parent", None) is not None:
-            # the engine exports the subtree under its cursor: printing it for another node would show the WRONG tree (ADVICE r4)
-            raise ValueError("MCTS.print_tree: root_node must be the root of the live position's tree (MCTS.py:312-319 prints any "
-                             "node's subtree; the engine exports the live root's)")
         tree = int(cls.game_env.state[4, 0, 0])
-        for info, level in cls._engine.subtree(0, tree, max_tree_depth):
+        parent = getattr(root_node, "parent", None)
+        skip_to, base = None, 0
+        if parent is not None:
+            # a child of the live root (the only other handles this facade hands out: root.children): its subtree is a contiguous run of
+            # the root's export -- children appear last-to-first, each followed by its descendants.  (The reference's traverse_tree, started
+            # on a node that has a parent, climbs into the parent afterwards and prints it and some of its other children too, with
+            # negative indentation, MCTS.py:338-341: not reproduced.)
+            if getattr(parent, "parent", None) is not None or root_node not in parent.children:
+                raise ValueError("MCTS.print_tree: root_node must be the root of the live position's tree or one of its children")
+            skip_to, base = len(parent.children) - 1 - parent.children.index(root_node), 1
+        seen, inside = -1, skip_to is None
+        for info, level in cls._engine.subtree(0, tree, max_tree_depth + base):
+            if skip_to is not None:
+                if level == 1:
+                    seen += 1
+                    inside = seen == skip_to
+                elif level == 0:
+                    inside = False
+            if not inside:
+                continue
             w, n = info["w"], info["n"]
             q = (w / n) if n else 0
             w_str = "{0}".format(str(round(w, 1) if w % 1 else int(w)))
-            print("\t" * level + "|- ({}/{}) ({:.1f}%)".format(w_str, n, np.round((q + 1) / 2 * 100, 1)))
+            print("\t" * (level - base) + "|- ({}/{}) ({:.1f}%)".format(w_str, n, np.round((q + 1) / 2 * 100, 1)))
 
 
 class MCTS_Node:
