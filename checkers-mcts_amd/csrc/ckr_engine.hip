@@ -111,12 +111,6 @@ struct Dev {
     int arena_games;             // ckr_config.arena_games: > 1 = worker id W is game W % G of reference worker W / G (concurrent arena games)
     // node pool, index = ((slot*2 + tree)*2 + half)*C + local; record i = nodes[3 i .. 3 i + 2] (see the accessors below)
     uint4* nodes;
-    // ... and its growth (round 6): n_big spare regions of two semispaces of Cbig = 8 C records behind the slots' own, at record big_off.
-    // A tree whose LIVE subtree leaves no room in its own semispace (the reference keeps a re-rooted subtree without limit,
-    // MCTS.py:251-295; forced lines of play retain all of it) moves into a spare region r and gives it back when its game ends: its
-    // t_half becomes 2 + 2 r + h (h = the live semispace of the region), so no state is added to the slot and `half ^ 1` still names
-    // the other semispace.  Only when no region is free (or Cbig is outgrown too) is a game abandoned (pool_overflows).
-    int Cbig, n_big; size_t big_off; int32_t* big_owner;
     // per slot
     uint4* g_board; uint32_t* g_status; int32_t* g_moves; int32_t* g_game; int32_t* g_phase; double* g_tau;
     int32_t* g_sims; int32_t* g_pending; uint32_t* g_rng;
@@ -162,6 +156,13 @@ struct Dev {
     int32_t* pf_counter;         // DEVICE: prefetched positions handed out in this step (zeroed by the step's prologue)
     int32_t* g_pf_net;           // [row] network id of the position handed out in that row by the last step (-1: none)
     uint4* g_pf_board;           // [row] its board record
+    // The node pool's growth (round 6; kept behind the fields the hot path reads, whose layout -- and with it the grouping of the
+    // descriptor's scalar loads -- stays as it was): n_big spare regions of two semispaces of Cbig = 8 C records behind the slots' own, at record big_off.
+    // A tree whose LIVE subtree leaves no room in its own semispace (the reference keeps a re-rooted subtree without limit,
+    // MCTS.py:251-295; forced lines of play retain all of it) moves into a spare region r and gives it back when its game ends: its
+    // t_half becomes 2 + 2 r + h (h = the live semispace of the region), so no state is added to the slot and `half ^ 1` still names
+    // the other semispace.  Only when no region is free (or Cbig is outgrown too) is a game abandoned (pool_overflows).
+    int Cbig, n_big; size_t big_off; int32_t* big_owner;
     unsigned long long* prof;    // -DCKR_KSTEP_PROF builds only (tools/kstep_phases.py): per-phase 100-MHz ticks of the tree kernel, else null
 };
 
@@ -1500,7 +1501,8 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
             // node pool full in the middle of a ply (start_search's margin is a heuristic: one expansion can add up
             // to 48 children): drop the garbage now and retry; the recorded path is stale after the move, so the
             // backup walks the parent links (plen > 64)
-            n = expand_after_compaction(w, t, pending, p + (size_t)row * 512, v[row], pnet, cslot0, cword0);
+            WaveT<WT> wc = w;                                                 // (a real call gets a COPY of the handle: see finish_ply below)
+            n = expand_after_compaction(wc, t, pending, p + (size_t)row * 512, v[row], pnet, cslot0, cword0);
             if (n >= 0) { int ph, sm; live_load(w, lv, ph, sm); }          // (everything moved: the live state anew)
         }
         if (n >= 0) {
