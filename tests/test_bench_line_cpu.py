@@ -43,7 +43,9 @@ def test_committed_bench_line_has_the_contract_fields():
     w = a["whole_share"]
     assert w["games"] == 4096 and w["new_net_wins"] + w["old_net_wins"] + w["draws"] == 4096 and w["pool_overflows"] == 0
     assert abs(w["sims_per_s"] - w["sims"] / w["seconds"]) < 1e-6 * w["sims_per_s"] and w["sims"] == 800 * w["plies"]
-    assert a["sims_per_s"] == w["sims_per_s"] < a["mid_game_window"]["sims_per_s"]          # the quoted figure is the whole tournament's
+    # the quoted figure is the whole tournament's (since round 6 all 4 096 games play from the first step, and the share's rate -- its tail
+    # chains many network-free simulations per step -- is no longer below the mid-game window's)
+    assert a["sims_per_s"] == w["sims_per_s"] and 0.5 * w["sims_per_s"] < a["mid_game_window"]["sims_per_s"] < 2.0 * w["sims_per_s"]
 
 
 def test_roofline_traffic_agrees_with_the_committed_pmc_table():
