@@ -3,7 +3,7 @@ kwargs (train_Checkers.py:88-102 self-play, :188-202 arena) on injected noise (c
 
 * fixtures the imported reference produced at 50 / 400 / 800 simulations per move (make_golden.gen_selfplay_budgets,
   gen_tournament_budgets): cfg1's complete game, one game at cfg4's budget, one arena pair at cfg5's played to its natural end;
-* whole jobs of 32-96 games at 100 / 400 / 800 simulations per move played by the PRODUCT configuration -- three part-batch engines
+* whole jobs of 64-128 games (64 concurrent slots each) at 100 / 400 / 800 simulations per move played by the PRODUCT configuration -- three part-batch engines
   on their own streams and HIP graphs (pipeline.SplitRunner), one shared leaf cache, dense rows, board-record leaves, evaluation
   ahead of the search, virtual workers, the default node pool -- against the C oracle's games: every tuple (position, legal mask,
   visit counts, root N / W bits, sampled move, q, z) and every game result.  The oracle is pinned against the reference by the
@@ -146,7 +146,7 @@ JOBS = [  # budget, self-play?, workers, slots, games per worker, TERMINATE_CNT,
     (100, 0, 64, 64, 2, 0, (3, 4), "float32", 101),        # arena of 128 games to the natural end: draws by the 80-state rule, long games
     (100, 1, 96, 64, 1, 200, (9, None), "float32", 102),   # cfg3's budget; 96 workers on 64 slots (virtual workers)
     (400, 1, 64, 64, 1, 200, (9, None), "float64", 103),   # cfg4's budget, the reference's pinned NumPy regime
-    (800, 0, 16, 16, 2, 0, (3, 4), "float32", 104),        # cfg5's budget: arena pairs, a game beyond 300 plies
+    (800, 0, 64, 64, 2, 0, (3, 4), "float32", 104),        # cfg5's budget: 128 arena games on 64 slots, a game beyond 300 plies
 ]
 
 
