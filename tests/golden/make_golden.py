@@ -21,6 +21,17 @@ Fixture families:
                      MCTS_Node.selection() calls
   text_v1.json       the text files the pipeline classes write: tournament_Checkers.start_tournament's two tables,
                      record_params' dumps, final_evaluation's score table (and the score matrix behind it)
+  search_noise_np{1,2}.npz, selfplay_noise_np{1,2}.npz, tournament_noise_v1.npz
+                     the STOCHASTIC search on injected noise (round 6): the reference driver's own kwargs -- epsilon 0.25 at every node of
+                     every descent, tau 1 with its decay (train_Checkers.py:88-102), arena settings (:188-202) -- with np.random.dirichlet /
+                     np.random.choice replaced, for the duration of a run, by ref_shim.NoiseInjector: a published function of (seed,
+                     worker, draw counter) that the C oracle and the HIP engine evaluate too; run under both interpreters
+  selfplay_budgets_np{1,2}.npz, tournament_budgets_v1.npz
+                     the same at the BASELINE budgets: cfg1's complete game (50 simulations per move, TERMINATE_CNT 200), one game at
+                     cfg4's 400, one arena pair at cfg5's 800 played to its natural end
+A complete regeneration takes ~5.6 min under this interpreter (python make_golden.py) plus ~1.4 min for the np1 families
+(/opt/conda/bin/python3.9 make_golden.py search_inexact selfplay_inexact search_noise selfplay_noise selfplay_budgets);
+compare_fixtures.py compares a regeneration with the committed files (VALIDATION.md).
 The fixtures are data (inputs + the reference's outputs); no reference source
 is stored.
 """
