@@ -2496,6 +2496,16 @@ int ckr_engine_leaves(ckr_engine* e, ckr_board* out) {
     return CKR_OK;
 }
 
+int ckr_engine_draw_counter(ckr_engine* e, int32_t slot, int32_t add, uint32_t* out) {
+    if (!e || slot < 0 || slot >= e->cfg.n_slots || add < 0 || !out) return fail(CKR_ERR_INVALID, "ckr_engine_draw_counter: bad argument");
+    CKR_HIP(hipDeviceSynchronize());
+    uint32_t c = 0;
+    CKR_HIP(hipMemcpy(&c, e->dev.g_rng + slot, sizeof(c), hipMemcpyDeviceToHost));
+    *out = c;
+    if (add) { c += (uint32_t)add; CKR_HIP(hipMemcpy(e->dev.g_rng + slot, &c, sizeof(c), hipMemcpyHostToDevice)); }
+    return CKR_OK;
+}
+
 // ---- probes (tests only; see include/ckr.h)
 static int probe_dev(Dev& D, Dev** d_dev, uint64_t seed, double alpha) {
     memset(&D, 0, sizeof(D));

@@ -407,6 +407,13 @@ class Engine:
         return [(dict(board=np.array(nodes[i].board[:], np.uint32), status=int(nodes[i].status), n=int(nodes[i].n), w=wt(nodes[i].w),
                       p=np.float32(nodes[i].p)), int(depth[i])) for i in range(n.value)]
 
+    def draw_counter(self, slot=0, add=0):
+        """The slot's draw counter (include/ckr.h, ckr_engine_draw_counter): np.random calls its worker has made so far; advanced by
+        `add` after the read (the facade's host-side best_child takes one draw per sampled move)."""
+        out = C.c_uint32(0)
+        _lib.check(self._L.ckr_engine_draw_counter(self._h, int(slot), int(add), C.addressof(out)))
+        return int(out.value)
+
     def leaves(self):
         out = np.zeros((self.cfg.n_slots, 4), np.uint32)
         _lib.check(self._L.ckr_engine_leaves(self._h, out.ctypes.data))
@@ -450,6 +457,27 @@ def tuple_q(t):
         return np.float32(t["q"])
     q = np.float64(t["root_w"]) / int(t["root_n"]) if int(t["root_n"]) else np.float64(0.0)
     return -q if kind == _lib.Q_F64_NEG else q
+
+
+def noise_hash(seed, worker, ctr, lane):
+    """The injected test noise of ckr_config.noise_mode 1 (include/ckr.h) on the host: five rounds of murmur3's fmix32 over
+    (seed, worker, draw counter, component) -- the device's noise_hash, for the search facade's host-side move sampling."""
+    def fm(h):
+        h &= 0xFFFFFFFF
+        h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        return h ^ (h >> 16)
+    k = 0x7F4A7C15
+    h = (fm((seed & 0xFFFFFFFF) ^ 0x9E3779B9) + k) & 0xFFFFFFFF
+    h = (fm(h ^ ((seed >> 32) & 0xFFFFFFFF)) + k) & 0xFFFFFFFF
+    h = (fm(h ^ (worker & 0xFFFFFFFF)) + k) & 0xFFFFFFFF
+    h = (fm(h ^ (ctr & 0xFFFFFFFF)) + k) & 0xFFFFFFFF
+    return fm(h ^ (lane & 0xFFFFFFFF))
+
+
+def noise_uniform(seed, worker, ctr):
+    """The uniform of pick `ctr` under noise_mode 1: hash(.., 0xFFFFFFFF) * 2^-32."""
+    return noise_hash(seed, worker, ctr, 0xFFFFFFFF) / 4294967296.0
 
 
 def hashnet_evaluator(salt_new=0, salt_old=None, inexact=False):

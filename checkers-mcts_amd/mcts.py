@@ -207,9 +207,14 @@ class MCTS:
         # low-latency kernel what one board costs, and the leaf of most later simulations is then served by the leaf cache.
         cls._lookahead = bool(kwargs["NEURAL_NET"] and kwargs.get("EVALUATOR") != "torch" and cls._fusable(getattr(cls.game_env, "neural_net", None))
                               and kwargs.get("LEAF_CACHE_LOG2", 18) and os.environ.get("CKR_PREFETCH", "1") != "0")
+        # parity tests: NOISE_MODE 1 = the injected noise of include/ckr.h (ckr_config.noise_mode), keyed by SEED and WORKER_ID -- the
+        # device's Dirichlet draws and this class's move sampling (best_child) then read ONE stream, as the reference's process does
+        cls._noise_mode = int(kwargs.get("NOISE_MODE", 0))
+        cls._seed = int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1)))
+        cls._worker_id = int(kwargs.get("WORKER_ID", 0))
         cfg = ckengine.config_from_kwargs(kwargs, n_slots=1, games_per_slot=1, manual_play=True,
                                           feature_dtype=ckengine.BOARDS if cls._lookahead else torch.float32,
-                                          seed=int(kwargs.get("SEED", np.random.randint(0, 2 ** 31 - 1))),
+                                          seed=cls._seed, first_worker_id=cls._worker_id,
                                           max_sims_per_step=1 << 30, nodes_per_tree=kwargs.get("NODES_PER_TREE"),
                                           # both players' trees (and transpositions) ask for the same positions again: 2^18 records
                                           # (69 MB) served for 16 384 - 32 768 simulation steps; flushed when the network changes
@@ -351,6 +356,13 @@ class MCTS:
             cls.tau -= cls.tau_decay
             if np.isclose(cls.tau, 0):
                 cls.tau = 0
+        if cls._noise_mode:
+            # the uniform np.random.choice would draw is the injected one of this worker's draw counter (which the device's Dirichlet draws
+            # share: Engine.draw_counter); RandomState.choice's own arithmetic on it: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted right
+            u = ckengine.noise_uniform(cls._seed, cls._worker_id, cls._engine.draw_counter(0, add=1))
+            cdf = np.array(probs, dtype=np.float64).cumsum()
+            cdf /= cdf[-1]
+            return node.children[int(cdf.searchsorted(u, side="right"))]
         return node.children[int(np.random.choice(len(node.children), p=probs))]
 
     @classmethod

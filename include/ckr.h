@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 127          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions) */
+#define CKR_VERSION 128          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions); 128: ckr_engine_draw_counter */
 
 typedef enum {
     CKR_OK = 0,
@@ -515,6 +515,11 @@ int ckr_engine_pack_tuples(ckr_engine* e, ckr_tuple* d_out, int64_t cap, int64_t
 int ckr_engine_root_stats(ckr_engine* e, double* w_out, float* p_out, int64_t cap);
 /* Leaf boards handed out by the last step (parity tests): HOST out[n_slots]. */
 int ckr_engine_leaves(ckr_engine* e, ckr_board* out);
+/* Interactive engines (manual_play): the slot's draw counter -- the number of np.random calls its worker has made so far (one per
+ * select_child call with epsilon != 0, MCTS.py:107-108, made on the device; one per sampled move, MCTS.py:246, made by the HOST facade's
+ * best_child).  *out = the counter, which is then advanced by `add` (>= 0): the facade reads it to key the uniform of its pick and adds 1,
+ * so that the device's next Dirichlet draw follows it as in the reference's one stream.  Synchronous. */
+int ckr_engine_draw_counter(ckr_engine* e, int32_t slot, int32_t add, uint32_t* out);
 
 /* ---- interactive search API (manual_play = 1) --------------------------- *
  * Backs the reference's per-tree search interface: MCTS.begin_tree_search /
