@@ -798,9 +798,10 @@ class generate_Checkers_data:
         # NUM_CPUS workers of the job are hosted on them one after the other, each still playing NUM_SELFPLAY_GAMES games with
         # its own noise / temperature streams -- the output is the same as with SLOTS = NUM_CPUS, bit for bit
         self.slots = selfplay_kwargs.get("SLOTS", 4096)
-        # True: generate_data() writes one pickle per WORKER and returns their NUM_CPUS names, like the reference's Pool.map over
-        # _generate_data (training_pipeline.py:323-332); default: one pickle for the job (merge_data takes either)
-        self.file_per_worker = selfplay_kwargs.get("FILE_PER_WORKER", False)
+        # one pickle per worker, as the reference's Pool.map returns them (training_pipeline.py:323-332), while NUM_CPUS is a host's
+        # worth of workers; a job of thousands of workers (NUM_CPUS counts concurrent games here) writes one pickle (merge_data takes either).  True / False force either
+        fpw = selfplay_kwargs.get("FILE_PER_WORKER")
+        self.file_per_worker = (self.num_cpus <= 64) if fpw is None else bool(fpw)
         self.stats = None
         self.results = None
 
@@ -878,8 +879,8 @@ class generate_Checkers_data:
 
     def generate_data(self):
         """Plays NUM_CPUS x NUM_SELFPLAY_GAMES games; returns the pickle's file
-        name (a str for one worker, a list otherwise, mirroring training_pipeline.py:325-332: one element, or -- FILE_PER_WORKER --
-        NUM_CPUS of them); None on ranks other than 0."""
+        name (a str for one worker, a list otherwise, mirroring training_pipeline.py:325-332: NUM_CPUS of them up to 64 workers or with
+        FILE_PER_WORKER=True, one element above); None on ranks other than 0."""
         t0 = time.perf_counter()
         gathered = self.generate_tuples()
         if gathered is None:

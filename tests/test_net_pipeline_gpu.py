@@ -84,8 +84,9 @@ def test_generate_checkers_data_dropin(tmp_path, monkeypatch):
     sk = dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=3, TERMINATE_CNT=24, NUM_CPUS=6, NN_FN="random:0", SEED=5)
     g = generate_Checkers_data(sk, dict(KW, BUDGET=20))
     fns = g.generate_data()
-    assert isinstance(fns, list) and len(fns) == 1 and fns[0].startswith("data/training_data/Checkers_Data3_")
-    mem = pickle.load(open(fns[0], "rb"))
+    assert isinstance(fns, list) and len(fns) == 6 and all(fn.startswith("data/training_data/Checkers_Data3_") for fn in fns)   # :325-332
+    assert [fn.rsplit("_P", 1)[1] for fn in fns] == ["%d.pkl" % w for w in range(6)]
+    mem = [t for fn in fns for t in pickle.load(open(fn, "rb"))]
     assert len(mem) >= 6 * 24
     for state, pi, q, z in mem:
         assert state.shape == (15, 8, 8) and state.dtype == np.float64 and pi.shape == (8, 8, 8)
@@ -149,7 +150,7 @@ def test_pipeline_bf16_uses_fused_kernels(tmp_path, monkeypatch):
     sk = dict(NUM_SELFPLAY_GAMES=1, TRAINING_ITERATION=0, TERMINATE_CNT=20, NUM_CPUS=10, NN_FN="random:0", SEED=3,
               NN_DTYPE=torch.bfloat16)
     g = generate_Checkers_data(sk, dict(KW, BUDGET=16))
-    mem = pickle.load(open(g.generate_data()[0], "rb"))
+    mem = [t for fn in g.generate_data() for t in pickle.load(open(fn, "rb"))]
     assert len(mem) >= 10 * 20 and g.stats["games"] == 10
     for state, pi, q, z in mem:
         if pi.sum() > 0:
