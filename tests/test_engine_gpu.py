@@ -560,6 +560,26 @@ def test_lockstep_live_subtree_outgrows_its_semispace(E, oracle, w_accum):
     eng.close()
 
 
+def test_growth_under_contention_changes_no_game(E):
+    """512 slots of the stochastic search (Philox noise, sampled moves, two games per slot) on the smallest node pool: every tree
+    outgrows its semispace within a few plies of every game, hundreds of waves of one launch take spare regions from the same owner
+    array (compare-and-swap) and give them back at the end of their games.  The search does not see where its nodes live: tuples and results are byte for
+    byte those of the same job on the default pool, which never grows."""
+    outs = []
+    for nodes, spares in ((256, 1100), (None, 0)):
+        eng, ev = run_engine(E, mk(60, eps=0.25, tau=1.0), [9] * 512, games_per_slot=2, terminate_cnt=30, nodes_per_tree=nodes, pool_spares=spares, seed=11,
+                             leaf_cache_log2=18, dense_rows=True)
+        eng.run(ev)
+        st, t = eng.stats(), eng.tuples_raw()
+        assert st["games"] == 1024 and st["pool_overflows"] == 0
+        outs.append((t[np.lexsort((t["ply"], t["game"], t["worker"]))], sorted((r["worker"], r["game"], r["outcome"], r["move_count"], r["failed"]) for r in eng.results()), st))
+        eng.close()
+    (a, ra, sa), (b, rb, sb) = outs
+    assert sa["pool_grown"] >= 1024 and sb["pool_grown"] == 0 and sa["compactions"] > sb["compactions"]
+    assert all(sa[k] == sb[k] for k in ("expansions", "terminal_visits", "plies", "reroot_misses", "nodes_created"))
+    assert ra == rb and len(a) == len(b) > 1024 * 20 and a.tobytes() == b.tobytes()
+
+
 def test_spare_pool_regions_run_out_gracefully(E):
     """More trees outgrow their semispaces than there are spare regions (4 for <= 128 slots): those games are abandoned and counted,
     the others finish; nothing hangs or corrupts (the accounting identities of the finished games hold)."""
