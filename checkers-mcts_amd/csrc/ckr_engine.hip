@@ -884,7 +884,10 @@ template <class Wave> __device__ __attribute__((noinline)) int expand_after_comp
 // leaf_b / leaf_st: the leaf's board record and status word, read with its parent's child scan (the root's own when the
 // root is the leaf).
 // The root's record comes from `lv` (registers): the first memory round of a descent is the root's child scan.
-template <class Wave> __device__ __forceinline__ int descend(Wave& w, Live& lv, int& plen_out, uint32_t& entry_out, ckr_board& leaf_b, uint32_t& leaf_st) {
+// forced: >= 0 (single-simulation steps of the interactive facade only; a kernel argument, uniform): the descent starts at that child of
+// the root -- MCTS_Node.selection() called on a child, MCTS.tree_policy(child) (MCTS.py:60-99,406-410): no selection and no noise
+// draw at the root, the backup still passes through it (the child's parent link).
+template <class Wave> __device__ __forceinline__ int descend(Wave& w, Live& lv, int& plen_out, uint32_t& entry_out, ckr_board& leaf_b, uint32_t& leaf_st, const int forced = -1) {
     const Dev& D = w.D;
     const int t = lv.t;
     const size_t tb = w.tbase(t, lv.half);
@@ -918,7 +921,8 @@ template <class Wave> __device__ __forceinline__ int descend(Wave& w, Live& lv, 
         const float cp = __uint_as_float(c1.y);
         const uint32_t cst = c2.x, ckids = c2.y;
         double dir = 0.0;
-        if (D.epsilon != 0.0) {
+        const bool at_forced = forced >= 0 && lvl == 1;
+        if (D.epsilon != 0.0 && !at_forced) {
             dir = dirichlet_lane(D, act, w.worker(), ctr, w.lane, n);
             ++ctr;
         }
@@ -928,7 +932,7 @@ template <class Wave> __device__ __forceinline__ int descend(Wave& w, Live& lv, 
         const double psa = (double)pf + D.epsilon * dir;
         const double u = ((D.uct_c * psa) * sqrt_n) / (double)(1 + cn);
         const double score = (double)q + u;
-        const int best = wave_argmax_first(score, n);
+        const int best = at_forced ? (forced < n ? forced : n - 1) : wave_argmax_first(score, n);
         const uint32_t bst = (uint32_t)bcast_i32((int)cst, best);
         const int child = base + best;
         if (st_outcome(bst) != 0u) {
@@ -1025,11 +1029,17 @@ template <int GAME, class Wave> __device__ uint32_t playout(Wave& w, ckr_board b
 }
 
 // one simulation of the non-NN tree policy; false when the node pool is full (nothing has been changed then)
-template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t) {
+// forced >= 0 (the interactive facade's MCTS_Node.selection() on a child of the root, MCTS.py:406-410): the tree policy starts at
+// that child; the backup walks the parent links and so passes through the root as the reference's does (:419-428)
+template <int GAME, class Wave> __device__ bool rollout_sim(Wave& w, int t, const int forced = -1) {
     const Dev& D = w.D;
     const int ti = w.slot * 2 + t;
     const size_t tb = w.tb(t);
     int node = D.t_cursor[ti];
+    if (forced >= 0) {
+        const uint32_t rk = nq(D, tb + node)[2].y;
+        if (forced < (int)(rk >> 24)) node = (int)(rk & 0xFFFFFFu) + forced;
+    }
     for (;;) {
         const uint4* np4 = nq(D, tb + node);
         const uint4 n0 = np4[0], n1 = np4[1], n2 = np4[2];
@@ -1549,7 +1559,7 @@ template <typename WT> __global__ __launch_bounds__(256, 4) void k_step(const De
         int found = resume;
         uint32_t lst_node = 0u;                                          // the leaf's status word (node record)
         PROF_LAP(PR_EXIT)
-        if (resume < 0) { found = descend(w, lv, plen, pentry, lb, lst_node); park_count = 0; }
+        if (resume < 0) { found = descend(w, lv, plen, pentry, lb, lst_node, (flags >> 8) - 1); park_count = 0; }
         else { const uint4* fp = nq(D, w.tbase(t, lv.half) + found); lb = ld_board(fp); lst_node = fp[2].x; }   // a parked leaf, looked up again
         resume = -1;
         asm volatile("" :: "v"(found));
@@ -1622,6 +1632,8 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), slot = blockIdx.x * 4 + wave;   // wave-uniform: slot addressing in SGPRs
     if (slot >= D.n_slots) return;
     WaveT<float> w{D, lds[wave], slot, lane_id()};   // W is a python int in this mode: exact in float
+    const int forced = (end_ply >> 8) - 1;            // ckr_engine_rollout_from: child of the root the one simulation starts at
+    end_ply &= 0xFF;
     w.wk = D.g_worker[slot];
     if (w.lane < CNT_N) w.L.cnt[w.lane] = 0u;
     if (slot == 0) w.count(CNT_STEPS);
@@ -1637,9 +1649,9 @@ template <int GAME> __global__ __launch_bounds__(256, 4) void k_rollout(const De
             continue;
         }
         const int t = (int)(D.g_board[slot].w & 1u);
-        bool ok = rollout_sim<GAME>(w, t);
-        if (!ok) { compact(w, t); ok = rollout_sim<GAME>(w, t); }               // pool full: a failed simulation has changed nothing yet
-        if (!ok && grow_pool(w, t) >= 0) ok = rollout_sim<GAME>(w, t);           // ... still full: a spare region (Dev.big_owner)
+        bool ok = rollout_sim<GAME>(w, t, forced);
+        if (!ok) { compact(w, t); ok = rollout_sim<GAME>(w, t, forced); }       // pool full: a failed simulation has changed nothing yet
+        if (!ok && grow_pool(w, t) >= 0) ok = rollout_sim<GAME>(w, t, forced);   // ... still full: a spare region (Dev.big_owner)
         if (ok) { if (w.lane == 0) D.g_sims[slot] += 1; }
         else { w.count(CNT_OVERFLOW); end_game<GAME>(w, 0u, 0, 1); }
         wave_mem_fence();
@@ -2127,12 +2139,21 @@ static int engine_rollout(ckr_engine* e, int32_t sims, int end_ply, void* stream
 }
 
 int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream) { return engine_rollout(e, sims, 0, stream); }
+int ckr_engine_rollout_from(ckr_engine* e, int32_t child, void* stream) {
+    if (!e || !e->cfg.manual_play || child < 0 || child >= CKR_MAX_CHILDREN) return fail(CKR_ERR_INVALID, "ckr_engine_rollout_from: an interactive engine and a child index");
+    return engine_rollout(e, 1, (child + 1) << 8, stream);
+}
 int ckr_engine_rollout_end_ply(ckr_engine* e, int32_t sims, void* stream) { return engine_rollout(e, sims, 1, stream); }
 
 static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream, int end_ply);
 
 int ckr_engine_step_single(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
     return engine_step(e, d_p, d_v, d_x, d_net, stream, 4);
+}
+
+int ckr_engine_step_single_from(ckr_engine* e, int32_t child, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
+    if (!e || !e->cfg.manual_play || child < 0 || child >= CKR_MAX_CHILDREN) return fail(CKR_ERR_INVALID, "ckr_engine_step_single_from: an interactive engine and a child index");
+    return engine_step(e, d_p, d_v, d_x, d_net, stream, 4 | ((child + 1) << 8));
 }
 
 int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream) {
@@ -2162,7 +2183,8 @@ static int engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* 
     if (prologue && e->cfg.n_slots > 4)
         hipLaunchKernelGGL(k_step_prologue, dim3(e->dev.dense_rows ? (n_rows + 255) / 256 : 1), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev,
                            e->dev.dense_rows ? e->d_range : (int32_t*)nullptr, d_net, n_rows);
-    const int flags = (end_ply == 1 ? 1 : 0) | (end_ply == 4 ? 4 : 0) | (prologue && e->cfg.n_slots <= 4 ? 2 : 0);
+    const int mode = end_ply & 0xFF;                                 // bits 8..: ckr_engine_step_single_from's child + 1
+    const int flags = (mode == 1 ? 1 : 0) | (mode == 4 ? 4 : 0) | (prologue && e->cfg.n_slots <= 4 ? 2 : 0) | (end_ply & ~0xFF);
     if (e->dev.w64) hipLaunchKernelGGL(k_step<double>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     else hipLaunchKernelGGL(k_step<float>, dim3((e->cfg.n_slots + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Dev*)e->d_dev, d_p, d_v, d_x, d_net, flags);
     CKR_HIP(hipGetLastError());

@@ -219,11 +219,12 @@ class Engine:
             raise ValueError("this engine hands out board records (feature_dtype BOARDS): there are no planes to view")
         return self.x.permute(0, 3, 1, 2)
 
-    def step(self, p=None, v=None, end_ply=False, single=False):
+    def step(self, p=None, v=None, end_ply=False, single=False, from_child=None):
         """One lock-step simulation.  p [S,512] float32 softmax output and
         v [S] float32 for the leaves of the previous step (None on the first).
         end_ply (CONSTRAINT == 'time', host clock): the wall-clock budget is used up -- every searching slot ends its ply in this step.
-        single: every slot runs at most ONE simulation in this step (MCTS_Node.selection(), MCTS.py:405-409)."""
+        single: every slot runs at most ONE simulation in this step (MCTS_Node.selection(), MCTS.py:405-409);
+        from_child: such a step whose simulation starts at that child of the root (selection() called on a child; interactive engines)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if p is not None:
             if not (p.dtype == torch.float32 and p.is_contiguous() and v.dtype == torch.float32 and v.is_contiguous()):
@@ -231,8 +232,11 @@ class Engine:
             pp, vp = p.data_ptr(), v.data_ptr()
         else:
             pp = vp = None
-        fn = self._L.ckr_engine_step_end_ply if end_ply else self._L.ckr_engine_step_single if single else self._L.ckr_engine_step
-        _lib.check(fn(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
+        if from_child is not None:                             # the one simulation starts at that child of the root (MCTS_Node.selection() on a child)
+            _lib.check(self._L.ckr_engine_step_single_from(self._h, int(from_child), pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
+        else:
+            fn = self._L.ckr_engine_step_end_ply if end_ply else self._L.ckr_engine_step_single if single else self._L.ckr_engine_step
+            _lib.check(fn(self._h, pp, vp, self.x.data_ptr(), self.net_id.data_ptr(), stream))
         self._first = False
 
     @property
@@ -276,10 +280,14 @@ class Engine:
                                                    self.row_range.data_ptr(), stream))
         return int(self.row_range[1].item())
 
-    def rollout(self, sims, end_ply=False):
+    def rollout(self, sims, end_ply=False, from_child=None):
         """Random-rollout mode: up to `sims` complete simulations per slot in one launch.
-        end_ply (CONSTRAINT == 'time'): the wall-clock budget is used up -- every searching slot ends its ply first."""
+        end_ply (CONSTRAINT == 'time'): the wall-clock budget is used up -- every searching slot ends its ply first.
+        from_child: ONE simulation whose tree policy starts at that child of the root (interactive engines)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if from_child is not None:
+            _lib.check(self._L.ckr_engine_rollout_from(self._h, int(from_child), stream))
+            return
         fn = self._L.ckr_engine_rollout_end_ply if end_ply else self._L.ckr_engine_rollout
         _lib.check(fn(self._h, int(sims), stream))
 

@@ -451,9 +451,13 @@ class MCTS_Node:
             return
         self._missing = False
         self._number_of_visits, self._total_reward, self._prior_prob = root["n"], root["w"], root["p"]
+        recs = np.array([k["board"] for k in kids], np.uint32).reshape(-1, 4)
+        if kids and len(self.children) == len(kids) and all((c._board == r).all() for c, r in zip(self.children, recs)):
+            for c, k in zip(self.children, kids):            # the same children: the handles the caller holds stay the tree's nodes
+                c._number_of_visits, c._total_reward, c._prior_prob = k["n"], k["w"], k["p"]
+            return
         self.children = []
         if kids:
-            recs = np.array([k["board"] for k in kids], np.uint32)
             mask, status = rules.movegen(rules.boards_to_device(recs))
             planes = codec.records_to_planes(recs, mask.cpu().numpy().view(np.uint32), status.cpu().numpy().view(np.uint32))
             for i, k in enumerate(kids):
@@ -463,7 +467,7 @@ class MCTS_Node:
                 c.history = self.history + [c.state]
                 c.depth = len(c.history)
                 c._number_of_visits, c._total_reward, c._prior_prob = k["n"], k["w"], k["p"]
-                c._status = k["status"]
+                c._status, c._board = k["status"], recs[i].copy()
                 c.terminal = bool(codec.status_outcome(k["status"]))
                 self.children.append(c)
 
@@ -483,27 +487,35 @@ class MCTS_Node:
         return np.round((self.q + 1) / 2 * 100, 1)
 
     def selection(self):
-        """ONE simulation of the tree policy from the root of the live position (MCTS.py:405-409: MCTS.tree_policy(self)): the
-        engine runs single-simulation steps (ckr_engine_step_single) until this root has one visit more; the node's statistics and
-        children are then reloaded.  Only roots can be stepped (the reference's recursion below the root happens inside the call)."""
+        """ONE simulation of the tree policy (MCTS.py:405-409: MCTS.tree_policy(self)) from the root of the live position or from
+        one of its children -- the handles this class hands out: the engine runs single-simulation steps (ckr_engine_step_single,
+        _from for a child: no selection and no noise draw at the root, the backup still passes through it) until the root has
+        one visit more; the root's and its children's statistics are then reloaded into the SAME node objects.  (The reference's
+        recursion below these nodes happens inside the call.)"""
+        top = self if self.parent is None else self.parent
+        child = None
         if self.parent is not None:
-            raise ValueError("MCTS_Node.selection: simulations start at the root of the live position (MCTS.begin_tree_search)")
+            if top.parent is not None or not any(c is self for c in top.children):
+                raise ValueError("MCTS_Node.selection: the root of the live position's tree or one of its children")
+            child = [c is self for c in top.children].index(True)
         MCTS._sync()
         eng = MCTS._engine
         if not eng.game(0)[3] and eng.command(CMD_SEARCH)[0]:
             raise ValueError("selection on a finished game")
-        root, _ = eng.root(0, int(MCTS.game_env.state[4, 0, 0]))
+        root, kids = eng.root(0, int(MCTS.game_env.state[4, 0, 0]))
         n0 = root["n"] if root is not None else 0
+        if child is not None and (root is None or child >= len(kids) or tuple(kids[child]["board"]) != tuple(int(v) for v in self._board)):
+            raise ValueError("MCTS_Node.selection: this node is not a child of the live position's root (any more)")
         if not MCTS.neural_net:
-            eng.rollout(1)
+            eng.rollout(1, from_child=child)
         else:
             runner = MCTS._search_runner()
-            for _ in range(4):                               # hand-out, evaluation, expansion: at most three steps
-                eng.step(runner.p, runner.v, single=True)
+            for i in range(4):                               # hand-out, evaluation, expansion: at most three steps
+                eng.step(runner.p, runner.v, single=True, from_child=child if i == 0 else None)
                 runner._eval_into_buffers()
                 runner.check_evaluator()
                 root, _ = eng.root(0, int(MCTS.game_env.state[4, 0, 0]))
                 if root is not None and root["n"] > n0:
                     break
-        self._load()
+        top._load()
         MCTS.rollout_count += 1

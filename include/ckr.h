@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 128          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions); 128: ckr_engine_draw_counter */
+#define CKR_VERSION 129          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions); 128: ckr_engine_draw_counter; 129: ckr_engine_step_single_from, ckr_engine_rollout_from */
 
 typedef enum {
     CKR_OK = 0,
@@ -426,6 +426,12 @@ int ckr_engine_step(ckr_engine* e, const float* d_p, const float* d_v, void* d_x
  * MCTS.py:405-409: one call of the tree policy): a slot whose pending leaf is expanded in this step has completed its simulation
  * and hands out no new leaf. */
 int ckr_engine_step_single(ckr_engine* e, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream);
+/* ckr_engine_step_single of an interactive engine whose simulation starts at child `child` (index in the root's child list, as
+ * ckr_engine_root returns it) of the live position's root instead of at the root: MCTS_Node.selection() called on a child,
+ * i.e. MCTS.tree_policy(child) (MCTS.py:60-99,406-410) -- no selection and no Dirichlet draw at the root; an unexpanded child is
+ * the leaf, a terminal child is backed up (:97-99), an expanded one is descended by PUCT; the backup passes through the root
+ * (:419-428).  Only the step that hands out the leaf needs it: the following ckr_engine_step_single consumes the answer. */
+int ckr_engine_step_single_from(ckr_engine* e, int32_t child, const float* d_p, const float* d_v, void* d_x, int32_t* d_net, void* stream);
 
 /* CONSTRAINT == 'time' with ONE clock, kept by the host, for all games of an engine (ckr_config.time_budget_us gives every search
  * its own clock on the device and needs none of this) (MCTS.computational_budget, MCTS.py:196-198: a search lasts BUDGET seconds of wall-clock time
@@ -440,6 +446,9 @@ int ckr_engine_step_end_ply(ckr_engine* e, const float* d_p, const float* d_v, v
  * (MCTS.py:112-116), one-child expansion (:78-81), uniform random playout (:132-143), backup -- plus
  * the end-of-ply work, all inside one kernel launch.  No network is involved. */
 int ckr_engine_rollout(ckr_engine* e, int32_t sims, void* stream);
+/* One simulation of the random-rollout tree policy started at child `child` of the root of an interactive engine
+ * (MCTS_Node.selection() on a child with NEURAL_NET False: MCTS.py:78-99 from that node). */
+int ckr_engine_rollout_from(ckr_engine* e, int32_t child, void* stream);
 /* CONSTRAINT == 'time' (MCTS.py:189-201) in the random-rollout mode: create the engine with budget = INT32_MAX, call
  * ckr_engine_rollout until BUDGET seconds have passed, then this: every searching slot ends its ply (MCTS.best_child on the
  * statistics gathered so far) and continues with up to `sims` simulations of the next search. */

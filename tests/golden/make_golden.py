@@ -29,6 +29,8 @@ Fixture families:
   selfplay_budgets_np{1,2}.npz, tournament_budgets_v1.npz
                      the same at the BASELINE budgets: cfg1's complete game (50 simulations per move, TERMINATE_CNT 200), one game at
                      cfg4's 400, one arena pair at cfg5's 800 played to its natural end
+  child_selections_v1.json
+                     MCTS_Node.selection() called on children of the root (network search, the same on injected noise, random rollouts)
 A complete regeneration takes ~5.6 min under this interpreter (python make_golden.py) plus ~1.4 min for the np1 families
 (/opt/conda/bin/python3.9 make_golden.py search_inexact selfplay_inexact search_noise selfplay_noise selfplay_budgets);
 compare_fixtures.py compares a regeneration with the committed files (VALIDATION.md).
@@ -760,9 +762,61 @@ def gen_console(budget=30, salt=0, plies=4, depth=2, n_selections=12):
                                                                                   out["trees"][0].count("\n"), len(out["selections"])))
 
 
+def gen_child_selections(budget=1000, salt=2, n_root=12, seq=(0, 0, 3, 6, 3, 0, 5, 5, 2, 0, 3, 3, 6, 1, 0, 0, 0, 4), depth=3, worker=4):
+    """MCTS_Node.selection() called on CHILDREN of the root (MCTS.py:406-410: MCTS.tree_policy(child) -- the tree policy from that node,
+    the backup through its parents, :419-428): after n_root selections on the root, one call per entry of `seq` on root.children[i];
+    after every call the root's N / W and its children's (action, N, W), and at the end print_tree(root, depth) for the statistics below.
+    Three cases: the network search without noise; with epsilon 0.25 on injected noise (no draw is made at the root by such a call);
+    NEURAL_NET False with the playout's randint pinned to 0 (the rollout fixtures' convention; ln table stored)."""
+    import contextlib
+    import io
+    import json
+
+    def view(root):
+        return dict(n=int(root.n), w=float(root.w), child_n=[int(c.n) for c in root.children], child_w=[float(c.w) for c in root.children],
+                    child_action=[_action_of(c.state) for c in root.children])
+
+    def run(mk, n_first, picks):
+        env = rt.new_env()
+        env.neural_net = ref_shim.HashNet(salt)
+        MCTS(**dict(mk, GAME_ENV=env))
+        MCTS.rollout_count = 0             # (begin_tree_search's job, MCTS.py:219; selection() called directly needs it set)
+        root = MCTS_Node(env.state, parent=None)
+        rows = []
+        for _ in range(n_first):
+            root.selection()
+            rows.append(dict(view(root), on=-1))
+        for i in picks:
+            i = i % len(root.children)
+            root.children[i].selection()
+            rows.append(dict(view(root), on=int(i)))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            MCTS.print_tree(root, max_tree_depth=depth)
+        return dict(rows=rows, tree=buf.getvalue(), rollout_count=int(MCTS.rollout_count))
+
+    out = dict(cfg=dict(budget=budget, salt=salt, n_root=n_root, seq=list(seq), depth=depth, worker=worker, noise_seed=NOISE_SEED))
+    out["plain"] = run(mcts_kwargs(budget, training=False), n_root, seq)
+    with ref_shim.NoiseInjector(NOISE_SEED, worker) as inj:
+        out["noise"] = run(mcts_kwargs(budget, eps=0.25, training=False), n_root, seq)
+    out["noise"]["draws"] = [int(inj.n_dirichlet), int(inj.n_choice), int(inj.ctr)]
+    real_randint = np.random.randint
+    np.random.randint = lambda *a, **k: 0
+    try:
+        mk = mcts_kwargs(budget, training=False)
+        mk["NEURAL_NET"] = False
+        out["rollout"] = run(mk, n_root, seq)
+    finally:
+        np.random.randint = real_randint
+    out["ln_table"] = [0.0] + [float(np.log(n)) for n in range(1, 256)]
+    with open(os.path.join(OUT, "child_selections_v1.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False, sort_keys=True)
+    print("child selections: %d + %d calls per case; draws %s; rollout tree %d lines" % (n_root, len(seq), out["noise"]["draws"], out["rollout"]["tree"].count("\n")))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rules", "predict", "search", "search_inexact", "selfplay", "selfplay_inexact", "tournament", "rollout", "training", "text", "ttt",
-                             "console", "search_noise", "selfplay_noise", "tournament_noise", "selfplay_budgets", "tournament_budgets"]
+                             "console", "search_noise", "selfplay_noise", "tournament_noise", "selfplay_budgets", "tournament_budgets", "child_selections"]
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
     for w in which:

@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.ckr_version() == 128
+    assert lib.ckr_version() == 129
     assert isinstance(lib.ckr_last_error(), bytes)
 
 
