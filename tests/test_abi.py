@@ -26,6 +26,16 @@ def test_header_symbols_exported(lib):
     assert sorted(_lib.EXPORTS) == declared
 
 
+def test_every_entry_point_cites_a_reference_interface_and_is_in_the_integration_guide():
+    """include/ckr.h: every declaration sits under a comment citing the reference lines it replaces (or says there is none);
+    INTEGRATION.md's table names every entry point beside the reference interface a maintainer would bind it to."""
+    hdr = open(os.path.join(ROOT, "include", "ckr.h")).read()
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = sorted(set(re.findall(r"\b(ckr_[a-z_0-9]+)\s*\(", hdr)))
+    assert [n for n in declared if n not in guide] == []
+    assert len(re.findall(r"[A-Za-z_]+\.py:\d+", hdr)) >= 60                 # file:line citations into the reference
+
+
 def test_version_and_error_string(lib):
     assert lib.ckr_version() == 129
     assert isinstance(lib.ckr_last_error(), bytes)
