@@ -77,6 +77,48 @@ def test_final_evaluation_table_text(tmp_path, monkeypatch):
         final_evaluation([0, 7], dict(NUM_CPUS=1), arena_kwargs(8))
 
 
+def test_the_authors_own_result_files_are_reproduced(tmp_path, monkeypatch, golden_dir):
+    """Known answers held by the reference repository itself: result files of the author's runs (tests/golden/reference_data/README.md).
+    The game list of a tournament file, read back out of its second table, is written again by tournament_Checkers._save_tourney_results
+    (training_pipeline.py:561-594) -- both tables byte for byte, incl. the win / loss / draw summary; the 11-model score table of the
+    final evaluation, turned back into game outcomes, by final_evaluation._parse_tourney_results (:668-711)."""
+    from checkers_mcts_amd.pipeline import tournament_Checkers, final_evaluation
+    monkeypatch.chdir(tmp_path)
+    ref = os.path.join(golden_dir, "reference_data")
+    for name in ("Tournament_12-Feb-2021.txt", "Tournament_29-Jan-2021.txt"):
+        text = open(os.path.join(ref, name), encoding="utf-8").read()
+        second = text.split("\n\n")[1]
+        rows = [[c.strip() for c in line.strip("│").split("│")] for line in second.splitlines() if line.startswith("│") and "Game Number" not in line]
+        games = [[int(r[0]), r[1], r[2], r[3], int(r[4])] for r in rows]
+        assert len(games) == 10
+        new_fn = [line.split("│")[1].strip() for line in text.split("\n\n")[0].splitlines() if ".h5" in line][0]
+        assert games[0][1] == new_fn                                      # the new network moves first in game 1 (:523-528)
+        t = tournament_Checkers(dict(NEW_NN_FN="data/model/" + new_fn, OLD_NN_FN="data/model/" + games[0][2], TOURNEY_GAMES=2, NUM_CPUS=5), arena_kwargs(400))
+        fn = t._save_tourney_results([list(g) for g in games])
+        assert open(fn, encoding="utf-8").read() == text, name
+    text = open(os.path.join(ref, "Checkers_Final_Evaluation_16-Feb-2021.txt"), encoding="utf-8").read()
+    rows = [[c.strip() for c in line.strip("│").split("│")] for line in text.splitlines() if line.startswith("│")]
+    iters = [int(c) for c in rows[0][1:-1]]
+    table = np.array([[int(c) for c in r[1:-1]] for r in rows[1:]])
+    assert iters == list(range(11)) and (table == -table.T).all() and [int(r[-1]) for r in rows[1:]] == table.sum(1).tolist()
+    os.makedirs("data/model", exist_ok=True)
+    for it in iters:
+        open("data/model/Checkers_Model%d_x.h5" % it, "w").close()
+    ev = final_evaluation(iters, dict(NUM_CPUS=5), arena_kwargs(400))
+    fns = ev.model_fn_list
+    pairs = {2: ["player1_wins", "player1_wins"], 1: ["player1_wins", "draw"], 0: ["draw", "draw"], -1: ["player2_wins", "draw"], -2: ["player2_wins", "player2_wins"]}
+    ev.game_outcomes = [[[g + 1, fns[i], fns[j], o, 100] for j in range(i) for g, o in enumerate(pairs[int(table[i, j])])] for i in range(len(iters) - 1, 0, -1)]
+    fn = ev._parse_tourney_results()
+    assert (ev.table == table).all() and open(fn, encoding="utf-8").read() == text
+    # the training phase's parameter dump of iteration 9 (training_pipeline.py:225-244), typed as train_Checkers.py:106-126 types them
+    from checkers_mcts_amd.train import record_params
+    text = open(os.path.join(ref, "Checkers_Training_Params_12-Feb-2021.txt")).read()
+    tk = dict(TRAINING_ITERATION=9, NN_BASE_LR=5e-5, NN_MAX_LR=1e-2, CLR_SS_COEFF=4, BATCH_SIZE=128, EPOCHS=100, CONV_REG=0.001, DENSE_REG=0.001,
+              NUM_KERNELS=128, VAL_SPLIT=0.20, MIN_DELTA=0.01, PATIENCE=20, POLICY_LOSS_WEIGHT=1.0, VALUE_LOSS_WEIGHT=1.0, SLIDING_WINDOW=1,
+              OLD_NN_FN="data/model/Checkers_Model9_11-Feb-2021(00:07:22).h5", NEW_NN_FN="data/model/Checkers_Model10_12-Feb-2021(14:50:36).h5")
+    assert open(record_params("training", **tk)).read() == text
+
+
 @pytest.mark.gpu
 def test_tournament_played_on_the_engine_writes_the_reference_file(tmp_path, monkeypatch):
     from checkers_mcts_amd.pipeline import tournament_Checkers
