@@ -246,7 +246,11 @@ def cpu_baseline(budget, seconds):
             "host": {"cpu_model": model, "nproc": nproc, "usable_cores": avail},
             "sample": "%d lock-step games x %d steps (%.1f s) of the same workload: C oracle search on %d threads (one game per "
                       "thread at a time) + PyTorch-CPU fp32 network on %d threads, batch %d"
-                      % (W, steps, dt, batch.threads, nn_threads, W)}
+                      % (W, steps, dt, batch.threads, nn_threads, W),
+            # the Python reference itself cannot travel to this host; its rates as measured where it runs (BASELINE.md:18,33-36)
+            "reference_python_fixed": {"sims_per_s_per_core_stub_net": 460, "sims_per_s_per_core_real_size_net_batch_1": 85,
+                                       "node_expansions_per_s_per_core_readme_derived": 15, "movegen_boards_per_s_per_core": 9400,
+                                       "source": "BASELINE.md (measured in the build container on the imported reference; README:312-derived row): not this host, not part of `value`"}}
 
 
 def movegen_probe(device):
