@@ -8,7 +8,10 @@ from checkers_mcts_amd import net as N
 from checkers_mcts_amd.fused import FusedEvaluator
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-m = N.PolicyValueNet(128).keras_init(0).eval().cuda()
+m = N.PolicyValueNet(128).keras_init(0)
+if os.environ.get("CONV_PERTURB_BN"):                          # non-trivial BatchNorm (a trained network's): the next layer's inputs are no longer ~50 % zeros
+    m = m.perturb_bn(int(os.environ["CONV_PERTURB_BN"]))
+m = m.eval().cuda()
 fe = FusedEvaluator(m, S, mode=os.environ.get("CONV_MODE", "bf16"))
 density = float(os.environ.get("CONV_DENSITY", "0.2"))       # 0 = all-zero planes: the same instruction stream on zero operands (power / DVFS probe)
 x = (torch.rand(S, 8, 8, 14, device="cuda") < density).to(torch.float32 if os.environ.get("CONV_MODE") == "f16x3" else torch.bfloat16).contiguous()
