@@ -66,9 +66,14 @@ def save_merged_files(memory, iteration, timestamp):
 
 
 def merge_data(data_fns, iteration):
-    training_data = []                                                            # training_pipeline.py:277-284
-    for fn in data_fns:
-        training_data.extend(load_training_data("data/training_data/" + fn))
+    """training_pipeline.merge_data (:277-284): the files' tuples in one list, saved as the iteration's merged pickle.  The reference
+    looks every name up under data/training_data/ -- names as os.listdir returns them (train_Checkers.py:140-143); handed
+    generate_data()'s return value, which already carries that directory (:457-463), its own driver fails with FileNotFoundError
+    (train_Checkers.py:138).  Here both kinds of name are found, and a single name (generate_data() with NUM_CPUS 1) is a list of one."""
+    training_data = []
+    for fn in ([data_fns] if isinstance(data_fns, str) else data_fns):
+        path = "data/training_data/" + fn
+        training_data.extend(load_training_data(path if os.path.exists(path) or not os.path.exists(fn) else fn))
     save_merged_files(training_data, iteration, create_timestamp())
     return training_data
 
