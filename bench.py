@@ -283,6 +283,41 @@ def movegen_probe(device):
             "frac": 52.0 * n / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": 52}
 
 
+def children_probe(device):
+    """K2 make_children on 2^22 boards (one wavefront per board; ordered successor lists into [n][48] record slots): achieved HBM
+    bandwidth on the ALGORITHMIC bytes -- 16 B board in, 4 B count and 16 B per successor out (133 B/board at 5.07 children)."""
+    from checkers_mcts_amd import _lib
+    L = _lib.load()
+    n = 1 << 22
+    g = torch.Generator(device="cpu").manual_seed(1)
+    occ = torch.randint(0, 2 ** 31 - 1, (65536, 2), generator=g, dtype=torch.int64)
+    p1 = (occ[:, 0] & occ[:, 1]).to(torch.int32)
+    p2 = ((occ[:, 0] >> 3) & ~occ[:, 1] & ~p1.to(torch.int64)).to(torch.int32)
+    kings = (occ[:, 1] >> 7).to(torch.int32) & (p1 | p2)
+    side = torch.arange(65536, dtype=torch.int32) & 1
+    boards = torch.stack([p1, p2, kings, side | (1 << 19)], dim=1).contiguous().to(device).repeat(n // 65536, 1).contiguous()
+    kids = torch.empty((n, 48, 4), dtype=torch.int32, device=device)
+    count = torch.empty((n,), dtype=torch.int32, device=device)
+    s = torch.cuda.current_stream(device).cuda_stream
+    for _ in range(2):
+        L.ckr_children_batch(boards.data_ptr(), n, kids.data_ptr(), count.data_ptr(), s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        L.ckr_children_batch(boards.data_ptr(), n, kids.data_ptr(), count.data_ptr(), s)
+    e1.record()
+    torch.cuda.synchronize(device)
+    sec = e0.elapsed_time(e1) / 1e3 / reps
+    mean_children = float(count.float().mean().item())
+    bytes_per_board = 16.0 + 4.0 + 16.0 * mean_children
+    del kids
+    return {"kernel": "k_children", "boards": n, "boards_per_s": n / sec, "us_per_launch": sec * 1e6, "mean_children": mean_children,
+            "bound": "hbm", "achieved": bytes_per_board * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_per_board * n / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": bytes_per_board,
+            "note": "successor lists are written into 768-byte slots (48 records) of which ~%.0f B are used: the stores are 16-byte records in partial cache lines" % (16.0 * mean_children)}
+
+
 def time_conv(evaluator, x, dev, groups=5, per_group=10):
     """Average launch duration of the conv-stack kernel: HIP events on the launch stream around a HIP
     graph of `per_group` back-to-back launches (graph dispatch, as in the real step: eager launches
@@ -966,7 +1001,7 @@ def main():
         value = exp_total / dt
         if whole is not None:
             whole["efficiency_vs_steady_state"] = whole["expansions_per_s"] / value
-        extra = {"movegen_k1": movegen_probe(dev)}
+        extra = {"movegen_k1": movegen_probe(dev), "children_k2": children_probe(dev)}
         if world == 1 and a.extra_steps > 0:
             if cache_log2:
                 off = throughput_leg(a, dev, mode, cache_log2=0)

@@ -52,26 +52,52 @@ __global__ __launch_bounds__(256) void k_movegen(const uint4* __restrict__ board
     }
 }
 
-// K2: one wavefront per board; successors compacted through LDS and written
-// as contiguous 16-B records (coalesced), reference list order.
+// K2: one board per LANE (round 6; rounds 1-5: one wavefront per board, 64 lanes for ~5 successors).  A lane walks its own pieces in the
+// reference's generation order -- men row-major then kings row-major (Checkers.py:111-116,124,168); ordinary moves men [right, left]
+// (:125,145), kings [UL,UR,BL,BR] (:169-170); jumps men [left, right] (:214), kings [UL,BL,UR,BR] (:266-267) -- and writes each successor
+// as one 16-byte record into the board's slot of CKR_MAX_CHILDREN records.
+__device__ __forceinline__ int lane_children(const ckr_board b, const uint32_t m[8], uint4* __restrict__ out) {
+    const uint32_t side = b.meta & 1u;
+    const uint32_t own = side ? b.p2 : b.p1, men = own & ~b.kings, kg = own & b.kings;
+    const bool jump = (m[4] | m[5] | m[6] | m[7]) != 0u;
+    // ONE loop, one successor per iteration, one make_child call site: the piece's square is the lowest set bit of the masks still
+    // to serve, its direction the first of the phase's direction order whose mask holds that bit.  Phase 0 = men (two directions),
+    // phase 1 = kings (four); a lane changes phase by exchanging its masks, not its control flow.
+    int c0 = jump ? (side == 0u ? 6 : 4) : (side == 0u ? 3 : 1), c1 = jump ? (side == 0u ? 7 : 5) : (side == 0u ? 2 : 0), c2 = 0, c3 = 0;
+    uint32_t q0 = sel8(m, c0) & men, q1 = sel8(m, c1) & men, q2 = 0u, q3 = 0u;
+    bool kings_next = true;
+    int k = 0;
+    for (;;) {
+        uint32_t u = q0 | q1 | q2 | q3;
+        if (u == 0u && kings_next) {
+            kings_next = false;
+            c0 = jump ? 4 : 0; c1 = jump ? 6 : 1; c2 = jump ? 5 : 2; c3 = jump ? 7 : 3;
+            q0 = m[jump ? 4 : 0] & kg; q1 = m[jump ? 6 : 1] & kg; q2 = m[jump ? 5 : 2] & kg; q3 = m[jump ? 7 : 3] & kg;
+            u = q0 | q1 | q2 | q3;
+        }
+        if (u == 0u) break;
+        const int s = __ffs((int)u) - 1;
+        const uint32_t bit = 1u << s;
+        int d;
+        if (q0 & bit) { d = c0; q0 &= ~bit; }
+        else if (q1 & bit) { d = c1; q1 &= ~bit; }
+        else if (q2 & bit) { d = c2; q2 &= ~bit; }
+        else { d = c3; q3 &= ~bit; }
+        const ckr_board c = make_child(b, d, s);
+        out[k++] = make_uint4(c.p1, c.p2, c.kings, c.meta);
+    }
+    return k;
+}
+
 __global__ __launch_bounds__(256) void k_children(const uint4* __restrict__ boards, int64_t n,
                                                   uint4* __restrict__ children, int32_t* __restrict__ count) {
-    __shared__ ckr_board lds[4][CKR_MAX_CHILDREN];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += nwaves) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint4 v = boards[i];
         const ckr_board b{v.x, v.y, v.z, v.w};
         uint32_t m[8], st;
         movegen(b, m, st);
-        const int k = wave_children(b, m, lds[wave], false);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < k) {
-            const ckr_board c = lds[wave][lane];
-            children[i * CKR_MAX_CHILDREN + lane] = make_uint4(c.p1, c.p2, c.kings, c.meta);
-        }
-        if (lane == 0) count[i] = k;
-        __builtin_amdgcn_wave_barrier();
+        count[i] = lane_children(b, m, children + i * CKR_MAX_CHILDREN);     // (from the masks alone, as the wave version did)
     }
 }
 
@@ -340,7 +366,7 @@ int ckr_children_batch(const ckr_board* d_boards, int64_t n, ckr_board* d_childr
     if (int rc = require_device()) return rc;
     if (n == 0) return CKR_OK;
     CKR_CHECK_ARGS(d_boards && d_children && d_count, "null device pointer");
-    hipLaunchKernelGGL(k_children, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_children, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)d_boards, n, (uint4*)d_children, d_count);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
