@@ -19,7 +19,7 @@ def render(path=LINE):
     e, r, w, c = d["extra"], d["roofline"], d["whole_run"], d["cpu_baseline"]
     ar = e["arena_cfg5_shape"]
     rows = [
-        ("source", "`profiles/%s`: `python bench.py` on one MI355X (boxes of the pool differ by a few %%)" % os.path.basename(path)),
+        ("source", "`profiles/%s`: `python bench.py` on one MI355X (boxes of the pool differ: the same code read 7.1-8.0 M over the round's sessions, with the conv stack's clock -- its lone launch takes 0.261-0.280 ms)" % os.path.basename(path)),
         ("BASELINE cfg 3 (100 sims/move, 4 096 concurrent games), float32-grade network, steady state",
          "**%.2f M node-expansions/s** (%.3f ms per step of 4 096 slots); %.2f M of them per second are network rows, %.2f M/s are positions the "
          "network had already evaluated (leaf cache)" % (d["value"] / 1e6, d["ms_per_step"], d["nn_evals_per_s"] / 1e6, d["cache_served_per_s"] / 1e6)),
