@@ -312,10 +312,29 @@ def children_probe(device):
     mean_children = float(count.float().mean().item())
     bytes_per_board = 16.0 + 4.0 + 16.0 * mean_children
     del kids
+    # the dense form (ckr_children_packed): lists back to back, + 8 B of offset per board
+    total = int(count.sum().item())
+    packed = torch.empty((total, 4), dtype=torch.int32, device=device)
+    offset = torch.empty((n,), dtype=torch.int64, device=device)
+    tot = torch.zeros((1,), dtype=torch.int64, device=device)
+    scratch = torch.empty(((n + 255) // 256 * 12 + 16,), dtype=torch.uint8, device=device)
+    for _ in range(2):
+        L.ckr_children_packed(boards.data_ptr(), n, packed.data_ptr(), total, offset.data_ptr(), count.data_ptr(), tot.data_ptr(), scratch.data_ptr(), s)
+    e0.record()
+    for _ in range(reps):
+        L.ckr_children_packed(boards.data_ptr(), n, packed.data_ptr(), total, offset.data_ptr(), count.data_ptr(), tot.data_ptr(), scratch.data_ptr(), s)
+    e1.record()
+    torch.cuda.synchronize(device)
+    psec = e0.elapsed_time(e1) / 1e3 / reps
+    assert int(tot.item()) == total
+    pbytes = bytes_per_board + 8.0
+    dense = {"kernel": "k_children_count + k_scan_tiles + k_children_packed", "boards_per_s": n / psec, "us_per_launch": psec * 1e6, "achieved": pbytes * n / psec / 1e9, "unit": "GB/s",
+             "frac": pbytes * n / psec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": pbytes}
     return {"kernel": "k_children", "boards": n, "boards_per_s": n / sec, "us_per_launch": sec * 1e6, "mean_children": mean_children,
             "bound": "hbm", "achieved": bytes_per_board * n / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_per_board * n / sec / 1e9 / HBM_PEAK_GBS, "bytes_per_board": bytes_per_board,
-            "note": "successor lists are written into 768-byte slots (48 records) of which ~%.0f B are used: the stores are 16-byte records in partial cache lines" % (16.0 * mean_children)}
+            "note": "successor lists are written into 768-byte slots (48 records) of which ~%.0f B are used: the stores are 16-byte records in partial cache lines" % (16.0 * mean_children),
+            "dense_output": dense}
 
 
 def time_conv(evaluator, x, dev, groups=5, per_group=10):

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CKR_LIB_PATH", os.path.join(HERE, "libckr.so"))   # override: kernel experiments
 MAX_CHILDREN = 48
-VERSION = 129                      # CKR_VERSION of include/ckr.h this binding was written against
+VERSION = 130                      # CKR_VERSION of include/ckr.h this binding was written against
 Q_F32, Q_INT, Q_F64, Q_F64_NEG = 0, 1, 2, 3      # ckr_tuple.q_kind
 
 
@@ -53,7 +53,7 @@ class Stats(C.Structure):
                                           "active_slots", "nn_evals", "dup_leaves", "cache_entries", "cache_dropped", "parked", "stalled_steps", "evaluated_ahead", "pool_grown")]
 
 
-EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_stream_create", "ckr_stream_destroy", "ckr_movegen_batch", "ckr_children_batch",
+EXPORTS = ["ckr_last_error", "ckr_version", "ckr_device_count", "ckr_stream_create", "ckr_stream_destroy", "ckr_movegen_batch", "ckr_children_batch", "ckr_children_packed",
            "ckr_features_batch", "ckr_mask_renorm_batch", "ckr_hashnet_batch", "ckr_training_batch", "ckr_arena_partition", "ckr_arena_merge", "ckr_conv_stack_bf16", "ckr_conv_stack_f16x3", "ckr_conv_stack_f16x3_boards", "ckr_conv_stack_f16x3_boards_pair", "ckr_value_mlp", "ckr_policy_head", "ckr_heads_tail", "ckr_heads_tail_pair", "ckr_leaf_cache_create", "ckr_leaf_cache_destroy", "ckr_leaf_cache_flush", "ckr_engine_attach_cache", "ckr_engine_create", "ckr_engine_compact_rows", "ckr_engine_set_row_range", "ckr_engine_set_eval_flag", "ckr_engine_set_prefetch",
            "ckr_engine_destroy", "ckr_engine_step", "ckr_engine_step_single", "ckr_engine_step_single_from", "ckr_engine_rollout_from", "ckr_engine_step_end_ply", "ckr_engine_subtree", "ckr_engine_stats", "ckr_engine_mark", "ckr_engine_stats_at_mark", "ckr_engine_cache_flush", "ckr_engine_results",
            "ckr_engine_tuples", "ckr_engine_pack_tuples", "ckr_engine_root_stats", "ckr_engine_leaves", "ckr_engine_draw_counter",
@@ -88,6 +88,7 @@ def load():
     L.ckr_stream_destroy.argtypes = [vp]
     L.ckr_movegen_batch.argtypes = [vp, i64, vp, vp, vp]
     L.ckr_children_batch.argtypes = [vp, i64, vp, vp, vp]
+    L.ckr_children_packed.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp]
     L.ckr_features_batch.argtypes = [vp, i64, vp, vp]
     L.ckr_mask_renorm_batch.argtypes = [vp, i64, vp, vp, vp]
     L.ckr_hashnet_batch.argtypes = [vp, i64, C.c_uint32, C.c_int32, vp, vp, vp]

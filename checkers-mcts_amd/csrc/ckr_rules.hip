@@ -101,6 +101,90 @@ __global__ __launch_bounds__(256) void k_children(const uint4* __restrict__ boar
     }
 }
 
+// K2 with a DENSE output (round 6): profiles/r06_k2_children.txt -- half of k_children's time is the partial-line writes of its 48-record slots.
+// Here the lists lie back to back in position order (a CSR: offset[i] = number of successors of the positions before i).  Three launches:
+// counts and per-tile sums (a tile = the 256 positions of a workgroup; the count is known from movegen's status word before any successor is
+// built), an exclusive scan of the tile sums by one workgroup, and the writing pass, which repeats movegen (17 us per 2^22 boards) and places
+// every lane by a wave scan.  (A first version reserved each wavefront's run with one atomicAdd on a global counter: 65 536 atomics on ONE
+// address took 0.8 ms, three times the whole slot kernel.)
+__device__ __forceinline__ int wave_incl_scan_i32(int v, int lane) {                    // Hillis-Steele on ds_bpermute
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, v);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_children_count(const uint4* __restrict__ boards, int64_t n, int32_t* __restrict__ count, int32_t* __restrict__ tile_sum) {
+    __shared__ int wsum[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    int k = 0;
+    if (i < n) {
+        const uint4 v = boards[i];
+        uint32_t m[8], st;
+        movegen(ckr_board{v.x, v.y, v.z, v.w}, m, st);
+        k = (int)st_nlegal(st);                                  // = the number of set mask bits = successors lane_children writes
+        count[i] = k;
+    }
+    const int incl = wave_incl_scan_i32(k, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the tile sums (int32 -> int64 bases) by ONE workgroup of 1 024 threads, 16 consecutive tiles per thread and round
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int32_t* __restrict__ tile_sum, int64_t tiles, long long* __restrict__ tile_base, long long* __restrict__ total) {
+    __shared__ long long wtot[16];
+    __shared__ long long carry_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < tiles; t0 += 16384) {
+        const int64_t mine = t0 + (int64_t)threadIdx.x * 16;
+        int loc[16]; int sum = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { loc[q] = mine + q < tiles ? tile_sum[mine + q] : 0; sum += loc[q]; }
+        const int incl = wave_incl_scan_i32(sum, lane);           // < 2^31: 64 threads x 16 tiles x 256 positions x 48
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        long long before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wtot[w];
+        long long run = before + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { if (mine + q < tiles) tile_base[mine + q] = run; run += loc[q]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_children_packed(const uint4* __restrict__ boards, int64_t n, uint4* __restrict__ packed, long long capacity,
+                                                         const long long* __restrict__ tile_base, long long* __restrict__ offset) {
+    __shared__ int wsum[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st = 0;
+    ckr_board b{0u, 0u, 0u, 0u};
+    if (i < n) {
+        const uint4 v = boards[i];
+        b = ckr_board{v.x, v.y, v.z, v.w};
+        movegen(b, m, st);
+    }
+    const int k = (int)st_nlegal(st);
+    const int incl = wave_incl_scan_i32(k, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long at = tile_base[blockIdx.x] + incl - k;
+    for (int w = 0; w < wave; ++w) at += wsum[w];
+    if (i < n) {
+        offset[i] = at;
+        if (k > 0 && at + k <= capacity) lane_children(b, m, packed + at);      // (beyond the buffer: nothing is written; the caller sees total > capacity)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_features(const uint4* __restrict__ boards, int64_t n, float* __restrict__ x) {
     __shared__ __attribute__((aligned(16))) float feat[4][896];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -368,6 +452,25 @@ int ckr_children_batch(const ckr_board* d_boards, int64_t n, ckr_board* d_childr
     CKR_CHECK_ARGS(d_boards && d_children && d_count, "null device pointer");
     hipLaunchKernelGGL(k_children, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)d_boards, n, (uint4*)d_children, d_count);
+    CKR_HIP(hipGetLastError());
+    return CKR_OK;
+}
+
+int ckr_children_packed(const ckr_board* d_boards, int64_t n, ckr_board* d_packed, int64_t capacity, int64_t* d_offset, int32_t* d_count,
+                        int64_t* d_total, void* d_scratch, void* stream) {
+    CKR_CHECK_ARGS(n >= 0 && capacity >= 0, "negative size");
+    if (int rc = require_device()) return rc;
+    CKR_CHECK_ARGS(d_total, "null device pointer");
+    if (n == 0) { CKR_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), (hipStream_t)stream)); return CKR_OK; }
+    CKR_CHECK_ARGS(d_boards && d_offset && d_count && d_scratch && (d_packed || capacity == 0), "null device pointer");
+    const int64_t tiles = (n + 255) / 256;
+    CKR_CHECK_ARGS(tiles <= 0x7FFFFFFF, "too many positions for one call");
+    int32_t* tile_sum = (int32_t*)d_scratch;                                           // [tiles] int32, then [tiles] int64 (8-byte aligned)
+    long long* tile_base = (long long*)((char*)d_scratch + ((tiles * 4 + 7) & ~(int64_t)7));
+    hipLaunchKernelGGL(k_children_count, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_boards, n, d_count, tile_sum);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int32_t*)tile_sum, tiles, tile_base, (long long*)d_total);
+    hipLaunchKernelGGL(k_children_packed, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)d_boards, n, (uint4*)d_packed, (long long)capacity, (const long long*)tile_base, (long long*)d_offset);
     CKR_HIP(hipGetLastError());
     return CKR_OK;
 }

@@ -48,6 +48,29 @@ def children(boards):
     return kids, cnt
 
 
+def children_packed(boards, capacity=None):
+    """[N,4] -> (packed int32 [total,4], offset int64 [N], count int32 [N]): the successor list of position i is
+    packed[offset[i] : offset[i] + count[i]], in the reference's list order (include/ckr.h, ckr_children_packed: dense output,
+    the lists back to back in position order -- offset is the exclusive running sum of count).  capacity: records to provide at first (default 8 per position);
+    the call is repeated with the exact size when the positions have more."""
+    L = _lib.load()
+    b = _boards(boards)
+    n = b.shape[0]
+    offset = torch.empty((n,), dtype=torch.int64, device=b.device)
+    cnt = torch.empty((n,), dtype=torch.int32, device=b.device)
+    total = torch.zeros((1,), dtype=torch.int64, device=b.device)
+    scratch = torch.empty(((n + 255) // 256 * 12 + 16,), dtype=torch.uint8, device=b.device)      # CKR_CHILDREN_PACKED_SCRATCH(n)
+    cap = int(capacity if capacity is not None else 8 * n)
+    while True:
+        packed = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=b.device)
+        _lib.check(L.ckr_children_packed(b.data_ptr(), n, packed.data_ptr(), cap, offset.data_ptr(), cnt.data_ptr(), total.data_ptr(),
+                                         scratch.data_ptr(), _stream()))
+        t = int(total.item())
+        if t <= cap:
+            return packed[:t], offset, cnt
+        cap = t
+
+
 def features(boards):
     """[N,4] -> float32 [N,8,8,14] NHWC network input."""
     L = _lib.load()

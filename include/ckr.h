@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CKR_VERSION 129          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions); 128: ckr_engine_draw_counter; 129: ckr_engine_step_single_from, ckr_engine_rollout_from */
+#define CKR_VERSION 130          /* 0.1.2: one leaf cache per GPU, virtual workers; 121: training GEMMs on operands split once (ckr_conv_gemm_pieces); 123: ckr_conv_stack_f16x3_boards_pair; 124: ckr_heads_tail_pair; 125: node pool as 48-byte records, ckr_stream_create / _destroy; 126: ckr_config.noise_mode, ckr_probe_noise_*; 127: ckr_config.arena_games, ckr_stats.pool_grown (spare node-pool regions); 128: ckr_engine_draw_counter; 129: ckr_engine_step_single_from, ckr_engine_rollout_from; 130: ckr_children_packed */
 
 typedef enum {
     CKR_OK = 0,
@@ -82,6 +82,15 @@ int ckr_movegen_batch(const ckr_board* d_boards, int64_t n, uint32_t* d_mask8,
  * wave-per-position kernel of rounds 1-5 was 5 x slower). */
 int ckr_children_batch(const ckr_board* d_boards, int64_t n, ckr_board* d_children,
                        int32_t* d_count, void* stream);
+/* K2 with a dense output (same successors, same order; Checkers.py:121-304): the lists of all n positions packed back to back in
+ * position order -- the list of position i is the d_count[i] records from record d_offset[i] = d_count[0] + ... + d_count[i - 1]
+ * (a CSR).  *d_total (device) receives the number of records of all positions; a list that would end beyond `capacity` records
+ * is not written (d_offset / d_count / *d_total are still complete): call again with a larger buffer.  d_scratch: device memory
+ * of CKR_CHILDREN_PACKED_SCRATCH(n) bytes.  Three launches (counts + tile sums, scan, write); on large batches 1.5 x the rate of
+ * ckr_children_batch, whose 48-record slots are written as partly filled cache lines (profiles/r06_k2_children.txt). */
+#define CKR_CHILDREN_PACKED_SCRATCH(n) ((((int64_t)(n) + 255) / 256) * 12 + 16)
+int ckr_children_packed(const ckr_board* d_boards, int64_t n, ckr_board* d_packed, int64_t capacity, int64_t* d_offset,
+                        int32_t* d_count, int64_t* d_total, void* d_scratch, void* stream);
 
 /* K8 planes_from_bitboards.  Replaces the network-input build of
  * Checkers.predict (Checkers.py:431-432): NHWC float32 x[n][8][8][14]. */

@@ -37,7 +37,7 @@ def test_every_entry_point_cites_a_reference_interface_and_is_in_the_integration
 
 
 def test_version_and_error_string(lib):
-    assert lib.ckr_version() == 129
+    assert lib.ckr_version() == 130
     assert isinstance(lib.ckr_last_error(), bytes)
 
 

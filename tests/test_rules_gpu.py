@@ -72,6 +72,30 @@ def test_random_boards_vs_oracle(R, oracle):
         assert cnt[i] == len(ok) and (kids[i, :cnt[i]] == ok).all()
 
 
+def test_packed_successor_lists_equal_the_slot_lists(R, golden_dir):
+    """ckr_children_packed (dense output: lists back to back, offset + count per position) against ckr_children_batch on the 16 919 golden
+    positions (whose slot lists are pinned to the reference above) and on 20 000 synthetic ones: every list record for record, offsets =
+    the exclusive running sum of the counts; a buffer too small is reported, not overrun."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "rules_v1.npz"))
+    for boards in (g["boards"], random_boards(20000, 12), g["boards"][:70], g["boards"][:1]):
+        b = R.boards_to_device(boards)
+        kids, cnt = R.children(b)
+        packed, off, pc = R.children_packed(b)
+        kids, cnt, packed, off, pc = _np(kids), cnt.cpu().numpy(), _np(packed), off.cpu().numpy(), pc.cpu().numpy()
+        assert (pc == cnt).all() and len(packed) == cnt.sum()
+        assert (off == np.concatenate([[0], np.cumsum(cnt.astype(np.int64))[:-1]])).all()        # a CSR: position order, no gaps
+        flat = np.concatenate([kids[i, :cnt[i]] for i in range(len(boards))])
+        gather = np.concatenate([np.arange(off[i], off[i] + cnt[i]) for i in range(len(boards))])
+        assert (packed[gather] == flat).all()
+    b = R.boards_to_device(g["boards"][:4096])
+    total_needed = int(R.children(b)[1].sum().item())
+    small, off2, pc2 = R.children_packed(b, capacity=total_needed // 3)                        # first call too small: repeated with the exact size
+    assert len(small) == total_needed and (_np(small)[off2.cpu().numpy()[0]:][:1] == _np(R.children(b)[0])[0, :1]).all()
+    empty, off0, pc0 = R.children_packed(torch.zeros((0, 4), dtype=torch.int32, device="cuda"))
+    assert len(empty) == 0 and len(off0) == 0
+
+
 def playout_positions(oracle, n, seed):
     """Every position of seeded uniform-random playouts from the initial position, until n are
     collected; the oracle supplies rules and successors (it is the checker: pinned to the reference on 10^6 positions)."""
