@@ -161,8 +161,15 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int32_t* __restrict__
     if (threadIdx.x == 0) *total = carry_s;
 }
 
+// The writing pass assigns SUCCESSORS to lanes, not boards: successor t of the tile (in list order) is built by thread t -- it finds its
+// board by a binary search in the tile's running sums, peels the board's action list down to its own entry, calls make_child once and
+// writes record t: every lane does one successor's work (a board-per-lane loop runs as long as the wave's busiest board, ~15 iterations
+// for ~3.3 successors on average) and consecutive lanes write consecutive 16-byte records.
 __global__ __launch_bounds__(256) void k_children_packed(const uint4* __restrict__ boards, int64_t n, uint4* __restrict__ packed, long long capacity,
                                                          const long long* __restrict__ tile_base, long long* __restrict__ offset) {
+    __shared__ uint4 sb[256];
+    __shared__ uint32_t sm[256][7];            // men masks in direction order (2), king masks in direction order (4), jump flag
+    __shared__ int pre[257];                   // exclusive running sum of the successor counts within the tile
     __shared__ int wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -173,15 +180,69 @@ __global__ __launch_bounds__(256) void k_children_packed(const uint4* __restrict
         b = ckr_board{v.x, v.y, v.z, v.w};
         movegen(b, m, st);
     }
+    {
+        const uint32_t side = b.meta & 1u, own = side ? b.p2 : b.p1, men = own & ~b.kings, kg = own & b.kings;
+        const bool jump = (m[4] | m[5] | m[6] | m[7]) != 0u;
+        sb[threadIdx.x] = make_uint4(b.p1, b.p2, b.kings, b.meta);
+        sm[threadIdx.x][0] = (jump ? (side == 0u ? m[6] : m[4]) : (side == 0u ? m[3] : m[1])) & men;      // (the orders of lane_children)
+        sm[threadIdx.x][1] = (jump ? (side == 0u ? m[7] : m[5]) : (side == 0u ? m[2] : m[0])) & men;
+        sm[threadIdx.x][2] = m[jump ? 4 : 0] & kg; sm[threadIdx.x][3] = m[jump ? 6 : 1] & kg;
+        sm[threadIdx.x][4] = m[jump ? 5 : 2] & kg; sm[threadIdx.x][5] = m[jump ? 7 : 3] & kg;
+        sm[threadIdx.x][6] = jump ? 1u : 0u;
+    }
     const int k = (int)st_nlegal(st);
     const int incl = wave_incl_scan_i32(k, lane);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    long long at = tile_base[blockIdx.x] + incl - k;
-    for (int w = 0; w < wave; ++w) at += wsum[w];
-    if (i < n) {
-        offset[i] = at;
-        if (k > 0 && at + k <= capacity) lane_children(b, m, packed + at);      // (beyond the buffer: nothing is written; the caller sees total > capacity)
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    pre[threadIdx.x] = before + incl - k;
+    if (threadIdx.x == 255) pre[256] = before + incl;
+    const long long base = tile_base[blockIdx.x];
+    if (i < n) offset[i] = base + before + incl - k;
+    __syncthreads();
+    const int S = pre[256];
+    for (int t = threadIdx.x; t < S; t += 256) {
+        int lo = 0, hi = 256;                                   // the board j with pre[j] <= t < pre[j + 1]
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { const int mid = (lo + hi) >> 1; if (pre[mid] <= t) lo = mid; else hi = mid; }
+        int r = t - pre[lo];
+        const uint4 v = sb[lo];
+        const ckr_board pb{v.x, v.y, v.z, v.w};
+        const uint32_t side = pb.meta & 1u;
+        const bool jump = sm[lo][6] != 0u;
+        const uint32_t a0 = sm[lo][0], a1 = sm[lo][1];
+        const int km = __popc(a0) + __popc(a1);
+        uint32_t q0, q1, q2, q3; int c0, c1, c2, c3;
+        if (r < km) {
+            q0 = a0; q1 = a1; q2 = q3 = 0u;
+            c0 = jump ? (side == 0u ? 6 : 4) : (side == 0u ? 3 : 1); c1 = jump ? (side == 0u ? 7 : 5) : (side == 0u ? 2 : 0); c2 = c3 = 0;
+        } else {
+            r -= km;
+            q0 = sm[lo][2]; q1 = sm[lo][3]; q2 = sm[lo][4]; q3 = sm[lo][5];
+            c0 = jump ? 4 : 0; c1 = jump ? 6 : 1; c2 = jump ? 5 : 2; c3 = jump ? 7 : 3;
+        }
+        // entry r of the list (square-major, direction-minor) without walking it: the square is the smallest s whose squares 0 .. s hold
+        // more than r entries (binary search on popcounts, 5 steps, no divergence), the direction the entry's rank among that square's bits
+        int lo_s = -1, hi_s = 31;                               // invariant: entries(<= lo_s) <= r < entries(<= hi_s)
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int mid = (lo_s + hi_s) >> 1;                 // lo_s < mid < hi_s while they differ by more than one
+            const uint32_t below = (2u << mid) - 1u;
+            const int cnt = __popc(q0 & below) + __popc(q1 & below) + __popc(q2 & below) + __popc(q3 & below);
+            if (cnt > r) hi_s = mid; else lo_s = mid;
+        }
+        const int sq = hi_s;
+        const uint32_t bit = 1u << sq, under = bit - 1u;
+        int rr = r - (__popc(q0 & under) + __popc(q1 & under) + __popc(q2 & under) + __popc(q3 & under));
+        int d = c3;
+        if (q0 & bit) { if (rr == 0) d = c0; --rr; }
+        if (q1 & bit) { if (rr == 0) d = c1; --rr; }
+        if (q2 & bit) { if (rr == 0) d = c2; --rr; }
+        if (base + t < capacity) {                              // (beyond the buffer: not written; the caller sees total > capacity)
+            const ckr_board c = make_child(pb, d, sq);
+            packed[base + t] = make_uint4(c.p1, c.p2, c.kings, c.meta);
+        }
     }
 }
 

@@ -84,9 +84,9 @@ int ckr_children_batch(const ckr_board* d_boards, int64_t n, ckr_board* d_childr
                        int32_t* d_count, void* stream);
 /* K2 with a dense output (same successors, same order; Checkers.py:121-304): the lists of all n positions packed back to back in
  * position order -- the list of position i is the d_count[i] records from record d_offset[i] = d_count[0] + ... + d_count[i - 1]
- * (a CSR).  *d_total (device) receives the number of records of all positions; a list that would end beyond `capacity` records
- * is not written (d_offset / d_count / *d_total are still complete): call again with a larger buffer.  d_scratch: device memory
- * of CKR_CHILDREN_PACKED_SCRATCH(n) bytes.  Three launches (counts + tile sums, scan, write); on large batches 1.5 x the rate of
+ * (a CSR).  *d_total (device) receives the number of records of all positions; records beyond `capacity` are not written
+ * (d_offset / d_count / *d_total are still complete): call again with a larger buffer.  d_scratch: device memory
+ * of CKR_CHILDREN_PACKED_SCRATCH(n) bytes.  Three launches (counts + tile sums, scan, write: one successor per lane); on large batches 1.7 x the rate of
  * ckr_children_batch, whose 48-record slots are written as partly filled cache lines (profiles/r06_k2_children.txt). */
 #define CKR_CHILDREN_PACKED_SCRATCH(n) ((((int64_t)(n) + 255) / 256) * 12 + 16)
 int ckr_children_packed(const ckr_board* d_boards, int64_t n, ckr_board* d_packed, int64_t capacity, int64_t* d_offset,
